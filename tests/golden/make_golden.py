@@ -1,0 +1,291 @@
+#!/usr/bin/env python3
+"""Generate the golden vectors in this directory from the REAL reference.
+
+Runs only in the authoring container (needs /root/reference; the reference's Python never
+travels to the GPU box -- only the .npz files written here do).  Usage:
+
+    python tests/golden/make_golden.py            # writes tests/golden/*.npz
+
+The reference is imported unmodified with three throw-away shims:
+a torchvision stand-in exposing resnet18 with the torchvision-0.4.2 topology, an `attrdict`
+stand-in, and `Tensor.cuda` neutralised (Unpool.__init__ calls .cuda(), models.py:23).
+Weights are filled procedurally by key name (radar_depth_amd/synthetic.py) so no state_dict
+has to be shipped; inputs come from the same module's counter-based generator.
+"""
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, REPO)
+from radar_depth_amd.synthetic import make_batch, procedural_fill_  # noqa: E402
+
+REF = "/root/reference"
+
+
+# --------------------------------------------------------------------------- shims
+def _install_shims():
+    def conv3x3(i, o, stride=1, groups=1, dilation=1):
+        return nn.Conv2d(i, o, 3, stride, dilation, dilation, groups, bias=False)
+
+    def conv1x1(i, o, stride=1):
+        return nn.Conv2d(i, o, 1, stride, bias=False)
+
+    class TVBlock(nn.Module):
+        expansion = 1
+
+        def __init__(self, inplanes, planes, stride=1, downsample=None, *a, **k):
+            super().__init__()
+            self.conv1, self.bn1 = conv3x3(inplanes, planes, stride), nn.BatchNorm2d(planes)
+            self.relu = nn.ReLU(inplace=True)
+            self.conv2, self.bn2 = conv3x3(planes, planes), nn.BatchNorm2d(planes)
+            self.downsample, self.stride = downsample, stride
+
+        def forward(self, x):
+            idt = x
+            out = self.relu(self.bn1(self.conv1(x)))
+            out = self.bn2(self.conv2(out))
+            if self.downsample is not None:
+                idt = self.downsample(x)
+            out += idt
+            return self.relu(out)
+
+    class Bottleneck(nn.Module):
+        expansion = 4
+
+    class TVResNet18(nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.conv1 = nn.Conv2d(3, 64, 7, 2, 3, bias=False)
+            self.bn1 = nn.BatchNorm2d(64)
+            self.relu = nn.ReLU(inplace=True)
+            self.maxpool = nn.MaxPool2d(3, 2, 1)
+            inpl = 64
+            for i, (planes, stride) in enumerate(((64, 1), (128, 2), (256, 2), (512, 2)), 1):
+                down = None
+                if stride != 1 or inpl != planes:
+                    down = nn.Sequential(conv1x1(inpl, planes, stride), nn.BatchNorm2d(planes))
+                setattr(self, "layer%d" % i, nn.Sequential(TVBlock(inpl, planes, stride, down), TVBlock(planes, planes)))
+                inpl = planes
+            for m in self.modules():
+                if isinstance(m, nn.Conv2d):
+                    nn.init.kaiming_normal_(m.weight, mode="fan_out", nonlinearity="relu")
+                elif isinstance(m, nn.BatchNorm2d):
+                    nn.init.constant_(m.weight, 1)
+                    nn.init.constant_(m.bias, 0)
+
+    tv = types.ModuleType("torchvision")
+    tvm = types.ModuleType("torchvision.models")
+    tvr = types.ModuleType("torchvision.models.resnet")
+    tvm.resnet18 = lambda pretrained=False, **kw: TVResNet18()
+    tvr.BasicBlock, tvr.Bottleneck, tvr.conv1x1, tvr.conv3x3 = TVBlock, Bottleneck, conv1x1, conv3x3
+    tv.models, tvm.resnet = tvm, tvr
+    sys.modules.update({"torchvision": tv, "torchvision.models": tvm, "torchvision.models.resnet": tvr})
+
+    ad = types.ModuleType("attrdict")
+
+    class AttrDict(dict):
+        __getattr__ = dict.__getitem__
+        __setattr__ = dict.__setitem__
+
+    ad.AttrDict = AttrDict
+    sys.modules["attrdict"] = ad
+    torch.Tensor.cuda = lambda self, *a, **k: self
+    sys.path.insert(0, REF)
+
+
+def _np(t):
+    return t.detach().cpu().numpy().astype(np.float32)
+
+
+def _stats(t):
+    t = t.detach().float()
+    return np.array([t.mean().item(), t.abs().mean().item(), t.abs().max().item()], dtype=np.float64)
+
+
+def _hook_stats(model, store):
+    handles = []
+    for name, mod in model.named_modules():
+        if len(list(mod.children())) == 0 and name:
+            handles.append(mod.register_forward_hook(
+                lambda m, i, o, name=name: store.__setitem__(name, _stats(o))))
+    return handles
+
+
+FULL_GRADS = ("conv3.weight", "conv1_depth.weight", "bn2.weight", "bn2.bias", "bn1.weight",
+              "decoder.layer4.upper_branch.conv2.weight", "layer4_depth.1.bn2.bias",
+              "layer1_depth.0.conv1.weight", "decoder.layer4.bottom_branch.batchnorm.weight")
+FULL_BUFFERS = ("bn1.running_mean", "bn1.running_var", "bn1_depth.running_mean", "bn1_depth.running_var",
+                "bn_fusion.running_mean", "bn_fusion.running_var", "decoder.layer4.upper_branch.batchnorm2.running_var",
+                "layer2.0.downsample.1.running_mean")
+
+
+def latefusion_case(ResNet_latefusion, MaskedL1Loss, batch, h, w, seed, sub, dense_small):
+    out = {}
+    torch.manual_seed(0)
+    model = ResNet_latefusion(18, "upproj", [h, w], 4, False)
+    procedural_fill_(model)
+    ref_px = h * w if dense_small else 450 * 800
+    x, t = make_batch(batch, h, w, seed, ref_pixels=ref_px)
+    crit = MaskedL1Loss()
+
+    model.eval()
+    with torch.no_grad():
+        y_eval = model(x)
+    out["eval_out"] = _np(y_eval)[:, :, ::sub, ::sub]
+
+    model.train()
+    stats = {}
+    handles = _hook_stats(model, stats)
+    opt = torch.optim.SGD(model.parameters(), 0.01, momentum=0.9, weight_decay=1e-4)
+    y = model(x)
+    for hd in handles:
+        hd.remove()
+    loss = crit(y, t)
+    opt.zero_grad()
+    loss.backward()
+    out["train_out"] = _np(y)[:, :, ::sub, ::sub]
+    out["train_out_stats"] = _stats(y)
+    out["loss"] = np.array([loss.item()], dtype=np.float64)
+    names = [n for n, _ in model.named_parameters()]
+    out["param_names"] = np.array(names)
+    out["grad_norms"] = np.array([p.grad.double().norm().item() for _, p in model.named_parameters()])
+    for n, p in model.named_parameters():
+        if n in FULL_GRADS:
+            out["grad/" + n] = _np(p.grad)
+    out["stat_names"] = np.array(list(stats.keys()))
+    out["stat_values"] = np.stack([stats[k] for k in stats])
+    opt.step()
+    sd = model.state_dict()
+    for n in FULL_BUFFERS:
+        out["buf1/" + n] = _np(sd[n])
+    out["nbt1"] = np.array([int(sd["bn1.num_batches_tracked"])])
+    # second step on a fresh batch
+    x2, t2 = make_batch(batch, h, w, seed + 1, ref_pixels=ref_px)
+    y2 = model(x2)
+    loss2 = crit(y2, t2)
+    opt.zero_grad()
+    loss2.backward()
+    opt.step()
+    out["loss2"] = np.array([loss2.item()], dtype=np.float64)
+    out["param_norms2"] = np.array([p.double().norm().item() for _, p in model.named_parameters()])
+    for n, p in model.named_parameters():
+        if n in FULL_GRADS:
+            out["param2/" + n] = _np(p)
+    return out
+
+
+def multistage_case(ResNet_multistage, MaskedL1Loss, SmoothnessLoss, batch, h, w, seed, sub):
+    out = {}
+    torch.manual_seed(0)
+    model = ResNet_multistage(18, "upproj", [h, w], False)
+    w1 = nn.Parameter(torch.tensor(1.0))
+    w2 = nn.Parameter(torch.tensor(1.0))
+    model.register_parameter("w_stage1", w1)   # main.py:166-172
+    model.register_parameter("w_stage2", w2)
+    procedural_fill_(model)
+    x, t = make_batch(batch, h, w, seed, ref_pixels=h * w)
+    # place a few radar returns far from any plausible prediction so the filter rejects some
+    x[:, 3, ::7, ::11] = torch.where(x[:, 3, ::7, ::11] > 0, x[:, 3, ::7, ::11], torch.full_like(x[:, 3, ::7, ::11], 60.0))
+    out["inputs_patch_note"] = np.array(["x[:,3,::7,::11] zeros replaced by 60.0"])
+    crit, smooth = MaskedL1Loss(), SmoothnessLoss()
+    model.train()
+    opt = torch.optim.SGD(model.parameters(), 0.01, momentum=0.9, weight_decay=1e-4)
+    o = model(x)
+    p1, p2 = o["stage1"], o["stage2"]
+    d1, d2, sm = crit(p1, t), crit(p2, t), smooth(p1, x)
+    loss = torch.exp(-w1) * (d1 + 0.1 * sm) + torch.exp(-w2) * d2 + (w1 + w2)   # main.py:423-429
+    opt.zero_grad()
+    loss.backward()
+    for k in ("stage1", "stage2", "mask", "radar_filtered"):
+        out["out/" + k] = _np(o[k])[:, :, ::sub, ::sub]
+    out["mask_density"] = np.array([o["mask"].mean().item()])
+    out["losses"] = np.array([d1.item(), d2.item(), sm.item(), loss.item()], dtype=np.float64)
+    out["w_grads"] = np.array([w1.grad.item(), w2.grad.item()], dtype=np.float64)
+    names = [n for n, _ in model.named_parameters()]
+    out["param_names"] = np.array(names)
+    out["grad_norms"] = np.array([p.grad.double().norm().item() for _, p in model.named_parameters()])
+    out["grad/stage1.conv3.weight"] = _np(model.stage1.conv3.weight.grad)
+    out["grad/stage2.conv1_depth.weight"] = _np(model.stage2.conv1_depth.weight.grad)
+    # coupling proof: gradient of d2 alone w.r.t. a stage-1 weight is non-zero (multistage_model.py:75)
+    g = torch.autograd.grad(crit(model(x)["stage2"], t), model.stage1.conv3.weight)[0]
+    out["coupling_norm"] = np.array([g.double().norm().item()])
+    opt.step()
+    out["param_norms1"] = np.array([p.double().norm().item() for _, p in model.named_parameters()])
+    return out
+
+
+def unit_cases(mm, crit_mod):
+    out = {}
+    g = torch.Generator().manual_seed(7)
+    # Filter_layer
+    dense = torch.rand(2, 1, 9, 13, generator=g) * 90
+    sparse = torch.where(torch.rand(2, 1, 9, 13, generator=g) < 0.4, dense + (torch.rand(2, 1, 9, 13, generator=g) - 0.5) * 60,
+                         torch.zeros(2, 1, 9, 13))
+    kept, mask = mm.Filter_layer()(sparse, dense)
+    out.update({"filter/sparse": _np(sparse), "filter/dense": _np(dense), "filter/kept": _np(kept), "filter/mask": _np(mask)})
+    # MaskedL1Loss + gradient, and the empty-mask NaN
+    pred = (torch.rand(2, 1, 9, 13, generator=g) * 50).requires_grad_(True)
+    target = torch.where(torch.rand(2, 1, 9, 13, generator=g) < 0.3, torch.rand(2, 1, 9, 13, generator=g) * 80, torch.zeros(2, 1, 9, 13))
+    l1 = crit_mod.MaskedL1Loss()(pred, target)
+    l1.backward()
+    out.update({"l1/pred": _np(pred), "l1/target": _np(target), "l1/loss": np.array([l1.item()]), "l1/grad": _np(pred.grad)})
+    l2 = crit_mod.MaskedMSELoss()(pred.detach(), target)
+    out["l2/loss"] = np.array([l2.item()])
+    nanloss = crit_mod.MaskedL1Loss()(pred.detach(), torch.zeros_like(target))
+    out["l1/empty_isnan"] = np.array([bool(torch.isnan(nanloss))])
+    # SmoothnessLoss with a 4-channel image + gradient
+    p = (torch.rand(2, 1, 9, 13, generator=g) * 30 + 1).requires_grad_(True)
+    img = torch.rand(2, 4, 9, 13, generator=g)
+    s = crit_mod.SmoothnessLoss()(p, img)
+    s.backward()
+    out.update({"smooth/pred": _np(p), "smooth/image": _np(img), "smooth/loss": np.array([s.item()]), "smooth/grad": _np(p.grad)})
+    return out
+
+
+def upproj_case(models):
+    """One UpProjModule (C=32) forward/backward on an odd-sized map: pins the 4-phase identity."""
+    out = {}
+    torch.manual_seed(0)
+    m = models.UpProj.UpProjModule(32)
+    procedural_fill_(m)
+    m.train()
+    g = torch.Generator().manual_seed(11)
+    x = torch.randn(2, 32, 7, 9, generator=g).requires_grad_(True)
+    y = m(x)
+    gy = torch.randn(y.shape, generator=g)
+    y.backward(gy)
+    out.update({"x": _np(x), "y": _np(y), "gy": _np(gy), "gx": _np(x.grad)})
+    for n, p in m.named_parameters():
+        out["grad/" + n] = _np(p.grad)
+    return out
+
+
+def main():
+    _install_shims()
+    from model import models, multistage_model as mm
+    from evaluation import criteria_new as crit_mod
+    torch.set_num_threads(8)
+
+    small = latefusion_case(models.ResNet_latefusion, crit_mod.MaskedL1Loss, 2, 97, 161, 4321, 1, True)
+    np.savez_compressed(os.path.join(HERE, "latefusion_small.npz"), **small)
+    full = latefusion_case(models.ResNet_latefusion, crit_mod.MaskedL1Loss, 2, 450, 800, 1234, 8, False)
+    for k in [k for k in full if k.startswith(("grad/", "param2/")) and full[k].size > 4096]:
+        del full[k]
+    np.savez_compressed(os.path.join(HERE, "latefusion_full.npz"), **full)
+    multi = multistage_case(mm.ResNet_multistage, crit_mod.MaskedL1Loss, crit_mod.SmoothnessLoss, 2, 97, 161, 777, 1)
+    np.savez_compressed(os.path.join(HERE, "multistage_small.npz"), **multi)
+    np.savez_compressed(os.path.join(HERE, "units.npz"), **unit_cases(mm, crit_mod))
+    np.savez_compressed(os.path.join(HERE, "upproj_module.npz"), **upproj_case(models))
+    for f in sorted(os.listdir(HERE)):
+        if f.endswith(".npz"):
+            print(f, os.path.getsize(os.path.join(HERE, f)))
+
+
+if __name__ == "__main__":
+    main()
