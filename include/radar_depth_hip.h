@@ -1,0 +1,233 @@
+/*
+ * radar_depth_hip.h -- C ABI of libradardepth_hip.so (gfx950 / MI355X).
+ *
+ * The reference (brade31919/radar_depth) has no FFI: its hot path is torch.nn layers that
+ * dispatch to ATen/cuDNN.  This library is the MI355X-native replacement for those
+ * dispatches, underneath the reference's nn.Module plugin surface.  Every entry point cites
+ * the reference call it replaces (paths relative to /root/reference).
+ *
+ * Conventions
+ *  - plain C: raw device pointers + sizes, no torch types.  Pointers are BORROWED for the
+ *    duration of the call; the library never allocates or frees device memory.
+ *  - activations are NHWC fp32 with an explicit channel stride `ld` (>= channels) so a
+ *    tensor may be a channel slice of a wider buffer (the late-fusion concat is free).
+ *  - every call is asynchronous on the caller's hipStream_t (passed as void*), never
+ *    synchronises, and is re-entrant per stream.
+ *  - returns 0 on success, a negative RD_E* code otherwise; rd_last_error() gives the text.
+ */
+#ifndef RADAR_DEPTH_HIP_H
+#define RADAR_DEPTH_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RD_OK 0
+#define RD_EINVAL (-1)   /* bad argument / unsupported shape */
+#define RD_ELAUNCH (-2)  /* HIP launch / runtime error */
+
+#define RD_MAX_TAPS 25
+#define RD_MAX_PHASES 4
+
+#define RD_ACT_NONE 0
+#define RD_ACT_RELU 1
+#define RD_ACT_LEAKY02 2 /* LeakyReLU(0.2), model/models.py:564 */
+
+const char* rd_last_error(void);
+int rd_abi_version(void);
+/* number of CUs / name of device 0 as the library sees it (diagnostics) */
+int rd_device_info(int* n_cu, char* name, int name_len);
+
+/* ---------------------------------------------------------------------------------------
+ * Generalised convolution ("gconv").  One descriptor expresses every conv on the path:
+ *
+ *   out[n, oh*out_stride + out_off_h, ow*out_stride + out_off_w, co] =
+ *       sum_{t < n_taps} sum_{ci}  in[n, oh*in_stride + dh[t], ow*in_stride + dw[t], ci]
+ *                                   * w[widx[t]][ci][co]            (out-of-range input = 0)
+ *
+ * for (oh, ow) over the phase's logical grid lh x lw.  Phases write disjoint output pixels.
+ *   - 3x3 / 1x1 forward, stride 1 or 2        : 1 phase          (nn.Conv2d, models.py:96-112)
+ *   - Unpool + 5x5 conv of an UpProj module    : 4 phases, 9/6/6/4 taps on the LOW-RES input,
+ *     both branches fused along co             (models.py:13-27,181-209; zero-skipping identity)
+ *   - every input-gradient (dgrad) of the above: same form with transposed weights
+ * Weights are the packed layout produced by rd_pack_weights: [slab][cin][cout], cout fastest.
+ * ------------------------------------------------------------------------------------- */
+typedef struct {
+    int32_t n_taps;
+    int32_t out_off_h, out_off_w;
+    int32_t lh, lw;                  /* logical output grid of this phase */
+    int32_t dh_min, dh_max, dw_min, dw_max;
+    int32_t tile_begin;              /* filled by the library */
+    int8_t dh[RD_MAX_TAPS];
+    int8_t dw[RD_MAX_TAPS];
+    int16_t widx[RD_MAX_TAPS];
+} RdPhase;
+
+typedef struct {
+    int32_t N;
+    int32_t Hi, Wi, Cin, ldi;
+    int32_t Ho, Wo, Cout, ldo;
+    int32_t in_stride, out_stride;
+    int32_t n_phases;
+    RdPhase phase[RD_MAX_PHASES];
+} RdConvDesc;
+
+/* Forward / dgrad convolution.  addend (optional, may be NULL): out += addend[pixel][co]
+ * (residual-gradient merge).  stat_partial (optional): per-pixel-tile partial (sum, sum of
+ * squares) per output channel for training-mode BatchNorm, layout [n_stat_tiles][2][Cout];
+ * the tile count is returned by rd_gconv_stat_tiles.  Replaces F.conv2d /
+ * conv_transpose2d+conv2d (models.py:27,203-206) and their autograd input-gradients. */
+int rd_gconv(const RdConvDesc* d, const float* in, const float* w_packed, float* out,
+             const float* addend, int32_t ld_add, float* stat_partial, void* stream);
+int rd_gconv_stat_tiles(const RdConvDesc* d);
+
+/* Weight gradient of the same descriptor: dw[slab][ci][co] = sum_pixels in(...) * dout(...).
+ * `d` is the FORWARD descriptor (in = forward input, "out" geometry = dout).  slabs is a
+ * workspace of rd_wgrad_workspace_floats(d) floats; the result is reduced deterministically
+ * into OIHW gradient tensors by rd_wgrad_reduce.  Replaces the weight half of
+ * convolution_backward (autograd of models.py:96-112,203-206; 50% of the reference CPU step). */
+int64_t rd_wgrad_workspace_floats(const RdConvDesc* d);
+int rd_wgrad(const RdConvDesc* d, const float* in, const float* dout, float* slabs, void* stream);
+/* grad_oihw[o][i][kh][kw] (+)= sum over slabs; o covers packed columns [co_off, co_off+O).
+ * slab index of (kh,kw) is kh*KW+kw. */
+int rd_wgrad_reduce(const RdConvDesc* d, const float* slabs, float* grad_oihw, int32_t O, int32_t I,
+                    int32_t KH, int32_t KW, int32_t co_off, int32_t accumulate, void* stream);
+
+/* OIHW -> packed [slab][I][ldc] at column offset co_off (forward operand), or, with
+ * transpose != 0, -> packed [slab][O.. as rows][I as columns] (dgrad operand: rows are the
+ * forward output channels at row offset co_off, ldc >= I).  flip != 0 reverses the slab order
+ * (kh,kw -> KH-1-kh, KW-1-kw).  Replaces nothing in the reference (layout glue). */
+int rd_pack_weights(const float* w_oihw, float* packed, int32_t O, int32_t I, int32_t KH, int32_t KW,
+                    int32_t ldc, int32_t co_off, int32_t rows_total, int32_t transpose, void* stream);
+
+/* ---------------------------------------------------------------------------------------
+ * Stem convolutions: 7x7 stride 2 pad 3 straight from the NCHW network input
+ * (models.py:539,559,633,643; multistage_model.py:163-164).  x is [N, Ctot, H, W]; channels
+ * [c0, c0+Cin) are used, or, when c_second >= 0 (stage 2), channel c0 from x and one channel
+ * from the separate NHWC-1 map `x2` (the stage-1 prediction).  Output NHWC [N,Ho,Wo,Cout].
+ * ------------------------------------------------------------------------------------- */
+int rd_stem_fwd(const float* x, int32_t N, int32_t Ctot, int32_t H, int32_t W, int32_t c0, int32_t Cin,
+                const float* x2, const float* w_oihw, int32_t Cout, float* out, float* stat_partial,
+                void* stream);
+int rd_stem_stat_tiles(int32_t N, int32_t H, int32_t W);
+/* weight gradient (OIHW, overwritten) of the stem; ws needs rd_stem_wgrad_workspace_floats */
+int64_t rd_stem_wgrad_workspace_floats(int32_t N, int32_t H, int32_t W, int32_t Cin, int32_t Cout);
+int rd_stem_wgrad(const float* x, int32_t N, int32_t Ctot, int32_t H, int32_t W, int32_t c0, int32_t Cin,
+                  const float* x2, const float* dout, int32_t Cout, float* grad_oihw, float* ws,
+                  void* stream);
+/* input gradient w.r.t. ONE input channel `ci` of the stem (stage-2 dense-depth channel,
+ * multistage_model.py:75 -- stage-1 prediction is not detached).  dx is [N,H,W] (overwritten). */
+int rd_stem_dgrad_channel(const float* dout, const float* w_oihw, int32_t N, int32_t H, int32_t W,
+                          int32_t Cin, int32_t ci, int32_t Cout, float* dx, void* stream);
+
+/* ---------------------------------------------------------------------------------------
+ * BatchNorm2d (training mode) + activation + residual join
+ * (torch.nn.BatchNorm2d defaults eps=1e-5 momentum=0.1; models.py:101-110,203-208).
+ * ------------------------------------------------------------------------------------- */
+/* Reduce conv-epilogue partials -> mean / invstd, fused scale = gamma*invstd and
+ * shift = beta - mean*scale; update running stats (unbiased var) and num_batches_tracked. */
+int rd_bn_finalize(const float* stat_partial, int32_t n_tiles, int32_t C, int64_t count,
+                   const float* gamma, const float* beta, float eps, float momentum,
+                   float* running_mean, float* running_var, int64_t* num_batches_tracked,
+                   float* mean, float* invstd, float* scale, float* shift, void* stream);
+/* eval mode: scale/shift from running stats */
+int rd_bn_eval_coeffs(int32_t C, const float* gamma, const float* beta, const float* running_mean,
+                      const float* running_var, float eps, float* scale, float* shift, void* stream);
+/* partial stats of an existing tensor (used where the producer has no fused epilogue) */
+int rd_bn_stats(const float* x, int64_t M, int32_t C, int32_t ldx, float* stat_partial, int32_t* n_tiles,
+                void* stream);
+int rd_bn_stats_tiles(int64_t M);
+/* y = act(scale1*x1 + shift1 [+ (scale2*x2 + shift2 | x2)]) ; scale2 == NULL -> identity residual */
+int rd_bn_act(const float* x1, int32_t ldx1, const float* scale1, const float* shift1,
+              const float* x2, int32_t ldx2, const float* scale2, const float* shift2,
+              float* y, int32_t ldy, int64_t M, int32_t C, int32_t act, void* stream);
+/* backward pass 1: g = dy * act'(y) (written to g, ldg); partial sums of g, g*x1 [, g*x2]
+ * -> red_partial [n_tiles][3][C]. */
+int rd_bn_bwd_reduce(const float* dy, int32_t lddy, const float* y, int32_t ldy,
+                     const float* x1, int32_t ldx1, const float* x2, int32_t ldx2,
+                     float* g, int32_t ldg, int64_t M, int32_t C, int32_t act,
+                     float* red_partial, void* stream);
+int rd_bn_bwd_tiles(int64_t M);
+/* backward pass 2 (per BN): finishes the reduction, writes dgamma/dbeta (overwrite) and
+ * dx = gamma*invstd*(g - mean(g) - xhat*mean(g*xhat)).  which = 1 or 2 selects the x1 / x2 sums. */
+int rd_bn_bwd_apply(const float* g, int32_t ldg, const float* x, int32_t ldx, const float* red_partial,
+                    int32_t n_tiles, int32_t which, const float* gamma, const float* mean,
+                    const float* invstd, float* dgamma, float* dbeta, float* dx, int32_t lddx,
+                    int64_t M, int32_t C, void* stream);
+
+/* MaxPool2d(3,2,1) fused with the stem's BN affine + activation (models.py:634-636,644-646):
+ * y = maxpool(act(scale*x+shift)); idx = argmax position 0..8 in the window. */
+int rd_bnact_maxpool_fwd(const float* x, const float* scale, const float* shift, int32_t act,
+                         int32_t N, int32_t H, int32_t W, int32_t C, float* y, int32_t ldy,
+                         uint8_t* idx, void* stream);
+/* gradient w.r.t. the pre-activation BN output: g[n,h,w,c] = act'(scale*x+shift) *
+ * sum of dy over the pooling windows whose argmax is (h,w). */
+int rd_bnact_maxpool_bwd(const float* dy, int32_t lddy, const uint8_t* idx, const float* x,
+                         const float* scale, const float* shift, int32_t act, int32_t N, int32_t H,
+                         int32_t W, int32_t C, float* g, void* stream);
+
+/* ---------------------------------------------------------------------------------------
+ * Head: conv3 (3x3, C->1, models.py:587,661) and bilinear align_corners=True resize
+ * (models.py:588,662).  d is NHWC-1 / NCHW-1 (same memory) [N,Hs,Ws]; out is [N,1,Ho,Wo].
+ * ------------------------------------------------------------------------------------- */
+int rd_head_conv_fwd(const float* x, int32_t ldx, const float* w_oihw, int32_t N, int32_t H, int32_t W,
+                     int32_t C, float* d, void* stream);
+int rd_head_conv_bwd(const float* x, int32_t ldx, const float* w_oihw, const float* dd, int32_t N,
+                     int32_t H, int32_t W, int32_t C, float* dx, int32_t lddx, float* dw_oihw,
+                     float* ws, void* stream);
+int64_t rd_head_conv_bwd_workspace_floats(int32_t N, int32_t H, int32_t W, int32_t C);
+int rd_bilinear_fwd(const float* d, int32_t N, int32_t Hs, int32_t Ws, float* out, int32_t Ho, int32_t Wo,
+                    void* stream);
+int rd_bilinear_bwd(const float* dout, int32_t N, int32_t Ho, int32_t Wo, float* dd, int32_t Hs, int32_t Ws,
+                    void* stream);
+
+/* ---------------------------------------------------------------------------------------
+ * Losses (evaluation/criteria_new.py) and the step tail (main.py:416-445).
+ * ------------------------------------------------------------------------------------- */
+/* MaskedL1Loss (:44-54): sums[0] = sum |t-p| over t>0, sums[1] = count.  ws: 2*rd_loss_tiles floats */
+int rd_masked_l1_sums(const float* pred, const float* target, int64_t n, float* ws, double* sums, void* stream);
+int rd_loss_tiles(int64_t n);
+/* dpred (+)= coef_dev[0] * (-sign(t-p)) / count on valid pixels; coef read on device */
+int rd_masked_l1_bwd(const float* pred, const float* target, int64_t n, const double* sums,
+                     const float* coef, float* dpred, int32_t accumulate, void* stream);
+/* SmoothnessLoss (:8-28) on pred [N,1,H,W] and image [N,C,H,W] (NCHW).  out[0] = loss.
+ * ws: rd_smooth_workspace_floats(N,H,W) floats. */
+int64_t rd_smooth_workspace_floats(int32_t N, int32_t H, int32_t W);
+int rd_smooth_fwd(const float* pred, const float* image, int32_t N, int32_t C, int32_t H, int32_t W,
+                  float* ws, double* out, void* stream);
+int rd_smooth_bwd(const float* pred, const float* image, int32_t N, int32_t C, int32_t H, int32_t W,
+                  const float* ws, const float* coef, float* dpred, int32_t accumulate, void* stream);
+/* Filter_layer (multistage_model.py:87-119): kept = sparse*mask, mask = |dense-sparse| <= 5*3.6^(dense/100).
+ * sparse is channel `c` of the NCHW input x [N,Ctot,H,W]. */
+int rd_radar_filter(const float* x, int32_t N, int32_t Ctot, int32_t c, int64_t hw, const float* dense,
+                    float* kept, float* mask, void* stream);
+/* uncertainty-weighted total (main.py:423-429).  in: l1 sums of both stages, smoothness, w1, w2.
+ * out_host-visible device scalars: loss[0..3] = d1, d2, smooth, total; coefs[0..2] = e^-w1, 0.1*e^-w1,
+ * e^-w2 (the factors the loss backward kernels read); dw[0..1] = gradients of w1, w2. */
+int rd_uncertainty_total(const double* sums1, const double* sums2, const double* smooth, const float* w1,
+                         const float* w2, float w_smooth, float* loss4, float* coefs3, float* dw1,
+                         float* dw2, void* stream);
+/* loss[0] = sums[0]/sums[1]; coef[0] = 1 (plain MaskedL1 step, main.py:440-441) */
+int rd_l1_total(const double* sums, float* loss, float* coef, void* stream);
+
+/* torch.optim.SGD step (main.py:285-290,445): g += wd*p; buf = first ? g : mom*buf + g; p -= lr*buf,
+ * over a flat arena.  grad_scale multiplies g first (1/world for data-parallel averaging). */
+int rd_sgd_step(float* p, const float* g, float* buf, int64_t n, float lr, float momentum, float wd,
+                float grad_scale, int32_t first_step, void* stream);
+int rd_fill(float* p, int64_t n, float v, void* stream);
+/* NCHW [N,C,H,W] (channel c0..c0+C of Ctot) <-> NHWC helpers for module-level tests */
+int rd_nchw_to_nhwc(const float* src, float* dst, int32_t N, int32_t C, int32_t H, int32_t W, void* stream);
+int rd_nhwc_to_nchw(const float* src, float* dst, int32_t N, int32_t C, int32_t H, int32_t W, void* stream);
+
+/* hipGraph capture helpers so a whole step replays without host launch cost */
+int rd_graph_begin(void* stream);
+int rd_graph_end(void* stream, void** graph_exec);
+int rd_graph_launch(void* graph_exec, void* stream);
+int rd_graph_destroy(void* graph_exec);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

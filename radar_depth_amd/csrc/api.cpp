@@ -1,0 +1,66 @@
+// Error reporting, device info, hipGraph helpers of libradardepth_hip.
+#include <stdarg.h>
+
+#include "common.h"
+
+namespace rd {
+static thread_local char g_err[512] = "";
+void set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+int num_cus() {
+    static int n = 0;
+    if (n == 0) {
+        hipDeviceProp_t prop;
+        int dev = 0;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) n = prop.multiProcessorCount;
+        if (n <= 0) n = 256;
+    }
+    return n;
+}
+}  // namespace rd
+
+extern "C" const char* rd_last_error(void) { return rd::g_err; }
+extern "C" int rd_abi_version(void) { return 1; }
+
+extern "C" int rd_device_info(int* n_cu, char* name, int name_len) {
+    hipDeviceProp_t prop;
+    int dev = 0;
+    RD_CHECK_HIP(hipGetDevice(&dev));
+    RD_CHECK_HIP(hipGetDeviceProperties(&prop, dev));
+    if (n_cu) *n_cu = prop.multiProcessorCount;
+    if (name && name_len > 0) {
+        snprintf(name, name_len, "%s (%s)", prop.name, prop.gcnArchName);
+    }
+    return RD_OK;
+}
+
+extern "C" int rd_graph_begin(void* stream) {
+    RD_CHECK_HIP(hipStreamBeginCapture(static_cast<hipStream_t>(stream), hipStreamCaptureModeThreadLocal));
+    return RD_OK;
+}
+extern "C" int rd_graph_end(void* stream, void** graph_exec) {
+    RD_CHECK_ARG(graph_exec != nullptr, "rd_graph_end: null out pointer");
+    hipGraph_t g = nullptr;
+    RD_CHECK_HIP(hipStreamEndCapture(static_cast<hipStream_t>(stream), &g));
+    hipGraphExec_t ge = nullptr;
+    hipError_t e = hipGraphInstantiate(&ge, g, nullptr, nullptr, 0);
+    hipGraphDestroy(g);
+    if (e != hipSuccess) {
+        rd::set_error("hipGraphInstantiate: %s", hipGetErrorString(e));
+        return RD_ELAUNCH;
+    }
+    *graph_exec = ge;
+    return RD_OK;
+}
+extern "C" int rd_graph_launch(void* graph_exec, void* stream) {
+    RD_CHECK_HIP(hipGraphLaunch(static_cast<hipGraphExec_t>(graph_exec), static_cast<hipStream_t>(stream)));
+    return RD_OK;
+}
+extern "C" int rd_graph_destroy(void* graph_exec) {
+    if (graph_exec) RD_CHECK_HIP(hipGraphExecDestroy(static_cast<hipGraphExec_t>(graph_exec)));
+    return RD_OK;
+}

@@ -1,0 +1,79 @@
+// Shared host/device helpers for libradardepth_hip (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "../../include/radar_depth_hip.h"
+
+namespace rd {
+
+void set_error(const char* fmt, ...);
+
+#define RD_CHECK_ARG(cond, ...)             \
+    do {                                    \
+        if (!(cond)) {                      \
+            rd::set_error(__VA_ARGS__);     \
+            return RD_EINVAL;               \
+        }                                   \
+    } while (0)
+
+#define RD_CHECK_LAUNCH(what)                                                     \
+    do {                                                                          \
+        hipError_t e__ = hipGetLastError();                                       \
+        if (e__ != hipSuccess) {                                                  \
+            rd::set_error("%s: %s", what, hipGetErrorString(e__));                \
+            return RD_ELAUNCH;                                                    \
+        }                                                                         \
+    } while (0)
+
+#define RD_CHECK_HIP(expr)                                                        \
+    do {                                                                          \
+        hipError_t e__ = (expr);                                                  \
+        if (e__ != hipSuccess) {                                                  \
+            rd::set_error("%s: %s", #expr, hipGetErrorString(e__));               \
+            return RD_ELAUNCH;                                                    \
+        }                                                                         \
+    } while (0)
+
+static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
+static inline int64_t cdiv64(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
+int num_cus();
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+#ifdef __HIPCC__
+// XCD-aware bijective remap of a 1-D grid: hardware places block b on XCD b % 8; give each XCD a
+// contiguous chunk of virtual ids so neighbouring tiles (shared halos / shared weights) hit one L2.
+__device__ __forceinline__ int xcd_remap(int bid, int nwg) {
+    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ double wave_sum_d(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float act_fwd(float z, int act) {
+    if (act == RD_ACT_RELU) return z > 0.f ? z : 0.f;
+    if (act == RD_ACT_LEAKY02) return z > 0.f ? z : 0.2f * z;
+    return z;
+}
+// derivative expressed on the activation OUTPUT y (sign(y) == sign(z) for both activations)
+__device__ __forceinline__ float act_grad_from_out(float y, int act) {
+    if (act == RD_ACT_RELU) return y > 0.f ? 1.f : 0.f;
+    if (act == RD_ACT_LEAKY02) return y > 0.f ? 1.f : 0.2f;
+    return 1.f;
+}
+#endif
+
+}  // namespace rd

@@ -1,0 +1,358 @@
+// Generalised NHWC fp32 convolution on the CDNA4 matrix cores (v_mfma_f32_32x32x2_f32: exact fp32,
+// 64 FLOP/clk/SIMD).  See include/radar_depth_hip.h for the descriptor.  Replaces F.conv2d /
+// conv_transpose2d+conv2d of the reference (model/models.py:27,96-112,203-206,652-657) and the
+// input-gradient half of their autograd.
+//
+// Structure per workgroup (256 threads = 4 waves, WM x WN wave grid):
+//   * a TH x TW tile of logical output pixels (BM = WM*MT*32 rows of the implicit GEMM) times
+//     BN = WN*NT*32 output channels;
+//   * the input halo patch of the tile is staged ONCE per 32-channel chunk in LDS and reused by every
+//     tap (direct convolution: no im2col buffer, input read once from HBM/L2);
+//   * weights stream through LDS in [taps][CKW][BN] slabs;
+//   * each wave keeps MT x NT accumulator tiles of 32x32 in registers; A fragments are ds_read_b32 with
+//     an odd pixel stride (conflict-free), B fragments are contiguous in cout;
+//   * epilogue: optional addend (residual-gradient merge), NHWC store through an output stride/offset
+//     (UpProj phases, stride-2 dgrad), and per-tile partial BatchNorm sums for the fused statistics.
+#include "common.h"
+
+namespace rd {
+
+struct GconvArgs {
+    RdConvDesc d;
+    const float* in;
+    const float* w;
+    float* out;
+    const float* addend;
+    float* stat;
+    int ld_add;
+    int ldw;           // packed weight row length (>= Cout)
+    int TH, TW;        // tile in logical output pixels
+    int PP;            // max patch pixels over phases
+    int CKP;           // patch channel chunk (16 or 32)
+    int tiles_total;   // tiles per image over all phases
+    int n_cotiles;
+    int taps_max;      // max taps over phases (sizes the LDS weight slab)
+};
+
+template <int MT, int NT, int WM, int WN, int CKW>
+__global__ __launch_bounds__(256) void gconv_kernel(const GconvArgs a) {
+    constexpr int BM = WM * MT * 32;
+    constexpr int BN = WN * NT * 32;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    const int l31 = lane & 31, hh = lane >> 5;
+    const RdConvDesc& D = a.d;
+
+    const int vid = xcd_remap(blockIdx.x, gridDim.x);
+    const int cot = vid % a.n_cotiles;
+    const int pt = vid / a.n_cotiles;
+    const int n = pt / a.tiles_total;
+    const int tt = pt - n * a.tiles_total;
+    int ph = 0;
+    for (int i = 1; i < D.n_phases; ++i)
+        if (tt >= D.phase[i].tile_begin) ph = i;
+    const RdPhase& P = D.phase[ph];
+    const int tloc = tt - P.tile_begin;
+    const int tiles_w = (P.lw + a.TW - 1) / a.TW;
+    const int r0 = (tloc / tiles_w) * a.TH, c0 = (tloc % tiles_w) * a.TW;
+    const int th_n = min(a.TH, P.lh - r0), tw_n = min(a.TW, P.lw - c0);
+    const int IS = D.in_stride, OS = D.out_stride;
+    const int PW = (a.TW - 1) * IS + (P.dw_max - P.dw_min) + 1;
+    const int PH = (th_n - 1) * IS + (P.dh_max - P.dh_min) + 1;
+    const int ih0 = r0 * IS + P.dh_min, iw0 = c0 * IS + P.dw_min;
+    const int CKP = a.CKP, PS = CKP + 1;
+    const int ntaps = P.n_taps;
+    const int co0 = cot * BN;
+
+    // LDS carve-up
+    int* s_opix = reinterpret_cast<int*>(smem);          // [BM] output pixel index or -1
+    int* s_apix = s_opix + BM;                           // [BM] patch pixel index of tap (0,0)
+    int* s_tapoff = s_apix + BM;                         // [32] patch float offset per tap
+    int* s_widx = s_tapoff + 32;                         // [32]
+    float* s_w = reinterpret_cast<float*>(s_widx + 32);  // [taps][CKW][BN]
+    float* s_patch = s_w + a.taps_max * CKW * BN;        // [PP][PS]
+
+    for (int m = tid; m < BM; m += 256) {
+        const int r = m / a.TW, c = m - r * a.TW;
+        const bool ok = (r < th_n) && (c < tw_n);
+        s_opix[m] = ok ? ((n * D.Ho + (r0 + r) * OS + P.out_off_h) * D.Wo + (c0 + c) * OS + P.out_off_w) : -1;
+        s_apix[m] = ok ? ((r * IS) * PW + c * IS) : 0;
+    }
+    if (tid < ntaps) {
+        s_tapoff[tid] = ((P.dh[tid] - P.dh_min) * PW + (P.dw[tid] - P.dw_min)) * PS;
+        s_widx[tid] = P.widx[tid];
+    }
+    __syncthreads();
+
+    int abase[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) abase[mt] = s_apix[(wm * MT + mt) * 32 + l31] * PS;
+    const int bcol = wn * NT * 32 + l31;
+
+    f32x16 acc[MT][NT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[mt][nt][i] = 0.f;
+
+    const int q4 = CKP >> 2;                 // float4 per patch pixel
+    const int patch_elems = PH * PW * q4;
+    const float* in_n = a.in + (size_t)n * D.Hi * D.Wi * D.ldi;
+
+    for (int cb = 0; cb < D.Cin; cb += CKP) {
+        __syncthreads();
+        // ---- stage the halo patch chunk [PH*PW][CKP] (zero outside the image / beyond Cin)
+        for (int e = tid; e < patch_elems; e += 256) {
+            const int pix = e / q4, qq = e - pix * q4;
+            const int py = pix / PW, px = pix - py * PW;
+            const int ih = ih0 + py, iw = iw0 + px, c = cb + qq * 4;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (ih >= 0 && ih < D.Hi && iw >= 0 && iw < D.Wi && c < D.Cin)
+                v = *reinterpret_cast<const float4*>(in_n + ((size_t)ih * D.Wi + iw) * D.ldi + c);
+            float* dst = s_patch + pix * PS + qq * 4;
+            dst[0] = v.x; dst[1] = v.y; dst[2] = v.z; dst[3] = v.w;
+        }
+        const int nsub = min(CKP, D.Cin - cb) / CKW;
+        for (int ks = 0; ks < nsub; ++ks) {
+            if (ks > 0) __syncthreads();
+            // ---- stage weights [taps][CKW][BN] for input channels cb+ks*CKW .. +CKW
+            const int welems = ntaps * CKW * (BN / 4);
+            for (int e = tid; e < welems; e += 256) {
+                const int j4 = e % (BN / 4);
+                const int tk = e / (BN / 4);
+                const int k = tk % CKW, t = tk / CKW;
+                const int co = co0 + j4 * 4;
+                const int ci = cb + ks * CKW + k;
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (co < D.Cout)  // Cout is a multiple of 4 (checked on the host)
+                    v = *reinterpret_cast<const float4*>(a.w + ((size_t)s_widx[t] * D.Cin + ci) * a.ldw + co);
+                *reinterpret_cast<float4*>(s_w + (size_t)tk * BN + j4 * 4) = v;
+            }
+            __syncthreads();
+            // ---- MFMA over taps x CKW
+            for (int t = 0; t < ntaps; ++t) {
+                const int toff = s_tapoff[t] + ks * CKW + hh;
+                const float* wt = s_w + (t * CKW + hh) * BN + bcol;
+#pragma unroll
+                for (int kk = 0; kk < CKW / 2; ++kk) {
+                    float av[MT], bv[NT];
+#pragma unroll
+                    for (int mt = 0; mt < MT; ++mt) av[mt] = s_patch[abase[mt] + toff + kk * 2];
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt) bv[nt] = wt[kk * 2 * BN + nt * 32];
+#pragma unroll
+                    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                        for (int nt = 0; nt < NT; ++nt)
+                            acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[mt], bv[nt], acc[mt][nt], 0, 0, 0);
+                }
+            }
+        }
+    }
+
+    // ---- epilogue
+    float ssum[NT], ssq[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) ssum[nt] = ssq[nt] = 0.f;
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int m = (wm * MT + mt) * 32 + (i & 3) + 8 * (i >> 2) + 4 * hh;
+            const int op = s_opix[m];
+            if (op >= 0) {
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) {
+                    const int co = co0 + wn * NT * 32 + nt * 32 + l31;
+                    if (co < D.Cout) {
+                        float v = acc[mt][nt][i];
+                        if (a.addend) v += a.addend[(size_t)op * a.ld_add + co];
+                        a.out[(size_t)op * D.ldo + co] = v;
+                        ssum[nt] += v;
+                        ssq[nt] += v * v;
+                    }
+                }
+            }
+        }
+    }
+    if (a.stat) {
+        __syncthreads();
+        float* red = s_w;  // [WM][2][BN]
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            const float s = ssum[nt] + __shfl_xor(ssum[nt], 32, 64);
+            const float q = ssq[nt] + __shfl_xor(ssq[nt], 32, 64);
+            if (hh == 0) {
+                red[(wm * 2 + 0) * BN + wn * NT * 32 + nt * 32 + l31] = s;
+                red[(wm * 2 + 1) * BN + wn * NT * 32 + nt * 32 + l31] = q;
+            }
+        }
+        __syncthreads();
+        if (tid < 2 * BN) {
+            const int which = tid / BN, j = tid - which * BN;
+            float s = 0.f;
+#pragma unroll
+            for (int w = 0; w < WM; ++w) s += red[(w * 2 + which) * BN + j];
+            const int co = co0 + j;
+            if (co < D.Cout) a.stat[((size_t)pt * 2 + which) * D.Cout + co] = s;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------ host
+struct GconvPlan {
+    int MT, NT, WM, WN, CKW, CKP, TH, TW, PP, tiles_total, n_cotiles, taps_max;
+    size_t lds_bytes;
+};
+
+static int patch_pixels(const RdConvDesc& d, const RdPhase& p, int TH, int TW) {
+    const int th = TH < p.lh ? TH : p.lh;
+    const int PH = (th - 1) * d.in_stride + (p.dh_max - p.dh_min) + 1;
+    const int PW = (TW - 1) * d.in_stride + (p.dw_max - p.dw_min) + 1;
+    return PH * PW;
+}
+
+static size_t lds_need(int BM, int BN, int CKW, int CKP, int PP, int taps_max) {
+    return (size_t)(2 * BM + 64) * 4 + (size_t)taps_max * CKW * BN * 4 + (size_t)PP * (CKP + 1) * 4;
+}
+
+// Choose wave tiling + pixel tile for a descriptor.  Heuristic: maximise useful-MAC fraction of the
+// BM x BN tile, penalise halo re-reads, prefer <= 80 KB of LDS (two workgroups per CU).
+static bool plan_gconv(const RdConvDesc& d, GconvPlan& best) {
+    struct Cfg { int MT, NT, WM, WN; };
+    static const Cfg cfgs[] = {{2, 2, 4, 1}, {2, 1, 4, 1}, {3, 2, 4, 1}, {1, 2, 4, 1}, {2, 2, 2, 2}, {4, 2, 2, 2}, {1, 1, 4, 1}};
+    int taps_max = 0;
+    for (int i = 0; i < d.n_phases; ++i) taps_max = taps_max > d.phase[i].n_taps ? taps_max : d.phase[i].n_taps;
+    const int CKW = taps_max > 9 ? 4 : 8;
+    double best_score = -1;
+    // reference phase for tile selection: the one with the largest logical grid
+    int pr = 0;
+    for (int i = 1; i < d.n_phases; ++i)
+        if ((int64_t)d.phase[i].lh * d.phase[i].lw > (int64_t)d.phase[pr].lh * d.phase[pr].lw) pr = i;
+    const RdPhase& P = d.phase[pr];
+    for (const Cfg& c : cfgs) {
+        const int BM = c.WM * c.MT * 32, BN = c.WN * c.NT * 32;
+        const int n_cot = cdiv(d.Cout, BN);
+        const double n_util = (double)d.Cout / (n_cot * BN);
+        for (int ckp = 32; ckp >= 16; ckp -= 16) {
+            if (ckp > d.Cin && ckp != 16) continue;
+            if (d.Cin % ckp != 0 && !(ckp == 16 && d.Cin % 16 == 0)) continue;
+            for (int twt = 1; twt <= cdiv(P.lw, 4); ++twt) {
+                const int TW = cdiv(P.lw, twt);
+                if (TW > BM) continue;
+                int TH = BM / TW;
+                if (TH > P.lh) TH = P.lh;
+                // balance rows across tiles
+                TH = cdiv(P.lh, cdiv(P.lh, TH));
+                int PP = 0;
+                for (int i = 0; i < d.n_phases; ++i) {
+                    const int pp = patch_pixels(d, d.phase[i], TH, TW);
+                    PP = PP > pp ? PP : pp;
+                }
+                const size_t lds = lds_need(BM, BN, CKW, ckp, PP, taps_max);
+                if (lds > 160 * 1024 - 512) continue;
+                const double m_util = (double)P.lh * P.lw / ((double)cdiv(P.lh, TH) * cdiv(P.lw, TW) * BM);
+                const double halo = (double)PP / (TH * TW * d.in_stride * d.in_stride);
+                double score = m_util * n_util / (1.0 + 0.04 * (halo - 1.0));
+                if (lds > 80 * 1024) score *= 0.85;          // one workgroup per CU only
+                if (ckp == 16 && d.Cin >= 32) score *= 0.97;  // half-line loads
+                // enough workgroups to fill 256 CUs x 2
+                const double wgs = (double)d.N * cdiv(P.lh, TH) * cdiv(P.lw, TW) * n_cot;
+                if (wgs < 256) score *= (0.5 + 0.5 * wgs / 256.0);
+                if (score > best_score) {
+                    best_score = score;
+                    best = GconvPlan{c.MT, c.NT, c.WM, c.WN, CKW, ckp, TH, TW, PP, 0, n_cot, taps_max, lds};
+                }
+            }
+        }
+    }
+    return best_score > 0;
+}
+
+template <int MT, int NT, int WM, int WN, int CKW>
+static int launch_cfg(const GconvArgs& a, int grid, size_t lds, hipStream_t s) {
+    static bool attr_set = false;
+    auto k = gconv_kernel<MT, NT, WM, WN, CKW>;
+    if (!attr_set) {
+        RD_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(k, dim3(grid), dim3(256), lds, s, a);
+    RD_CHECK_LAUNCH("gconv_kernel");
+    return RD_OK;
+}
+
+static int validate_desc(const RdConvDesc* d) {
+    RD_CHECK_ARG(d != nullptr, "gconv: null descriptor");
+    RD_CHECK_ARG(d->n_phases >= 1 && d->n_phases <= RD_MAX_PHASES, "gconv: n_phases=%d", d->n_phases);
+    RD_CHECK_ARG(d->Cin % 16 == 0 && d->ldi % 4 == 0, "gconv: Cin=%d must be a multiple of 16, ldi=%d of 4", d->Cin, d->ldi);
+    RD_CHECK_ARG(d->Cout % 4 == 0, "gconv: Cout=%d must be a multiple of 4", d->Cout);
+    RD_CHECK_ARG(d->in_stride >= 1 && d->in_stride <= 2 && d->out_stride >= 1 && d->out_stride <= 2, "gconv: strides");
+    for (int i = 0; i < d->n_phases; ++i) {
+        const RdPhase& p = d->phase[i];
+        RD_CHECK_ARG(p.n_taps >= 1 && p.n_taps <= RD_MAX_TAPS, "gconv: phase %d has %d taps", i, p.n_taps);
+        RD_CHECK_ARG(p.lh >= 1 && p.lw >= 1, "gconv: empty phase %d", i);
+        for (int t = 0; t < p.n_taps; ++t)
+            RD_CHECK_ARG(p.dh[t] >= p.dh_min && p.dh[t] <= p.dh_max && p.dw[t] >= p.dw_min && p.dw[t] <= p.dw_max,
+                         "gconv: tap %d of phase %d outside its declared range", t, i);
+    }
+    return RD_OK;
+}
+
+static void fill_tiles(RdConvDesc& d, GconvPlan& pl) {
+    int tb = 0;
+    for (int i = 0; i < d.n_phases; ++i) {
+        d.phase[i].tile_begin = tb;
+        tb += cdiv(d.phase[i].lh, pl.TH) * cdiv(d.phase[i].lw, pl.TW);
+    }
+    pl.tiles_total = tb;
+}
+
+}  // namespace rd
+
+using namespace rd;
+
+extern "C" int rd_gconv_stat_tiles(const RdConvDesc* d) {
+    if (validate_desc(d) != RD_OK) return RD_EINVAL;
+    GconvPlan pl;
+    RdConvDesc dd = *d;
+    if (!plan_gconv(dd, pl)) { set_error("gconv: no feasible tiling"); return RD_EINVAL; }
+    fill_tiles(dd, pl);
+    return d->N * pl.tiles_total;
+}
+
+extern "C" int rd_gconv(const RdConvDesc* d, const float* in, const float* w_packed, float* out, const float* addend,
+                        int32_t ld_add, float* stat_partial, void* stream) {
+    int rc = validate_desc(d);
+    if (rc != RD_OK) return rc;
+    RD_CHECK_ARG(in && w_packed && out, "gconv: null tensor");
+    GconvArgs a;
+    a.d = *d;
+    GconvPlan pl;
+    if (!plan_gconv(a.d, pl)) { set_error("gconv: no feasible tiling"); return RD_EINVAL; }
+    fill_tiles(a.d, pl);
+    a.in = in; a.w = w_packed; a.out = out; a.addend = addend; a.stat = stat_partial;
+    a.ld_add = ld_add; a.ldw = d->Cout;
+    a.TH = pl.TH; a.TW = pl.TW; a.PP = pl.PP; a.CKP = pl.CKP;
+    a.tiles_total = pl.tiles_total; a.n_cotiles = pl.n_cotiles; a.taps_max = pl.taps_max;
+    const int grid = d->N * pl.tiles_total * pl.n_cotiles;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+#define RD_TRY(MT_, NT_, WM_, WN_)                                                                  \
+    if (pl.MT == MT_ && pl.NT == NT_ && pl.WM == WM_ && pl.WN == WN_) {                             \
+        if (pl.CKW == 8) return launch_cfg<MT_, NT_, WM_, WN_, 8>(a, grid, pl.lds_bytes, s);        \
+        return launch_cfg<MT_, NT_, WM_, WN_, 4>(a, grid, pl.lds_bytes, s);                         \
+    }
+    RD_TRY(2, 2, 4, 1)
+    RD_TRY(2, 1, 4, 1)
+    RD_TRY(3, 2, 4, 1)
+    RD_TRY(1, 2, 4, 1)
+    RD_TRY(2, 2, 2, 2)
+    RD_TRY(4, 2, 2, 2)
+    RD_TRY(1, 1, 4, 1)
+#undef RD_TRY
+    set_error("gconv: unsupported plan");
+    return RD_EINVAL;
+}

@@ -1,0 +1,94 @@
+// Layout glue: weight packing for gconv, NCHW<->NHWC transposes (module boundary), fills.
+#include "common.h"
+
+namespace rd {
+
+// packed[slab][row][col]: transpose==0 -> row=i (I rows), col=co_off+o ; transpose!=0 -> row=co_off+o, col=i
+__global__ void pack_weights_kernel(const float* __restrict__ w, float* __restrict__ packed, int O, int I, int T,
+                                    int ldc, int off, int rows_total, int transpose) {
+    const int64_t total = (int64_t)O * I * T;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+        // destination-major enumeration keeps the writes coalesced
+        int t, o, i;
+        if (!transpose) {
+            o = (int)(e % O);
+            const int64_t r = e / O;
+            i = (int)(r % I);
+            t = (int)(r / I);
+            packed[((int64_t)t * I + i) * ldc + off + o] = w[((int64_t)o * I + i) * T + t];
+        } else {
+            i = (int)(e % I);
+            const int64_t r = e / I;
+            o = (int)(r % O);
+            t = (int)(r / O);
+            packed[((int64_t)t * rows_total + off + o) * ldc + i] = w[((int64_t)o * I + i) * T + t];
+        }
+    }
+}
+
+__global__ void fill_kernel(float* __restrict__ p, int64_t n, float v) {
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (int64_t)gridDim.x * blockDim.x) p[e] = v;
+}
+
+// 32x32 LDS-tiled transpose between [C][HW] and [HW][C] per image
+__global__ void transpose_kernel(const float* __restrict__ src, float* __restrict__ dst, int rows, int cols) {
+    __shared__ float tile[32][33];
+    const int n = blockIdx.z;
+    src += (size_t)n * rows * cols;
+    dst += (size_t)n * rows * cols;
+    const int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32;
+    for (int j = threadIdx.y; j < 32; j += blockDim.y) {
+        const int r = r0 + j, c = c0 + threadIdx.x;
+        if (r < rows && c < cols) tile[j][threadIdx.x] = src[(size_t)r * cols + c];
+    }
+    __syncthreads();
+    for (int j = threadIdx.y; j < 32; j += blockDim.y) {
+        const int c = c0 + j, r = r0 + threadIdx.x;
+        if (r < rows && c < cols) dst[(size_t)c * rows + r] = tile[threadIdx.x][j];
+    }
+}
+
+static int grid_for(int64_t n, int block) {
+    int64_t g = cdiv64(n, block);
+    const int64_t cap = (int64_t)num_cus() * 8;
+    return (int)(g < cap ? (g > 0 ? g : 1) : cap);
+}
+
+}  // namespace rd
+using namespace rd;
+
+extern "C" int rd_pack_weights(const float* w_oihw, float* packed, int32_t O, int32_t I, int32_t KH, int32_t KW,
+                               int32_t ldc, int32_t co_off, int32_t rows_total, int32_t transpose, void* stream) {
+    RD_CHECK_ARG(w_oihw && packed && O > 0 && I > 0 && KH > 0 && KW > 0, "pack_weights: bad arguments");
+    const int64_t total = (int64_t)O * I * KH * KW;
+    hipLaunchKernelGGL(pack_weights_kernel, dim3(grid_for(total, 256)), dim3(256), 0, static_cast<hipStream_t>(stream),
+                       w_oihw, packed, O, I, KH * KW, ldc, co_off, rows_total, transpose);
+    RD_CHECK_LAUNCH("pack_weights_kernel");
+    return RD_OK;
+}
+
+extern "C" int rd_fill(float* p, int64_t n, float v, void* stream) {
+    if (n <= 0) return RD_OK;
+    RD_CHECK_ARG(p != nullptr, "fill: null pointer");
+    hipLaunchKernelGGL(fill_kernel, dim3(grid_for(n, 256)), dim3(256), 0, static_cast<hipStream_t>(stream), p, n, v);
+    RD_CHECK_LAUNCH("fill_kernel");
+    return RD_OK;
+}
+
+extern "C" int rd_nchw_to_nhwc(const float* src, float* dst, int32_t N, int32_t C, int32_t H, int32_t W, void* stream) {
+    RD_CHECK_ARG(src && dst && N > 0 && C > 0 && H > 0 && W > 0, "nchw_to_nhwc: bad arguments");
+    const int rows = C, cols = H * W;
+    hipLaunchKernelGGL(transpose_kernel, dim3(cdiv(cols, 32), cdiv(rows, 32), N), dim3(32, 8), 0,
+                       static_cast<hipStream_t>(stream), src, dst, rows, cols);
+    RD_CHECK_LAUNCH("transpose_kernel");
+    return RD_OK;
+}
+
+extern "C" int rd_nhwc_to_nchw(const float* src, float* dst, int32_t N, int32_t C, int32_t H, int32_t W, void* stream) {
+    RD_CHECK_ARG(src && dst && N > 0 && C > 0 && H > 0 && W > 0, "nhwc_to_nchw: bad arguments");
+    const int rows = H * W, cols = C;
+    hipLaunchKernelGGL(transpose_kernel, dim3(cdiv(cols, 32), cdiv(rows, 32), N), dim3(32, 8), 0,
+                       static_cast<hipStream_t>(stream), src, dst, rows, cols);
+    RD_CHECK_LAUNCH("transpose_kernel");
+    return RD_OK;
+}

@@ -1,0 +1,354 @@
+// Weight gradient of the generalised convolution on the matrix cores:
+//   dW[slab][ci][co] = sum over (n, oh, ow) of in[n, oh*IS+dh, ow*IS+dw, ci] * dout[n, oh*OS+off_h, ow*OS+off_w, co]
+// i.e. a GEMM whose K dimension is the pixel index.  Replaces the weight half of ATen's
+// convolution_backward for every conv of the reference's step (autograd of model/models.py:96-112,203-206,
+// 652-657; ~50 % of the reference's CPU step time).
+//
+// A workgroup owns a (ci-block, co-block, tap-group) of dW and a contiguous range of pixel tiles
+// (split-K over pixels).  Per tile it stages the input halo patch [pixels][CIB] and the dout tile
+// [pixels][COB] in LDS; each wave keeps TG accumulator tiles (one per tap of its group) and walks the
+// tile's pixels 2 (32x32x2) or 4 (16x16x4) at a time: A[ci][pixel] and B[pixel][co] fragments are both
+// contiguous-in-channel ds_read_b32 (conflict-free).  Partial results go to per-split slabs that
+// rd_wgrad_reduce sums in a fixed order (deterministic, no atomics) straight into OIHW gradients.
+#include "common.h"
+
+namespace rd {
+
+constexpr int WG_MAX_TG = 9;     // taps per group
+constexpr int WG_MAX_GROUPS = 5;
+constexpr int WG_MAX_PIX = 512;  // logical pixels per tile
+
+struct WgTapGroup {
+    int n;
+    int8_t dh[WG_MAX_TG], dw[WG_MAX_TG], oh[WG_MAX_TG], ow[WG_MAX_TG];
+    int16_t widx[WG_MAX_TG];
+};
+
+struct WgradArgs {
+    const float* in;
+    const float* dout;
+    float* slabs;
+    int N, Hi, Wi, Cin, ldi, Ho, Wo, Cout, ldo, IS, OS;
+    int lh, lw, TH, TW, tiles_h, tiles_w, total_tiles, tiles_per_split, n_splits;
+    int dh_min, dh_max, dw_min, dw_max;
+    int n_cib, n_cob, n_tg;
+    int S;  // slabs (= kernel taps) per split
+    WgTapGroup tg[WG_MAX_GROUPS];
+};
+
+// LAYOUT_A: waves arranged 2 (ci) x 2 (co), all see every pixel.  Otherwise: one (ci,co) block, the four
+// waves take interleaved pixel groups and each writes its own slab.
+template <int TG, int MF, bool LAYOUT_A>
+__global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs a) {
+    constexpr int CIB = LAYOUT_A ? 64 : MF;
+    constexpr int COB = LAYOUT_A ? 64 : MF;
+    constexpr int KP = MF == 32 ? 2 : 4;   // pixels per MFMA
+    constexpr int WLP = LAYOUT_A ? 1 : 4;  // waves splitting the pixel walk
+    constexpr int NACC = MF == 32 ? 16 : 4;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int lm = lane & (MF - 1), lk = lane / MF;
+    const int wci = LAYOUT_A ? (wave >> 1) : 0, wco = LAYOUT_A ? (wave & 1) : 0;
+    const int wpix = LAYOUT_A ? 0 : wave;
+
+    const int vid = xcd_remap(blockIdx.x, gridDim.x);
+    const int n_groups = a.n_cib * a.n_cob * a.n_tg;
+    const int g = vid % n_groups, split = vid / n_groups;
+    const int tgi = g % a.n_tg;
+    const int cob0 = ((g / a.n_tg) % a.n_cob) * COB;
+    const int cib0 = (g / (a.n_tg * a.n_cob)) * CIB;
+    const WgTapGroup& G = a.tg[tgi];
+    const int ntap = G.n;
+
+    const int PWmax = (a.TW - 1) * a.IS + (a.dw_max - a.dw_min) + 1;
+    const int PHmax = (a.TH - 1) * a.IS + (a.dh_max - a.dh_min) + 1;
+    const int DW = a.TW * a.OS, DHmax = a.TH * a.OS;
+    int2* s_tab = reinterpret_cast<int2*>(smem);                        // [WG_MAX_PIX + 8]
+    float* s_in = smem + 2 * (WG_MAX_PIX + 8);                          // [PHmax*PWmax][CIB]
+    float* s_do = s_in + (size_t)PHmax * PWmax * CIB;                    // [DHmax*DW + 1][COB], last row zero
+    const int zero_row = DHmax * DW;
+
+    // per-tap LDS offsets (loop invariant)
+    int tin[TG], tout[TG];
+#pragma unroll
+    for (int t = 0; t < TG; ++t) {
+        const int tt = t < ntap ? t : 0;
+        tin[t] = ((G.dh[tt] - a.dh_min) * PWmax + (G.dw[tt] - a.dw_min)) * CIB + wci * 32 + lm;
+        tout[t] = (G.oh[tt] * DW + G.ow[tt]) * COB + wco * 32 + lm;
+    }
+
+    typedef float accv __attribute__((ext_vector_type(NACC)));
+    accv acc[TG];
+#pragma unroll
+    for (int t = 0; t < TG; ++t)
+#pragma unroll
+        for (int i = 0; i < NACC; ++i) acc[t][i] = 0.f;
+
+    const int tile_begin = split * a.tiles_per_split;
+    const int tile_end = min(tile_begin + a.tiles_per_split, a.total_tiles);
+    for (int tile = tile_begin; tile < tile_end; ++tile) {
+        const int n = tile / (a.tiles_h * a.tiles_w);
+        const int trem = tile - n * (a.tiles_h * a.tiles_w);
+        const int r0 = (trem / a.tiles_w) * a.TH, c0 = (trem % a.tiles_w) * a.TW;
+        const int th_n = min(a.TH, a.lh - r0), tw_n = min(a.TW, a.lw - c0);
+        const int npix = th_n * tw_n;
+        const int npad = ((npix + KP * WLP - 1) / (KP * WLP)) * (KP * WLP);
+        __syncthreads();  // previous tile fully consumed
+        for (int p = tid; p < npad; p += 256) {
+            int2 e;
+            if (p < npix) {
+                const int r = p / tw_n, c = p - r * tw_n;
+                e.x = ((r * a.IS) * PWmax + c * a.IS) * CIB;
+                e.y = ((r * a.OS) * DW + c * a.OS) * COB;
+            } else {
+                e.x = 0;
+                e.y = zero_row * COB;
+            }
+            s_tab[p] = e;
+        }
+        if (tid < COB) s_do[(size_t)zero_row * COB + tid] = 0.f;
+        // input halo patch
+        {
+            const int PH = (th_n - 1) * a.IS + (a.dh_max - a.dh_min) + 1;
+            const int ih0 = r0 * a.IS + a.dh_min, iw0 = c0 * a.IS + a.dw_min;
+            const float* in_n = a.in + (size_t)n * a.Hi * a.Wi * a.ldi;
+            constexpr int q4 = CIB / 4;
+            const int elems = PH * PWmax * q4;
+            for (int e = tid; e < elems; e += 256) {
+                const int pix = e / q4, qq = e - pix * q4;
+                const int py = pix / PWmax, px = pix - py * PWmax;
+                const int ih = ih0 + py, iw = iw0 + px, c = cib0 + qq * 4;
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (ih >= 0 && ih < a.Hi && iw >= 0 && iw < a.Wi && c < a.Cin)
+                    v = *reinterpret_cast<const float4*>(in_n + ((size_t)ih * a.Wi + iw) * a.ldi + c);
+                *reinterpret_cast<float4*>(s_in + (size_t)pix * CIB + qq * 4) = v;
+            }
+        }
+        // dout tile (rows/cols beyond the image or beyond the tile's valid extent are zero)
+        {
+            const int DH = th_n * a.OS;
+            const int oh0 = r0 * a.OS, ow0 = c0 * a.OS;
+            const float* do_n = a.dout + (size_t)n * a.Ho * a.Wo * a.ldo;
+            constexpr int q4 = COB / 4;
+            const int elems = DH * DW * q4;
+            const int ow_lim = min(a.Wo, ow0 + tw_n * a.OS);
+            for (int e = tid; e < elems; e += 256) {
+                const int pix = e / q4, qq = e - pix * q4;
+                const int py = pix / DW, px = pix - py * DW;
+                const int oh = oh0 + py, ow = ow0 + px, c = cob0 + qq * 4;
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (oh < a.Ho && ow < ow_lim && c < a.Cout)
+                    v = *reinterpret_cast<const float4*>(do_n + ((size_t)oh * a.Wo + ow) * a.ldo + c);
+                *reinterpret_cast<float4*>(s_do + (size_t)pix * COB + qq * 4) = v;
+            }
+        }
+        __syncthreads();
+        const int nq = npad / KP;
+        for (int q = wpix; q < nq; q += WLP) {
+            const int2 e = s_tab[q * KP + lk];
+#pragma unroll
+            for (int t = 0; t < TG; ++t) {
+                if (t < ntap) {
+                    const float av = s_in[e.x + tin[t]];
+                    const float bv = s_do[e.y + tout[t]];
+                    if constexpr (MF == 32)
+                        acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[t], 0, 0, 0);
+                    else
+                        acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, acc[t], 0, 0, 0);
+                }
+            }
+        }
+    }
+
+    // ---- write this workgroup's (wave's) partial slab
+    const int split_id = LAYOUT_A ? split : split * 4 + wave;
+    float* slab = a.slabs + (size_t)split_id * a.S * a.Cin * a.Cout;
+    const int co = cob0 + wco * 32 + lm;
+#pragma unroll
+    for (int t = 0; t < TG; ++t) {
+        if (t < ntap) {
+            float* dst = slab + (size_t)G.widx[t] * a.Cin * a.Cout;
+#pragma unroll
+            for (int i = 0; i < NACC; ++i) {
+                const int row = MF == 32 ? ((i & 3) + 8 * (i >> 2) + 4 * lk) : (lk * 4 + i);
+                const int ci = cib0 + wci * 32 + row;
+                if (ci < a.Cin && co < a.Cout) dst[(size_t)ci * a.Cout + co] = acc[t][i];
+            }
+        }
+    }
+}
+
+// grad[o][i][t] (+)= sum_split slabs[split][t][i][co_off + o]
+__global__ void wgrad_reduce_kernel(const float* __restrict__ slabs, float* __restrict__ grad, int n_splits, int S,
+                                    int Cin, int Cout, int O, int I, int co_off, int accumulate) {
+    const int64_t total = (int64_t)S * I * O;
+    const int64_t split_stride = (int64_t)S * Cin * Cout;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+        const int o = (int)(e % O);
+        const int64_t r = e / O;
+        const int i = (int)(r % I), t = (int)(r / I);
+        const float* src = slabs + ((int64_t)t * Cin + i) * Cout + co_off + o;
+        float s = 0.f;
+        for (int k = 0; k < n_splits; ++k) s += src[k * split_stride];
+        float* dst = grad + ((int64_t)o * I + i) * S + t;
+        *dst = accumulate ? *dst + s : s;
+    }
+}
+
+struct WgradPlan {
+    int TG, MF, layoutA;
+    int TH, TW, tiles_h, tiles_w, total_tiles, tiles_per_split, n_splits, slab_splits;
+    int n_cib, n_cob, n_tg, S;
+    size_t lds;
+};
+
+static int plan_wgrad(const RdConvDesc& d, WgradPlan& pl, WgradArgs* out) {
+    const RdPhase& P0 = d.phase[0];
+    int ntaps = 0, S = 0;
+    int dh_min = 127, dh_max = -127, dw_min = 127, dw_max = -127;
+    for (int i = 0; i < d.n_phases; ++i) {
+        const RdPhase& p = d.phase[i];
+        RD_CHECK_ARG(p.lh == P0.lh && p.lw == P0.lw, "wgrad: phases must share one logical grid");
+        ntaps += p.n_taps;
+        for (int t = 0; t < p.n_taps; ++t) S = S > p.widx[t] + 1 ? S : p.widx[t] + 1;
+        dh_min = dh_min < p.dh_min ? dh_min : p.dh_min;
+        dh_max = dh_max > p.dh_max ? dh_max : p.dh_max;
+        dw_min = dw_min < p.dw_min ? dw_min : p.dw_min;
+        dw_max = dw_max > p.dw_max ? dw_max : p.dw_max;
+    }
+    RD_CHECK_ARG(ntaps == 1 || ntaps == 9 || ntaps == 25, "wgrad: %d taps unsupported", ntaps);
+    RD_CHECK_ARG(d.Cin % 4 == 0 && d.Cout % 4 == 0 && d.ldi % 4 == 0 && d.ldo % 4 == 0, "wgrad: channels must be multiples of 4");
+    pl.TG = ntaps == 25 ? 5 : ntaps;
+    pl.n_tg = ntaps == 25 ? 5 : 1;
+    const int cmax = d.Cin > d.Cout ? d.Cin : d.Cout;
+    pl.layoutA = cmax >= 64;
+    pl.MF = (!pl.layoutA && cmax <= 16) ? 16 : 32;
+    const int CIB = pl.layoutA ? 64 : pl.MF, COB = CIB;
+    pl.n_cib = cdiv(d.Cin, CIB);
+    pl.n_cob = cdiv(d.Cout, COB);
+    pl.S = S;
+    // tile: largest pixel count within the LDS budget, preferring full-width rows
+    const size_t budget = 78 * 1024;
+    double best = -1;
+    pl.TH = pl.TW = 0;
+    for (int twt = 1; twt <= P0.lw; ++twt) {
+        const int TW = cdiv(P0.lw, twt);
+        for (int TH = 1; TH <= P0.lh; ++TH) {
+            if (TH * TW > WG_MAX_PIX) break;
+            const int PH = (TH - 1) * d.in_stride + (dh_max - dh_min) + 1;
+            const int PW = (TW - 1) * d.in_stride + (dw_max - dw_min) + 1;
+            const size_t lds = (size_t)2 * (WG_MAX_PIX + 8) * 4 + (size_t)PH * PW * CIB * 4 +
+                               ((size_t)TH * d.out_stride * TW * d.out_stride + 1) * COB * 4;
+            if (lds > budget) break;
+            const double useful = (double)P0.lh * P0.lw / ((double)cdiv(P0.lh, TH) * TH * cdiv(P0.lw, TW) * TW);
+            const double halo = (double)PH * PW / ((double)TH * TW * d.in_stride * d.in_stride);
+            const double score = useful * (TH * TW >= 64 ? 1.0 : TH * TW / 64.0) / (1.0 + 0.15 * (halo - 1.0));
+            if (score > best) {
+                best = score;
+                pl.TH = TH; pl.TW = TW; pl.lds = lds;
+            }
+        }
+        if (TW <= 4) break;
+    }
+    RD_CHECK_ARG(pl.TH > 0, "wgrad: no tile fits in LDS");
+    pl.tiles_h = cdiv(P0.lh, pl.TH);
+    pl.tiles_w = cdiv(P0.lw, pl.TW);
+    pl.total_tiles = d.N * pl.tiles_h * pl.tiles_w;
+    const int groups = pl.n_cib * pl.n_cob * pl.n_tg;
+    int want = cdiv(2 * num_cus(), groups);
+    if (want < 1) want = 1;
+    if (want > pl.total_tiles) want = pl.total_tiles;
+    pl.tiles_per_split = cdiv(pl.total_tiles, want);
+    pl.n_splits = cdiv(pl.total_tiles, pl.tiles_per_split);
+    pl.slab_splits = pl.layoutA ? pl.n_splits : pl.n_splits * 4;
+    if (out) {
+        WgradArgs& a = *out;
+        a.N = d.N; a.Hi = d.Hi; a.Wi = d.Wi; a.Cin = d.Cin; a.ldi = d.ldi;
+        a.Ho = d.Ho; a.Wo = d.Wo; a.Cout = d.Cout; a.ldo = d.ldo; a.IS = d.in_stride; a.OS = d.out_stride;
+        a.lh = P0.lh; a.lw = P0.lw; a.TH = pl.TH; a.TW = pl.TW; a.tiles_h = pl.tiles_h; a.tiles_w = pl.tiles_w;
+        a.total_tiles = pl.total_tiles; a.tiles_per_split = pl.tiles_per_split; a.n_splits = pl.n_splits;
+        a.dh_min = dh_min; a.dh_max = dh_max; a.dw_min = dw_min; a.dw_max = dw_max;
+        a.n_cib = pl.n_cib; a.n_cob = pl.n_cob; a.n_tg = pl.n_tg; a.S = S;
+        // distribute taps over groups: 25 taps -> one kernel row (5 taps) per group; else a single group
+        for (int gi = 0; gi < WG_MAX_GROUPS; ++gi) a.tg[gi].n = 0;
+        for (int i = 0; i < d.n_phases; ++i) {
+            const RdPhase& p = d.phase[i];
+            for (int t = 0; t < p.n_taps; ++t) {
+                const int gi = ntaps == 25 ? (p.widx[t] / 5) : 0;
+                WgTapGroup& G = a.tg[gi];
+                RD_CHECK_ARG(G.n < pl.TG, "wgrad: tap grouping overflow");
+                G.dh[G.n] = p.dh[t]; G.dw[G.n] = p.dw[t];
+                G.oh[G.n] = (int8_t)p.out_off_h; G.ow[G.n] = (int8_t)p.out_off_w;
+                G.widx[G.n] = p.widx[t];
+                ++G.n;
+            }
+        }
+    }
+    return RD_OK;
+}
+
+template <int TG, int MF, bool LA>
+static int launch_wgrad(const WgradArgs& a, int grid, size_t lds, hipStream_t s) {
+    static bool attr_set = false;
+    auto k = wgrad_kernel<TG, MF, LA>;
+    if (!attr_set) {
+        RD_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(k, dim3(grid), dim3(256), lds, s, a);
+    RD_CHECK_LAUNCH("wgrad_kernel");
+    return RD_OK;
+}
+
+}  // namespace rd
+using namespace rd;
+
+extern "C" int64_t rd_wgrad_workspace_floats(const RdConvDesc* d) {
+    if (!d) return RD_EINVAL;
+    WgradPlan pl;
+    if (plan_wgrad(*d, pl, nullptr) != RD_OK) return RD_EINVAL;
+    return (int64_t)pl.slab_splits * pl.S * d->Cin * d->Cout;
+}
+
+extern "C" int rd_wgrad(const RdConvDesc* d, const float* in, const float* dout, float* slabs, void* stream) {
+    RD_CHECK_ARG(d && in && dout && slabs, "wgrad: null argument");
+    WgradPlan pl;
+    WgradArgs a;
+    int rc = plan_wgrad(*d, pl, &a);
+    if (rc != RD_OK) return rc;
+    a.in = in; a.dout = dout; a.slabs = slabs;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    // slabs are written sparsely when a channel block is ragged or a split has no taps: clear first
+    const int64_t nfl = (int64_t)pl.slab_splits * pl.S * d->Cin * d->Cout;
+    RD_CHECK_HIP(hipMemsetAsync(slabs, 0, (size_t)nfl * sizeof(float), s));
+    const int grid = pl.n_cib * pl.n_cob * pl.n_tg * pl.n_splits;
+#define RD_W(TG_, MF_, LA_) \
+    if (pl.TG == TG_ && pl.MF == MF_ && (pl.layoutA != 0) == LA_) return launch_wgrad<TG_, MF_, LA_>(a, grid, pl.lds, s);
+    RD_W(9, 32, true)
+    RD_W(9, 32, false)
+    RD_W(9, 16, false)
+    RD_W(5, 32, true)
+    RD_W(5, 32, false)
+    RD_W(1, 32, true)
+    RD_W(1, 32, false)
+    RD_W(1, 16, false)
+#undef RD_W
+    set_error("wgrad: unsupported plan TG=%d MF=%d layoutA=%d", pl.TG, pl.MF, pl.layoutA);
+    return RD_EINVAL;
+}
+
+extern "C" int rd_wgrad_reduce(const RdConvDesc* d, const float* slabs, float* grad_oihw, int32_t O, int32_t I, int32_t KH,
+                               int32_t KW, int32_t co_off, int32_t accumulate, void* stream) {
+    RD_CHECK_ARG(d && slabs && grad_oihw, "wgrad_reduce: null argument");
+    WgradPlan pl;
+    int rc = plan_wgrad(*d, pl, nullptr);
+    if (rc != RD_OK) return rc;
+    RD_CHECK_ARG(KH * KW == pl.S && I == d->Cin && co_off + O <= d->Cout, "wgrad_reduce: shape mismatch");
+    const int64_t total = (int64_t)pl.S * I * O;
+    int64_t g = cdiv64(total, 256);
+    if (g > 4096) g = 4096;
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((int)g), dim3(256), 0, static_cast<hipStream_t>(stream), slabs, grad_oihw,
+                       pl.slab_splits, pl.S, d->Cin, d->Cout, O, I, co_off, accumulate);
+    RD_CHECK_LAUNCH("wgrad_reduce_kernel");
+    return RD_OK;
+}

@@ -1,0 +1,63 @@
+"""Thin torch-tensor wrappers over the C ABI (one function per entry point of include/radar_depth_hip.h).
+Tensors must live on the GPU; all calls are asynchronous on torch's current HIP stream."""
+import ctypes as C
+
+import torch
+
+from . import _lib
+from ._lib import check, current_stream, lib, ptr
+
+
+def _f32(t):
+    assert t.dtype == torch.float32 and t.is_cuda and t.is_contiguous(), "expected contiguous CUDA float32 tensor"
+    return t
+
+
+def pack_weights(w_oihw, transpose=False, out=None, ldc=None, off=0, rows_total=None):
+    """OIHW -> [slab][I][ldc] (forward operand) or [slab][rows_total][ldc>=I] (dgrad operand)."""
+    o, i, kh, kw = w_oihw.shape
+    if not transpose:
+        ldc = ldc or o
+        rows_total = i
+        shape = (kh * kw, i, ldc)
+    else:
+        ldc = ldc or i
+        rows_total = rows_total or o
+        shape = (kh * kw, rows_total, ldc)
+    if out is None:
+        out = torch.zeros(shape, dtype=torch.float32, device=w_oihw.device)
+    check(lib().rd_pack_weights(ptr(_f32(w_oihw)), ptr(out), o, i, kh, kw, ldc, off, rows_total, int(transpose),
+                                current_stream()), "rd_pack_weights")
+    return out
+
+
+def gconv_stat_tiles(desc):
+    n = lib().rd_gconv_stat_tiles(C.byref(desc))
+    if n < 0:
+        check(n, "rd_gconv_stat_tiles")
+    return n
+
+
+def gconv(desc, x, w_packed, out, addend=None, ld_add=0, stat=None):
+    check(lib().rd_gconv(C.byref(desc), ptr(x), ptr(w_packed), ptr(out), ptr(addend), ld_add, ptr(stat),
+                         current_stream()), "rd_gconv")
+    return out
+
+
+def fill(t, v):
+    check(lib().rd_fill(ptr(t), C.c_int64(t.numel()), C.c_float(v), current_stream()), "rd_fill")
+    return t
+
+
+def nchw_to_nhwc(x):
+    n, c, h, w = x.shape
+    out = torch.empty((n, h, w, c), dtype=torch.float32, device=x.device)
+    check(lib().rd_nchw_to_nhwc(ptr(_f32(x)), ptr(out), n, c, h, w, current_stream()), "rd_nchw_to_nhwc")
+    return out
+
+
+def nhwc_to_nchw(x):
+    n, h, w, c = x.shape
+    out = torch.empty((n, c, h, w), dtype=torch.float32, device=x.device)
+    check(lib().rd_nhwc_to_nchw(ptr(_f32(x)), ptr(out), n, c, h, w, current_stream()), "rd_nhwc_to_nchw")
+    return out

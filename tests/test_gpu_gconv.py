@@ -1,0 +1,125 @@
+"""GPU parity of the generalised MFMA convolution (rd_gconv / rd_pack_weights) against torch CPU fp32
+convolutions, through the C ABI.  Tolerance: 2e-5 relative to the output's max magnitude (fp32 MFMA is an
+exact-fp32 fma chain; only the summation order differs from oneDNN)."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+def _rel(a, b):
+    return ((a - b).abs().max() / b.abs().max().clamp_min(1e-30)).item()
+
+
+def _run_fwd(n, ci, co, k, s, p, h, w, seed=0):
+    from radar_depth_amd import convdesc as cd, ops
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randn(n, ci, h, w, generator=g)
+    wt = torch.randn(co, ci, k, k, generator=g) * (2.0 / (k * k * ci)) ** 0.5
+    y = F.conv2d(x, wt, stride=s, padding=p)
+    d = cd.conv_fwd(n, h, w, ci, co, k, s, p)
+    xg = ops.nchw_to_nhwc(x.cuda())
+    wp = ops.pack_weights(wt.cuda())
+    out = torch.full((n, d.Ho, d.Wo, co), float("nan"), device="cuda")
+    tiles = ops.gconv_stat_tiles(d)
+    stat = torch.zeros(tiles, 2, co, device="cuda")
+    ops.gconv(d, xg, wp, out, stat=stat)
+    torch.cuda.synchronize()
+    got = out.permute(0, 3, 1, 2).cpu()
+    assert not torch.isnan(got).any()
+    assert _rel(got, y) < 2e-5, (_rel(got, y), (n, ci, co, k, s, p, h, w))
+    s_ = stat.sum(0).cpu().double()
+    ref_s = y.double().sum((0, 2, 3))
+    ref_q = (y.double() ** 2).sum((0, 2, 3))
+    assert ((s_[0] - ref_s).abs().max() / ref_q.sqrt().max()).item() < 1e-4
+    assert _rel(s_[1], ref_q) < 1e-4
+    return x, wt, y
+
+
+@pytest.mark.parametrize("cfg", [
+    (2, 64, 64, 3, 1, 1, 113, 200),   # layer1
+    (2, 64, 128, 3, 2, 1, 113, 200),  # layer2.0.conv1
+    (2, 128, 128, 3, 1, 1, 57, 100),
+    (2, 64, 128, 1, 2, 0, 113, 200),  # downsample
+    (2, 256, 256, 3, 1, 1, 29, 50),
+    (2, 512, 512, 3, 1, 1, 15, 25),   # layer4
+    (2, 640, 512, 1, 1, 0, 15, 25),   # conv_fusion
+    (2, 16, 16, 3, 1, 1, 113, 200),   # depth layer1
+    (2, 16, 32, 3, 2, 1, 113, 200),
+    (2, 32, 32, 3, 1, 1, 120, 200),   # decoder.layer3 conv2
+    (1, 16, 16, 3, 1, 1, 240, 400),   # decoder.layer4 conv2
+    (3, 32, 48, 3, 1, 1, 9, 7),       # tiny / ragged
+])
+def test_gconv_forward(cfg):
+    _run_fwd(*cfg)
+
+
+@pytest.mark.parametrize("cfg", [
+    (2, 64, 64, 3, 1, 1, 113, 200),
+    (2, 64, 128, 3, 2, 1, 113, 200),
+    (2, 64, 128, 1, 2, 0, 113, 200),
+    (2, 256, 512, 3, 2, 1, 29, 50),
+    (2, 16, 32, 3, 2, 1, 57, 101),
+])
+def test_gconv_dgrad(cfg):
+    from radar_depth_amd import convdesc as cd, ops
+    n, ci, co, k, s, p, h, w = cfg
+    g = torch.Generator().manual_seed(1)
+    x = torch.randn(n, ci, h, w, generator=g, requires_grad=True)
+    wt = torch.randn(co, ci, k, k, generator=g) * (2.0 / (k * k * co)) ** 0.5
+    y = F.conv2d(x, wt, stride=s, padding=p)
+    gy = torch.randn(y.shape, generator=g)
+    y.backward(gy)
+    d, zero_fill = cd.conv_dgrad(n, h, w, ci, co, k, s, p)
+    wp = ops.pack_weights(wt.cuda(), transpose=True)
+    dy = ops.nchw_to_nhwc(gy.cuda())
+    dx = torch.full((n, h, w, ci), float("nan"), device="cuda")
+    if zero_fill:
+        ops.fill(dx, 0.0)
+    add = torch.randn(n, h, w, ci, generator=g)
+    ops.gconv(d, dy, wp, dx, addend=add.cuda() if not zero_fill else None, ld_add=ci)
+    torch.cuda.synchronize()
+    want = x.grad + (add.permute(0, 3, 1, 2) if not zero_fill else 0)
+    got = dx.permute(0, 3, 1, 2).cpu()
+    assert not torch.isnan(got).any()
+    assert _rel(got, want) < 2e-5
+
+
+@pytest.mark.parametrize("c,h,w", [(256, 15, 25), (64, 60, 100), (32, 13, 9)])
+def test_gconv_upproj(c, h, w):
+    from radar_depth_amd import convdesc as cd, ops
+    n = 2
+    g = torch.Generator().manual_seed(2)
+    x = torch.randn(n, c, h, w, generator=g, requires_grad=True)
+    w_up = torch.randn(c // 2, c, 5, 5, generator=g) * (2.0 / (25 * c)) ** 0.5
+    w_bt = torch.randn(c // 2, c, 5, 5, generator=g) * (2.0 / (25 * c)) ** 0.5
+    u = torch.zeros(n, c, 2 * h, 2 * w)
+    xs = x.detach()
+    u[:, :, ::2, ::2] = xs
+    u.requires_grad_(True)
+    wcat = torch.cat((w_up, w_bt), 0)
+    y = F.conv2d(u, wcat, padding=2)
+    gy = torch.randn(y.shape, generator=g)
+    y.backward(gy)
+    gx_want = u.grad[:, :, ::2, ::2]
+    d = cd.upproj_fwd(n, h, w, c, c)
+    wp = torch.zeros(25, c, c, device="cuda")
+    ops.pack_weights(w_up.cuda(), out=wp, ldc=c, off=0)
+    ops.pack_weights(w_bt.cuda(), out=wp, ldc=c, off=c // 2)
+    out = torch.full((n, 2 * h, 2 * w, c), float("nan"), device="cuda")
+    stat = torch.zeros(ops.gconv_stat_tiles(d), 2, c, device="cuda")
+    ops.gconv(d, ops.nchw_to_nhwc(xs.cuda()), wp, out, stat=stat)
+    dd = cd.upproj_dgrad(n, h, w, c, c)
+    wd = torch.zeros(25, c, c, device="cuda")
+    ops.pack_weights(w_up.cuda(), transpose=True, out=wd, ldc=c, off=0, rows_total=c)
+    ops.pack_weights(w_bt.cuda(), transpose=True, out=wd, ldc=c, off=c // 2, rows_total=c)
+    dx = torch.full((n, h, w, c), float("nan"), device="cuda")
+    ops.gconv(dd, ops.nchw_to_nhwc(gy.cuda()), wd, dx)
+    torch.cuda.synchronize()
+    got = out.permute(0, 3, 1, 2).cpu()
+    assert not torch.isnan(got).any()
+    assert _rel(got, y.detach()) < 2e-5
+    assert _rel(stat.sum(0)[0].cpu().double(), y.detach().double().sum((0, 2, 3))) < 1e-3
+    gotx = dx.permute(0, 3, 1, 2).cpu()
+    assert _rel(gotx, gx_want) < 2e-5
