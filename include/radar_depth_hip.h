@@ -82,6 +82,8 @@ typedef struct {
 int rd_gconv(const RdConvDesc* d, const float* in, const float* w_packed, float* out,
              const float* addend, int32_t ld_add, float* stat_partial, void* stream);
 int rd_gconv_stat_tiles(const RdConvDesc* d);
+/* diagnostics: out[0..9] = MT, NT, WM, WN, CKW, CKP, TH, TW, lds_bytes, workgroups chosen for d */
+int rd_gconv_plan_info(const RdConvDesc* d, int32_t* out);
 
 /* Weight gradient of the same descriptor: dw[slab][ci][co] = sum_pixels in(...) * dout(...).
  * `d` is the FORWARD descriptor (in = forward input, "out" geometry = dout).  slabs is a
@@ -103,32 +105,35 @@ int rd_pack_weights(const float* w_oihw, float* packed, int32_t O, int32_t I, in
                     int32_t ldc, int32_t co_off, int32_t rows_total, int32_t transpose, void* stream);
 
 /* ---------------------------------------------------------------------------------------
- * Stem convolutions: 7x7 stride 2 pad 3 straight from the NCHW network input
- * (models.py:539,559,633,643; multistage_model.py:163-164).  x is [N, Ctot, H, W]; channels
- * [c0, c0+Cin) are used, or, when c_second >= 0 (stage 2), channel c0 from x and one channel
- * from the separate NHWC-1 map `x2` (the stage-1 prediction).  Output NHWC [N,Ho,Wo,Cout].
+ * Stem convolutions: 7x7 stride 2 pad 3 read straight from the network's NCHW input
+ * (models.py:539,559,633,643; multistage_model.py:163-164,236-241).  The Cin (1..3) input
+ * channels are given as separate planes: planes[i] points at image 0 of channel i ([H,W] each),
+ * strides[i] is the element distance between consecutive images (Ctot*H*W for a channel of the
+ * network input, H*W for a stand-alone map such as the stage-1 prediction).  Both arrays live in
+ * host memory and are copied at call time.  Weights are packed [49][Cin][Cout]
+ * (rd_pack_weights).  Output NHWC [N,Ho,Wo,Cout], Ho = (H-1)/2+1.
  * ------------------------------------------------------------------------------------- */
-int rd_stem_fwd(const float* x, int32_t N, int32_t Ctot, int32_t H, int32_t W, int32_t c0, int32_t Cin,
-                const float* x2, const float* w_oihw, int32_t Cout, float* out, float* stat_partial,
+int rd_stem_fwd(const float* const* planes, const int64_t* strides, int32_t Cin, int32_t N, int32_t H,
+                int32_t W, const float* w_packed, int32_t Cout, float* out, float* stat_partial,
                 void* stream);
 int rd_stem_stat_tiles(int32_t N, int32_t H, int32_t W);
 /* weight gradient (OIHW, overwritten) of the stem; ws needs rd_stem_wgrad_workspace_floats */
 int64_t rd_stem_wgrad_workspace_floats(int32_t N, int32_t H, int32_t W, int32_t Cin, int32_t Cout);
-int rd_stem_wgrad(const float* x, int32_t N, int32_t Ctot, int32_t H, int32_t W, int32_t c0, int32_t Cin,
-                  const float* x2, const float* dout, int32_t Cout, float* grad_oihw, float* ws,
-                  void* stream);
+int rd_stem_wgrad(const float* const* planes, const int64_t* strides, int32_t Cin, int32_t N, int32_t H,
+                  int32_t W, const float* dout, int32_t Cout, float* grad_oihw, float* ws, void* stream);
 /* input gradient w.r.t. ONE input channel `ci` of the stem (stage-2 dense-depth channel,
- * multistage_model.py:75 -- stage-1 prediction is not detached).  dx is [N,H,W] (overwritten). */
-int rd_stem_dgrad_channel(const float* dout, const float* w_oihw, int32_t N, int32_t H, int32_t W,
+ * multistage_model.py:75 -- the stage-1 prediction is not detached).  dx is [N,H,W] (overwritten). */
+int rd_stem_dgrad_channel(const float* dout, const float* w_packed, int32_t N, int32_t H, int32_t W,
                           int32_t Cin, int32_t ci, int32_t Cout, float* dx, void* stream);
 
 /* ---------------------------------------------------------------------------------------
  * BatchNorm2d (training mode) + activation + residual join
  * (torch.nn.BatchNorm2d defaults eps=1e-5 momentum=0.1; models.py:101-110,203-208).
  * ------------------------------------------------------------------------------------- */
-/* Reduce conv-epilogue partials -> mean / invstd, fused scale = gamma*invstd and
- * shift = beta - mean*scale; update running stats (unbiased var) and num_batches_tracked. */
-int rd_bn_finalize(const float* stat_partial, int32_t n_tiles, int32_t C, int64_t count,
+/* Reduce conv-epilogue partials [n_tiles][2][ld] over channels [c0, c0+C) -> mean / invstd, fused
+ * scale = gamma*invstd and shift = beta - mean*scale; update running stats (unbiased var) and
+ * num_batches_tracked (running_* / nbt may be NULL). */
+int rd_bn_finalize(const float* stat_partial, int32_t n_tiles, int32_t ld, int32_t c0, int32_t C, int64_t count,
                    const float* gamma, const float* beta, float eps, float momentum,
                    float* running_mean, float* running_var, int64_t* num_batches_tracked,
                    float* mean, float* invstd, float* scale, float* shift, void* stream);
@@ -143,10 +148,11 @@ int rd_bn_stats_tiles(int64_t M);
 int rd_bn_act(const float* x1, int32_t ldx1, const float* scale1, const float* shift1,
               const float* x2, int32_t ldx2, const float* scale2, const float* shift2,
               float* y, int32_t ldy, int64_t M, int32_t C, int32_t act, void* stream);
-/* backward pass 1: g = dy * act'(y) (written to g, ldg); partial sums of g, g*x1 [, g*x2]
+/* backward pass 1: g = dy * act'(y) (written to g, ldg); partial sums of g, g*(x1-mean1) [, g*(x2-mean2)]
  * -> red_partial [n_tiles][3][C]. */
 int rd_bn_bwd_reduce(const float* dy, int32_t lddy, const float* y, int32_t ldy,
-                     const float* x1, int32_t ldx1, const float* x2, int32_t ldx2,
+                     const float* x1, int32_t ldx1, const float* mean1,
+                     const float* x2, int32_t ldx2, const float* mean2,
                      float* g, int32_t ldg, int64_t M, int32_t C, int32_t act,
                      float* red_partial, void* stream);
 int rd_bn_bwd_tiles(int64_t M);
@@ -154,8 +160,8 @@ int rd_bn_bwd_tiles(int64_t M);
  * dx = gamma*invstd*(g - mean(g) - xhat*mean(g*xhat)).  which = 1 or 2 selects the x1 / x2 sums. */
 int rd_bn_bwd_apply(const float* g, int32_t ldg, const float* x, int32_t ldx, const float* red_partial,
                     int32_t n_tiles, int32_t which, const float* gamma, const float* mean,
-                    const float* invstd, float* dgamma, float* dbeta, float* dx, int32_t lddx,
-                    int64_t M, int32_t C, void* stream);
+                    const float* invstd, float* dgamma, float* dbeta, float* coef_ws /* 3*C floats */,
+                    float* dx, int32_t lddx, int64_t M, int32_t C, void* stream);
 
 /* MaxPool2d(3,2,1) fused with the stem's BN affine + activation (models.py:634-636,644-646):
  * y = maxpool(act(scale*x+shift)); idx = argmax position 0..8 in the window. */
@@ -186,19 +192,20 @@ int rd_bilinear_bwd(const float* dout, int32_t N, int32_t Ho, int32_t Wo, float*
 /* ---------------------------------------------------------------------------------------
  * Losses (evaluation/criteria_new.py) and the step tail (main.py:416-445).
  * ------------------------------------------------------------------------------------- */
-/* MaskedL1Loss (:44-54): sums[0] = sum |t-p| over t>0, sums[1] = count.  ws: 2*rd_loss_tiles floats */
+/* MaskedL1Loss (:44-54): sums[0] = sum |t-p| over t>0, sums[1] = count.  ws: 2*rd_loss_tiles(n) DOUBLES
+ * (8-byte aligned), passed as float*. */
 int rd_masked_l1_sums(const float* pred, const float* target, int64_t n, float* ws, double* sums, void* stream);
 int rd_loss_tiles(int64_t n);
 /* dpred (+)= coef_dev[0] * (-sign(t-p)) / count on valid pixels; coef read on device */
 int rd_masked_l1_bwd(const float* pred, const float* target, int64_t n, const double* sums,
                      const float* coef, float* dpred, int32_t accumulate, void* stream);
 /* SmoothnessLoss (:8-28) on pred [N,1,H,W] and image [N,C,H,W] (NCHW).  out[0] = loss.
- * ws: rd_smooth_workspace_floats(N,H,W) floats. */
+ * ws: rd_smooth_workspace_floats(N,H,W) floats, 8-byte aligned; rd_smooth_bwd reuses what fwd left there. */
 int64_t rd_smooth_workspace_floats(int32_t N, int32_t H, int32_t W);
 int rd_smooth_fwd(const float* pred, const float* image, int32_t N, int32_t C, int32_t H, int32_t W,
                   float* ws, double* out, void* stream);
-int rd_smooth_bwd(const float* pred, const float* image, int32_t N, int32_t C, int32_t H, int32_t W,
-                  const float* ws, const float* coef, float* dpred, int32_t accumulate, void* stream);
+int rd_smooth_bwd(int32_t N, int32_t H, int32_t W, const float* ws, const float* coef, float* dpred,
+                  int32_t accumulate, void* stream);
 /* Filter_layer (multistage_model.py:87-119): kept = sparse*mask, mask = |dense-sparse| <= 5*3.6^(dense/100).
  * sparse is channel `c` of the NCHW input x [N,Ctot,H,W]. */
 int rd_radar_filter(const float* x, int32_t N, int32_t Ctot, int32_t c, int64_t hw, const float* dense,

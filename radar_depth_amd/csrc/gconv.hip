@@ -315,6 +315,18 @@ static void fill_tiles(RdConvDesc& d, GconvPlan& pl) {
 
 using namespace rd;
 
+// diagnostics: out[0..9] = MT, NT, WM, WN, CKW, CKP, TH, TW, lds_bytes, workgroups
+extern "C" int rd_gconv_plan_info(const RdConvDesc* d, int32_t* out) {
+    if (validate_desc(d) != RD_OK) return RD_EINVAL;
+    GconvPlan pl;
+    RdConvDesc dd = *d;
+    if (!plan_gconv(dd, pl)) { set_error("gconv: no feasible tiling"); return RD_EINVAL; }
+    fill_tiles(dd, pl);
+    const int v[10] = {pl.MT, pl.NT, pl.WM, pl.WN, pl.CKW, pl.CKP, pl.TH, pl.TW, (int)pl.lds_bytes, d->N * pl.tiles_total * pl.n_cotiles};
+    for (int i = 0; i < 10; ++i) out[i] = v[i];
+    return RD_OK;
+}
+
 extern "C" int rd_gconv_stat_tiles(const RdConvDesc* d) {
     if (validate_desc(d) != RD_OK) return RD_EINVAL;
     GconvPlan pl;

@@ -1,0 +1,251 @@
+// Network head: conv3 (3x3, C -> 1, pad 1, no bias; model/models.py:587,661) and the bilinear
+// align_corners=True resize to output_size (models.py:588,662), forward and backward.
+// All HBM-streaming kernels (one channel out); no matrix cores.
+#include "common.h"
+
+namespace rd {
+
+int launch_slab_reduce(const float* slabs, int n_splits, int64_t E, float* tmp, float* grad_oihw, int S, int Cin, int Cout,
+                       int O, int I, int co_off, int accumulate, hipStream_t s);
+
+// d[n,h,w] = sum_{kh,kw,c} x[n,h+kh-1,w+kw-1,c] * w[c][kh][kw]      (w: OIHW with O == 1)
+template <int C>
+__global__ __launch_bounds__(256) void head_conv_fwd_kernel(const float* __restrict__ x, int ldx, const float* __restrict__ w,
+                                                            int N, int H, int W, float* __restrict__ d) {
+    __shared__ float s_w[9 * C];
+    for (int e = threadIdx.x; e < 9 * C; e += blockDim.x) {
+        const int t = e / C, c = e - t * C;
+        s_w[e] = w[c * 9 + t];
+    }
+    __syncthreads();
+    const int64_t total = (int64_t)N * H * W;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+        const int wx = (int)(e % W);
+        const int64_t r = e / W;
+        const int h = (int)(r % H), n = (int)(r / H);
+        float s = 0.f;
+#pragma unroll
+        for (int kh = 0; kh < 3; ++kh) {
+            const int ih = h + kh - 1;
+            if (ih < 0 || ih >= H) continue;
+#pragma unroll
+            for (int kw = 0; kw < 3; ++kw) {
+                const int iw = wx + kw - 1;
+                if (iw < 0 || iw >= W) continue;
+                const float* px = x + (((size_t)n * H + ih) * W + iw) * ldx;
+                const float* wt = s_w + (kh * 3 + kw) * C;
+#pragma unroll
+                for (int c = 0; c < C; c += 4) {
+                    const float4 v = *reinterpret_cast<const float4*>(px + c);
+                    s = fmaf(v.x, wt[c], s); s = fmaf(v.y, wt[c + 1], s);
+                    s = fmaf(v.z, wt[c + 2], s); s = fmaf(v.w, wt[c + 3], s);
+                }
+            }
+        }
+        d[e] = s;
+    }
+}
+
+// dx[n,h,w,c] = sum_{kh,kw} dd[n,h-kh+1,w-kw+1] * w[c][kh][kw]
+template <int C>
+__global__ __launch_bounds__(256) void head_conv_dgrad_kernel(const float* __restrict__ dd, const float* __restrict__ w, int N,
+                                                              int H, int W, float* __restrict__ dx, int lddx) {
+    __shared__ float s_w[9 * C];
+    for (int e = threadIdx.x; e < 9 * C; e += blockDim.x) {
+        const int t = e / C, c = e - t * C;
+        s_w[e] = w[c * 9 + t];
+    }
+    __syncthreads();
+    constexpr int Q = C / 4;
+    const int64_t total = (int64_t)N * H * W * Q;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+        const int c = (int)(e % Q) * 4;
+        int64_t r = e / Q;
+        const int wx = (int)(r % W); r /= W;
+        const int h = (int)(r % H), n = (int)(r / H);
+        float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int kh = 0; kh < 3; ++kh) {
+            const int oh = h - kh + 1;
+            if (oh < 0 || oh >= H) continue;
+#pragma unroll
+            for (int kw = 0; kw < 3; ++kw) {
+                const int ow = wx - kw + 1;
+                if (ow < 0 || ow >= W) continue;
+                const float g = dd[((size_t)n * H + oh) * W + ow];
+                const float* wt = s_w + (kh * 3 + kw) * C + c;
+                s.x = fmaf(g, wt[0], s.x); s.y = fmaf(g, wt[1], s.y); s.z = fmaf(g, wt[2], s.z); s.w = fmaf(g, wt[3], s.w);
+            }
+        }
+        *reinterpret_cast<float4*>(dx + (((size_t)n * H + h) * W + wx) * lddx + c) = s;
+    }
+}
+
+// partial[block][t][c] = sum over the block's pixels of x[pix + tap t][c] * dd[pix]
+// thread = (tap, channel quad, pixel lane); pixel lanes are reduced through LDS.
+template <int C>
+__global__ __launch_bounds__(256) void head_conv_wgrad_kernel(const float* __restrict__ x, int ldx, const float* __restrict__ dd,
+                                                              int N, int H, int W, int64_t pix_per_block,
+                                                              float* __restrict__ partial) {
+    constexpr int Q = C / 4, COMBOS = 9 * Q, PL = 256 / COMBOS;
+    __shared__ float4 s_red[PL * COMBOS];
+    const int combo = threadIdx.x % COMBOS, pl = threadIdx.x / COMBOS;
+    const int t = combo / Q, c = (combo - t * Q) * 4;
+    const int kh = t / 3, kw = t - kh * 3;
+    const int64_t total = (int64_t)N * H * W;
+    const int64_t p0 = (int64_t)blockIdx.x * pix_per_block;
+    const int64_t p1 = p0 + pix_per_block < total ? p0 + pix_per_block : total;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (pl < PL) {
+        for (int64_t p = p0 + pl; p < p1; p += PL) {
+            const int wx = (int)(p % W);
+            const int64_t r = p / W;
+            const int h = (int)(r % H);
+            const int ih = h + kh - 1, iw = wx + kw - 1;
+            if (ih < 0 || ih >= H || iw < 0 || iw >= W) continue;
+            const float g = dd[p];
+            const float4 v = *reinterpret_cast<const float4*>(x + (p + (int64_t)(kh - 1) * W + (kw - 1)) * ldx + c);
+            acc.x = fmaf(g, v.x, acc.x); acc.y = fmaf(g, v.y, acc.y); acc.z = fmaf(g, v.z, acc.z); acc.w = fmaf(g, v.w, acc.w);
+        }
+        s_red[pl * COMBOS + combo] = acc;
+    }
+    __syncthreads();
+    if (threadIdx.x < COMBOS) {
+        float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int k = 0; k < PL; ++k) {
+            const float4 v = s_red[k * COMBOS + threadIdx.x];
+            s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+        }
+        *reinterpret_cast<float4*>(partial + (size_t)blockIdx.x * 9 * C + t * C + c) = s;
+    }
+}
+
+// align_corners=True bilinear; scale and source index computed in fp32 exactly as ATen does for float tensors
+__device__ __forceinline__ void src_index(int o, float scale, int in_size, int& i0, int& i1, float& l1) {
+    const float src = scale * (float)o;
+    i0 = (int)src;
+    if (i0 > in_size - 1) i0 = in_size - 1;
+    i1 = i0 + (i0 < in_size - 1 ? 1 : 0);
+    l1 = fminf(fmaxf(src - (float)i0, 0.f), 1.f);
+}
+
+__global__ __launch_bounds__(256) void bilinear_fwd_kernel(const float* __restrict__ d, int N, int Hs, int Ws,
+                                                           float* __restrict__ out, int Ho, int Wo, float sh, float sw) {
+    const int64_t total = (int64_t)N * Ho * Wo;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+        const int ox = (int)(e % Wo);
+        const int64_t r = e / Wo;
+        const int oy = (int)(r % Ho), n = (int)(r / Ho);
+        int y0, y1, x0, x1;
+        float ly, lx;
+        src_index(oy, sh, Hs, y0, y1, ly);
+        src_index(ox, sw, Ws, x0, x1, lx);
+        const float* src = d + (size_t)n * Hs * Ws;
+        const float hy = 1.f - ly, hx = 1.f - lx;
+        out[e] = hy * (hx * src[y0 * Ws + x0] + lx * src[y0 * Ws + x1]) + ly * (hx * src[y1 * Ws + x0] + lx * src[y1 * Ws + x1]);
+    }
+}
+
+// gather form of the backward: each source pixel sums the output pixels that read it (deterministic, no atomics)
+__global__ __launch_bounds__(256) void bilinear_bwd_kernel(const float* __restrict__ dout, int N, int Ho, int Wo,
+                                                           float* __restrict__ dd, int Hs, int Ws, float sh, float sw) {
+    const int64_t total = (int64_t)N * Hs * Ws;
+    const float inv_h = sh > 0.f ? 1.f / sh : 0.f, inv_w = sw > 0.f ? 1.f / sw : 0.f;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+        const int x = (int)(e % Ws);
+        const int64_t r = e / Ws;
+        const int y = (int)(r % Hs), n = (int)(r / Hs);
+        int oy_lo = (int)floorf((float)(y - 1) * inv_h) - 1, oy_hi = (int)ceilf((float)(y + 1) * inv_h) + 1;
+        int ox_lo = (int)floorf((float)(x - 1) * inv_w) - 1, ox_hi = (int)ceilf((float)(x + 1) * inv_w) + 1;
+        if (sh == 0.f) { oy_lo = 0; oy_hi = Ho - 1; }
+        if (sw == 0.f) { ox_lo = 0; ox_hi = Wo - 1; }
+        oy_lo = max(oy_lo, 0); oy_hi = min(oy_hi, Ho - 1);
+        ox_lo = max(ox_lo, 0); ox_hi = min(ox_hi, Wo - 1);
+        const float* src = dout + (size_t)n * Ho * Wo;
+        float s = 0.f;
+        for (int oy = oy_lo; oy <= oy_hi; ++oy) {
+            int y0, y1;
+            float ly;
+            src_index(oy, sh, Hs, y0, y1, ly);
+            float wy = 0.f;
+            if (y0 == y) wy += 1.f - ly;
+            if (y1 == y) wy += ly;
+            if (wy == 0.f) continue;
+            for (int ox = ox_lo; ox <= ox_hi; ++ox) {
+                int x0, x1;
+                float lx;
+                src_index(ox, sw, Ws, x0, x1, lx);
+                float wx = 0.f;
+                if (x0 == x) wx += 1.f - lx;
+                if (x1 == x) wx += lx;
+                if (wx != 0.f) s = fmaf(wy * wx, src[(size_t)oy * Wo + ox], s);
+            }
+        }
+        dd[e] = s;
+    }
+}
+
+static int ew_grid64(int64_t elems) {
+    int64_t g = cdiv64(elems, 256);
+    const int64_t cap = (int64_t)num_cus() * 16;
+    if (g > cap) g = cap;
+    return (int)(g < 1 ? 1 : g);
+}
+static int head_wgrad_blocks(int64_t pixels) {
+    int64_t b = cdiv64(pixels, 512);
+    const int64_t cap = (int64_t)num_cus() * 4;
+    return (int)(b > cap ? cap : (b < 1 ? 1 : b));
+}
+
+}  // namespace rd
+using namespace rd;
+
+extern "C" int rd_head_conv_fwd(const float* x, int32_t ldx, const float* w_oihw, int32_t N, int32_t H, int32_t W, int32_t C,
+                                float* d, void* stream) {
+    RD_CHECK_ARG(x && w_oihw && d && C == 16 && ldx % 4 == 0, "head_conv_fwd: bad arguments (C must be 16)");
+    hipLaunchKernelGGL(head_conv_fwd_kernel<16>, dim3(ew_grid64((int64_t)N * H * W)), dim3(256), 0,
+                       static_cast<hipStream_t>(stream), x, ldx, w_oihw, N, H, W, d);
+    RD_CHECK_LAUNCH("head_conv_fwd_kernel");
+    return RD_OK;
+}
+
+extern "C" int64_t rd_head_conv_bwd_workspace_floats(int32_t N, int32_t H, int32_t W, int32_t C) {
+    const int blocks = head_wgrad_blocks((int64_t)N * H * W);
+    return (int64_t)(blocks + 16) * 9 * C;
+}
+
+extern "C" int rd_head_conv_bwd(const float* x, int32_t ldx, const float* w_oihw, const float* dd, int32_t N, int32_t H, int32_t W,
+                                int32_t C, float* dx, int32_t lddx, float* dw_oihw, float* ws, void* stream) {
+    RD_CHECK_ARG(x && w_oihw && dd && dx && dw_oihw && ws && C == 16 && ldx % 4 == 0 && lddx % 4 == 0,
+                 "head_conv_bwd: bad arguments (C must be 16)");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    hipLaunchKernelGGL(head_conv_dgrad_kernel<16>, dim3(ew_grid64((int64_t)N * H * W * 4)), dim3(256), 0, s, dd, w_oihw, N, H, W,
+                       dx, lddx);
+    RD_CHECK_LAUNCH("head_conv_dgrad_kernel");
+    const int64_t pixels = (int64_t)N * H * W;
+    const int blocks = head_wgrad_blocks(pixels);
+    hipLaunchKernelGGL(head_conv_wgrad_kernel<16>, dim3(blocks), dim3(256), 0, s, x, ldx, dd, N, H, W, cdiv64(pixels, blocks), ws);
+    RD_CHECK_LAUNCH("head_conv_wgrad_kernel");
+    const int64_t E = 9 * C;
+    return launch_slab_reduce(ws, blocks, E, ws + (int64_t)blocks * E, dw_oihw, 9, C, 1, 1, C, 0, 0, s);
+}
+
+extern "C" int rd_bilinear_fwd(const float* d, int32_t N, int32_t Hs, int32_t Ws, float* out, int32_t Ho, int32_t Wo, void* stream) {
+    RD_CHECK_ARG(d && out && N > 0 && Hs > 0 && Ws > 0 && Ho > 0 && Wo > 0, "bilinear_fwd: bad arguments");
+    const float sh = Ho > 1 ? (float)(Hs - 1) / (float)(Ho - 1) : 0.f;
+    const float sw = Wo > 1 ? (float)(Ws - 1) / (float)(Wo - 1) : 0.f;
+    hipLaunchKernelGGL(bilinear_fwd_kernel, dim3(ew_grid64((int64_t)N * Ho * Wo)), dim3(256), 0, static_cast<hipStream_t>(stream),
+                       d, N, Hs, Ws, out, Ho, Wo, sh, sw);
+    RD_CHECK_LAUNCH("bilinear_fwd_kernel");
+    return RD_OK;
+}
+
+extern "C" int rd_bilinear_bwd(const float* dout, int32_t N, int32_t Ho, int32_t Wo, float* dd, int32_t Hs, int32_t Ws, void* stream) {
+    RD_CHECK_ARG(dout && dd && N > 0 && Hs > 0 && Ws > 0 && Ho > 0 && Wo > 0, "bilinear_bwd: bad arguments");
+    const float sh = Ho > 1 ? (float)(Hs - 1) / (float)(Ho - 1) : 0.f;
+    const float sw = Wo > 1 ? (float)(Ws - 1) / (float)(Wo - 1) : 0.f;
+    hipLaunchKernelGGL(bilinear_bwd_kernel, dim3(ew_grid64((int64_t)N * Hs * Ws)), dim3(256), 0, static_cast<hipStream_t>(stream),
+                       dout, N, Ho, Wo, dd, Hs, Ws, sh, sw);
+    RD_CHECK_LAUNCH("bilinear_bwd_kernel");
+    return RD_OK;
+}

@@ -1,0 +1,410 @@
+// Training-mode BatchNorm2d + activation + residual joins, and the stem's fused BN/act/max-pool,
+// as HBM-streaming NHWC kernels (float4 over channels, per-channel coefficients).
+// Replaces nn.BatchNorm2d / ReLU / LeakyReLU / `out += identity` / MaxPool2d(3,2,1) and their backward
+// (model/models.py:96-112,203-208,633-650).
+#include "common.h"
+
+namespace rd {
+
+// ------------------------------------------------------------------------------------------------
+// finalize: reduce [n_tiles][2][C] partial (sum, sumsq) in double -> mean/invstd/scale/shift, running stats
+__global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restrict__ part, int n_tiles, int ld, int c0, double count,
+                                                          const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                          float eps, float momentum, float* running_mean, float* running_var,
+                                                          int64_t* nbt, float* mean, float* invstd, float* scale, float* shift) {
+    const int c = blockIdx.x;
+    double s = 0.0, q = 0.0;
+    for (int t = threadIdx.x; t < n_tiles; t += blockDim.x) {
+        s += (double)part[((size_t)t * 2 + 0) * ld + c0 + c];
+        q += (double)part[((size_t)t * 2 + 1) * ld + c0 + c];
+    }
+    __shared__ double sh[2][4];
+    s = wave_sum_d(s);
+    q = wave_sum_d(q);
+    const int w = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) { sh[0][w] = s; sh[1][w] = q; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        s = sh[0][0] + sh[0][1] + sh[0][2] + sh[0][3];
+        q = sh[1][0] + sh[1][1] + sh[1][2] + sh[1][3];
+        const double m = s / count;
+        double var = q / count - m * m;
+        if (var < 0.0) var = 0.0;
+        const double r = 1.0 / sqrt(var + (double)eps);
+        const double g = gamma[c], b = beta[c];
+        mean[c] = (float)m;
+        invstd[c] = (float)r;
+        scale[c] = (float)(g * r);
+        shift[c] = (float)(b - m * g * r);
+        if (running_mean) {
+            const double unbiased = count > 1.0 ? var * count / (count - 1.0) : var;
+            running_mean[c] = (float)((1.0 - momentum) * running_mean[c] + momentum * m);
+            running_var[c] = (float)((1.0 - momentum) * running_var[c] + momentum * unbiased);
+        }
+        if (c == 0 && nbt) *nbt += 1;
+    }
+}
+
+__global__ void bn_eval_coeffs_kernel(int C, const float* gamma, const float* beta, const float* rm, const float* rv, float eps,
+                                      float* scale, float* shift) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c < C) {
+        const float r = 1.0f / sqrtf(rv[c] + eps);
+        scale[c] = gamma[c] * r;
+        shift[c] = beta[c] - rm[c] * gamma[c] * r;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// row-block reductions: thread (q = channel quad, rl = row lane); block covers rows [b*RPB, (b+1)*RPB)
+static inline int rows_per_block(int64_t M) {
+    int64_t r = cdiv64(M, 2048);
+    return (int)(r < 64 ? 64 : r);
+}
+
+template <int NS>  // number of per-channel sums
+__device__ __forceinline__ void block_reduce_store(float4 (&acc)[NS], int Q, int RL, int q, int rl, bool active, float* out,
+                                                   int C, float* sm) {
+    // sm: [RL][NS][Q*4]
+    if (active) {
+#pragma unroll
+        for (int s = 0; s < NS; ++s) *reinterpret_cast<float4*>(sm + ((size_t)(rl * NS + s) * Q + q) * 4) = acc[s];
+    }
+    __syncthreads();
+    for (int e = threadIdx.x; e < NS * Q * 4; e += blockDim.x) {
+        const int s = e / (Q * 4), c = e - s * (Q * 4);
+        float v = 0.f;
+        for (int r = 0; r < RL; ++r) v += sm[(size_t)(r * NS + s) * Q * 4 + c];
+        out[(size_t)s * C + c] = v;
+    }
+}
+
+__global__ __launch_bounds__(256) void bn_stats_kernel(const float* __restrict__ x, int64_t M, int C, int ldx, int RPB,
+                                                       float* __restrict__ part) {
+    extern __shared__ float sm[];
+    const int Q = C >> 2, RL = 256 / Q;
+    const int q = threadIdx.x % Q, rl = threadIdx.x / Q;
+    const bool active = rl < RL;
+    const int64_t r0 = (int64_t)blockIdx.x * RPB, r1 = r0 + RPB < M ? r0 + RPB : M;
+    float4 acc[2] = {make_float4(0, 0, 0, 0), make_float4(0, 0, 0, 0)};
+    if (active)
+        for (int64_t r = r0 + rl; r < r1; r += RL) {
+            const float4 v = *reinterpret_cast<const float4*>(x + r * ldx + q * 4);
+            acc[0].x += v.x; acc[0].y += v.y; acc[0].z += v.z; acc[0].w += v.w;
+            acc[1].x += v.x * v.x; acc[1].y += v.y * v.y; acc[1].z += v.z * v.z; acc[1].w += v.w * v.w;
+        }
+    block_reduce_store<2>(acc, Q, RL, q, rl, active, part + (size_t)blockIdx.x * 2 * C, C, sm);
+}
+
+// y = act(s1*x1 + t1 [+ (s2*x2 + t2 | x2)])
+__global__ __launch_bounds__(256) void bn_act_kernel(const float* __restrict__ x1, int ldx1, const float* __restrict__ s1,
+                                                     const float* __restrict__ t1, const float* __restrict__ x2, int ldx2,
+                                                     const float* __restrict__ s2, const float* __restrict__ t2,
+                                                     float* __restrict__ y, int ldy, int64_t M, int C, int act) {
+    const int Q = C >> 2;
+    const int64_t total = M * Q;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t r = e / Q;
+        const int c = (int)(e - r * Q) * 4;
+        const float4 v = *reinterpret_cast<const float4*>(x1 + r * ldx1 + c);
+        const float4 a = *reinterpret_cast<const float4*>(s1 + c);
+        const float4 b = *reinterpret_cast<const float4*>(t1 + c);
+        float4 z = make_float4(fmaf(a.x, v.x, b.x), fmaf(a.y, v.y, b.y), fmaf(a.z, v.z, b.z), fmaf(a.w, v.w, b.w));
+        if (x2) {
+            float4 u = *reinterpret_cast<const float4*>(x2 + r * ldx2 + c);
+            if (s2) {
+                const float4 a2 = *reinterpret_cast<const float4*>(s2 + c);
+                const float4 b2 = *reinterpret_cast<const float4*>(t2 + c);
+                u = make_float4(fmaf(a2.x, u.x, b2.x), fmaf(a2.y, u.y, b2.y), fmaf(a2.z, u.z, b2.z), fmaf(a2.w, u.w, b2.w));
+            }
+            z.x += u.x; z.y += u.y; z.z += u.z; z.w += u.w;
+        }
+        z.x = act_fwd(z.x, act); z.y = act_fwd(z.y, act); z.z = act_fwd(z.z, act); z.w = act_fwd(z.w, act);
+        *reinterpret_cast<float4*>(y + r * ldy + c) = z;
+    }
+}
+
+// backward pass 1: g = dy * act'(y); sums of g, g*(x1-m1), g*(x2-m2)
+__global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restrict__ dy, int lddy, const float* __restrict__ y,
+                                                            int ldy, const float* __restrict__ x1, int ldx1,
+                                                            const float* __restrict__ m1, const float* __restrict__ x2, int ldx2,
+                                                            const float* __restrict__ m2, float* __restrict__ g, int ldg,
+                                                            int64_t M, int C, int act, int RPB, float* __restrict__ part) {
+    extern __shared__ float sm[];
+    const int Q = C >> 2, RL = 256 / Q;
+    const int q = threadIdx.x % Q, rl = threadIdx.x / Q;
+    const bool active = rl < RL;
+    const int64_t r0 = (int64_t)blockIdx.x * RPB, r1 = r0 + RPB < M ? r0 + RPB : M;
+    float4 acc[3] = {make_float4(0, 0, 0, 0), make_float4(0, 0, 0, 0), make_float4(0, 0, 0, 0)};
+    if (active) {
+        const int c = q * 4;
+        const float4 mu1 = x1 ? *reinterpret_cast<const float4*>(m1 + c) : make_float4(0, 0, 0, 0);
+        const float4 mu2 = x2 ? *reinterpret_cast<const float4*>(m2 + c) : make_float4(0, 0, 0, 0);
+        for (int64_t r = r0 + rl; r < r1; r += RL) {
+            float4 gv = *reinterpret_cast<const float4*>(dy + r * lddy + c);
+            if (act != RD_ACT_NONE) {
+                const float4 yv = *reinterpret_cast<const float4*>(y + r * ldy + c);
+                gv.x *= act_grad_from_out(yv.x, act); gv.y *= act_grad_from_out(yv.y, act);
+                gv.z *= act_grad_from_out(yv.z, act); gv.w *= act_grad_from_out(yv.w, act);
+            }
+            if (g) *reinterpret_cast<float4*>(g + r * ldg + c) = gv;
+            acc[0].x += gv.x; acc[0].y += gv.y; acc[0].z += gv.z; acc[0].w += gv.w;
+            if (x1) {
+                const float4 v = *reinterpret_cast<const float4*>(x1 + r * ldx1 + c);
+                acc[1].x += gv.x * (v.x - mu1.x); acc[1].y += gv.y * (v.y - mu1.y);
+                acc[1].z += gv.z * (v.z - mu1.z); acc[1].w += gv.w * (v.w - mu1.w);
+            }
+            if (x2) {
+                const float4 v = *reinterpret_cast<const float4*>(x2 + r * ldx2 + c);
+                acc[2].x += gv.x * (v.x - mu2.x); acc[2].y += gv.y * (v.y - mu2.y);
+                acc[2].z += gv.z * (v.z - mu2.z); acc[2].w += gv.w * (v.w - mu2.w);
+            }
+        }
+    }
+    block_reduce_store<3>(acc, Q, RL, q, rl, active, part + (size_t)blockIdx.x * 3 * C, C, sm);
+}
+
+// per channel: finish the reduction; dgamma, dbeta; coefficients of dx = A*g + B*(x-mean) + Cc
+__global__ __launch_bounds__(256) void bn_bwd_coeffs_kernel(const float* __restrict__ part, int n_tiles, int C, int which,
+                                                            double count, const float* __restrict__ gamma,
+                                                            const float* __restrict__ invstd, float* dgamma, float* dbeta,
+                                                            float* coef) {
+    const int c = blockIdx.x;
+    double s0 = 0.0, s1 = 0.0;
+    for (int t = threadIdx.x; t < n_tiles; t += blockDim.x) {
+        s0 += (double)part[((size_t)t * 3 + 0) * C + c];
+        s1 += (double)part[((size_t)t * 3 + which) * C + c];
+    }
+    __shared__ double sh[2][4];
+    s0 = wave_sum_d(s0);
+    s1 = wave_sum_d(s1);
+    const int w = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) { sh[0][w] = s0; sh[1][w] = s1; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        s0 = sh[0][0] + sh[0][1] + sh[0][2] + sh[0][3];
+        s1 = sh[1][0] + sh[1][1] + sh[1][2] + sh[1][3];
+        const double r = invstd[c], gm = gamma[c];
+        if (dgamma) dgamma[c] = (float)(r * s1);
+        if (dbeta) dbeta[c] = (float)s0;
+        const double A = gm * r;
+        coef[c] = (float)A;
+        coef[C + c] = (float)(-gm * r * r * r * s1 / count);
+        coef[2 * C + c] = (float)(-A * s0 / count);
+    }
+}
+
+__global__ __launch_bounds__(256) void bn_bwd_dx_kernel(const float* __restrict__ g, int ldg, const float* __restrict__ x, int ldx,
+                                                        const float* __restrict__ mean, const float* __restrict__ coef,
+                                                        float* __restrict__ dx, int lddx, int64_t M, int C) {
+    const int Q = C >> 2;
+    const int64_t total = M * Q;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t r = e / Q;
+        const int c = (int)(e - r * Q) * 4;
+        const float4 gv = *reinterpret_cast<const float4*>(g + r * ldg + c);
+        const float4 xv = *reinterpret_cast<const float4*>(x + r * ldx + c);
+        const float4 mu = *reinterpret_cast<const float4*>(mean + c);
+        const float4 A = *reinterpret_cast<const float4*>(coef + c);
+        const float4 B = *reinterpret_cast<const float4*>(coef + C + c);
+        const float4 K = *reinterpret_cast<const float4*>(coef + 2 * C + c);
+        float4 o;
+        o.x = fmaf(A.x, gv.x, fmaf(B.x, xv.x - mu.x, K.x));
+        o.y = fmaf(A.y, gv.y, fmaf(B.y, xv.y - mu.y, K.y));
+        o.z = fmaf(A.z, gv.z, fmaf(B.z, xv.z - mu.z, K.z));
+        o.w = fmaf(A.w, gv.w, fmaf(B.w, xv.w - mu.w, K.w));
+        *reinterpret_cast<float4*>(dx + r * lddx + c) = o;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// stem: y = maxpool3x3/2/1(act(scale*x+shift)), argmax position saved (first max wins, like ATen's CPU kernel)
+__global__ __launch_bounds__(256) void bnact_maxpool_fwd_kernel(const float* __restrict__ x, const float* __restrict__ scale,
+                                                                const float* __restrict__ shift, int act, int N, int H, int W,
+                                                                int C, int Ho, int Wo, float* __restrict__ y, int ldy,
+                                                                uint8_t* __restrict__ idx) {
+    const int Q = C >> 2;
+    const int64_t total = (int64_t)N * Ho * Wo * Q;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+        const int c = (int)(e % Q) * 4;
+        int64_t r = e / Q;
+        const int ow = (int)(r % Wo); r /= Wo;
+        const int oh = (int)(r % Ho);
+        const int n = (int)(r / Ho);
+        const float4 a = *reinterpret_cast<const float4*>(scale + c);
+        const float4 b = *reinterpret_cast<const float4*>(shift + c);
+        float best[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+        int bi[4] = {0, 0, 0, 0};
+        bool first = true;
+        for (int kh = 0; kh < 3; ++kh) {
+            const int ih = 2 * oh - 1 + kh;
+            if (ih < 0 || ih >= H) continue;
+            for (int kw = 0; kw < 3; ++kw) {
+                const int iw = 2 * ow - 1 + kw;
+                if (iw < 0 || iw >= W) continue;
+                const float4 v = *reinterpret_cast<const float4*>(x + (((size_t)n * H + ih) * W + iw) * C + c);
+                const float z[4] = {act_fwd(fmaf(a.x, v.x, b.x), act), act_fwd(fmaf(a.y, v.y, b.y), act),
+                                    act_fwd(fmaf(a.z, v.z, b.z), act), act_fwd(fmaf(a.w, v.w, b.w), act)};
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    if (first || z[j] > best[j]) { best[j] = z[j]; bi[j] = kh * 3 + kw; }
+                first = false;
+            }
+        }
+        const size_t o = ((size_t)n * Ho + oh) * Wo + ow;
+        *reinterpret_cast<float4*>(y + o * ldy + c) = make_float4(best[0], best[1], best[2], best[3]);
+        *reinterpret_cast<uchar4*>(idx + o * C + c) = make_uchar4(bi[0], bi[1], bi[2], bi[3]);
+    }
+}
+
+// g[n,h,w,c] = act'(scale*x+shift) * sum over windows whose argmax is (h,w) of dy
+__global__ __launch_bounds__(256) void bnact_maxpool_bwd_kernel(const float* __restrict__ dy, int lddy,
+                                                                const uint8_t* __restrict__ idx, const float* __restrict__ x,
+                                                                const float* __restrict__ scale, const float* __restrict__ shift,
+                                                                int act, int N, int H, int W, int C, int Ho, int Wo,
+                                                                float* __restrict__ g) {
+    const int Q = C >> 2;
+    const int64_t total = (int64_t)N * H * W * Q;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+        const int c = (int)(e % Q) * 4;
+        int64_t r = e / Q;
+        const int w = (int)(r % W); r /= W;
+        const int h = (int)(r % H);
+        const int n = (int)(r / H);
+        float s[4] = {0.f, 0.f, 0.f, 0.f};
+        const int oh_lo = h >> 1, oh_hi = (h + 1) >> 1;   // oh with 2*oh-1 <= h <= 2*oh+1
+        const int ow_lo = w >> 1, ow_hi = (w + 1) >> 1;
+        for (int oh = oh_lo; oh <= oh_hi; ++oh) {
+            if (oh >= Ho) continue;
+            const int kh = h - (2 * oh - 1);
+            for (int ow = ow_lo; ow <= ow_hi; ++ow) {
+                if (ow >= Wo) continue;
+                const int kw = w - (2 * ow - 1);
+                const size_t o = ((size_t)n * Ho + oh) * Wo + ow;
+                const uchar4 id = *reinterpret_cast<const uchar4*>(idx + o * C + c);
+                const float4 d = *reinterpret_cast<const float4*>(dy + o * lddy + c);
+                const int pos = kh * 3 + kw;
+                if (id.x == pos) s[0] += d.x;
+                if (id.y == pos) s[1] += d.y;
+                if (id.z == pos) s[2] += d.z;
+                if (id.w == pos) s[3] += d.w;
+            }
+        }
+        const size_t i = (((size_t)n * H + h) * W + w) * C + c;
+        const float4 v = *reinterpret_cast<const float4*>(x + i);
+        const float4 a = *reinterpret_cast<const float4*>(scale + c);
+        const float4 b = *reinterpret_cast<const float4*>(shift + c);
+        float4 o4;
+        o4.x = s[0] * act_grad_from_out(fmaf(a.x, v.x, b.x), act);
+        o4.y = s[1] * act_grad_from_out(fmaf(a.y, v.y, b.y), act);
+        o4.z = s[2] * act_grad_from_out(fmaf(a.z, v.z, b.z), act);
+        o4.w = s[3] * act_grad_from_out(fmaf(a.w, v.w, b.w), act);
+        *reinterpret_cast<float4*>(g + i) = o4;
+    }
+}
+
+static int ew_grid(int64_t elems) {
+    int64_t g = cdiv64(elems, 256);
+    const int64_t cap = (int64_t)num_cus() * 16;
+    if (g > cap) g = cap;
+    return (int)(g < 1 ? 1 : g);
+}
+
+}  // namespace rd
+using namespace rd;
+
+extern "C" int rd_bn_finalize(const float* stat_partial, int32_t n_tiles, int32_t ld, int32_t c0, int32_t C, int64_t count, const float* gamma,
+                              const float* beta, float eps, float momentum, float* running_mean, float* running_var,
+                              int64_t* nbt, float* mean, float* invstd, float* scale, float* shift, void* stream) {
+    RD_CHECK_ARG(stat_partial && gamma && beta && mean && invstd && scale && shift && n_tiles > 0 && C > 0 && count > 0 &&
+                     c0 >= 0 && c0 + C <= ld, "bn_finalize: bad arguments");
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3(C), dim3(256), 0, static_cast<hipStream_t>(stream), stat_partial, n_tiles, ld, c0,
+                       (double)count, gamma, beta, eps, momentum, running_mean, running_var, nbt, mean, invstd, scale, shift);
+    RD_CHECK_LAUNCH("bn_finalize_kernel");
+    return RD_OK;
+}
+
+extern "C" int rd_bn_eval_coeffs(int32_t C, const float* gamma, const float* beta, const float* running_mean,
+                                 const float* running_var, float eps, float* scale, float* shift, void* stream) {
+    RD_CHECK_ARG(C > 0 && gamma && beta && running_mean && running_var && scale && shift, "bn_eval_coeffs: bad arguments");
+    hipLaunchKernelGGL(bn_eval_coeffs_kernel, dim3(cdiv(C, 256)), dim3(256), 0, static_cast<hipStream_t>(stream), C, gamma, beta,
+                       running_mean, running_var, eps, scale, shift);
+    RD_CHECK_LAUNCH("bn_eval_coeffs_kernel");
+    return RD_OK;
+}
+
+extern "C" int rd_bn_stats_tiles(int64_t M) { return (int)cdiv64(M, rows_per_block(M)); }
+extern "C" int rd_bn_bwd_tiles(int64_t M) { return (int)cdiv64(M, rows_per_block(M)); }
+
+extern "C" int rd_bn_stats(const float* x, int64_t M, int32_t C, int32_t ldx, float* stat_partial, int32_t* n_tiles,
+                           void* stream) {
+    RD_CHECK_ARG(x && stat_partial && M > 0 && C >= 4 && C % 4 == 0 && C <= 1024 && ldx % 4 == 0, "bn_stats: bad arguments");
+    const int RPB = rows_per_block(M), grid = (int)cdiv64(M, RPB);
+    const int Q = C / 4, RL = 256 / Q;
+    hipLaunchKernelGGL(bn_stats_kernel, dim3(grid), dim3(256), (size_t)RL * 2 * C * sizeof(float),
+                       static_cast<hipStream_t>(stream), x, M, C, ldx, RPB, stat_partial);
+    RD_CHECK_LAUNCH("bn_stats_kernel");
+    if (n_tiles) *n_tiles = grid;
+    return RD_OK;
+}
+
+extern "C" int rd_bn_act(const float* x1, int32_t ldx1, const float* scale1, const float* shift1, const float* x2, int32_t ldx2,
+                         const float* scale2, const float* shift2, float* y, int32_t ldy, int64_t M, int32_t C, int32_t act,
+                         void* stream) {
+    RD_CHECK_ARG(x1 && scale1 && shift1 && y && M > 0 && C % 4 == 0 && ldx1 % 4 == 0 && ldy % 4 == 0 && (!x2 || ldx2 % 4 == 0),
+                 "bn_act: bad arguments");
+    hipLaunchKernelGGL(bn_act_kernel, dim3(ew_grid(M * (C / 4))), dim3(256), 0, static_cast<hipStream_t>(stream), x1, ldx1,
+                       scale1, shift1, x2, ldx2, scale2, shift2, y, ldy, M, C, act);
+    RD_CHECK_LAUNCH("bn_act_kernel");
+    return RD_OK;
+}
+
+extern "C" int rd_bn_bwd_reduce(const float* dy, int32_t lddy, const float* y, int32_t ldy, const float* x1, int32_t ldx1,
+                                const float* mean1, const float* x2, int32_t ldx2, const float* mean2, float* g, int32_t ldg,
+                                int64_t M, int32_t C, int32_t act, float* red_partial, void* stream) {
+    RD_CHECK_ARG(dy && red_partial && M > 0 && C >= 4 && C % 4 == 0 && C <= 1024, "bn_bwd_reduce: bad arguments");
+    RD_CHECK_ARG(act == RD_ACT_NONE || y, "bn_bwd_reduce: activation needs y");
+    RD_CHECK_ARG((!x1 || mean1) && (!x2 || mean2), "bn_bwd_reduce: x without mean");
+    const int RPB = rows_per_block(M), grid = (int)cdiv64(M, RPB);
+    const int Q = C / 4, RL = 256 / Q;
+    hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(grid), dim3(256), (size_t)RL * 3 * C * sizeof(float),
+                       static_cast<hipStream_t>(stream), dy, lddy, y, ldy, x1, ldx1, mean1, x2, ldx2, mean2, g, ldg, M, C, act, RPB,
+                       red_partial);
+    RD_CHECK_LAUNCH("bn_bwd_reduce_kernel");
+    return RD_OK;
+}
+
+extern "C" int rd_bn_bwd_apply(const float* g, int32_t ldg, const float* x, int32_t ldx, const float* red_partial, int32_t n_tiles,
+                               int32_t which, const float* gamma, const float* mean, const float* invstd, float* dgamma,
+                               float* dbeta, float* coef_ws, float* dx, int32_t lddx, int64_t M, int32_t C, void* stream) {
+    RD_CHECK_ARG(g && x && red_partial && gamma && mean && invstd && coef_ws && dx && (which == 1 || which == 2) && M > 0 &&
+                     C % 4 == 0, "bn_bwd_apply: bad arguments");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    hipLaunchKernelGGL(bn_bwd_coeffs_kernel, dim3(C), dim3(256), 0, s, red_partial, n_tiles, C, which, (double)M, gamma, invstd,
+                       dgamma, dbeta, coef_ws);
+    RD_CHECK_LAUNCH("bn_bwd_coeffs_kernel");
+    hipLaunchKernelGGL(bn_bwd_dx_kernel, dim3(ew_grid(M * (C / 4))), dim3(256), 0, s, g, ldg, x, ldx, mean, coef_ws, dx, lddx, M, C);
+    RD_CHECK_LAUNCH("bn_bwd_dx_kernel");
+    return RD_OK;
+}
+
+extern "C" int rd_bnact_maxpool_fwd(const float* x, const float* scale, const float* shift, int32_t act, int32_t N, int32_t H,
+                                    int32_t W, int32_t C, float* y, int32_t ldy, uint8_t* idx, void* stream) {
+    RD_CHECK_ARG(x && scale && shift && y && idx && C % 4 == 0 && ldy % 4 == 0, "bnact_maxpool_fwd: bad arguments");
+    const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
+    hipLaunchKernelGGL(bnact_maxpool_fwd_kernel, dim3(ew_grid((int64_t)N * Ho * Wo * (C / 4))), dim3(256), 0,
+                       static_cast<hipStream_t>(stream), x, scale, shift, act, N, H, W, C, Ho, Wo, y, ldy, idx);
+    RD_CHECK_LAUNCH("bnact_maxpool_fwd_kernel");
+    return RD_OK;
+}
+
+extern "C" int rd_bnact_maxpool_bwd(const float* dy, int32_t lddy, const uint8_t* idx, const float* x, const float* scale,
+                                    const float* shift, int32_t act, int32_t N, int32_t H, int32_t W, int32_t C, float* g,
+                                    void* stream) {
+    RD_CHECK_ARG(dy && idx && x && scale && shift && g && C % 4 == 0 && lddy % 4 == 0, "bnact_maxpool_bwd: bad arguments");
+    const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
+    hipLaunchKernelGGL(bnact_maxpool_bwd_kernel, dim3(ew_grid((int64_t)N * H * W * (C / 4))), dim3(256), 0,
+                       static_cast<hipStream_t>(stream), dy, lddy, idx, x, scale, shift, act, N, H, W, C, Ho, Wo, g);
+    RD_CHECK_LAUNCH("bnact_maxpool_bwd_kernel");
+    return RD_OK;
+}

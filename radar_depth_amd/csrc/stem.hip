@@ -1,0 +1,374 @@
+// Stem convolutions: 7x7, stride 2, pad 3, read straight from the network's NCHW input planes
+// (model/models.py:539,559,633,643; multistage_model.py:163-164,236-241), output NHWC.
+//   forward : implicit GEMM  [pixels] x [K = 49*Cin] x [Cout]  on v_mfma_f32_32x32x2_f32; the input patch of
+//             an 8x32 output tile lives in LDS as planes, an LDS table maps k -> (ci,kh,kw) patch offset.
+//   wgrad   : [K] x [pixels] x [Cout] with the pixel walk split over the four waves, slabs reduced like wgrad.hip.
+//   dgrad   : only the stage-2 dense-depth input channel needs one (stage-1 output is not detached).
+// Weights use the packed layout [49][Cin][Cout] (rd_pack_weights), i.e. k = (kh*7+kw)*Cin + ci.
+#include "common.h"
+
+namespace rd {
+
+int launch_slab_reduce(const float* slabs, int n_splits, int64_t E, float* tmp, float* grad_oihw, int S, int Cin, int Cout,
+                       int O, int I, int co_off, int accumulate, hipStream_t s);
+
+struct StemArgs {
+    const float* plane[3];
+    long long stride[3];  // elements between consecutive images of each plane
+    const float* w;       // packed [49][Cin][Cout]
+    const float* dout;    // wgrad: NHWC [N,Ho,Wo,Cout]
+    float* out;
+    float* stat;
+    int Cin, N, H, W, Ho, Wo, Cout, tiles_h, tiles_w;
+    int total_tiles, tiles_per_split;  // wgrad
+};
+
+constexpr int ST_TW = 32;
+constexpr int ST_PW = 2 * ST_TW + 5;  // 69
+
+template <int NT>
+__global__ __launch_bounds__(256) void stem_fwd_kernel(const StemArgs a) {
+    constexpr int TH = 8, PH = 2 * TH + 5, BN = NT * 32, MT = 2;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, hh = lane >> 5;
+    const int K = 49 * a.Cin, Kp = (K + 1) & ~1;
+    const int PLANE = PH * ST_PW;
+    int* s_koff = reinterpret_cast<int*>(smem);        // [Kp]
+    float* s_w = smem + ((Kp + 3) & ~3);               // [Kp][BN]
+    float* s_patch = s_w + (size_t)Kp * BN;            // [Cin][PH][PW]
+
+    const int bid = xcd_remap(blockIdx.x, gridDim.x);
+    const int n = bid / (a.tiles_h * a.tiles_w);
+    const int trem = bid - n * (a.tiles_h * a.tiles_w);
+    const int r0 = (trem / a.tiles_w) * TH, c0 = (trem % a.tiles_w) * ST_TW;
+
+    for (int k = tid; k < Kp; k += 256) {
+        int off = 0;
+        if (k < K) {
+            const int t = k / a.Cin, ci = k - t * a.Cin;
+            off = ci * PLANE + (t / 7) * ST_PW + (t % 7);
+        }
+        s_koff[k] = off;
+    }
+    for (int e = tid; e < Kp * (BN / 4); e += 256) {
+        const int k = e / (BN / 4), j = (e - k * (BN / 4)) * 4;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (k < K && j < a.Cout) v = *reinterpret_cast<const float4*>(a.w + (size_t)k * a.Cout + j);
+        *reinterpret_cast<float4*>(s_w + (size_t)k * BN + j) = v;
+    }
+    const int ih0 = 2 * r0 - 3, iw0 = 2 * c0 - 3;
+    for (int e = tid; e < a.Cin * PLANE; e += 256) {
+        const int ci = e / PLANE, rem = e - ci * PLANE;
+        const int py = rem / ST_PW, px = rem - py * ST_PW;
+        const int ih = ih0 + py, iw = iw0 + px;
+        float v = 0.f;
+        if (ih >= 0 && ih < a.H && iw >= 0 && iw < a.W) v = a.plane[ci][(size_t)n * a.stride[ci] + (size_t)ih * a.W + iw];
+        s_patch[e] = v;
+    }
+    __syncthreads();
+
+    // wave w owns output rows 2w, 2w+1 of the tile (two 32-pixel M tiles)
+    int abase[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) abase[mt] = (2 * (wave * MT + mt)) * ST_PW + 2 * l31;
+    f32x16 acc[MT][NT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[mt][nt][i] = 0.f;
+
+#pragma unroll 2
+    for (int kk = 0; kk < Kp; kk += 2) {
+        const int k = kk + hh;
+        const int ko = s_koff[k];
+        float av[MT], bv[NT];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) av[mt] = s_patch[abase[mt] + ko];
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) bv[nt] = s_w[(size_t)k * BN + nt * 32 + l31];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+                acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[mt], bv[nt], acc[mt][nt], 0, 0, 0);
+    }
+
+    float ssum[NT], ssq[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) ssum[nt] = ssq[nt] = 0.f;
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+        const int oh = r0 + wave * MT + mt;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int ow = c0 + (i & 3) + 8 * (i >> 2) + 4 * hh;
+            if (oh < a.Ho && ow < a.Wo) {
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) {
+                    const int co = nt * 32 + l31;
+                    if (co < a.Cout) {
+                        const float v = acc[mt][nt][i];
+                        a.out[(((size_t)n * a.Ho + oh) * a.Wo + ow) * a.Cout + co] = v;
+                        ssum[nt] += v;
+                        ssq[nt] += v * v;
+                    }
+                }
+            }
+        }
+    }
+    if (a.stat) {
+        __syncthreads();
+        float* red = s_w;  // [4][2][BN]
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            const float s = ssum[nt] + __shfl_xor(ssum[nt], 32, 64);
+            const float q = ssq[nt] + __shfl_xor(ssq[nt], 32, 64);
+            if (hh == 0) {
+                red[(wave * 2 + 0) * BN + nt * 32 + l31] = s;
+                red[(wave * 2 + 1) * BN + nt * 32 + l31] = q;
+            }
+        }
+        __syncthreads();
+        if (tid < 2 * BN) {
+            const int which = tid / BN, j = tid - which * BN;
+            const float s = red[(0 * 2 + which) * BN + j] + red[(1 * 2 + which) * BN + j] + red[(2 * 2 + which) * BN + j] +
+                            red[(3 * 2 + which) * BN + j];
+            if (j < a.Cout) a.stat[((size_t)bid * 2 + which) * a.Cout + j] = s;
+        }
+    }
+}
+
+// wgrad: D[k][co] += sum_pixels patch(k, pixel) * dout[pixel][co];  MTK = ceil(K/32) row tiles
+template <int MTK, int NT>
+__global__ __launch_bounds__(256) void stem_wgrad_kernel(const StemArgs a, float* __restrict__ slabs) {
+    constexpr int TH = 4, PH = 2 * TH + 5, BN = NT * 32, NPIX = TH * ST_TW;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, hh = lane >> 5;
+    const int K = 49 * a.Cin;
+    const int PLANE = PH * ST_PW;
+    float* s_do = smem;                                 // [NPIX][BN]
+    float* s_patch = s_do + (size_t)NPIX * BN;          // [Cin][PH][PW]
+
+    int koff[MTK];
+#pragma unroll
+    for (int mt = 0; mt < MTK; ++mt) {
+        const int k = mt * 32 + l31;
+        int off = 0;
+        if (k < K) {
+            const int t = k / a.Cin, ci = k - t * a.Cin;
+            off = ci * PLANE + (t / 7) * ST_PW + (t % 7);
+        }
+        koff[mt] = off;
+    }
+    f32x16 acc[MTK][NT];
+#pragma unroll
+    for (int mt = 0; mt < MTK; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[mt][nt][i] = 0.f;
+
+    const int split = blockIdx.x;
+    const int tile_begin = split * a.tiles_per_split;
+    const int tile_end = min(tile_begin + a.tiles_per_split, a.total_tiles);
+    for (int tile = tile_begin; tile < tile_end; ++tile) {
+        const int n = tile / (a.tiles_h * a.tiles_w);
+        const int trem = tile - n * (a.tiles_h * a.tiles_w);
+        const int r0 = (trem / a.tiles_w) * TH, c0 = (trem % a.tiles_w) * ST_TW;
+        __syncthreads();
+        const int ih0 = 2 * r0 - 3, iw0 = 2 * c0 - 3;
+        for (int e = tid; e < a.Cin * PLANE; e += 256) {
+            const int ci = e / PLANE, rem = e - ci * PLANE;
+            const int py = rem / ST_PW, px = rem - py * ST_PW;
+            const int ih = ih0 + py, iw = iw0 + px;
+            float v = 0.f;
+            if (ih >= 0 && ih < a.H && iw >= 0 && iw < a.W) v = a.plane[ci][(size_t)n * a.stride[ci] + (size_t)ih * a.W + iw];
+            s_patch[e] = v;
+        }
+        for (int e = tid; e < NPIX * (BN / 4); e += 256) {
+            const int p = e / (BN / 4), j = (e - p * (BN / 4)) * 4;
+            const int oh = r0 + (p >> 5), ow = c0 + (p & 31);
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (oh < a.Ho && ow < a.Wo && j < a.Cout)
+                v = *reinterpret_cast<const float4*>(a.dout + (((size_t)n * a.Ho + oh) * a.Wo + ow) * a.Cout + j);
+            *reinterpret_cast<float4*>(s_do + (size_t)p * BN + j) = v;
+        }
+        __syncthreads();
+        for (int q = wave; q < NPIX / 2; q += 4) {
+            const int p = 2 * q + hh;
+            const int aoff = (2 * (p >> 5)) * ST_PW + 2 * (p & 31);
+            float av[MTK], bv[NT];
+#pragma unroll
+            for (int mt = 0; mt < MTK; ++mt) av[mt] = s_patch[aoff + koff[mt]];
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) bv[nt] = s_do[(size_t)p * BN + nt * 32 + l31];
+#pragma unroll
+            for (int mt = 0; mt < MTK; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[mt], bv[nt], acc[mt][nt], 0, 0, 0);
+        }
+    }
+    // combine the four waves through LDS, one accumulator tile at a time; slab layout [K][Cout]
+    float* slab = slabs + (size_t)split * K * a.Cout;
+    float* red = smem;  // [4][16][64]
+#pragma unroll
+    for (int mt = 0; mt < MTK; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            __syncthreads();
+#pragma unroll
+            for (int i = 0; i < 16; ++i) red[(wave * 16 + i) * 64 + lane] = acc[mt][nt][i];
+            __syncthreads();
+#pragma unroll
+            for (int ii = 0; ii < 4; ++ii) {
+                const int i = ii * 4 + wave;
+                const float v = red[(0 * 16 + i) * 64 + lane] + red[(1 * 16 + i) * 64 + lane] + red[(2 * 16 + i) * 64 + lane] +
+                                red[(3 * 16 + i) * 64 + lane];
+                const int k = mt * 32 + (i & 3) + 8 * (i >> 2) + 4 * hh;
+                const int co = nt * 32 + l31;
+                if (k < K && co < a.Cout) slab[(size_t)k * a.Cout + co] = v;
+            }
+        }
+}
+
+// dx[n,h,w] = sum_{co,kh,kw} dout[n,(h+3-kh)/2,(w+3-kw)/2,co] * w[(kh*7+kw)][ci][co]  over taps of matching parity
+__global__ __launch_bounds__(256) void stem_dgrad_channel_kernel(const float* __restrict__ dout, const float* __restrict__ wp,
+                                                                 int N, int H, int W, int Ho, int Wo, int Cin, int ci, int Cout,
+                                                                 float* __restrict__ dx) {
+    __shared__ float s_w[49 * 64];
+    for (int e = threadIdx.x; e < 49 * Cout; e += blockDim.x) {
+        const int t = e / Cout, co = e - t * Cout;
+        s_w[e] = wp[((size_t)t * Cin + ci) * Cout + co];
+    }
+    __syncthreads();
+    const int64_t total = (int64_t)N * H * W;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+        const int w = (int)(e % W);
+        const int64_t r = e / W;
+        const int h = (int)(r % H), n = (int)(r / H);
+        float s = 0.f;
+        for (int kh = (h + 3) & 1; kh < 7; kh += 2) {
+            const int oh = (h + 3 - kh) >> 1;
+            if (oh < 0 || oh >= Ho) continue;
+            for (int kw = (w + 3) & 1; kw < 7; kw += 2) {
+                const int ow = (w + 3 - kw) >> 1;
+                if (ow < 0 || ow >= Wo) continue;
+                const float* d = dout + (((size_t)n * Ho + oh) * Wo + ow) * Cout;
+                const float* wv = s_w + (kh * 7 + kw) * Cout;
+                for (int co = 0; co < Cout; co += 4) {
+                    const float4 dv = *reinterpret_cast<const float4*>(d + co);
+                    s = fmaf(dv.x, wv[co], s); s = fmaf(dv.y, wv[co + 1], s);
+                    s = fmaf(dv.z, wv[co + 2], s); s = fmaf(dv.w, wv[co + 3], s);
+                }
+            }
+        }
+        dx[e] = s;
+    }
+}
+
+static int stem_fill(StemArgs& a, const float* const* planes, const int64_t* strides, int Cin, int N, int H, int W, int Cout) {
+    RD_CHECK_ARG(planes && strides && Cin >= 1 && Cin <= 3 && N > 0 && H > 6 && W > 6, "stem: bad arguments");
+    RD_CHECK_ARG(Cout == 64 || Cout == 16 || Cout == 32, "stem: Cout=%d unsupported", Cout);
+    for (int i = 0; i < 3; ++i) {
+        a.plane[i] = i < Cin ? planes[i] : nullptr;
+        a.stride[i] = i < Cin ? strides[i] : 0;
+        RD_CHECK_ARG(i >= Cin || planes[i], "stem: null plane %d", i);
+    }
+    a.Cin = Cin; a.N = N; a.H = H; a.W = W; a.Cout = Cout;
+    a.Ho = (H + 6 - 7) / 2 + 1;
+    a.Wo = (W + 6 - 7) / 2 + 1;
+    return RD_OK;
+}
+
+static int stem_wgrad_splits(int total_tiles) {
+    int want = 2 * num_cus();
+    return want < total_tiles ? want : total_tiles;
+}
+
+}  // namespace rd
+using namespace rd;
+
+extern "C" int rd_stem_stat_tiles(int32_t N, int32_t H, int32_t W) {
+    const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
+    return N * cdiv(Ho, 8) * cdiv(Wo, ST_TW);
+}
+
+extern "C" int rd_stem_fwd(const float* const* planes, const int64_t* strides, int32_t Cin, int32_t N, int32_t H, int32_t W,
+                           const float* w_packed, int32_t Cout, float* out, float* stat_partial, void* stream) {
+    StemArgs a;
+    int rc = stem_fill(a, planes, strides, Cin, N, H, W, Cout);
+    if (rc != RD_OK) return rc;
+    RD_CHECK_ARG(w_packed && out, "stem_fwd: null tensor");
+    a.w = w_packed; a.out = out; a.stat = stat_partial; a.dout = nullptr;
+    a.tiles_h = cdiv(a.Ho, 8); a.tiles_w = cdiv(a.Wo, ST_TW);
+    const int grid = N * a.tiles_h * a.tiles_w;
+    const int NT = Cout > 32 ? 2 : 1, BN = NT * 32;
+    const int Kp = (49 * Cin + 1) & ~1;
+    const size_t lds = ((size_t)((Kp + 3) & ~3) + (size_t)Kp * BN + (size_t)Cin * 21 * ST_PW) * 4;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    static bool attr = false;
+    if (!attr) {
+        RD_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(stem_fwd_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
+        RD_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(stem_fwd_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
+        attr = true;
+    }
+    if (NT == 2) hipLaunchKernelGGL(stem_fwd_kernel<2>, dim3(grid), dim3(256), lds, s, a);
+    else hipLaunchKernelGGL(stem_fwd_kernel<1>, dim3(grid), dim3(256), lds, s, a);
+    RD_CHECK_LAUNCH("stem_fwd_kernel");
+    return RD_OK;
+}
+
+extern "C" int64_t rd_stem_wgrad_workspace_floats(int32_t N, int32_t H, int32_t W, int32_t Cin, int32_t Cout) {
+    const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
+    const int total = N * cdiv(Ho, 4) * cdiv(Wo, ST_TW);
+    const int splits = stem_wgrad_splits(total);
+    const int tps = cdiv(total, splits);
+    const int n_splits = cdiv(total, tps);
+    const int J = n_splits < 16 ? n_splits : 16;
+    return (int64_t)(n_splits + J) * 49 * Cin * Cout;
+}
+
+extern "C" int rd_stem_wgrad(const float* const* planes, const int64_t* strides, int32_t Cin, int32_t N, int32_t H, int32_t W,
+                             const float* dout, int32_t Cout, float* grad_oihw, float* ws, void* stream) {
+    StemArgs a;
+    int rc = stem_fill(a, planes, strides, Cin, N, H, W, Cout);
+    if (rc != RD_OK) return rc;
+    RD_CHECK_ARG(dout && grad_oihw && ws, "stem_wgrad: null tensor");
+    a.w = nullptr; a.out = nullptr; a.stat = nullptr; a.dout = dout;
+    a.tiles_h = cdiv(a.Ho, 4); a.tiles_w = cdiv(a.Wo, ST_TW);
+    a.total_tiles = N * a.tiles_h * a.tiles_w;
+    const int splits = stem_wgrad_splits(a.total_tiles);
+    a.tiles_per_split = cdiv(a.total_tiles, splits);
+    const int n_splits = cdiv(a.total_tiles, a.tiles_per_split);
+    const int K = 49 * Cin, MTK = cdiv(K, 32), NT = Cout > 32 ? 2 : 1, BN = NT * 32;
+    size_t lds = ((size_t)4 * 32 * BN + (size_t)Cin * 13 * ST_PW) * 4;
+    if (lds < 4 * 16 * 64 * 4) lds = 4 * 16 * 64 * 4;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+#define RD_SW(M_, N_)                                                                             \
+    if (MTK == M_ && NT == N_) {                                                                  \
+        hipLaunchKernelGGL((stem_wgrad_kernel<M_, N_>), dim3(n_splits), dim3(256), lds, s, a, ws); \
+        RD_CHECK_LAUNCH("stem_wgrad_kernel");                                                     \
+    } else
+    RD_SW(5, 2) RD_SW(2, 1) RD_SW(4, 1) {
+        set_error("stem_wgrad: unsupported shape Cin=%d Cout=%d", Cin, Cout);
+        return RD_EINVAL;
+    }
+#undef RD_SW
+    const int64_t E = (int64_t)K * Cout;
+    return launch_slab_reduce(ws, n_splits, E, ws + (int64_t)n_splits * E, grad_oihw, 49, Cin, Cout, Cout, Cin, 0, 0, s);
+}
+
+extern "C" int rd_stem_dgrad_channel(const float* dout, const float* w_packed, int32_t N, int32_t H, int32_t W, int32_t Cin,
+                                     int32_t ci, int32_t Cout, float* dx, void* stream) {
+    RD_CHECK_ARG(dout && w_packed && dx && ci >= 0 && ci < Cin && Cout % 4 == 0 && Cout <= 64, "stem_dgrad_channel: bad arguments");
+    const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
+    int64_t g = cdiv64((int64_t)N * H * W, 256);
+    if (g > (int64_t)num_cus() * 16) g = (int64_t)num_cus() * 16;
+    hipLaunchKernelGGL(stem_dgrad_channel_kernel, dim3((int)g), dim3(256), 0, static_cast<hipStream_t>(stream), dout, w_packed, N,
+                       H, W, Ho, Wo, Cin, ci, Cout, dx);
+    RD_CHECK_LAUNCH("stem_dgrad_channel_kernel");
+    return RD_OK;
+}

@@ -58,23 +58,21 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs a) {
     const int cob0 = ((g / a.n_tg) % a.n_cob) * COB;
     const int cib0 = (g / (a.n_tg * a.n_cob)) * CIB;
     const WgTapGroup& G = a.tg[tgi];
-    const int ntap = G.n;
 
     const int PWmax = (a.TW - 1) * a.IS + (a.dw_max - a.dw_min) + 1;
     const int PHmax = (a.TH - 1) * a.IS + (a.dh_max - a.dh_min) + 1;
     const int DW = a.TW * a.OS, DHmax = a.TH * a.OS;
-    int2* s_tab = reinterpret_cast<int2*>(smem);                        // [WG_MAX_PIX + 8]
-    float* s_in = smem + 2 * (WG_MAX_PIX + 8);                          // [PHmax*PWmax][CIB]
-    float* s_do = s_in + (size_t)PHmax * PWmax * CIB;                    // [DHmax*DW + 1][COB], last row zero
-    const int zero_row = DHmax * DW;
+    int2* s_tab = reinterpret_cast<int2*>(smem);                        // [WG_MAX_PIX + 32]
+    float* s_in = smem + 2 * (WG_MAX_PIX + 32);                         // [PHmax*PWmax][CIB]
+    float* s_do = s_in + (size_t)PHmax * PWmax * CIB;                    // [DHmax*DW][COB]
+    (void)DHmax;
 
     // per-tap LDS offsets (loop invariant)
     int tin[TG], tout[TG];
 #pragma unroll
     for (int t = 0; t < TG; ++t) {
-        const int tt = t < ntap ? t : 0;
-        tin[t] = ((G.dh[tt] - a.dh_min) * PWmax + (G.dw[tt] - a.dw_min)) * CIB + wci * 32 + lm;
-        tout[t] = (G.oh[tt] * DW + G.ow[tt]) * COB + wco * 32 + lm;
+        tin[t] = ((G.dh[t] - a.dh_min) * PWmax + (G.dw[t] - a.dw_min)) * CIB + wci * 32 + lm;
+        tout[t] = (G.oh[t] * DW + G.ow[t]) * COB + wco * 32 + lm;
     }
 
     typedef float accv __attribute__((ext_vector_type(NACC)));
@@ -94,19 +92,15 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs a) {
         const int npix = th_n * tw_n;
         const int npad = ((npix + KP * WLP - 1) / (KP * WLP)) * (KP * WLP);
         __syncthreads();  // previous tile fully consumed
-        for (int p = tid; p < npad; p += 256) {
-            int2 e;
+        for (int p = tid; p < npad + KP * WLP; p += 256) {
+            int2 e = make_int2(0, 0);  // padding entries read a valid location; their B value is masked to 0
             if (p < npix) {
                 const int r = p / tw_n, c = p - r * tw_n;
                 e.x = ((r * a.IS) * PWmax + c * a.IS) * CIB;
                 e.y = ((r * a.OS) * DW + c * a.OS) * COB;
-            } else {
-                e.x = 0;
-                e.y = zero_row * COB;
             }
             s_tab[p] = e;
         }
-        if (tid < COB) s_do[(size_t)zero_row * COB + tid] = 0.f;
         // input halo patch
         {
             const int PH = (th_n - 1) * a.IS + (a.dh_max - a.dh_min) + 1;
@@ -144,61 +138,141 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs a) {
         }
         __syncthreads();
         const int nq = npad / KP;
-        for (int q = wpix; q < nq; q += WLP) {
-            const int2 e = s_tab[q * KP + lk];
+        // software pipeline: fragments of step q+WLP are fetched from LDS while step q's MFMAs issue
+        float av[TG], bv[TG];
+        {
+            const int p = wpix * KP + lk;
+            const int2 e = s_tab[p];
+            const bool pv = p < npix;
 #pragma unroll
             for (int t = 0; t < TG; ++t) {
-                if (t < ntap) {
-                    const float av = s_in[e.x + tin[t]];
-                    const float bv = s_do[e.y + tout[t]];
-                    if constexpr (MF == 32)
-                        acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[t], 0, 0, 0);
-                    else
-                        acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, acc[t], 0, 0, 0);
+                av[t] = s_in[e.x + tin[t]];
+                const float b = s_do[e.y + tout[t]];
+                bv[t] = pv ? b : 0.f;
+            }
+        }
+        for (int q = wpix; q < nq; q += WLP) {
+            float na[TG], nb[TG];
+            {
+                const int p = (q + WLP) * KP + lk;   // table is padded by one extra step
+                const int2 e = s_tab[p];
+                const bool pv = p < npix;
+#pragma unroll
+                for (int t = 0; t < TG; ++t) {
+                    na[t] = s_in[e.x + tin[t]];
+                    const float b = s_do[e.y + tout[t]];
+                    nb[t] = pv ? b : 0.f;
                 }
             }
+#pragma unroll
+            for (int t = 0; t < TG; ++t) {
+                if constexpr (MF == 32)
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[t], bv[t], acc[t], 0, 0, 0);
+                else
+                    acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[t], bv[t], acc[t], 0, 0, 0);
+            }
+#pragma unroll
+            for (int t = 0; t < TG; ++t) { av[t] = na[t]; bv[t] = nb[t]; }
         }
     }
 
-    // ---- write this workgroup's (wave's) partial slab
-    const int split_id = LAYOUT_A ? split : split * 4 + wave;
-    float* slab = a.slabs + (size_t)split_id * a.S * a.Cin * a.Cout;
+    // ---- write this workgroup's partial slab
+    float* slab = a.slabs + (size_t)split * a.S * a.Cin * a.Cout;
     const int co = cob0 + wco * 32 + lm;
+    if constexpr (LAYOUT_A) {
 #pragma unroll
-    for (int t = 0; t < TG; ++t) {
-        if (t < ntap) {
+        for (int t = 0; t < TG; ++t) {
             float* dst = slab + (size_t)G.widx[t] * a.Cin * a.Cout;
 #pragma unroll
             for (int i = 0; i < NACC; ++i) {
-                const int row = MF == 32 ? ((i & 3) + 8 * (i >> 2) + 4 * lk) : (lk * 4 + i);
-                const int ci = cib0 + wci * 32 + row;
+                const int ci = cib0 + wci * 32 + (i & 3) + 8 * (i >> 2) + 4 * lk;
                 if (ci < a.Cin && co < a.Cout) dst[(size_t)ci * a.Cout + co] = acc[t][i];
+            }
+        }
+    } else {
+        // the four waves walked disjoint pixels of the same (ci,co) block: combine them through LDS, one tap
+        // at a time; wave w then owns accumulator rows i == w (mod 4)
+        float* red = smem;  // [4][NACC][64]
+#pragma unroll
+        for (int t = 0; t < TG; ++t) {
+            __syncthreads();
+#pragma unroll
+            for (int i = 0; i < NACC; ++i) red[(wave * NACC + i) * 64 + lane] = acc[t][i];
+            __syncthreads();
+            float* dst = slab + (size_t)G.widx[t] * a.Cin * a.Cout;
+#pragma unroll
+            for (int ii = 0; ii < NACC / 4; ++ii) {
+                const int i = ii * 4 + wave;
+                const float v = red[(0 * NACC + i) * 64 + lane] + red[(1 * NACC + i) * 64 + lane] +
+                                red[(2 * NACC + i) * 64 + lane] + red[(3 * NACC + i) * 64 + lane];
+                const int row = MF == 32 ? ((i & 3) + 8 * (i >> 2) + 4 * lk) : (lk * 4 + i);
+                const int ci = cib0 + row;
+                if (ci < a.Cin && co < a.Cout) dst[(size_t)ci * a.Cout + co] = v;
             }
         }
     }
 }
 
-// grad[o][i][t] (+)= sum_split slabs[split][t][i][co_off + o]
-__global__ void wgrad_reduce_kernel(const float* __restrict__ slabs, float* __restrict__ grad, int n_splits, int S,
-                                    int Cin, int Cout, int O, int I, int co_off, int accumulate) {
+// Deterministic two-stage reduction of the per-split slabs.
+// stage 1: tmp[j][e] = sum over splits k == j (mod J) of slabs[k][e]        (J partial sums, wide parallelism)
+// stage 2: grad[o][i][t] (+)= sum_j tmp[j][(t*Cin+i)*Cout + co_off + o]
+__global__ __launch_bounds__(256) void wgrad_reduce1_kernel(const float* __restrict__ slabs, float* __restrict__ tmp,
+                                                            int n_splits, int J, int64_t E4) {
+    const int j = blockIdx.y;
+    const float4* src = reinterpret_cast<const float4*>(slabs);
+    float4* dst = reinterpret_cast<float4*>(tmp);
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < E4; e += (int64_t)gridDim.x * blockDim.x) {
+        float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll 4
+        for (int k = j; k < n_splits; k += J) {
+            const float4 v = src[(int64_t)k * E4 + e];
+            s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+        }
+        dst[(int64_t)j * E4 + e] = s;
+    }
+}
+
+__global__ __launch_bounds__(256) void wgrad_reduce2_kernel(const float* __restrict__ tmp, float* __restrict__ grad, int J,
+                                                            int64_t E, int S, int Cin, int Cout, int O, int I, int co_off,
+                                                            int accumulate) {
     const int64_t total = (int64_t)S * I * O;
-    const int64_t split_stride = (int64_t)S * Cin * Cout;
     for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
         const int o = (int)(e % O);
         const int64_t r = e / O;
         const int i = (int)(r % I), t = (int)(r / I);
-        const float* src = slabs + ((int64_t)t * Cin + i) * Cout + co_off + o;
+        const float* src = tmp + ((int64_t)t * Cin + i) * Cout + co_off + o;
         float s = 0.f;
-        for (int k = 0; k < n_splits; ++k) s += src[k * split_stride];
+        for (int k = 0; k < J; ++k) s += src[k * E];
         float* dst = grad + ((int64_t)o * I + i) * S + t;
         *dst = accumulate ? *dst + s : s;
     }
 }
 
+// stage 1 (once per slab set, when co_off == 0: callers reduce column ranges in increasing co_off order) + stage 2
+int launch_slab_reduce(const float* slabs, int n_splits, int64_t E, float* tmp, float* grad_oihw, int S, int Cin, int Cout,
+                       int O, int I, int co_off, int accumulate, hipStream_t s) {
+    RD_CHECK_ARG(E % 4 == 0, "slab_reduce: slab size must be a multiple of 4");
+    const int J = n_splits < 16 ? n_splits : 16;
+    const int64_t E4 = E / 4;
+    if (co_off == 0) {
+        int64_t g1 = cdiv64(E4, 256);
+        if (g1 > 2048) g1 = 2048;
+        hipLaunchKernelGGL(wgrad_reduce1_kernel, dim3((int)g1, J), dim3(256), 0, s, slabs, tmp, n_splits, J, E4);
+        RD_CHECK_LAUNCH("wgrad_reduce1_kernel");
+    }
+    const int64_t total = (int64_t)S * I * O;
+    int64_t g = cdiv64(total, 256);
+    if (g > 4096) g = 4096;
+    hipLaunchKernelGGL(wgrad_reduce2_kernel, dim3((int)g), dim3(256), 0, s, tmp, grad_oihw, J, E, S, Cin, Cout, O, I, co_off,
+                       accumulate);
+    RD_CHECK_LAUNCH("wgrad_reduce2_kernel");
+    return RD_OK;
+}
+
 struct WgradPlan {
     int TG, MF, layoutA;
     int TH, TW, tiles_h, tiles_w, total_tiles, tiles_per_split, n_splits, slab_splits;
-    int n_cib, n_cob, n_tg, S;
+    int n_cib, n_cob, n_tg, S, J;
     size_t lds;
 };
 
@@ -237,8 +311,8 @@ static int plan_wgrad(const RdConvDesc& d, WgradPlan& pl, WgradArgs* out) {
             if (TH * TW > WG_MAX_PIX) break;
             const int PH = (TH - 1) * d.in_stride + (dh_max - dh_min) + 1;
             const int PW = (TW - 1) * d.in_stride + (dw_max - dw_min) + 1;
-            const size_t lds = (size_t)2 * (WG_MAX_PIX + 8) * 4 + (size_t)PH * PW * CIB * 4 +
-                               ((size_t)TH * d.out_stride * TW * d.out_stride + 1) * COB * 4;
+            const size_t lds = (size_t)2 * (WG_MAX_PIX + 32) * 4 + (size_t)PH * PW * CIB * 4 +
+                               ((size_t)TH * d.out_stride * TW * d.out_stride) * COB * 4;
             if (lds > budget) break;
             const double useful = (double)P0.lh * P0.lw / ((double)cdiv(P0.lh, TH) * TH * cdiv(P0.lw, TW) * TW);
             const double halo = (double)PH * PW / ((double)TH * TW * d.in_stride * d.in_stride);
@@ -260,7 +334,8 @@ static int plan_wgrad(const RdConvDesc& d, WgradPlan& pl, WgradArgs* out) {
     if (want > pl.total_tiles) want = pl.total_tiles;
     pl.tiles_per_split = cdiv(pl.total_tiles, want);
     pl.n_splits = cdiv(pl.total_tiles, pl.tiles_per_split);
-    pl.slab_splits = pl.layoutA ? pl.n_splits : pl.n_splits * 4;
+    pl.slab_splits = pl.n_splits;
+    pl.J = pl.n_splits < 16 ? pl.n_splits : 16;
     if (out) {
         WgradArgs& a = *out;
         a.N = d.N; a.Hi = d.Hi; a.Wi = d.Wi; a.Cin = d.Cin; a.ldi = d.ldi;
@@ -307,7 +382,7 @@ extern "C" int64_t rd_wgrad_workspace_floats(const RdConvDesc* d) {
     if (!d) return RD_EINVAL;
     WgradPlan pl;
     if (plan_wgrad(*d, pl, nullptr) != RD_OK) return RD_EINVAL;
-    return (int64_t)pl.slab_splits * pl.S * d->Cin * d->Cout;
+    return (int64_t)(pl.slab_splits + pl.J) * pl.S * d->Cin * d->Cout;
 }
 
 extern "C" int rd_wgrad(const RdConvDesc* d, const float* in, const float* dout, float* slabs, void* stream) {
@@ -318,9 +393,9 @@ extern "C" int rd_wgrad(const RdConvDesc* d, const float* in, const float* dout,
     if (rc != RD_OK) return rc;
     a.in = in; a.dout = dout; a.slabs = slabs;
     hipStream_t s = static_cast<hipStream_t>(stream);
-    // slabs are written sparsely when a channel block is ragged or a split has no taps: clear first
-    const int64_t nfl = (int64_t)pl.slab_splits * pl.S * d->Cin * d->Cout;
-    RD_CHECK_HIP(hipMemsetAsync(slabs, 0, (size_t)nfl * sizeof(float), s));
+    for (int gi = 0; gi < pl.n_tg; ++gi) RD_CHECK_ARG(a.tg[gi].n == pl.TG, "wgrad: tap group %d has %d taps, expected %d", gi, a.tg[gi].n, pl.TG);
+    // layout-B epilogue reuses the head of LDS for its cross-wave reduction
+    if (!pl.layoutA && pl.lds < (size_t)4 * 16 * 64 * 4) pl.lds = (size_t)4 * 16 * 64 * 4;
     const int grid = pl.n_cib * pl.n_cob * pl.n_tg * pl.n_splits;
 #define RD_W(TG_, MF_, LA_) \
     if (pl.TG == TG_ && pl.MF == MF_ && (pl.layoutA != 0) == LA_) return launch_wgrad<TG_, MF_, LA_>(a, grid, pl.lds, s);
@@ -344,11 +419,8 @@ extern "C" int rd_wgrad_reduce(const RdConvDesc* d, const float* slabs, float* g
     int rc = plan_wgrad(*d, pl, nullptr);
     if (rc != RD_OK) return rc;
     RD_CHECK_ARG(KH * KW == pl.S && I == d->Cin && co_off + O <= d->Cout, "wgrad_reduce: shape mismatch");
-    const int64_t total = (int64_t)pl.S * I * O;
-    int64_t g = cdiv64(total, 256);
-    if (g > 4096) g = 4096;
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((int)g), dim3(256), 0, static_cast<hipStream_t>(stream), slabs, grad_oihw,
-                       pl.slab_splits, pl.S, d->Cin, d->Cout, O, I, co_off, accumulate);
-    RD_CHECK_LAUNCH("wgrad_reduce_kernel");
-    return RD_OK;
+    const int64_t E = (int64_t)pl.S * d->Cin * d->Cout;
+    float* tmp = const_cast<float*>(slabs) + (int64_t)pl.slab_splits * E;
+    return launch_slab_reduce(slabs, pl.slab_splits, E, tmp, grad_oihw, pl.S, d->Cin, d->Cout, O, I, co_off, accumulate,
+                              static_cast<hipStream_t>(stream));
 }

@@ -1,0 +1,470 @@
+"""Static execution plan of the late-fusion network on the HIP C ABI.
+
+A LateFusionPlan is built once per (module, batch, input size, train/eval): it allocates every activation /
+gradient / workspace buffer up front (addresses never change, so a whole step can be captured in a hipGraph)
+and records the forward and backward passes as flat lists of C-ABI calls.  Running a pass is a loop over
+prebuilt ctypes argument tuples; nothing is allocated and nothing synchronises.
+
+Layout in HBM: activations NHWC fp32 with a channel stride, so the RGB and depth encoders write straight into
+one 640-channel buffer (the torch.cat of model/models.py:652 costs nothing) and an UpProj module's two 5x5
+convolutions write one [N,2H,2W,C] buffer (upper | bottom halves).  Parameters stay OIHW torch tensors (the
+reference's state_dict contract); packed copies for the kernels are refreshed by rd_pack_weights each forward.
+
+What is saved for backward: every conv input, every raw conv output, BN (mean, invstd), the activated
+outputs (ReLU masks are re-derived from them) and the max-pool argmax bytes.
+
+Forward structure follows model/models.py:627-664 (ResNet_latefusion.forward); the training-mode BatchNorm,
+ReLU / LeakyReLU, residual joins and max-pool follow models.py:96-112,203-208,633-650.
+"""
+import ctypes as C
+
+import torch
+
+from . import convdesc as cd
+from ._lib import ACT_LEAKY02, ACT_NONE, ACT_RELU, check, lib
+
+BN_EPS = 1e-5
+BN_MOMENTUM = 0.1
+
+
+class Act:
+    """A channel slice [c0, c0+C) of an NHWC fp32 buffer t[N,H,W,ld]."""
+    __slots__ = ("t", "c0", "C")
+
+    def __init__(self, t, c0=0, C_=None):
+        self.t, self.c0 = t, c0
+        self.C = t.shape[3] - c0 if C_ is None else C_
+
+    @property
+    def N(self):
+        return self.t.shape[0]
+
+    @property
+    def H(self):
+        return self.t.shape[1]
+
+    @property
+    def W(self):
+        return self.t.shape[2]
+
+    @property
+    def ld(self):
+        return self.t.shape[3]
+
+    @property
+    def M(self):
+        return self.t.shape[0] * self.t.shape[1] * self.t.shape[2]
+
+    @property
+    def ptr(self):
+        return C.c_void_p(self.t.data_ptr() + 4 * self.c0)
+
+    def chan(self, c0, C_):
+        return Act(self.t, self.c0 + c0, C_)
+
+    def view(self):
+        return self.t[..., self.c0:self.c0 + self.C]
+
+
+def _p(t):
+    return C.c_void_p(0 if t is None else t.data_ptr())
+
+
+class LateFusionPlan:
+    def __init__(self, module, batch, height, width, train=True, depth_planes=None):
+        """module: a radar_depth_amd ResNet_latefusion(2); depth_planes: None (depth stem reads channel(s) 3.. of the
+        network input) or, for stage 2 of the multistage net, a list of stand-alone [N,H,W] maps."""
+        self.m = module
+        self.N, self.H, self.W = batch, height, width
+        self.train = train
+        self.dev = module.conv1.weight.device
+        assert self.dev.type == "cuda", "the HIP path needs the module on a GPU"
+        self.L = lib()
+        self.stream = C.c_void_p(0)
+        self.fwd, self.bwd = [], []
+        self.prep = []
+        self.taps = {}         # name -> Act of intermediate tensors (tests / debugging)
+        self.meta = {}         # op name -> (kernel family, descriptor) for the conv launches (bench roofline accounting)
+        self.keep = []         # keep ctypes descriptors and tensors alive
+        self.depth_planes = depth_planes
+        self.Ho, self.Wo = module.output_size
+        self._build()
+
+    # ------------------------------------------------------------------ small helpers
+    def buf(self, *shape, dtype=torch.float32):
+        t = torch.empty(shape, dtype=dtype, device=self.dev)
+        self.keep.append(t)
+        return t
+
+    def act(self, N, H, W, Cc):
+        return Act(self.buf(N, H, W, Cc))
+
+    def op(self, lst, name, fn, *args):
+        lst.append((name, fn, args))
+
+    def grad_of(self, param):
+        """fp32 gradient buffer of a parameter (the module's flat gradient arena view)."""
+        return self.m._grad_view(param)
+
+    # ------------------------------------------------------------------ convolution (gconv family)
+    def conv_fwd(self, name, x, weights, k, stride, pad, out=None, upproj=False, lst=None):
+        """weights: list of (param OIHW, column offset).  Returns (raw Act, ctx)."""
+        lst = self.fwd if lst is None else lst
+        N, H, W = x.N, x.H, x.W
+        cout = sum(w.shape[0] for w, _ in weights)
+        cin = x.C
+        if upproj:
+            d = cd.upproj_fwd(N, H, W, cin, cout, ldi=x.ld)
+        else:
+            d = cd.conv_fwd(N, H, W, cin, cout, k, stride, pad, ldi=x.ld)
+        if out is None:
+            out = self.act(N, d.Ho, d.Wo, cout)
+        d.ldo = out.ld
+        S = k * k
+        wp = self.buf(S, cin, cout)
+        wd = self.buf(S, cout, cin)
+        for w, off in weights:
+            o, i, kh, kw = w.shape
+            self.op(self.prep, name + ".pack", self.L.rd_pack_weights, _p(w), _p(wp), o, i, kh, kw, cout, off, i, 0, self.stream)
+            self.op(self.prep, name + ".packT", self.L.rd_pack_weights, _p(w), _p(wd), o, i, kh, kw, cin, off, cout, 1, self.stream)
+        tiles = self.L.rd_gconv_stat_tiles(C.byref(d))
+        if tiles < 0:
+            check(tiles, "rd_gconv_stat_tiles(%s)" % name)
+        stat = self.buf(tiles, 2, cout) if self.train else None
+        self.keep.append(d)
+        self.op(lst, name, self.L.rd_gconv, C.byref(d), x.ptr, _p(wp), out.ptr, C.c_void_p(0), 0, _p(stat), self.stream)
+        self.taps[name] = out
+        self.meta[name] = ("gconv", d)
+        ctx = dict(name=name, d=d, x=x, out=out, weights=weights, wd=wd, k=k, stride=stride, pad=pad, upproj=upproj,
+                   stat=stat, tiles=tiles, cin=cin, cout=cout)
+        return out, ctx
+
+    def conv_bwd(self, ctx, dout, need_dx=True, addend=None, dx=None):
+        """Appends wgrad (+ reduce into the parameters' gradient views) and, optionally, dgrad.  Returns dx Act."""
+        name, d, x = ctx["name"], ctx["d"], ctx["x"]
+        N, H, W, cin, cout, k = x.N, x.H, x.W, ctx["cin"], ctx["cout"], ctx["k"]
+        # wgrad uses the forward descriptor with dout's stride
+        dwd = type(d)()
+        C.memmove(C.byref(dwd), C.byref(d), C.sizeof(d))
+        dwd.ldo = dout.ld
+        self.keep.append(dwd)
+        nws = self.L.rd_wgrad_workspace_floats(C.byref(dwd))
+        if nws < 0:
+            check(int(nws), "rd_wgrad_workspace_floats(%s)" % name)
+        ws = self.buf(int(nws))
+        self.op(self.bwd, name + ".wgrad", self.L.rd_wgrad, C.byref(dwd), x.ptr, dout.ptr, _p(ws), self.stream)
+        self.meta[name + ".wgrad"] = ("wgrad", dwd)
+        for w, off in sorted(ctx["weights"], key=lambda t: t[1]):
+            o, i, kh, kw = w.shape
+            self.op(self.bwd, name + ".wreduce", self.L.rd_wgrad_reduce, C.byref(dwd), _p(ws), _p(self.grad_of(w)), o, i, kh, kw,
+                    off, 0, self.stream)
+        if not need_dx:
+            return None
+        if dx is None:
+            dx = self.act(N, H, W, cin)
+        if ctx["upproj"]:
+            dd, zero_fill = cd.upproj_dgrad(N, H, W, cin, cout, ld_dy=dout.ld, ld_dx=dx.ld), False
+        else:
+            dd, zero_fill = cd.conv_dgrad(N, H, W, cin, cout, k, ctx["stride"], ctx["pad"], ld_dy=dout.ld, ld_dx=dx.ld)
+        self.keep.append(dd)
+        if zero_fill:
+            assert dx.C == dx.ld, "zero-filled dgrad target must be a whole buffer"
+            self.op(self.bwd, name + ".zero", self.L.rd_fill, dx.ptr, C.c_int64(dx.t.numel()), C.c_float(0.0), self.stream)
+            if addend is not None:
+                raise NotImplementedError("addend with a zero-filled stride-2 dgrad")
+        self.meta[name + ".dgrad"] = ("gconv", dd)
+        self.op(self.bwd, name + ".dgrad", self.L.rd_gconv, C.byref(dd), dout.ptr, _p(ctx["wd"]), dx.ptr,
+                addend.ptr if addend is not None else C.c_void_p(0), addend.ld if addend is not None else 0,
+                C.c_void_p(0), self.stream)
+        return dx
+
+    # ------------------------------------------------------------------ batch norm
+    def bn_coeffs(self, name, bn, stat, tiles, ld, c0, count, lst=None):
+        """Per-channel (mean, invstd, scale, shift) of a BatchNorm2d over channels [c0, c0+C) of fused stats."""
+        lst = self.fwd if lst is None else lst
+        Cc = bn.weight.shape[0]
+        co = dict(name=name, bn=bn, C=Cc, count=count, mean=self.buf(Cc), invstd=self.buf(Cc), scale=self.buf(Cc), shift=self.buf(Cc))
+        if self.train:
+            self.op(lst, name + ".finalize", self.L.rd_bn_finalize, _p(stat), tiles, ld, c0, Cc, C.c_int64(count), _p(bn.weight),
+                    _p(bn.bias), C.c_float(BN_EPS), C.c_float(BN_MOMENTUM), _p(bn.running_mean), _p(bn.running_var),
+                    _p(bn.num_batches_tracked), _p(co["mean"]), _p(co["invstd"]), _p(co["scale"]), _p(co["shift"]), self.stream)
+        else:
+            self.op(lst, name + ".evalcoef", self.L.rd_bn_eval_coeffs, Cc, _p(bn.weight), _p(bn.bias), _p(bn.running_mean),
+                    _p(bn.running_var), C.c_float(BN_EPS), _p(co["scale"]), _p(co["shift"]), self.stream)
+        return co
+
+    def bn_act(self, name, x1, co1, act, x2=None, co2=None, out=None):
+        """out = act(bn1(x1) [+ bn2(x2) | + x2])."""
+        if out is None:
+            out = self.act(x1.N, x1.H, x1.W, x1.C)
+        self.op(self.fwd, name, self.L.rd_bn_act, x1.ptr, x1.ld, _p(co1["scale"]), _p(co1["shift"]),
+                x2.ptr if x2 is not None else C.c_void_p(0), x2.ld if x2 is not None else 0,
+                _p(co2["scale"]) if co2 is not None else C.c_void_p(0), _p(co2["shift"]) if co2 is not None else C.c_void_p(0),
+                out.ptr, out.ld, C.c_int64(x1.M), x1.C, act, self.stream)
+        self.taps[name] = out
+        return out
+
+    def bn_join_bwd(self, name, dy, y, act, x1, co1, x2=None, co2=None, dx2=None):
+        """Backward of out = act(bn1(x1) [+ bn2(x2) | + x2]).  Returns (dx1, dx2 or g-if-identity-residual)."""
+        M, Cc = x1.M, x1.C
+        tiles = self.L.rd_bn_bwd_tiles(C.c_int64(M))
+        red = self.buf(tiles, 3, Cc)
+        # with no activation g == dy: skip the copy and let the apply pass read dy directly
+        g = self.act(x1.N, x1.H, x1.W, Cc) if act != ACT_NONE else dy
+        self.op(self.bwd, name + ".bwd_reduce", self.L.rd_bn_bwd_reduce, dy.ptr, dy.ld, y.ptr if y is not None else C.c_void_p(0),
+                y.ld if y is not None else 0, x1.ptr, x1.ld, _p(co1["mean"]),
+                x2.ptr if co2 is not None else C.c_void_p(0), x2.ld if co2 is not None else 0,
+                _p(co2["mean"]) if co2 is not None else C.c_void_p(0), g.ptr if act != ACT_NONE else C.c_void_p(0), g.ld,
+                C.c_int64(M), Cc, act, _p(red), self.stream)
+        dx1 = self.act(x1.N, x1.H, x1.W, Cc)
+        self._bn_apply(name + ".bn1", g, x1, red, tiles, 1, co1, dx1)
+        if co2 is not None:
+            if dx2 is None:
+                dx2 = self.act(x2.N, x2.H, x2.W, Cc)
+            self._bn_apply(name + ".bn2", g, x2, red, tiles, 2, co2, dx2)
+            return dx1, dx2
+        return dx1, g
+
+    def _bn_apply(self, name, g, x, red, tiles, which, co, dx):
+        bn = co["bn"]
+        coef = self.buf(3 * co["C"])
+        self.op(self.bwd, name + ".bwd_apply", self.L.rd_bn_bwd_apply, g.ptr, g.ld, x.ptr, x.ld, _p(red), tiles, which,
+                _p(bn.weight), _p(co["mean"]), _p(co["invstd"]), _p(self.grad_of(bn.weight)), _p(self.grad_of(bn.bias)),
+                _p(coef), dx.ptr, dx.ld, C.c_int64(x.M), co["C"], self.stream)
+
+    # ------------------------------------------------------------------ network pieces
+    def _stem(self, name, planes, strides, conv, bn, act, out_name):
+        """7x7/2 conv straight from input planes -> BN -> act -> maxpool(3,2,1)."""
+        N, H, W = self.N, self.H, self.W
+        cin, cout = conv.weight.shape[1], conv.weight.shape[0]
+        Hc, Wc = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+        raw = self.act(N, Hc, Wc, cout)
+        wp = self.buf(49, cin, cout)
+        self.op(self.prep, name + ".pack", self.L.rd_pack_weights, _p(conv.weight), _p(wp), cout, cin, 7, 7, cout, 0, cin, 0, self.stream)
+        tiles = self.L.rd_stem_stat_tiles(N, H, W)
+        stat = self.buf(tiles, 2, cout) if self.train else None
+        pl = (C.c_void_p * 3)(*([p for p in planes] + [None] * (3 - len(planes))))
+        st = (C.c_int64 * 3)(*(list(strides) + [0] * (3 - len(strides))))
+        self.keep += [pl, st]
+        self.op(self.fwd, name, self.L.rd_stem_fwd, pl, st, cin, N, H, W, _p(wp), cout, raw.ptr, _p(stat), self.stream)
+        co = self.bn_coeffs(name + ".bn", bn, stat, tiles, cout, 0, N * Hc * Wc)
+        Hp, Wp = (Hc - 1) // 2 + 1, (Wc - 1) // 2 + 1
+        pooled = self.act(N, Hp, Wp, cout)
+        idx = self.buf(N, Hp, Wp, cout, dtype=torch.uint8)
+        self.op(self.fwd, name + ".bnact_pool", self.L.rd_bnact_maxpool_fwd, raw.ptr, _p(co["scale"]), _p(co["shift"]), act, N, Hc, Wc,
+                cout, pooled.ptr, pooled.ld, _p(idx), self.stream)
+        self.taps[out_name] = pooled
+        return pooled, dict(name=name, pl=pl, st=st, cin=cin, cout=cout, raw=raw, wp=wp, co=co, idx=idx, act=act, conv=conv,
+                            pooled=pooled, Hc=Hc, Wc=Wc)
+
+    def _stem_bwd(self, ctx, dpooled, dgrad_channel=None):
+        N, H, W = self.N, self.H, self.W
+        raw, co, cout, cin = ctx["raw"], ctx["co"], ctx["cout"], ctx["cin"]
+        g = self.act(N, ctx["Hc"], ctx["Wc"], cout)
+        self.op(self.bwd, ctx["name"] + ".pool_bwd", self.L.rd_bnact_maxpool_bwd, dpooled.ptr, dpooled.ld, _p(ctx["idx"]), raw.ptr,
+                _p(co["scale"]), _p(co["shift"]), ctx["act"], N, ctx["Hc"], ctx["Wc"], cout, g.ptr, self.stream)
+        # BN backward on g (activation derivative already applied by the pooling gather)
+        dx, _ = self.bn_join_bwd(ctx["name"] + ".bn", g, None, ACT_NONE, raw, co)
+        nws = self.L.rd_stem_wgrad_workspace_floats(N, H, W, cin, cout)
+        ws = self.buf(int(nws))
+        self.op(self.bwd, ctx["name"] + ".wgrad", self.L.rd_stem_wgrad, ctx["pl"], ctx["st"], cin, N, H, W, dx.ptr, cout,
+                _p(self.grad_of(ctx["conv"].weight)), _p(ws), self.stream)
+        if dgrad_channel is not None:
+            ci, dst = dgrad_channel
+            self.op(self.bwd, ctx["name"] + ".dgrad_ch", self.L.rd_stem_dgrad_channel, dx.ptr, _p(ctx["wp"]), N, H, W, cin, ci, cout,
+                    _p(dst), self.stream)
+
+    def _block(self, name, blk, x, out=None):
+        """BasicBlock forward (models.py:96-112)."""
+        stride = blk.stride
+        r1, c1 = self.conv_fwd(name + ".conv1", x, [(blk.conv1.weight, 0)], 3, stride, 1)
+        co1 = self.bn_coeffs(name + ".bn1", blk.bn1, c1["stat"], c1["tiles"], r1.C, 0, r1.M)
+        y1 = self.bn_act(name + ".relu1", r1, co1, ACT_RELU)
+        r2, c2 = self.conv_fwd(name + ".conv2", y1, [(blk.conv2.weight, 0)], 3, 1, 1)
+        co2 = self.bn_coeffs(name + ".bn2", blk.bn2, c2["stat"], c2["tiles"], r2.C, 0, r2.M)
+        ctx = dict(name=name, x=x, r1=r1, c1=c1, co1=co1, y1=y1, r2=r2, c2=c2, co2=co2, ds=None)
+        if blk.downsample is not None:
+            rd_, cds = self.conv_fwd(name + ".downsample.0", x, [(blk.downsample[0].weight, 0)], 1, stride, 0)
+            cods = self.bn_coeffs(name + ".downsample.1", blk.downsample[1], cds["stat"], cds["tiles"], rd_.C, 0, rd_.M)
+            y = self.bn_act(name, r2, co2, ACT_RELU, x2=rd_, co2=cods, out=out)
+            ctx.update(ds=dict(rd=rd_, c=cds, co=cods))
+        else:
+            y = self.bn_act(name, r2, co2, ACT_RELU, x2=x, out=out)
+        ctx["y"] = y
+        return y, ctx
+
+    def _block_bwd(self, ctx, dy):
+        """Returns the gradient w.r.t. the block input."""
+        name = ctx["name"]
+        if ctx["ds"] is not None:
+            ds = ctx["ds"]
+            dr2, drd = self.bn_join_bwd(name, dy, ctx["y"], ACT_RELU, ctx["r2"], ctx["co2"], x2=ds["rd"], co2=ds["co"])
+        else:
+            dr2, g = self.bn_join_bwd(name, dy, ctx["y"], ACT_RELU, ctx["r2"], ctx["co2"])
+        dy1 = self.conv_bwd(ctx["c2"], dr2)
+        dr1, _ = self.bn_join_bwd(name + ".relu1", dy1, ctx["y1"], ACT_RELU, ctx["r1"], ctx["co1"])
+        self.taps["grad_out:" + name] = dy
+        if ctx["ds"] is not None:
+            dx_part = self.conv_bwd(ctx["ds"]["c"], drd)          # 1x1 stride-2 dgrad (zero-filled odd pixels)
+            dx = self.conv_bwd(ctx["c1"], dr1, addend=dx_part)
+        else:
+            dx = self.conv_bwd(ctx["c1"], dr1, addend=g)
+        self.taps["grad_in:" + name] = dx
+        return dx
+
+    def _upproj(self, name, mod, x):
+        """UpProjModule forward (models.py:181-209) with the unpool folded into a 4-phase convolution."""
+        Cc = x.C
+        half = Cc // 2
+        ub, bb = mod.upper_branch, mod.bottom_branch
+        R, cR = self.conv_fwd(name + ".conv5x5", x, [(ub.conv1.weight, 0), (bb.conv.weight, half)], 5, 1, 2, upproj=True)
+        M = R.M
+        co_u1 = self.bn_coeffs(name + ".upper_branch.batchnorm1", ub.batchnorm1, cR["stat"], cR["tiles"], Cc, 0, M)
+        co_b = self.bn_coeffs(name + ".bottom_branch.batchnorm", bb.batchnorm, cR["stat"], cR["tiles"], Cc, half, M)
+        y1 = self.bn_act(name + ".upper_branch.relu", R.chan(0, half), co_u1, ACT_RELU)
+        r2, c2 = self.conv_fwd(name + ".upper_branch.conv2", y1, [(ub.conv2.weight, 0)], 3, 1, 1)
+        co_u2 = self.bn_coeffs(name + ".upper_branch.batchnorm2", ub.batchnorm2, c2["stat"], c2["tiles"], half, 0, M)
+        y = self.bn_act(name, r2, co_u2, ACT_RELU, x2=R.chan(half, half), co2=co_b)
+        return y, dict(name=name, x=x, R=R, cR=cR, co_u1=co_u1, co_b=co_b, y1=y1, r2=r2, c2=c2, co_u2=co_u2, y=y, half=half)
+
+    def _upproj_bwd(self, ctx, dy):
+        name, half, R = ctx["name"], ctx["half"], ctx["R"]
+        dR = self.act(R.N, R.H, R.W, R.C)
+        dr2, _ = self.bn_join_bwd(name, dy, ctx["y"], ACT_RELU, ctx["r2"], ctx["co_u2"], x2=R.chan(half, half), co2=ctx["co_b"],
+                                  dx2=dR.chan(half, half))
+        dy1 = self.conv_bwd(ctx["c2"], dr2)
+        M, tiles = R.M, self.L.rd_bn_bwd_tiles(C.c_int64(R.M))
+        red = self.buf(tiles, 3, half)
+        g = self.act(R.N, R.H, R.W, half)
+        y1, x1, co = ctx["y1"], R.chan(0, half), ctx["co_u1"]
+        self.op(self.bwd, name + ".bn1.bwd_reduce", self.L.rd_bn_bwd_reduce, dy1.ptr, dy1.ld, y1.ptr, y1.ld, x1.ptr, x1.ld,
+                _p(co["mean"]), C.c_void_p(0), 0, C.c_void_p(0), g.ptr, g.ld, C.c_int64(M), half, ACT_RELU, _p(red), self.stream)
+        self._bn_apply(name + ".bn1", g, x1, red, tiles, 1, co, dR.chan(0, half))
+        dx = self.conv_bwd(ctx["cR"], dR)
+        self.taps["grad_out:" + name] = dy
+        self.taps["grad_in:" + name] = dx
+        self.taps["grad_R:" + name] = dR
+        self.taps["grad_y1:" + name] = dy1
+        return dx
+
+    # ------------------------------------------------------------------ whole network
+    def _build(self):
+        m, N, H, W = self.m, self.N, self.H, self.W
+        hw = H * W
+        ndep_in = m.conv1_depth.weight.shape[1]
+        self.x_in = self.buf(N, 3 + (ndep_in if self.depth_planes is None else 1), H, W)
+        ctot = self.x_in.shape[1]
+        xp = self.x_in.data_ptr()
+        rgb_planes = [xp + 4 * hw * c for c in range(3)]
+        rgb_strides = [ctot * hw] * 3
+        if self.depth_planes is None:
+            ndep = m.conv1_depth.weight.shape[1]
+            dep_planes = [xp + 4 * hw * (3 + c) for c in range(ndep)]
+            dep_strides = [ctot * hw] * ndep
+        else:
+            dep_planes = [t.data_ptr() for t in self.depth_planes]
+            dep_strides = [hw] * len(dep_planes)
+        # encoders
+        a, self.c_stem_rgb = self._stem("conv1", rgb_planes, rgb_strides, m.conv1, m.bn1, ACT_RELU, "maxpool")
+        d_, self.c_stem_d = self._stem("conv1_depth", dep_planes, dep_strides, m.conv1_depth, m.bn1_depth, ACT_LEAKY02, "maxpool_depth")
+        self.blocks_rgb, self.blocks_d = [], []
+        layers_rgb = [("layer1", m.layer1), ("layer2", m.layer2), ("layer3", m.layer3), ("layer4", m.layer4)]
+        layers_d = [("layer1_depth", m.layer1_depth), ("layer2_depth", m.layer2_depth), ("layer3_depth", m.layer3_depth),
+                    ("layer4_depth", m.layer4_depth)]
+        # size of the fused 640-channel buffer: spatial size after three stride-2 blocks
+        hh, ww = a.H, a.W
+        for _ in range(3):
+            hh, ww = (hh - 1) // 2 + 1, (ww - 1) // 2 + 1
+        c_rgb = m.layer4[1].conv2.weight.shape[0]
+        c_dep = m.layer4_depth[1].conv2.weight.shape[0]
+        self.cat = self.act(N, hh, ww, c_rgb + c_dep)
+        x = a
+        for li, (lname, layer) in enumerate(layers_rgb):
+            for bi, blk in enumerate(layer):
+                last = li == 3 and bi == len(layer) - 1
+                x, ctx = self._block("%s.%d" % (lname, bi), blk, x, out=self.cat.chan(0, c_rgb) if last else None)
+                self.blocks_rgb.append(ctx)
+        x = d_
+        for li, (lname, layer) in enumerate(layers_d):
+            for bi, blk in enumerate(layer):
+                last = li == 3 and bi == len(layer) - 1
+                x, ctx = self._block("%s.%d" % (lname, bi), blk, x, out=self.cat.chan(c_rgb, c_dep) if last else None)
+                self.blocks_d.append(ctx)
+        # fusion 1x1 convs (no activation, models.py:652-657)
+        rf, self.c_fus = self.conv_fwd("conv_fusion", self.cat, [(m.conv_fusion.weight, 0)], 1, 1, 0)
+        self.co_fus = self.bn_coeffs("bn_fusion", m.bn_fusion, self.c_fus["stat"], self.c_fus["tiles"], rf.C, 0, rf.M)
+        self.yf = self.bn_act("bn_fusion", rf, self.co_fus, ACT_NONE)
+        r2, self.c_c2 = self.conv_fwd("conv2", self.yf, [(m.conv2.weight, 0)], 1, 1, 0)
+        self.co_c2 = self.bn_coeffs("bn2", m.bn2, self.c_c2["stat"], self.c_c2["tiles"], r2.C, 0, r2.M)
+        z = self.bn_act("bn2", r2, self.co_c2, ACT_NONE)
+        self.rf, self.r2 = rf, r2
+        # decoder
+        self.ups = []
+        for i, mod in enumerate((m.decoder.layer1, m.decoder.layer2, m.decoder.layer3, m.decoder.layer4), 1):
+            z, ctx = self._upproj("decoder.layer%d" % i, mod, z)
+            self.ups.append(ctx)
+        # head
+        self.z = z
+        self.dmap = self.buf(N, z.H, z.W)
+        self.op(self.fwd, "conv3", self.L.rd_head_conv_fwd, z.ptr, z.ld, _p(m.conv3.weight), N, z.H, z.W, z.C, _p(self.dmap), self.stream)
+        self.pred = self.buf(N, 1, self.Ho, self.Wo)
+        self.op(self.fwd, "bilinear", self.L.rd_bilinear_fwd, _p(self.dmap), N, z.H, z.W, _p(self.pred), self.Ho, self.Wo, self.stream)
+        if self.train:
+            self._build_backward()
+
+    def _build_backward(self):
+        m, N = self.m, self.N
+        z = self.z
+        self.dpred = self.buf(N, 1, self.Ho, self.Wo)
+        self.dx_dense = None
+        ddm = self.buf(N, z.H, z.W)
+        self.op(self.bwd, "bilinear.bwd", self.L.rd_bilinear_bwd, _p(self.dpred), N, self.Ho, self.Wo, _p(ddm), z.H, z.W, self.stream)
+        dz = self.act(N, z.H, z.W, z.C)
+        ws = self.buf(int(self.L.rd_head_conv_bwd_workspace_floats(N, z.H, z.W, z.C)))
+        self.op(self.bwd, "conv3.bwd", self.L.rd_head_conv_bwd, z.ptr, z.ld, _p(m.conv3.weight), _p(ddm), N, z.H, z.W, z.C, dz.ptr, dz.ld,
+                _p(self.grad_of(m.conv3.weight)), _p(ws), self.stream)
+        for ctx in reversed(self.ups):
+            dz = self._upproj_bwd(ctx, dz)
+        dr2, _ = self.bn_join_bwd("bn2", dz, None, ACT_NONE, self.r2, self.co_c2)
+        dyf = self.conv_bwd(self.c_c2, dr2)
+        drf, _ = self.bn_join_bwd("bn_fusion", dyf, None, ACT_NONE, self.rf, self.co_fus)
+        dcat = self.act(N, self.cat.H, self.cat.W, self.cat.C)
+        self.conv_bwd(self.c_fus, drf, dx=dcat)
+        c_rgb = self.blocks_rgb[-1]["y"].C
+        g = dcat.chan(0, c_rgb)
+        for ctx in reversed(self.blocks_rgb):
+            g = self._block_bwd(ctx, g)
+        self._stem_bwd(self.c_stem_rgb, g)
+        g = dcat.chan(c_rgb, dcat.C - c_rgb)
+        for ctx in reversed(self.blocks_d):
+            g = self._block_bwd(ctx, g)
+        dense = None
+        if self.depth_planes is not None and len(self.depth_planes) == 2:
+            self.dx_dense = self.buf(N, self.H, self.W)
+            dense = (1, self.dx_dense)
+        self._stem_bwd(self.c_stem_d, g, dgrad_channel=dense)
+
+    # ------------------------------------------------------------------ execution
+    def _run(self, ops):
+        for name, fn, args in ops:
+            rc = fn(*args)
+            if rc != 0:
+                check(rc, name)
+
+    def set_stream(self):
+        self.stream.value = torch.cuda.current_stream().cuda_stream
+
+    def run_forward(self, x=None):
+        """x: [N,>=4,H,W] fp32 CUDA tensor (copied into the plan's static input buffer) or None if already there."""
+        self.set_stream()
+        if x is not None:
+            self.x_in.copy_(x[:, :self.x_in.shape[1]])
+        self._run(self.prep)
+        self._run(self.fwd)
+        return self.pred
+
+    def run_backward(self, dpred=None):
+        self.set_stream()
+        if dpred is not None:
+            self.dpred.copy_(dpred)
+        self._run(self.bwd)

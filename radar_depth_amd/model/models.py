@@ -1,0 +1,292 @@
+"""MI355X-native counterpart of the reference's model/models.py (hot-path subset).
+
+Same public surface -- Unpool, weights_init*, BasicBlock, Decoder, UpProj, choose_decoder,
+ResNet_latefusion with the reference's constructor signatures, attribute names and state_dict keys
+(/root/reference/model/models.py:13-27,30-72,75-133,178-230,519-664) -- but the arithmetic runs in
+hand-written HIP kernels through the C ABI (include/radar_depth_hip.h):
+
+  * the child nn.Conv2d / nn.BatchNorm2d objects are parameter containers (OIHW weights, BN affine and
+    running statistics) so that checkpoints, `weights_init`-style initialisers and optimizers see exactly
+    the reference's tensors;
+  * `ResNet_latefusion.forward` runs a static plan (radar_depth_amd/engine.py) of HIP kernels and is
+    differentiable through torch.autograd (`loss.backward()` fills `.grad` of every parameter);
+  * there is NO CPU / PyTorch fallback: calling forward on a CPU tensor or without the built library raises.
+
+Out of scope here (other --arch/--decoder choices of the reference): ResNet, ResNet_pnp, ResNet2,
+ResNet_multifusion, DeConv, UpConv; `choose_decoder` rejects them.
+"""
+import math
+import os
+import weakref
+from collections import OrderedDict
+
+import torch
+import torch.nn as nn
+
+_DEPTHS = (18, 34, 50, 101, 152)
+
+
+def _conv(cin, cout, k, stride=1, pad=None):
+    return nn.Conv2d(cin, cout, kernel_size=k, stride=stride, padding=(k // 2 if pad is None else pad), bias=False)
+
+
+class _PlanOnly(nn.Module):
+    """Container whose arithmetic is executed by the parent network's HIP plan."""
+
+    def forward(self, *args, **kwargs):
+        raise RuntimeError("%s is a parameter container: its arithmetic runs inside the parent network's HIP plan "
+                           "(call the ResNet_latefusion / ResNet_multistage module)" % type(self).__name__)
+
+
+class Unpool(_PlanOnly):
+    """Zero-stuffing x2 upsample (models.py:13-27).  Holds no tensor: the HIP path folds it into the following
+    5x5 convolution (four-phase zero-skipping form), so there is nothing to move with .cuda()/.to()."""
+
+    def __init__(self, num_channels, stride=2):
+        super().__init__()
+        self.num_channels, self.stride = num_channels, stride
+
+
+def weights_init(m):
+    if isinstance(m, nn.Conv2d):
+        fan = m.kernel_size[0] * m.kernel_size[1] * m.out_channels
+        m.weight.data.normal_(0, math.sqrt(2.0 / fan))
+        if m.bias is not None:
+            m.bias.data.zero_()
+    elif isinstance(m, nn.BatchNorm2d):
+        m.weight.data.fill_(1)
+        m.bias.data.zero_()
+
+
+def _kaiming(m, nonlin):
+    if isinstance(m, nn.Conv2d):
+        nn.init.kaiming_normal_(m.weight, mode="fan_out", nonlinearity=nonlin)
+        if m.bias is not None:
+            m.bias.data.zero_()
+    elif isinstance(m, (nn.BatchNorm2d, nn.GroupNorm)):
+        nn.init.constant_(m.weight, 1)
+        nn.init.constant_(m.bias, 0)
+
+
+def weights_init_kaiming(m):
+    _kaiming(m, "relu")
+
+
+def weights_init_kaiming_leaky(m):
+    _kaiming(m, "leaky_relu")
+
+
+class BasicBlock(_PlanOnly):
+    expansion = 1
+
+    def __init__(self, inplanes, planes, stride=1, downsample=None, groups=1, base_width=64, dilation=1, norm_layer=None):
+        super().__init__()
+        if dilation > 1:
+            raise NotImplementedError("Dilation > 1 not supported in BasicBlock")
+        self.conv1 = _conv(inplanes, planes, 3, stride)
+        self.bn1 = nn.BatchNorm2d(planes)
+        self.relu = nn.ReLU(inplace=True)
+        self.conv2 = _conv(planes, planes, 3)
+        self.bn2 = nn.BatchNorm2d(planes)
+        self.downsample = downsample
+        self.stride = stride
+
+
+def _make_layer(inplanes, planes, blocks, stride, init=None):
+    down = None
+    if stride != 1 or inplanes != planes:
+        down = nn.Sequential(_conv(inplanes, planes, 1, stride, pad=0), nn.BatchNorm2d(planes))
+    seq = nn.Sequential(BasicBlock(inplanes, planes, stride, down), *[BasicBlock(planes, planes) for _ in range(1, blocks)])
+    if init is not None:
+        for mod in seq.modules():
+            init(mod)
+    return seq
+
+
+class Decoder(_PlanOnly):
+    names = ["deconv2", "deconv3", "upconv", "upproj"]
+
+    def __init__(self):
+        super().__init__()
+        self.layer1 = self.layer2 = self.layer3 = self.layer4 = None
+
+
+class UpProj(Decoder):
+    class UpProjModule(_PlanOnly):
+        def __init__(self, in_channels):
+            super().__init__()
+            half = in_channels // 2
+            self.unpool = Unpool(in_channels)
+            self.upper_branch = nn.Sequential(OrderedDict([
+                ("conv1", _conv(in_channels, half, 5)),
+                ("batchnorm1", nn.BatchNorm2d(half)),
+                ("relu", nn.ReLU()),
+                ("conv2", _conv(half, half, 3)),
+                ("batchnorm2", nn.BatchNorm2d(half)),
+            ]))
+            self.bottom_branch = nn.Sequential(OrderedDict([
+                ("conv", _conv(in_channels, half, 5)),
+                ("batchnorm", nn.BatchNorm2d(half)),
+            ]))
+            self.relu = nn.ReLU()
+
+    def __init__(self, in_channels):
+        super().__init__()
+        self.layer1 = self.UpProjModule(in_channels)
+        self.layer2 = self.UpProjModule(in_channels // 2)
+        self.layer3 = self.UpProjModule(in_channels // 4)
+        self.layer4 = self.UpProjModule(in_channels // 8)
+
+
+def choose_decoder(decoder, in_channels):
+    if decoder == "upproj":
+        return UpProj(in_channels)
+    assert False, "invalid option for decoder: {}".format(decoder)
+
+
+# ------------------------------------------------------------------------------------------------
+class ArenaOwner:
+    """Mixin: keeps every parameter of the (top-level) network in one flat fp32 arena, with matching flat
+    gradient and momentum arenas.  Parameters remain ordinary nn.Parameters (views into the arena), so
+    state_dict / load_state_dict / external optimizers work unchanged, while the HIP SGD kernel and the RCCL
+    gradient all-reduce see one contiguous buffer each."""
+
+    def _arena_root(self):
+        ref = getattr(self, "_arena_owner_ref", None)
+        owner = ref() if ref is not None else None
+        return owner._arena_root() if owner is not None else self
+
+    def _ensure_arenas(self):
+        root = self._arena_root()
+        params = [p for _, p in root.named_parameters()]
+        st = root.__dict__.get("_arena_state")
+        if st is not None and len(st["ptrs"]) == len(params) and all(p.data_ptr() == q for p, q in zip(params, st["ptrs"])):
+            return st
+        dev = params[0].device
+        offs, total = [], 0
+        for p in params:
+            offs.append(total)
+            total += (p.numel() + 3) // 4 * 4           # 16-byte aligned slots
+        arena = torch.zeros(total, dtype=torch.float32, device=dev)
+        grads = torch.zeros(total, dtype=torch.float32, device=dev)
+        mom = torch.zeros(total, dtype=torch.float32, device=dev)
+        gviews = {}
+        for p, off in zip(params, offs):
+            v = arena[off:off + p.numel()].view(p.shape)
+            v.copy_(p.data)
+            p.data = v
+            gviews[id(p)] = grads[off:off + p.numel()].view(p.shape)
+        st = dict(arena=arena, grads=grads, mom=mom, gviews=gviews, ptrs=[p.data_ptr() for p in params], params=params,
+                  version=(root.__dict__.get("_arena_state") or {}).get("version", 0) + 1, total=total)
+        root.__dict__["_arena_state"] = st
+        return st
+
+    def _grad_view(self, param):
+        return self._arena_root()._ensure_arenas()["gviews"][id(param)]
+
+
+class ResNet_latefusion(ArenaOwner, nn.Module):
+    def __init__(self, layers, decoder, output_size, in_channels=4, pretrained=True):
+        if layers not in _DEPTHS:
+            raise RuntimeError("Only 18, 34, 50, 101, and 152 layer model are defined for ResNet. Got {}".format(layers))
+        super().__init__()
+        if layers != 18:
+            raise NotImplementedError("the MI355X hot path covers the resnet18 variants (layers=18)")
+        assert in_channels > 3
+        self.in_channels = in_channels
+        self._norm_layer = nn.BatchNorm2d
+        self.output_size = output_size
+
+        self.conv1 = _conv(3, 64, 7, 2)
+        self.bn1 = nn.BatchNorm2d(64)
+        weights_init(self.conv1)
+        weights_init(self.bn1)
+        self.relu = nn.ReLU(inplace=True)
+        self.maxpool = nn.MaxPool2d(kernel_size=3, stride=2, padding=1)
+        self.layer1 = _make_layer(64, 64, 2, 1, weights_init_kaiming)
+        self.layer2 = _make_layer(64, 128, 2, 2, weights_init_kaiming)
+        self.layer3 = _make_layer(128, 256, 2, 2, weights_init_kaiming)
+        self.layer4 = _make_layer(256, 512, 2, 2, weights_init_kaiming)
+        if pretrained:
+            self._load_imagenet_encoder()
+
+        self.conv1_depth = _conv(self._depth_inputs(), 16, 7, 2)
+        self.bn1_depth = nn.BatchNorm2d(16)
+        weights_init_kaiming_leaky(self.conv1)   # sic: the reference re-initialises the RGB stem here (models.py:561-562)
+        weights_init_kaiming(self.bn1)
+        self.relu_depth = nn.LeakyReLU(0.2, inplace=True)
+        self.maxpool_depth = nn.MaxPool2d(kernel_size=3, stride=2, padding=1)
+        self.layer1_depth = _make_layer(16, 16, 2, 1, weights_init_kaiming)
+        self.layer2_depth = _make_layer(16, 32, 2, 2, weights_init_kaiming)
+        self.layer3_depth = _make_layer(32, 64, 2, 2, weights_init_kaiming)
+        self.layer4_depth = _make_layer(64, 128, 2, 2, weights_init_kaiming)
+
+        self.conv_fusion = _conv(512 + 128, 512, 1, pad=0)
+        self.bn_fusion = nn.BatchNorm2d(512)
+        self.conv2 = _conv(512, 256, 1, pad=0)
+        self.bn2 = nn.BatchNorm2d(256)
+        self.decoder = choose_decoder(decoder, 256)
+        self.conv3 = _conv(16, 1, 3)
+        self.bilinear = nn.Upsample(size=self.output_size, mode="bilinear", align_corners=True)
+
+        self.conv2.apply(weights_init)
+        self.bn2.apply(weights_init)
+        self.decoder.apply(weights_init)
+        self.conv3.apply(weights_init)
+        self.__dict__["_plans"] = {}
+
+    # the reference takes the encoder from torchvision.models.resnet18(pretrained=True) (models.py:526,546-551); there is
+    # no torchvision / network here, so ImageNet weights come from a local torchvision-format state_dict instead.
+    def _load_imagenet_encoder(self):
+        path = os.environ.get("RADAR_DEPTH_RESNET18_WEIGHTS", "")
+        if not os.path.exists(path):
+            raise RuntimeError("pretrained=True needs ImageNet ResNet-18 weights: set RADAR_DEPTH_RESNET18_WEIGHTS to a "
+                               "torchvision resnet18 state_dict file, or construct with pretrained=False (--no-pretrain)")
+        sd = torch.load(path, map_location="cpu")
+        own = self.state_dict()
+        picked = {k: v for k, v in sd.items() if k.split(".")[0] in ("layer1", "layer2", "layer3", "layer4") and k in own}
+        self.load_state_dict(picked, strict=False)
+
+    def _depth_inputs(self):
+        return 1
+
+    # ------------------------------------------------------------------ HIP execution
+    def _plan(self, batch, height, width, train, depth_planes=None):
+        from ..engine import LateFusionPlan
+        st = self._ensure_arenas()
+        key = (batch, height, width, bool(train), st["version"], None if depth_planes is None else tuple(t.data_ptr() for t in depth_planes))
+        plans = self.__dict__.setdefault("_plans", {})
+        if key not in plans:
+            for k in [k for k in plans if k[4] != st["version"]]:
+                del plans[k]
+            plans[key] = LateFusionPlan(self, batch, height, width, train=train, depth_planes=depth_planes)
+        return plans[key]
+
+    def forward(self, x):
+        if not x.is_cuda:
+            raise RuntimeError("radar_depth_amd modules run on MI355X only (HIP kernels); got a %s tensor" % x.device.type)
+        assert x.dim() == 4 and x.shape[1] >= 4
+        x = x.contiguous().float()
+        plan = self._plan(x.shape[0], x.shape[2], x.shape[3], self.training)
+        if self.training and torch.is_grad_enabled():
+            return _PlanFunction.apply(plan, x, *self._arena_root()._ensure_arenas()["params"])
+        return plan.run_forward(x).clone()
+
+
+class _PlanFunction(torch.autograd.Function):
+    """Bridges a LateFusionPlan into torch.autograd: backward returns the plan's gradient-arena views."""
+
+    @staticmethod
+    def forward(ctx, plan, x, *params):
+        ctx.plan = plan
+        ctx.n_params = len(params)
+        ctx.params = params
+        return plan.run_forward(x).clone()
+
+    @staticmethod
+    def backward(ctx, gout):
+        plan = ctx.plan
+        plan.run_backward(gout.contiguous())
+        own = {id(p) for p in plan.m.parameters()}
+        grads = [plan.m._grad_view(p) if id(p) in own else None for p in ctx.params]
+        return (None, None) + tuple(grads)

@@ -61,3 +61,34 @@ def nhwc_to_nchw(x):
     out = torch.empty((n, c, h, w), dtype=torch.float32, device=x.device)
     check(lib().rd_nhwc_to_nchw(ptr(_f32(x)), ptr(out), n, c, h, w, current_stream()), "rd_nhwc_to_nchw")
     return out
+
+
+def wgrad_workspace_floats(desc):
+    n = lib().rd_wgrad_workspace_floats(C.byref(desc))
+    if n < 0:
+        check(int(n), "rd_wgrad_workspace_floats")
+    return int(n)
+
+
+def wgrad(desc, x, dout, slabs):
+    check(lib().rd_wgrad(C.byref(desc), ptr(x), ptr(dout), ptr(slabs), current_stream()), "rd_wgrad")
+    return slabs
+
+
+def wgrad_reduce(desc, slabs, grad_oihw, co_off=0, accumulate=False):
+    o, i, kh, kw = grad_oihw.shape
+    check(lib().rd_wgrad_reduce(C.byref(desc), ptr(slabs), ptr(_f32(grad_oihw)), o, i, kh, kw, co_off, int(accumulate),
+                                current_stream()), "rd_wgrad_reduce")
+    return grad_oihw
+
+
+# ---- BatchNorm / activation helpers (used by the unit tests; the engine calls the C ABI directly)
+def bn_stats(x2d, C_):
+    """x2d: [M, ld] view (ld >= C_).  Returns (partial [tiles,2,C], tiles)."""
+    M = x2d.shape[0]
+    tiles = lib().rd_bn_stats_tiles(C.c_int64(M))
+    part = torch.zeros(tiles, 2, C_, device=x2d.device)
+    nt = C.c_int32(0)
+    check(lib().rd_bn_stats(ptr(x2d), C.c_int64(M), C_, x2d.stride(0), ptr(part), C.byref(nt), current_stream()), "rd_bn_stats")
+    assert nt.value == tiles
+    return part, tiles
