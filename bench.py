@@ -1,0 +1,206 @@
+#!/usr/bin/env python3
+"""Headline benchmark: training samples/sec of resnet18_latefusion (upproj, rgbd), b=16 per GPU, 450x800, fp32,
+full step = forward + MaskedL1 + zero_grad + backward + SGD(momentum .9, wd 1e-4)  (reference main.py:400-447).
+
+    python bench.py --gpus 1 --steps 20 --warmup 5
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+One process per GPU; inputs are resident in HBM before the timed region (synthetic batch, SURVEY.md 8d recipe,
+seed = 1234 + 1000*rank).  Timed region: K steps bracketed by barrier + synchronize, max over ranks.  Rank 0
+prints ONE JSON line.  Extra objects:
+  roofline     -- the dominant kernel (largest total time among the conv kernel instantiations) measured with HIP
+                  events in an instrumented eager pass on the step's own stream: algorithmic FLOPs per launch /
+                  average launch duration against the fp32 MFMA/vector peak (157.3 TFLOP/s);
+  cpu_baseline -- the CPU oracle (plain PyTorch restatement of the reference) timed on the host cores of this
+                  box on a bounded sample (rank 0, N=1 only).
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import torch
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, REPO)
+
+PEAK_FP32_TFLOPS = 157.3   # MI355X fp32 vector == f32-MFMA peak (guides/MI355X_MICROARCH.md)
+METRIC = "training samples/sec, resnet18_latefusion b=16 450x800 rgbd, 1/2/4/8 MI355X"
+
+
+def desc_flops(d):
+    f = 0
+    for i in range(d.n_phases):
+        p = d.phase[i]
+        f += p.lh * p.lw * p.n_taps
+    return 2.0 * f * d.N * d.Cin * d.Cout
+
+
+def kernel_identity(L, kind, d):
+    if kind == "gconv":
+        info = (C.c_int32 * 10)()
+        L.rd_gconv_plan_info(C.byref(d), info)
+        return "gconv_kernel<%d,%d,%d,%d,%d>" % tuple(info[:5])
+    ntaps = sum(d.phase[i].n_taps for i in range(d.n_phases))
+    tg = 5 if ntaps == 25 else ntaps
+    cmax = max(d.Cin, d.Cout)
+    la = cmax >= 64
+    mf = 16 if (not la and cmax <= 16) else 32
+    return "wgrad_kernel<%d,%d,%s>" % (tg, mf, "true" if la else "false")
+
+
+def instrumented_pass(ts):
+    """One eager step with every conv launch bracketed by events on the step's stream.
+    Returns {kernel: [total_ms, launches, total_flops]} and the per-step op breakdown by family."""
+    plan = ts.plan
+    L = ts.L
+    agg, fam = {}, {}
+    with torch.cuda.stream(ts.side):
+        plan.set_stream()
+        recs = []
+        for lst in (plan.prep, plan.fwd, plan.bwd):
+            for name, fn, args in lst:
+                e0 = torch.cuda.Event(enable_timing=True)
+                e1 = torch.cuda.Event(enable_timing=True)
+                e0.record()
+                rc = fn(*args)
+                e1.record()
+                assert rc == 0, name
+                recs.append((name, e0, e1))
+        torch.cuda.synchronize()
+        for name, e0, e1 in recs:
+            ms = e0.elapsed_time(e1)
+            tag = name.rsplit(".", 1)[-1]
+            family = {"wgrad": "wgrad", "dgrad": "dgrad", "wreduce": "wgrad_reduce", "pack": "pack", "packT": "pack"}.get(tag)
+            if family is None:
+                family = "conv_fwd" if name in plan.meta else ("bn/act/pool/head" if True else "other")
+            fam[family] = fam.get(family, 0.0) + ms
+            if name in plan.meta:
+                kind, d = plan.meta[name]
+                k = kernel_identity(L, kind, d)
+                a = agg.setdefault(k, [0.0, 0, 0.0])
+                a[0] += ms
+                a[1] += 1
+                a[2] += desc_flops(d)
+    return agg, fam
+
+
+def cpu_baseline(height, width, sample_batch=4, timed=3):
+    """Oracle (CPU restatement of the reference) full SGD steps on the host cores; bounded sample."""
+    from oracle.criteria import MaskedL1Loss
+    from oracle.models import ResNet_latefusion
+    from radar_depth_amd.synthetic import make_batch
+    torch.manual_seed(0)
+    m = ResNet_latefusion(18, "upproj", [height, width], 4, False).train()
+    opt = torch.optim.SGD(m.parameters(), 0.01, momentum=0.9, weight_decay=1e-4)
+    crit = MaskedL1Loss()
+    x, t = make_batch(sample_batch, height, width, 1234)
+    times = []
+    for it in range(1 + timed):
+        t0 = time.perf_counter()
+        loss = crit(m(x), t)
+        opt.zero_grad()
+        loss.backward()
+        opt.step()
+        times.append(time.perf_counter() - t0)
+    best = min(times[1:])
+    return {"value": round(sample_batch / best, 3), "unit": "samples/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": "oracle (PyTorch CPU restatement pinned to the reference by golden vectors), resnet18_latefusion full SGD "
+                      "step, b=%d %dx%d fp32, 1 warm-up + %d timed steps, best step %.2f s, %d threads of %d host cpus"
+                      % (sample_batch, height, width, timed, best, torch.get_num_threads(), os.cpu_count())}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=16, help="per-GPU batch (weak scaling)")
+    ap.add_argument("--height", type=int, default=450)
+    ap.add_argument("--width", type=int, default=800)
+    ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (no CPU fallback for the HIP path)")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.distributed.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+    assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node %d (WORLD_SIZE=%d)" % (args.gpus, world)
+
+    from radar_depth_amd.main import HipTrainStep
+    from radar_depth_amd.model.models import ResNet_latefusion
+    from radar_depth_amd.synthetic import make_batch
+
+    torch.manual_seed(0)                                     # identical random init on every rank
+    model = ResNet_latefusion(18, "upproj", [args.height, args.width], 4, False).cuda()
+    ts = HipTrainStep(model, args.batch, args.height, args.width, lr=0.01, momentum=0.9, weight_decay=1e-4,
+                      use_graph=not args.no_graph)
+    x, t = make_batch(args.batch, args.height, args.width, 1234 + 1000 * rank)
+    x, t = x.cuda(), t.cuda()
+
+    def sync():
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        ts.step(x, t)
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss, _ = ts.step(x, t)
+    sync()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([dt], device="cuda", dtype=torch.float64)
+        torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
+        dt = tt.item()
+    final_loss = float(loss.item())
+
+    out = {
+        "metric": METRIC, "value": round(world * args.batch * args.steps / dt, 2), "unit": "samples/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 3),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "resnet18_latefusion --decoder upproj --modality rgbd, b=%d/GPU %dx%d fp32, full step "
+                               "(fwd + MaskedL1 + bwd + SGD momentum .9 wd 1e-4), random init" % (args.batch, args.height, args.width),
+                   "global_batch": world * args.batch, "parallelism": "dp%d" % world if world > 1 else "single",
+                   "hipgraph": not args.no_graph, "final_loss": round(final_loss, 5)},
+    }
+    if rank == 0 and not args.no_roofline:
+        agg, fam = instrumented_pass(ts)
+        name, (ms, n, flops) = max(agg.items(), key=lambda kv: kv[1][0])
+        achieved = flops / (ms * 1e-3) / 1e12
+        # algorithmic work of one training sample (UpProj zero-skipped, stem dgrads omitted): 104.57 GFLOP at 450x800
+        alg_gflop = 104.57 * (args.height * args.width) / (450.0 * 800.0)
+        step_flops = alg_gflop * 1e9 * args.batch
+        out["roofline"] = {"bound": "mfma", "kernel": name, "launches_per_step": n, "avg_launch_us": round(1e3 * ms / n, 2),
+                           "achieved": round(achieved, 2), "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
+                           "frac": round(achieved / PEAK_FP32_TFLOPS, 4), "traffic": None,
+                           "algorithmic_gflop_per_sample": round(alg_gflop, 2),
+                           "step_conv_tflops": round(step_flops * args.steps / dt / 1e12, 2),
+                           "step_frac_of_peak": round(step_flops * args.steps / dt / 1e12 / PEAK_FP32_TFLOPS, 4),
+                           "eager_ms_by_family": {k: round(v, 3) for k, v in sorted(fam.items(), key=lambda kv: -kv[1])},
+                           "eager_ms_by_kernel": {k: [round(v[0], 3), v[1], round(v[2] / (v[0] * 1e-3) / 1e12, 1)]
+                                                  for k, v in sorted(agg.items(), key=lambda kv: -kv[1][0])}}
+    if world > 1:
+        torch.distributed.barrier()
+    if rank == 0:
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args.height, args.width)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
