@@ -84,6 +84,8 @@ int rd_gconv(const RdConvDesc* d, const float* in, const float* w_packed, float*
 int rd_gconv_stat_tiles(const RdConvDesc* d);
 /* diagnostics: out[0..9] = MT, NT, WM, WN, CKW, CKP, TH, TW, lds_bytes, workgroups chosen for d */
 int rd_gconv_plan_info(const RdConvDesc* d, int32_t* out);
+/* diagnostics: workgroups per CU the HIP occupancy API reports for that plan (-1 without a GPU) */
+int rd_gconv_occupancy(const RdConvDesc* d);
 
 /* Weight gradient of the same descriptor: dw[slab][ci][co] = sum_pixels in(...) * dout(...).
  * `d` is the FORWARD descriptor (in = forward input, "out" geometry = dout).  slabs is a

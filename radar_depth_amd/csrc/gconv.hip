@@ -13,6 +13,8 @@
 //     an odd pixel stride (conflict-free), B fragments are contiguous in cout;
 //   * epilogue: optional addend (residual-gradient merge), NHWC store through an output stride/offset
 //     (UpProj phases, stride-2 dgrad), and per-tile partial BatchNorm sums for the fused statistics.
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace rd {
@@ -32,6 +34,7 @@ struct GconvArgs {
     int tiles_total;   // tiles per image over all phases
     int n_cotiles;
     int taps_max;      // max taps over phases (sizes the LDS weight slab)
+    int debug;         // ablation bits (RD_GCONV_DEBUG env): 1 skip patch staging, 2 skip weight staging, 4 skip MFMA loop
 };
 
 template <int MT, int NT, int WM, int WN, int CKW>
@@ -105,7 +108,7 @@ __global__ __launch_bounds__(256) void gconv_kernel(const GconvArgs a) {
     for (int cb = 0; cb < D.Cin; cb += CKP) {
         __syncthreads();
         // ---- stage the halo patch chunk [PH*PW][CKP] (zero outside the image / beyond Cin)
-        for (int e = tid; e < patch_elems; e += 256) {
+        for (int e = tid; e < ((a.debug & 1) && cb > 0 ? 0 : patch_elems); e += 256) {
             const int pix = e / q4, qq = e - pix * q4;
             const int py = pix / PW, px = pix - py * PW;
             const int ih = ih0 + py, iw = iw0 + px, c = cb + qq * 4;
@@ -120,7 +123,7 @@ __global__ __launch_bounds__(256) void gconv_kernel(const GconvArgs a) {
             if (ks > 0) __syncthreads();
             // ---- stage weights [taps][CKW][BN] for input channels cb+ks*CKW .. +CKW
             const int welems = ntaps * CKW * (BN / 4);
-            for (int e = tid; e < welems; e += 256) {
+            for (int e = tid; e < ((a.debug & 2) && (cb > 0 || ks > 0) ? 0 : welems); e += 256) {
                 const int j4 = e % (BN / 4);
                 const int tk = e / (BN / 4);
                 const int k = tk % CKW, t = tk / CKW;
@@ -132,22 +135,53 @@ __global__ __launch_bounds__(256) void gconv_kernel(const GconvArgs a) {
                 *reinterpret_cast<float4*>(s_w + (size_t)tk * BN + j4 * 4) = v;
             }
             __syncthreads();
-            // ---- MFMA over taps x CKW
-            for (int t = 0; t < ntaps; ++t) {
-                const int toff = s_tapoff[t] + ks * CKW + hh;
-                const float* wt = s_w + (t * CKW + hh) * BN + bcol;
+            // ---- MFMA over taps x CKW.  Tap-level software pipeline pinned with sched_barrier: the A/B fragments of
+            // tap t+1 (and the patch offset of tap t+2) are in flight from LDS while tap t's MFMAs issue.
+            constexpr int KK = CKW / 2;
+            float ca[KK][MT], cb[KK][NT];
+            int toff_n;
+            {
+                const int toff = s_tapoff[0] + ks * CKW + hh;
+                const float* wt = s_w + hh * BN + bcol;
 #pragma unroll
-                for (int kk = 0; kk < CKW / 2; ++kk) {
-                    float av[MT], bv[NT];
+                for (int kk = 0; kk < KK; ++kk) {
 #pragma unroll
-                    for (int mt = 0; mt < MT; ++mt) av[mt] = s_patch[abase[mt] + toff + kk * 2];
+                    for (int mt = 0; mt < MT; ++mt) ca[kk][mt] = s_patch[abase[mt] + toff + kk * 2];
 #pragma unroll
-                    for (int nt = 0; nt < NT; ++nt) bv[nt] = wt[kk * 2 * BN + nt * 32];
+                    for (int nt = 0; nt < NT; ++nt) cb[kk][nt] = wt[kk * 2 * BN + nt * 32];
+                }
+                toff_n = s_tapoff[ntaps > 1 ? 1 : 0];
+            }
+            for (int t = 0; t < ((a.debug & 4) ? 0 : ntaps); ++t) {
+                float na[KK][MT], nb[KK][NT];
+                const int tn = t + 1 < ntaps ? t + 1 : t;          // the last step re-reads its own tap (harmless)
+                {
+                    const int toff = toff_n + ks * CKW + hh;
+                    const float* wt = s_w + (tn * CKW + hh) * BN + bcol;
+#pragma unroll
+                    for (int kk = 0; kk < KK; ++kk) {
+#pragma unroll
+                        for (int mt = 0; mt < MT; ++mt) na[kk][mt] = s_patch[abase[mt] + toff + kk * 2];
+#pragma unroll
+                        for (int nt = 0; nt < NT; ++nt) nb[kk][nt] = wt[kk * 2 * BN + nt * 32];
+                    }
+                    toff_n = s_tapoff[t + 2 < ntaps ? t + 2 : ntaps - 1];
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int kk = 0; kk < KK; ++kk)
 #pragma unroll
                     for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
                         for (int nt = 0; nt < NT; ++nt)
-                            acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[mt], bv[nt], acc[mt][nt], 0, 0, 0);
+                            acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(ca[kk][mt], cb[kk][nt], acc[mt][nt], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int kk = 0; kk < KK; ++kk) {
+#pragma unroll
+                    for (int mt = 0; mt < MT; ++mt) ca[kk][mt] = na[kk][mt];
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt) cb[kk][nt] = nb[kk][nt];
                 }
             }
         }
@@ -327,6 +361,28 @@ extern "C" int rd_gconv_plan_info(const RdConvDesc* d, int32_t* out) {
     return RD_OK;
 }
 
+template <int MT, int NT, int WM, int WN, int CKW>
+static int occ_cfg(size_t lds) {
+    int n = -1;
+    auto k = gconv_kernel<MT, NT, WM, WN, CKW>;
+    hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k, 256, lds) != hipSuccess) n = -1;
+    return n;
+}
+// diagnostics: resident workgroups per CU the HIP occupancy API reports for the plan chosen for d (-1 without a GPU)
+extern "C" int rd_gconv_occupancy(const RdConvDesc* d) {
+    if (validate_desc(d) != RD_OK) return RD_EINVAL;
+    GconvPlan pl;
+    RdConvDesc dd = *d;
+    if (!plan_gconv(dd, pl)) return RD_EINVAL;
+#define RD_OCC(MT_, NT_, WM_, WN_) \
+    if (pl.MT == MT_ && pl.NT == NT_ && pl.WM == WM_ && pl.WN == WN_) \
+        return pl.CKW == 8 ? occ_cfg<MT_, NT_, WM_, WN_, 8>(pl.lds_bytes) : occ_cfg<MT_, NT_, WM_, WN_, 4>(pl.lds_bytes);
+    RD_OCC(2, 2, 4, 1) RD_OCC(2, 1, 4, 1) RD_OCC(3, 2, 4, 1) RD_OCC(1, 2, 4, 1) RD_OCC(2, 2, 2, 2) RD_OCC(4, 2, 2, 2) RD_OCC(1, 1, 4, 1)
+#undef RD_OCC
+    return -1;
+}
+
 extern "C" int rd_gconv_stat_tiles(const RdConvDesc* d) {
     if (validate_desc(d) != RD_OK) return RD_EINVAL;
     GconvPlan pl;
@@ -350,6 +406,7 @@ extern "C" int rd_gconv(const RdConvDesc* d, const float* in, const float* w_pac
     a.ld_add = ld_add; a.ldw = d->Cout;
     a.TH = pl.TH; a.TW = pl.TW; a.PP = pl.PP; a.CKP = pl.CKP;
     a.tiles_total = pl.tiles_total; a.n_cotiles = pl.n_cotiles; a.taps_max = pl.taps_max;
+    { static const char* dbg = getenv("RD_GCONV_DEBUG"); a.debug = dbg ? atoi(dbg) : 0; }
     const int grid = d->N * pl.tiles_total * pl.n_cotiles;
     hipStream_t s = static_cast<hipStream_t>(stream);
 #define RD_TRY(MT_, NT_, WM_, WN_)                                                                  \

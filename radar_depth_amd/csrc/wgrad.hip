@@ -92,7 +92,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs a) {
         const int npix = th_n * tw_n;
         const int npad = ((npix + KP * WLP - 1) / (KP * WLP)) * (KP * WLP);
         __syncthreads();  // previous tile fully consumed
-        for (int p = tid; p < npad + KP * WLP; p += 256) {
+        for (int p = tid; p < npad + 2 * KP * WLP; p += 256) {
             int2 e = make_int2(0, 0);  // padding entries read a valid location; their B value is masked to 0
             if (p < npix) {
                 const int r = p / tw_n, c = p - r * tw_n;
@@ -138,8 +138,12 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs a) {
         }
         __syncthreads();
         const int nq = npad / KP;
-        // software pipeline: fragments of step q+WLP are fetched from LDS while step q's MFMAs issue
+        // Software pipeline, pinned with sched_barrier (hipcc otherwise sinks every ds_read next to its MFMA and waits
+        // lgkmcnt(0) per instruction): while step q's TG MFMAs issue, the fragments of step q+WLP are in flight from
+        // LDS and the pixel-table entry of step q+2*WLP is being fetched.
         float av[TG], bv[TG];
+        int2 e_next;
+        bool pv_next;
         {
             const int p = wpix * KP + lk;
             const int2 e = s_tab[p];
@@ -150,20 +154,22 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs a) {
                 const float b = s_do[e.y + tout[t]];
                 bv[t] = pv ? b : 0.f;
             }
+            const int p1 = (wpix + WLP) * KP + lk;          // table is padded by two extra steps
+            e_next = s_tab[p1];
+            pv_next = p1 < npix;
         }
         for (int q = wpix; q < nq; q += WLP) {
             float na[TG], nb[TG];
-            {
-                const int p = (q + WLP) * KP + lk;   // table is padded by one extra step
-                const int2 e = s_tab[p];
-                const bool pv = p < npix;
 #pragma unroll
-                for (int t = 0; t < TG; ++t) {
-                    na[t] = s_in[e.x + tin[t]];
-                    const float b = s_do[e.y + tout[t]];
-                    nb[t] = pv ? b : 0.f;
-                }
+            for (int t = 0; t < TG; ++t) {
+                na[t] = s_in[e_next.x + tin[t]];
+                nb[t] = s_do[e_next.y + tout[t]];
             }
+            const bool pv_cur = pv_next;
+            const int p2 = (q + 2 * WLP) * KP + lk;
+            e_next = s_tab[p2];
+            pv_next = p2 < npix;
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int t = 0; t < TG; ++t) {
                 if constexpr (MF == 32)
@@ -171,8 +177,9 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs a) {
                 else
                     acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[t], bv[t], acc[t], 0, 0, 0);
             }
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int t = 0; t < TG; ++t) { av[t] = na[t]; bv[t] = nb[t]; }
+            for (int t = 0; t < TG; ++t) { av[t] = na[t]; bv[t] = pv_cur ? nb[t] : 0.f; }
         }
     }
 
