@@ -71,9 +71,11 @@ def _p(t):
 
 
 class LateFusionPlan:
-    def __init__(self, module, batch, height, width, train=True, depth_planes=None):
+    def __init__(self, module, batch, height, width, train=True, depth_planes=None, x_source=None, dense_grad_dst=None):
         """module: a radar_depth_amd ResNet_latefusion(2); depth_planes: None (depth stem reads channel(s) 3.. of the
-        network input) or, for stage 2 of the multistage net, a list of stand-alone [N,H,W] maps."""
+        network input) or, for stage 2 of the multistage net, a list of stand-alone [N,H,W] maps; x_source: share another
+        plan's static input buffer (stage 2 reads the RGB planes of stage 1's); dense_grad_dst: [N,H,W]-sized buffer that
+        receives the gradient w.r.t. the second depth plane (stage-1 prediction, multistage_model.py:75)."""
         self.m = module
         self.N, self.H, self.W = batch, height, width
         self.train = train
@@ -87,6 +89,8 @@ class LateFusionPlan:
         self.meta = {}         # op name -> (kernel family, descriptor) for the conv launches (bench roofline accounting)
         self.keep = []         # keep ctypes descriptors and tensors alive
         self.depth_planes = depth_planes
+        self.x_source = x_source
+        self.dense_grad_dst = dense_grad_dst
         self.Ho, self.Wo = module.output_size
         self._build()
 
@@ -352,7 +356,10 @@ class LateFusionPlan:
         m, N, H, W = self.m, self.N, self.H, self.W
         hw = H * W
         ndep_in = m.conv1_depth.weight.shape[1]
-        self.x_in = self.buf(N, 3 + (ndep_in if self.depth_planes is None else 1), H, W)
+        if self.x_source is not None:
+            self.x_in = self.x_source
+        else:
+            self.x_in = self.buf(N, 3 + (ndep_in if self.depth_planes is None else 1), H, W)
         ctot = self.x_in.shape[1]
         xp = self.x_in.data_ptr()
         rgb_planes = [xp + 4 * hw * c for c in range(3)]
@@ -440,7 +447,7 @@ class LateFusionPlan:
             g = self._block_bwd(ctx, g)
         dense = None
         if self.depth_planes is not None and len(self.depth_planes) == 2:
-            self.dx_dense = self.buf(N, self.H, self.W)
+            self.dx_dense = self.dense_grad_dst if self.dense_grad_dst is not None else self.buf(N, self.H, self.W)
             dense = (1, self.dx_dense)
         self._stem_bwd(self.c_stem_d, g, dgrad_channel=dense)
 
@@ -457,7 +464,7 @@ class LateFusionPlan:
     def run_forward(self, x=None):
         """x: [N,>=4,H,W] fp32 CUDA tensor (copied into the plan's static input buffer) or None if already there."""
         self.set_stream()
-        if x is not None:
+        if x is not None and self.x_source is None:
             self.x_in.copy_(x[:, :self.x_in.shape[1]])
         self._run(self.prep)
         self._run(self.fwd)

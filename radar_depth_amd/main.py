@@ -50,57 +50,99 @@ _BUCKETS = (("conv_fusion", "bn_fusion", "conv2", "bn2", "decoder", "conv3"), ("
             ("conv1_depth", "bn1_depth", "layer1_depth", "layer2_depth", "layer3_depth", "layer4_depth"))
 
 
-class HipTrainStep:
-    """One reference training step (main.py:440-445 for resnet18_latefusion) entirely on the device."""
+def _param_offsets(root):
+    """name -> (begin, end) element offsets in the flat arenas (16-byte aligned slots, named_parameters order)."""
+    offs, off = {}, 0
+    for name, p in root.named_parameters():
+        offs[name] = (off, off + p.numel())
+        off += (p.numel() + 3) // 4 * 4
+    return offs
 
-    def __init__(self, model, batch, height, width, lr=0.01, momentum=0.9, weight_decay=1e-4, use_graph=True):
-        assert isinstance(model, ResNet_latefusion)
+
+def bucket_segments(op_names, param_offsets, prefix=""):
+    """Split one plan's backward op list into gradient buckets.  Returns [(op_begin, op_end, lo, hi)]: after ops
+    [op_begin, op_end) have run, arena elements [lo, hi) (parameters `prefix`+bucket names) are final."""
+    segs, start = [], 0
+    for names in _BUCKETS:
+        idx = [i for i, nm in enumerate(op_names) if nm.split(".")[0] in names]
+        sl = [v for k, v in param_offsets.items() if k.startswith(prefix) and k[len(prefix):].split(".")[0] in names]
+        if not idx or not sl:
+            continue
+        end = max(idx) + 1
+        segs.append([start, end, min(s[0] for s in sl), (max(s[1] for s in sl) + 3) // 4 * 4])
+        start = end
+    segs[-1][1] = len(op_names)
+    assert all(a[1] == b[0] for a, b in zip(segs, segs[1:])) and segs[0][0] == 0, "backward ops are not ordered by bucket"
+    return [tuple(s) for s in segs]
+
+
+class HipTrainStep:
+    """One reference training step entirely on the device (no host synchronisation inside):
+
+      resnet18_latefusion                    main.py:440-445   loss = MaskedL1(pred, target)
+      resnet18_multistage                    main.py:431-438   loss = d1 + d2
+      resnet18_multistage_uncertainty_fixs   main.py:416-429   loss = e^-w1 (d1 + 0.1 smooth) + e^-w2 d2 + w1 + w2
+
+    followed by zero_grad / backward / SGD(momentum, weight decay) (main.py:443-445).  With torch.distributed initialised
+    (one process per GPU, backend nccl = RCCL) gradients are averaged with bucketed all-reduces launched as soon as each
+    bucket's last backward kernel has been enqueued, overlapping the rest of backward."""
+
+    def __init__(self, model, batch, height, width, lr=0.01, momentum=0.9, weight_decay=1e-4, loss_weights=None, use_graph=True):
+        from .model.multistage_model import ResNet_multistage
         self.model = model
         self.L = lib()
         model.train()
-        self.plan = model._plan(batch, height, width, True)
+        self.multistage = isinstance(model, ResNet_multistage)
+        if self.multistage:
+            self.mp = model._plans(batch, height, width, True)
+            self.plans = [self.mp.p1, self.mp.p2]
+        else:
+            assert isinstance(model, ResNet_latefusion)
+            self.mp = None
+            self.plans = [model._plan(batch, height, width, True)]
+        self.plan = self.plans[0]
         self.st = model._ensure_arenas()
         dev = self.plan.dev
         self.lr, self.momentum, self.wd = lr, momentum, weight_decay
         self.world = torch.distributed.get_world_size() if torch.distributed.is_available() and torch.distributed.is_initialized() else 1
-        n = batch * self.plan.Ho * self.plan.Wo
-        self.n_out = n
-        self.target = torch.zeros(batch, 1, self.plan.Ho, self.plan.Wo, device=dev)
-        tiles = self.L.rd_loss_tiles(C.c_int64(n))
+        p = self.plan
+        self.n_out = batch * p.Ho * p.Wo
+        self.target = torch.zeros(batch, 1, p.Ho, p.Wo, device=dev)
+        tiles = self.L.rd_loss_tiles(C.c_int64(self.n_out))
         self.l1_ws = torch.zeros(2 * tiles, dtype=torch.float64, device=dev)
         self.sums = torch.zeros(2, dtype=torch.float64, device=dev)
+        self.sums2 = torch.zeros(2, dtype=torch.float64, device=dev)
         self.loss = torch.zeros(1, device=dev)
         self.coef = torch.zeros(1, device=dev)
+        if self.multistage:
+            self.uncertainty = loss_weights is not None
+            self.w_smooth = float(loss_weights["w_smooth"]) if self.uncertainty else 0.0
+            self.loss4 = torch.zeros(4, device=dev)           # d1, d2, smooth, total
+            self.coefs3 = torch.zeros(3, device=dev)          # e^-w1, w_smooth e^-w1, e^-w2
+            self.smooth_out = torch.zeros(1, dtype=torch.float64, device=dev)
+            nfl = int(self.L.rd_smooth_workspace_floats(batch, height, width))
+            self.smooth_ws = torch.zeros((nfl + 1) // 2, dtype=torch.float64, device=dev)
+            if self.uncertainty:
+                self.w1, self.w2 = model.w_stage1, model.w_stage2
+                self.dw1, self.dw2 = model._grad_view(self.w1), model._grad_view(self.w2)
+            else:                                             # loss = d1 + d2: the same kernel with w1 = w2 = 0
+                self.w1, self.w2 = torch.zeros(1, device=dev), torch.zeros(1, device=dev)
+                self.dw1, self.dw2 = torch.zeros(1, device=dev), torch.zeros(1, device=dev)
+            self.loss = self.loss4[3:4]
         self.use_graph = use_graph
         self.graphs = None
+        self.steps = 0
         # hipGraph capture is illegal on the legacy default stream: the step owns a stream and fences it against the caller's
         self.side = torch.cuda.Stream(device=dev)
-        self.steps = 0
-        self._segments = self._split_backward()
-
-    # gradient buckets: (last backward-op index, arena slice)
-    def _split_backward(self):
-        names = [n for n, _ in self.model.named_parameters()]
-        params = self.st["params"]
-        offs, off = {}, 0
-        for nme, p in zip(names, params):
-            offs[nme] = (off, off + p.numel())
-            off += (p.numel() + 3) // 4 * 4
-        segs, start = [], 0
-        ops = self.plan.bwd
-        for prefixes in _BUCKETS:
-            idx = [i for i, (nm, _, _) in enumerate(ops) if nm.split(".")[0] in prefixes]
-            sl = [offs[nme] for nme in names if nme.split(".")[0] in prefixes]
-            if not idx or not sl:
-                continue
-            lo, hi = min(s[0] for s in sl), max(s[1] for s in sl)
-            segs.append((start, max(idx) + 1, lo, (hi + 3) // 4 * 4))
-            start = max(idx) + 1
-        if start < len(ops):
-            s0, _, lo, hi = segs[-1]
-            segs[-1] = (s0, len(ops), lo, hi)
-        assert [s[0] for s in segs[1:]] == [s[1] for s in segs[:-1]], "backward ops are not ordered by bucket"
-        return segs
+        offs = _param_offsets(model)
+        if self.multistage:
+            s1 = [v for k, v in offs.items() if not k.startswith("stage2.")]
+            s2 = [v for k, v in offs.items() if k.startswith("stage2.")]
+            self._buckets = [(min(v[0] for v in s2), (max(v[1] for v in s2) + 3) // 4 * 4),
+                             (min(v[0] for v in s1), (max(v[1] for v in s1) + 3) // 4 * 4)]
+        else:
+            self._segments = bucket_segments([nm for nm, _, _ in self.plan.bwd], offs)
+            self._buckets = [(lo, hi) for _, _, lo, hi in self._segments]
 
     def set_lr(self, lr):
         if lr != self.lr:
@@ -113,19 +155,56 @@ class HipTrainStep:
                 self.L.rd_graph_destroy(g)
         self.graphs = None
 
-    # ---- the pieces of one step, each a sequence of C-ABI launches on the current stream
-    def _fwd_loss(self):
-        p, s = self.plan, self.plan.stream
-        p._run(p.prep)
-        p._run(p.fwd)
-        check(self.L.rd_masked_l1_sums(ptr(p.pred), ptr(self.target), C.c_int64(self.n_out), ptr(self.l1_ws), ptr(self.sums), s), "l1_sums")
-        check(self.L.rd_l1_total(ptr(self.sums), ptr(self.loss), ptr(self.coef), s), "l1_total")
-        check(self.L.rd_masked_l1_bwd(ptr(p.pred), ptr(self.target), C.c_int64(self.n_out), ptr(self.sums), ptr(self.coef), ptr(p.dpred), 0, s),
-              "l1_bwd")
+    # ---- pieces of one step: each is a sequence of C-ABI launches on the step's stream, separately graph-capturable;
+    # ---- after piece i (i < len(buckets)) the gradient bucket i is final
+    def _l1(self, pred, sums):
+        check(self.L.rd_masked_l1_sums(ptr(pred), ptr(self.target), C.c_int64(self.n_out), ptr(self.l1_ws), ptr(sums), self.plan.stream), "l1_sums")
 
-    def _bwd_segment(self, k):
-        a, b, _, _ = self._segments[k]
-        self.plan._run(self.plan.bwd[a:b])
+    def _l1_bwd(self, pred, sums, coef, dpred, accumulate):
+        check(self.L.rd_masked_l1_bwd(ptr(pred), ptr(self.target), C.c_int64(self.n_out), ptr(sums), coef, ptr(dpred), accumulate,
+                                      self.plan.stream), "l1_bwd")
+
+    def _latefusion_pieces(self):
+        p = self.plan
+
+        def head():
+            p._run(p.prep)
+            p._run(p.fwd)
+            self._l1(p.pred, self.sums)
+            check(self.L.rd_l1_total(ptr(self.sums), ptr(self.loss), ptr(self.coef), p.stream), "l1_total")
+            self._l1_bwd(p.pred, self.sums, ptr(self.coef), p.dpred, 0)
+        segs = self._segments
+        pieces = [lambda: (head(), p._run(p.bwd[segs[0][0]:segs[0][1]]))]
+        pieces += [(lambda k=k: p._run(p.bwd[segs[k][0]:segs[k][1]])) for k in range(1, len(segs))]
+        return pieces
+
+    def _multistage_pieces(self):
+        mp, p1, p2, s = self.mp, self.mp.p1, self.mp.p2, self.plan.stream
+        fptr = lambda t, i: C.c_void_p(t.data_ptr() + 4 * i)
+
+        def stage2_part():
+            p1._run(p1.prep)
+            p1._run(p1.fwd)
+            mp.filter_op()
+            p2._run(p2.prep)
+            p2._run(p2.fwd)
+            self._l1(p1.pred, self.sums)
+            self._l1(p2.pred, self.sums2)
+            if self.uncertainty:
+                check(self.L.rd_smooth_fwd(ptr(p1.pred), ptr(p1.x_in), p1.N, p1.x_in.shape[1], p1.H, p1.W, ptr(self.smooth_ws),
+                                           ptr(self.smooth_out), s), "smooth_fwd")
+            check(self.L.rd_uncertainty_total(ptr(self.sums), ptr(self.sums2), ptr(self.smooth_out), ptr(self.w1), ptr(self.w2),
+                                              C.c_float(self.w_smooth), ptr(self.loss4), ptr(self.coefs3), ptr(self.dw1), ptr(self.dw2), s),
+                  "uncertainty_total")
+            self._l1_bwd(p2.pred, self.sums2, fptr(self.coefs3, 2), p2.dpred, 0)
+            p2._run(p2.bwd)                                   # also writes d(loss)/d(stage-1 prediction) into p1.dpred
+
+        def stage1_part():
+            self._l1_bwd(p1.pred, self.sums, fptr(self.coefs3, 0), p1.dpred, 1)
+            if self.uncertainty:
+                check(self.L.rd_smooth_bwd(p1.N, p1.H, p1.W, ptr(self.smooth_ws), fptr(self.coefs3, 1), ptr(p1.dpred), 1, s), "smooth_bwd")
+            p1._run(p1.bwd)
+        return [stage2_part, stage1_part]
 
     def _sgd(self):
         st = self.st
@@ -133,33 +212,28 @@ class HipTrainStep:
                                  C.c_float(self.momentum), C.c_float(self.wd), C.c_float(1.0 / self.world), 0, self.plan.stream), "sgd_step")
 
     def _pieces(self):
-        """Graph-capturable pieces: with one GPU the whole step is one piece; with DP the all-reduces sit between them."""
-        nseg = len(self._segments)
-        if self.world == 1:
-            return [lambda: (self._fwd_loss(), [self._bwd_segment(k) for k in range(nseg)], self._sgd())]
-        pieces = [lambda: (self._fwd_loss(), self._bwd_segment(0))]
-        pieces += [(lambda k=k: self._bwd_segment(k)) for k in range(1, nseg)]
-        pieces.append(self._sgd)
-        return pieces
+        parts = self._multistage_pieces() if self.multistage else self._latefusion_pieces()
+        if self.world == 1:                                   # single GPU: the whole step is one graph
+            return [lambda: ([f() for f in parts], self._sgd())]
+        return parts + [self._sgd]
 
     def step(self, inputs, target):
         """inputs [B,4,H,W], target [B,1,Ho,Wo] CUDA fp32.  Returns (loss[1], pred) device tensors (no sync)."""
-        p = self.plan
         caller = torch.cuda.current_stream()
         self.side.wait_stream(caller)
         with torch.cuda.stream(self.side):
             self._step_on_side(inputs, target)
         caller.wait_stream(self.side)
-        return self.loss, p.pred
+        return self.loss, self.plans[-1].pred
 
     def _step_on_side(self, inputs, target):
         p = self.plan
-        p.set_stream()
+        for pl in self.plans:
+            pl.set_stream()
         p.x_in.copy_(inputs[:, :p.x_in.shape[1]])
         self.target.copy_(target)
         pieces = self._pieces()
-        capture = self.use_graph and self.steps >= 1 and self.graphs is None
-        if capture:
+        if self.use_graph and self.steps >= 1 and self.graphs is None:
             self.graphs = []
             for piece in pieces:
                 check(self.L.rd_graph_begin(p.stream), "graph_begin")
@@ -173,10 +247,10 @@ class HipTrainStep:
                 check(self.L.rd_graph_launch(self.graphs[i], p.stream), "graph_launch")
             else:
                 piece()
-            if self.world > 1 and i < len(self._segments):
-                _, _, lo, hi = self._segments[i]
+            if self.world > 1 and i < len(self._buckets):
+                lo, hi = self._buckets[i]
                 works.append(torch.distributed.all_reduce(self.st["grads"][lo:hi], async_op=True))
-                if i == len(self._segments) - 1:
+                if i == len(self._buckets) - 1:
                     for w in works:
                         w.wait()
         self.steps += 1
