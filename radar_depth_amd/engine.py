@@ -71,7 +71,8 @@ def _p(t):
 
 
 class LateFusionPlan:
-    def __init__(self, module, batch, height, width, train=True, depth_planes=None, x_source=None, dense_grad_dst=None):
+    def __init__(self, module, batch, height, width, train=True, depth_planes=None, x_source=None, dense_grad_dst=None,
+                 dry_run=False):
         """module: a radar_depth_amd ResNet_latefusion(2); depth_planes: None (depth stem reads channel(s) 3.. of the
         network input) or, for stage 2 of the multistage net, a list of stand-alone [N,H,W] maps; x_source: share another
         plan's static input buffer (stage 2 reads the RGB planes of stage 1's); dense_grad_dst: [N,H,W]-sized buffer that
@@ -80,7 +81,9 @@ class LateFusionPlan:
         self.N, self.H, self.W = batch, height, width
         self.train = train
         self.dev = module.conv1.weight.device
-        assert self.dev.type == "cuda", "the HIP path needs the module on a GPU"
+        # dry_run: record the op lists against host buffers without ever launching (CPU tests of the host logic)
+        assert dry_run or self.dev.type == "cuda", "the HIP path needs the module on a GPU"
+        self.dry_run = dry_run
         self.L = lib()
         self.stream = C.c_void_p(0)
         self.fwd, self.bwd = [], []
@@ -453,6 +456,8 @@ class LateFusionPlan:
 
     # ------------------------------------------------------------------ execution
     def _run(self, ops):
+        if self.dry_run:
+            raise RuntimeError("dry-run plans cannot execute: the HIP path has no CPU fallback")
         for name, fn, args in ops:
             rc = fn(*args)
             if rc != 0:

@@ -76,6 +76,18 @@ def bucket_segments(op_names, param_offsets, prefix=""):
     return [tuple(s) for s in segs]
 
 
+def reduce_gradient_buckets(grads, buckets, done_after=None):
+    """Sum-all-reduce the arena slices `buckets` = [(lo, hi)] of the flat gradient tensor across the default process
+    group.  Generator form: yields before each bucket so the caller can enqueue the backward segment that completes it;
+    all collectives are asynchronous and waited for at the end (RCCL over xGMI on the GPU, gloo in the CPU tests)."""
+    works = []
+    for lo, hi in buckets:
+        yield (lo, hi)
+        works.append(torch.distributed.all_reduce(grads[lo:hi], async_op=True))
+    for wk in works:
+        wk.wait()
+
+
 class HipTrainStep:
     """One reference training step entirely on the device (no host synchronisation inside):
 
@@ -241,16 +253,16 @@ class HipTrainStep:
                 g = C.c_void_p(0)
                 check(self.L.rd_graph_end(p.stream, C.byref(g)), "graph_end")
                 self.graphs.append(g)
-        works = []
-        for i, piece in enumerate(pieces):
+        def launch(i):
             if self.graphs is not None:
                 check(self.L.rd_graph_launch(self.graphs[i], p.stream), "graph_launch")
             else:
-                piece()
-            if self.world > 1 and i < len(self._buckets):
-                lo, hi = self._buckets[i]
-                works.append(torch.distributed.all_reduce(self.st["grads"][lo:hi], async_op=True))
-                if i == len(self._buckets) - 1:
-                    for w in works:
-                        w.wait()
+                pieces[i]()
+        if self.world == 1:
+            launch(0)
+        else:
+            # piece i completes gradient bucket i; its all-reduce is enqueued right behind it and overlaps pieces i+1..
+            for i, _ in enumerate(reduce_gradient_buckets(self.st["grads"], self._buckets)):
+                launch(i)
+            launch(len(self._buckets))                        # SGD, after every bucket has been waited for
         self.steps += 1

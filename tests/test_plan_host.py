@@ -1,0 +1,80 @@
+"""Host logic of the execution plan and of the data-parallel path, without a GPU:
+ * a dry-run LateFusionPlan records the op lists on host buffers: every parameter gets exactly one gradient writer, the
+   backward ops are ordered so that the gradient buckets complete in arena-contiguous slices;
+ * world_size-2 gloo run of reduce_gradient_buckets == gradient averaging over the flat arena."""
+import os
+
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+
+def _model(h=97, w=161):
+    from radar_depth_amd.model.models import ResNet_latefusion
+    torch.manual_seed(0)
+    return ResNet_latefusion(18, "upproj", [h, w], 4, False)
+
+
+def test_dry_run_plan_structure():
+    from radar_depth_amd.engine import LateFusionPlan
+    from radar_depth_amd.main import _param_offsets, bucket_segments
+    m = _model()
+    plan = LateFusionPlan(m, 2, 97, 161, train=True, dry_run=True)
+    names = [n for n, _, _ in plan.bwd]
+    fwd_convs = [n for n, _, _ in plan.fwd if n in plan.meta]
+    assert len(fwd_convs) == 55 - 3 - 4            # 55 convs - (2 stems + conv3: own kernels) - 4 (each UpProj 5x5 pair is one fused launch)
+    with pytest.raises(RuntimeError):
+        plan.run_forward()
+    offs = _param_offsets(m)
+    segs = bucket_segments(names, offs)
+    # buckets tile the whole arena exactly once
+    cover = sorted((lo, hi) for _, _, lo, hi in segs)
+    assert cover[0][0] == 0 and all(a[1] == b[0] for a, b in zip(cover, cover[1:]))
+    assert cover[-1][1] == m._ensure_arenas()["total"]
+    # every conv weight has a wgrad reduce and every BN a backward apply
+    n_w = sum(1 for n, p in m.named_parameters() if p.dim() == 4)
+    n_reduce = sum(1 for n in names if n.endswith(".wreduce")) + 2 + 1      # + two stems + conv3 (own kernels)
+    assert n_reduce == n_w
+    n_bn = sum(1 for n, p in m.named_parameters() if n.endswith(".bias"))
+    assert sum(1 for n in names if n.endswith(".bwd_apply")) == n_bn
+    # an op never belongs to an earlier bucket than the one being completed
+    for a, b, _, _ in segs:
+        assert a < b
+
+
+def _dp_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    torch.distributed.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from radar_depth_amd.engine import LateFusionPlan
+        from radar_depth_amd.main import _param_offsets, bucket_segments, reduce_gradient_buckets
+        m = _model()
+        plan = LateFusionPlan(m, 2, 97, 161, train=True, dry_run=True)
+        st = m._ensure_arenas()
+        segs = bucket_segments([n for n, _, _ in plan.bwd], _param_offsets(m))
+        g = torch.Generator().manual_seed(100 + rank)
+        st["grads"].copy_(torch.randn(st["total"], generator=g))
+        mine = st["grads"].clone()
+        order = []
+        for lo, hi in reduce_gradient_buckets(st["grads"], [(lo, hi) for _, _, lo, hi in segs]):
+            order.append((lo, hi))
+        other = torch.randn(st["total"], generator=torch.Generator().manual_seed(100 + (1 - rank)))
+        ok = torch.allclose(st["grads"], mine + other, atol=1e-6) and len(order) == len(segs)
+        # the per-parameter views see the reduced values (what the SGD kernel reads, scaled by 1/world)
+        ok = ok and torch.equal(m._grad_view(m.conv3.weight).flatten(), st["grads"][-m.conv3.weight.numel() - (-m.conv3.weight.numel()) % 4:][:m.conv3.weight.numel()])
+        q.put((rank, bool(ok)))
+    finally:
+        torch.distributed.destroy_process_group()
+
+
+def test_bucketed_allreduce_gloo_world2():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + os.getpid() % 2000
+    procs = [ctx.Process(target=_dp_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=300) for _ in procs)
+    for p in procs:
+        p.join(60)
+    assert res == [(0, True), (1, True)]
