@@ -13,6 +13,7 @@
 //     an odd pixel stride (conflict-free), B fragments are contiguous in cout;
 //   * epilogue: optional addend (residual-gradient merge), NHWC store through an output stride/offset
 //     (UpProj phases, stride-2 dgrad), and per-tile partial BatchNorm sums for the fused statistics.
+#include <math.h>
 #include <stdlib.h>
 
 #include "common.h"
@@ -34,6 +35,7 @@ struct GconvArgs {
     int tiles_total;   // tiles per image over all phases
     int n_cotiles;
     int taps_max;      // max taps over phases (sizes the LDS weight slab)
+    int WSD;           // input channels per weight slab staged in LDS (multiple of CKW, divides CKP)
     int debug;         // ablation bits (RD_GCONV_DEBUG env): 1 skip patch staging, 2 skip weight staging, 4 skip MFMA loop
 };
 
@@ -73,8 +75,8 @@ __global__ __launch_bounds__(256) void gconv_kernel(const GconvArgs a) {
     int* s_apix = s_opix + BM;                           // [BM] patch pixel index of tap (0,0)
     int* s_tapoff = s_apix + BM;                         // [32] patch float offset per tap
     int* s_widx = s_tapoff + 32;                         // [32]
-    float* s_w = reinterpret_cast<float*>(s_widx + 32);  // [taps][CKW][BN]
-    float* s_patch = s_w + a.taps_max * CKW * BN;        // [PP][PS]
+    float* s_w = reinterpret_cast<float*>(s_widx + 32);  // [taps][WSD][BN]
+    float* s_patch = s_w + a.taps_max * a.WSD * BN;      // [PP][PS]
 
     for (int m = tid; m < BM; m += 256) {
         const int r = m / a.TW, c = m - r * a.TW;
@@ -107,83 +109,101 @@ __global__ __launch_bounds__(256) void gconv_kernel(const GconvArgs a) {
 
     for (int cb = 0; cb < D.Cin; cb += CKP) {
         __syncthreads();
-        // ---- stage the halo patch chunk [PH*PW][CKP] (zero outside the image / beyond Cin)
-        for (int e = tid; e < ((a.debug & 1) && cb > 0 ? 0 : patch_elems); e += 256) {
-            const int pix = e / q4, qq = e - pix * q4;
-            const int py = pix / PW, px = pix - py * PW;
-            const int ih = ih0 + py, iw = iw0 + px, c = cb + qq * 4;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (ih >= 0 && ih < D.Hi && iw >= 0 && iw < D.Wi && c < D.Cin)
-                v = *reinterpret_cast<const float4*>(in_n + ((size_t)ih * D.Wi + iw) * D.ldi + c);
-            float* dst = s_patch + pix * PS + qq * 4;
-            dst[0] = v.x; dst[1] = v.y; dst[2] = v.z; dst[3] = v.w;
+        // ---- stage the halo patch chunk [PH*PW][CKP] (zero outside the image / beyond Cin).  Batched: U independent
+        // global loads per thread are in flight before the first LDS write (a load-wait-store loop exposes every latency).
+        constexpr int U = 8;
+        for (int base = tid; base < ((a.debug & 1) && cb > 0 ? 0 : patch_elems); base += 256 * U) {
+            float4 v[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int e = base + u * 256;
+                const int pix = e / q4, qq = e - pix * q4;
+                const int py = pix / PW, px = pix - py * PW;
+                const int ih = ih0 + py, iw = iw0 + px, c = cb + qq * 4;
+                v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (e < patch_elems && ih >= 0 && ih < D.Hi && iw >= 0 && iw < D.Wi && c < D.Cin)
+                    v[u] = *reinterpret_cast<const float4*>(in_n + ((size_t)ih * D.Wi + iw) * D.ldi + c);
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int e = base + u * 256;
+                if (e < patch_elems) {
+                    const int pix = e / q4, qq = e - pix * q4;
+                    float* dst = s_patch + pix * PS + qq * 4;
+                    dst[0] = v[u].x; dst[1] = v[u].y; dst[2] = v[u].z; dst[3] = v[u].w;
+                }
+            }
         }
-        const int nsub = min(CKP, D.Cin - cb) / CKW;
+        const int WSD = a.WSD;
+        const int nsub = min(CKP, D.Cin - cb) / WSD;
         for (int ks = 0; ks < nsub; ++ks) {
             if (ks > 0) __syncthreads();
-            // ---- stage weights [taps][CKW][BN] for input channels cb+ks*CKW .. +CKW
-            const int welems = ntaps * CKW * (BN / 4);
-            for (int e = tid; e < ((a.debug & 2) && (cb > 0 || ks > 0) ? 0 : welems); e += 256) {
-                const int j4 = e % (BN / 4);
-                const int tk = e / (BN / 4);
-                const int k = tk % CKW, t = tk / CKW;
-                const int co = co0 + j4 * 4;
-                const int ci = cb + ks * CKW + k;
-                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (co < D.Cout)  // Cout is a multiple of 4 (checked on the host)
-                    v = *reinterpret_cast<const float4*>(a.w + ((size_t)s_widx[t] * D.Cin + ci) * a.ldw + co);
-                *reinterpret_cast<float4*>(s_w + (size_t)tk * BN + j4 * 4) = v;
+            // ---- stage weights [taps][WSD][BN] for input channels cb+ks*WSD .. +WSD
+            const int welems = ntaps * WSD * (BN / 4);
+            for (int base = tid; base < ((a.debug & 2) && (cb > 0 || ks > 0) ? 0 : welems); base += 256 * U) {
+                float4 v[U];
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    const int e = base + u * 256;
+                    const int j4 = e % (BN / 4);
+                    const int tk = e / (BN / 4);
+                    const int k = tk % WSD, t = min(tk / WSD, ntaps - 1);
+                    const int co = co0 + j4 * 4;
+                    const int ci = cb + ks * WSD + k;
+                    v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (e < welems && co < D.Cout)  // Cout is a multiple of 4 (checked on the host)
+                        v[u] = *reinterpret_cast<const float4*>(a.w + ((size_t)s_widx[t] * D.Cin + ci) * a.ldw + co);
+                }
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    const int e = base + u * 256;
+                    if (e < welems) *reinterpret_cast<float4*>(s_w + (size_t)e * 4) = v[u];   // [tk][BN] is linear in e
+                }
             }
             __syncthreads();
-            // ---- MFMA over taps x CKW.  Tap-level software pipeline pinned with sched_barrier: the A/B fragments of
-            // tap t+1 (and the patch offset of tap t+2) are in flight from LDS while tap t's MFMAs issue.
+            // ---- MFMA over (k-quantum, tap) steps.  One step = CKW input channels of one tap = KK*MT*NT MFMAs.  Software
+            // pipeline pinned with sched_barrier: the A/B fragments of step s+1 (and the patch offset of step s+2) are in
+            // flight from LDS while step s's MFMAs issue.
             constexpr int KK = CKW / 2;
-            float ca[KK][MT], cb[KK][NT];
-            int toff_n;
-            {
-                const int toff = s_tapoff[0] + ks * CKW + hh;
-                const float* wt = s_w + hh * BN + bcol;
-#pragma unroll
-                for (int kk = 0; kk < KK; ++kk) {
-#pragma unroll
-                    for (int mt = 0; mt < MT; ++mt) ca[kk][mt] = s_patch[abase[mt] + toff + kk * 2];
-#pragma unroll
-                    for (int nt = 0; nt < NT; ++nt) cb[kk][nt] = wt[kk * 2 * BN + nt * 32];
-                }
-                toff_n = s_tapoff[ntaps > 1 ? 1 : 0];
+            const int nq = WSD / CKW;
+            const int nsteps = (a.debug & 4) ? 0 : nq * ntaps;
+            float ca[KK][MT], cb_[KK][NT];
+            int t_n = 0, kq_n = 0;         // (tap, k-quantum) of the step whose fragments are loaded next
+            int toff_n = s_tapoff[0];
+#define RD_GC_LOAD(AV, BV)                                                                     \
+            {                                                                                  \
+                const int toff = toff_n + ks * WSD + kq_n * CKW + hh;                          \
+                const float* wt = s_w + ((t_n * WSD + kq_n * CKW + hh) * BN + bcol);           \
+                _Pragma("unroll") for (int kk = 0; kk < KK; ++kk) {                            \
+                    _Pragma("unroll") for (int mt = 0; mt < MT; ++mt) AV[kk][mt] = s_patch[abase[mt] + toff + kk * 2]; \
+                    _Pragma("unroll") for (int nt = 0; nt < NT; ++nt) BV[kk][nt] = wt[kk * 2 * BN + nt * 32];          \
+                }                                                                              \
+                if (++t_n == ntaps) { t_n = 0; ++kq_n; }                                       \
+                toff_n = s_tapoff[t_n];                                                        \
             }
-            for (int t = 0; t < ((a.debug & 4) ? 0 : ntaps); ++t) {
+#define RD_GC_MFMA(AV, BV)                                                                     \
+            _Pragma("unroll") for (int kk = 0; kk < KK; ++kk)                                  \
+                _Pragma("unroll") for (int mt = 0; mt < MT; ++mt)                              \
+                    _Pragma("unroll") for (int nt = 0; nt < NT; ++nt)                          \
+                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(AV[kk][mt], BV[kk][nt], acc[mt][nt], 0, 0, 0);
+            RD_GC_LOAD(ca, cb_)
+            for (int st = 0; st < nsteps; st += 2) {
                 float na[KK][MT], nb[KK][NT];
-                const int tn = t + 1 < ntaps ? t + 1 : t;          // the last step re-reads its own tap (harmless)
-                {
-                    const int toff = toff_n + ks * CKW + hh;
-                    const float* wt = s_w + (tn * CKW + hh) * BN + bcol;
-#pragma unroll
-                    for (int kk = 0; kk < KK; ++kk) {
-#pragma unroll
-                        for (int mt = 0; mt < MT; ++mt) na[kk][mt] = s_patch[abase[mt] + toff + kk * 2];
-#pragma unroll
-                        for (int nt = 0; nt < NT; ++nt) nb[kk][nt] = wt[kk * 2 * BN + nt * 32];
-                    }
-                    toff_n = s_tapoff[t + 2 < ntaps ? t + 2 : ntaps - 1];
-                }
+                // (the step after the last one re-reads in-bounds LDS: kq_n may reach nq, still inside the patch/slab rows
+                //  because one extra quantum is reserved by the host-side LDS sizing)
+                RD_GC_LOAD(na, nb)
                 __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int kk = 0; kk < KK; ++kk)
-#pragma unroll
-                    for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-                        for (int nt = 0; nt < NT; ++nt)
-                            acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(ca[kk][mt], cb[kk][nt], acc[mt][nt], 0, 0, 0);
+                RD_GC_MFMA(ca, cb_)
                 __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int kk = 0; kk < KK; ++kk) {
-#pragma unroll
-                    for (int mt = 0; mt < MT; ++mt) ca[kk][mt] = na[kk][mt];
-#pragma unroll
-                    for (int nt = 0; nt < NT; ++nt) cb[kk][nt] = nb[kk][nt];
+                if (st + 1 < nsteps) {
+                    RD_GC_LOAD(ca, cb_)
+                    __builtin_amdgcn_sched_barrier(0);
+                    RD_GC_MFMA(na, nb)
+                    __builtin_amdgcn_sched_barrier(0);
                 }
             }
+#undef RD_GC_LOAD
+#undef RD_GC_MFMA
         }
     }
 
@@ -238,7 +258,7 @@ __global__ __launch_bounds__(256) void gconv_kernel(const GconvArgs a) {
 
 // ------------------------------------------------------------------------------------------ host
 struct GconvPlan {
-    int MT, NT, WM, WN, CKW, CKP, TH, TW, PP, tiles_total, n_cotiles, taps_max;
+    int MT, NT, WM, WN, CKW, CKP, TH, TW, PP, tiles_total, n_cotiles, taps_max, WSD;
     size_t lds_bytes;
 };
 
@@ -249,15 +269,26 @@ static int patch_pixels(const RdConvDesc& d, const RdPhase& p, int TH, int TW) {
     return PH * PW;
 }
 
+// weight-slab depth: as many input channels as fit ~40 KB (fewer barriers), at least one CKW quantum
+static int pick_wsd(int taps_max, int BN, int CKW, int CKP) {
+    int w = CKP;
+    while (w > CKW && (size_t)taps_max * w * BN * 4 > 40 * 1024) w >>= 1;
+    return w < CKW ? CKW : w;
+}
 static size_t lds_need(int BM, int BN, int CKW, int CKP, int PP, int taps_max) {
-    return (size_t)(2 * BM + 64) * 4 + (size_t)taps_max * CKW * BN * 4 + (size_t)PP * (CKP + 1) * 4;
+    // + one CKW quantum of slab rows and one patch pixel row of slack: the pipelined loop prefetches one step past the end
+    return (size_t)(2 * BM + 64) * 4 + ((size_t)taps_max * pick_wsd(taps_max, BN, CKW, CKP) + CKW) * BN * 4 +
+           (size_t)(PP + 1) * (CKP + 1) * 4 + 64;
 }
 
 // Choose wave tiling + pixel tile for a descriptor.  Heuristic: maximise useful-MAC fraction of the
 // BM x BN tile, penalise halo re-reads, prefer <= 80 KB of LDS (two workgroups per CU).
 static bool plan_gconv(const RdConvDesc& d, GconvPlan& best) {
-    struct Cfg { int MT, NT, WM, WN; };
-    static const Cfg cfgs[] = {{2, 2, 4, 1}, {2, 1, 4, 1}, {3, 2, 4, 1}, {1, 2, 4, 1}, {2, 2, 2, 2}, {4, 2, 2, 2}, {1, 1, 4, 1}};
+    // prior = measured relative efficiency of the register tile on large layers (tools/sweep_gconv.py, B=16 layer1/layer2);
+    // the WN=2 tilings never won a shape and carry a low prior.
+    struct Cfg { int MT, NT, WM, WN; double prior; };
+    static const Cfg cfgs[] = {{2, 2, 4, 1, 0.93}, {2, 1, 4, 1, 0.82}, {3, 2, 4, 1, 1.0}, {1, 2, 4, 1, 0.78},
+                               {2, 2, 2, 2, 0.6}, {4, 2, 2, 2, 0.5}, {1, 1, 4, 1, 0.76}};
     int taps_max = 0;
     for (int i = 0; i < d.n_phases; ++i) taps_max = taps_max > d.phase[i].n_taps ? taps_max : d.phase[i].n_taps;
     const int CKW = taps_max > 9 ? 4 : 8;
@@ -267,7 +298,11 @@ static bool plan_gconv(const RdConvDesc& d, GconvPlan& best) {
     for (int i = 1; i < d.n_phases; ++i)
         if ((int64_t)d.phase[i].lh * d.phase[i].lw > (int64_t)d.phase[pr].lh * d.phase[pr].lw) pr = i;
     const RdPhase& P = d.phase[pr];
+    static const char* force = getenv("RD_GCONV_FORCE");   // diagnostics: index into cfgs
+    int cfg_i = -1;
     for (const Cfg& c : cfgs) {
+        ++cfg_i;
+        if (force && atoi(force) != cfg_i) continue;
         const int BM = c.WM * c.MT * 32, BN = c.WN * c.NT * 32;
         const int n_cot = cdiv(d.Cout, BN);
         const double n_util = (double)d.Cout / (n_cot * BN);
@@ -290,15 +325,16 @@ static bool plan_gconv(const RdConvDesc& d, GconvPlan& best) {
                 if (lds > 160 * 1024 - 512) continue;
                 const double m_util = (double)P.lh * P.lw / ((double)cdiv(P.lh, TH) * cdiv(P.lw, TW) * BM);
                 const double halo = (double)PP / (TH * TW * d.in_stride * d.in_stride);
-                double score = m_util * n_util / (1.0 + 0.04 * (halo - 1.0));
+                double score = c.prior * m_util * n_util / (1.0 + 0.04 * (halo - 1.0));
                 if (lds > 80 * 1024) score *= 0.85;          // one workgroup per CU only
                 if (ckp == 16 && d.Cin >= 32) score *= 0.97;  // half-line loads
-                // enough workgroups to fill 256 CUs x 2
-                const double wgs = (double)d.N * cdiv(P.lh, TH) * cdiv(P.lw, TW) * n_cot;
-                if (wgs < 256) score *= (0.5 + 0.5 * wgs / 256.0);
+                // CU load balance: the kernel is MFMA-bound, so the time is set by the CU that owns the most workgroups
+                const double wgs = (double)d.N * cdiv(P.lh, TH) * cdiv(P.lw, TW) * n_cot * d.n_phases;
+                const double ncu = (double)num_cus();
+                score *= wgs / (ncu * ceil(wgs / ncu));
                 if (score > best_score) {
                     best_score = score;
-                    best = GconvPlan{c.MT, c.NT, c.WM, c.WN, CKW, ckp, TH, TW, PP, 0, n_cot, taps_max, lds};
+                    best = GconvPlan{c.MT, c.NT, c.WM, c.WN, CKW, ckp, TH, TW, PP, 0, n_cot, taps_max, pick_wsd(taps_max, BN, CKW, ckp), lds};
                 }
             }
         }
@@ -405,7 +441,7 @@ extern "C" int rd_gconv(const RdConvDesc* d, const float* in, const float* w_pac
     a.in = in; a.w = w_packed; a.out = out; a.addend = addend; a.stat = stat_partial;
     a.ld_add = ld_add; a.ldw = d->Cout;
     a.TH = pl.TH; a.TW = pl.TW; a.PP = pl.PP; a.CKP = pl.CKP;
-    a.tiles_total = pl.tiles_total; a.n_cotiles = pl.n_cotiles; a.taps_max = pl.taps_max;
+    a.tiles_total = pl.tiles_total; a.n_cotiles = pl.n_cotiles; a.taps_max = pl.taps_max; a.WSD = pl.WSD;
     { static const char* dbg = getenv("RD_GCONV_DEBUG"); a.debug = dbg ? atoi(dbg) : 0; }
     const int grid = d->N * pl.tiles_total * pl.n_cotiles;
     hipStream_t s = static_cast<hipStream_t>(stream);

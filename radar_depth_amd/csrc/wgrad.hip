@@ -10,6 +10,8 @@
 // tile's pixels 2 (32x32x2) or 4 (16x16x4) at a time: A[ci][pixel] and B[pixel][co] fragments are both
 // contiguous-in-channel ds_read_b32 (conflict-free).  Partial results go to per-split slabs that
 // rd_wgrad_reduce sums in a fixed order (deterministic, no atomics) straight into OIHW gradients.
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace rd {
@@ -33,12 +35,14 @@ struct WgradArgs {
     int dh_min, dh_max, dw_min, dw_max;
     int n_cib, n_cob, n_tg;
     int S;  // slabs (= kernel taps) per split
+    int debug;  // ablation bits (RD_WGRAD_DEBUG): 1 skip staging after the first tile, 2 skip the MFMA walk
     WgTapGroup tg[WG_MAX_GROUPS];
 };
 
 // LAYOUT_A: waves arranged 2 (ci) x 2 (co), all see every pixel.  Otherwise: one (ci,co) block, the four
 // waves take interleaved pixel groups and each writes its own slab.
-template <int TG, int MF, bool LAYOUT_A>
+// SHB: every tap of the group reads the same dout pixel (stride-1/2 k x k convs) -> one shared B fragment per step.
+template <int TG, int MF, bool LAYOUT_A, bool SHB>
 __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs a) {
     constexpr int CIB = LAYOUT_A ? 64 : MF;
     constexpr int COB = LAYOUT_A ? 64 : MF;
@@ -62,10 +66,11 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs a) {
     const int PWmax = (a.TW - 1) * a.IS + (a.dw_max - a.dw_min) + 1;
     const int PHmax = (a.TH - 1) * a.IS + (a.dh_max - a.dh_min) + 1;
     const int DW = a.TW * a.OS, DHmax = a.TH * a.OS;
-    int2* s_tab = reinterpret_cast<int2*>(smem);                        // [WG_MAX_PIX + 32]
-    float* s_in = smem + 2 * (WG_MAX_PIX + 32);                         // [PHmax*PWmax][CIB]
-    float* s_do = s_in + (size_t)PHmax * PWmax * CIB;                    // [DHmax*DW][COB]
-    (void)DHmax;
+    int2* s_tab = reinterpret_cast<int2*>(smem);                        // [WG_MAX_PIX + 64]
+    float* s_in = smem + 2 * (WG_MAX_PIX + 64);                         // [PHmax*PWmax][CIB]
+    float* s_do = s_in + (size_t)PHmax * PWmax * CIB;                    // [DHmax*DW + 1][COB], last row zero (SHB padding)
+    const int zero_row = DHmax * DW;
+    if (tid < COB) s_do[(size_t)zero_row * COB + tid] = 0.f;
 
     // per-tap LDS offsets (loop invariant)
     int tin[TG], tout[TG];
@@ -90,10 +95,11 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs a) {
         const int r0 = (trem / a.tiles_w) * a.TH, c0 = (trem % a.tiles_w) * a.TW;
         const int th_n = min(a.TH, a.lh - r0), tw_n = min(a.TW, a.lw - c0);
         const int npix = th_n * tw_n;
-        const int npad = ((npix + KP * WLP - 1) / (KP * WLP)) * (KP * WLP);
+        const int npad = ((npix + 2 * KP * WLP - 1) / (2 * KP * WLP)) * (2 * KP * WLP);   // even number of steps
         __syncthreads();  // previous tile fully consumed
-        for (int p = tid; p < npad + 2 * KP * WLP; p += 256) {
-            int2 e = make_int2(0, 0);  // padding entries read a valid location; their B value is masked to 0
+        if (!((a.debug & 1) && tile > tile_begin)) {
+        for (int p = tid; p < npad + 3 * KP * WLP; p += 256) {
+            int2 e = make_int2(0, SHB ? zero_row * COB : 0);  // padding: A reads a valid location, B reads zeros (SHB) or is masked
             if (p < npix) {
                 const int r = p / tw_n, c = p - r * tw_n;
                 e.x = ((r * a.IS) * PWmax + c * a.IS) * CIB;
@@ -101,86 +107,102 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs a) {
             }
             s_tab[p] = e;
         }
-        // input halo patch
-        {
+        // Staging is batched: U independent global loads per thread are issued before any LDS write, otherwise every
+        // load's full L2/HBM latency is exposed (measured: 100 us of a 390 us kernel).
+        constexpr int U = 8;
+        {   // input halo patch
             const int PH = (th_n - 1) * a.IS + (a.dh_max - a.dh_min) + 1;
             const int ih0 = r0 * a.IS + a.dh_min, iw0 = c0 * a.IS + a.dw_min;
             const float* in_n = a.in + (size_t)n * a.Hi * a.Wi * a.ldi;
             constexpr int q4 = CIB / 4;
             const int elems = PH * PWmax * q4;
-            for (int e = tid; e < elems; e += 256) {
-                const int pix = e / q4, qq = e - pix * q4;
-                const int py = pix / PWmax, px = pix - py * PWmax;
-                const int ih = ih0 + py, iw = iw0 + px, c = cib0 + qq * 4;
-                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (ih >= 0 && ih < a.Hi && iw >= 0 && iw < a.Wi && c < a.Cin)
-                    v = *reinterpret_cast<const float4*>(in_n + ((size_t)ih * a.Wi + iw) * a.ldi + c);
-                *reinterpret_cast<float4*>(s_in + (size_t)pix * CIB + qq * 4) = v;
+            for (int base = tid; base < elems; base += 256 * U) {
+                float4 v[U];
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    const int e = base + u * 256;
+                    const int pix = e / q4, qq = e - pix * q4;
+                    const int py = pix / PWmax, px = pix - py * PWmax;
+                    const int ih = ih0 + py, iw = iw0 + px, c = cib0 + qq * 4;
+                    v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (e < elems && ih >= 0 && ih < a.Hi && iw >= 0 && iw < a.Wi && c < a.Cin)
+                        v[u] = *reinterpret_cast<const float4*>(in_n + ((size_t)ih * a.Wi + iw) * a.ldi + c);
+                }
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    const int e = base + u * 256;
+                    if (e < elems) *reinterpret_cast<float4*>(s_in + (size_t)e * 4) = v[u];   // [pix][CIB] is linear in e
+                }
             }
         }
-        // dout tile (rows/cols beyond the image or beyond the tile's valid extent are zero)
-        {
+        {   // dout tile (rows/cols beyond the image or beyond the tile's valid extent are zero)
             const int DH = th_n * a.OS;
             const int oh0 = r0 * a.OS, ow0 = c0 * a.OS;
             const float* do_n = a.dout + (size_t)n * a.Ho * a.Wo * a.ldo;
             constexpr int q4 = COB / 4;
             const int elems = DH * DW * q4;
             const int ow_lim = min(a.Wo, ow0 + tw_n * a.OS);
-            for (int e = tid; e < elems; e += 256) {
-                const int pix = e / q4, qq = e - pix * q4;
-                const int py = pix / DW, px = pix - py * DW;
-                const int oh = oh0 + py, ow = ow0 + px, c = cob0 + qq * 4;
-                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (oh < a.Ho && ow < ow_lim && c < a.Cout)
-                    v = *reinterpret_cast<const float4*>(do_n + ((size_t)oh * a.Wo + ow) * a.ldo + c);
-                *reinterpret_cast<float4*>(s_do + (size_t)pix * COB + qq * 4) = v;
+            for (int base = tid; base < elems; base += 256 * U) {
+                float4 v[U];
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    const int e = base + u * 256;
+                    const int pix = e / q4, qq = e - pix * q4;
+                    const int py = pix / DW, px = pix - py * DW;
+                    const int oh = oh0 + py, ow = ow0 + px, c = cob0 + qq * 4;
+                    v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (e < elems && oh < a.Ho && ow < ow_lim && c < a.Cout)
+                        v[u] = *reinterpret_cast<const float4*>(do_n + ((size_t)oh * a.Wo + ow) * a.ldo + c);
+                }
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    const int e = base + u * 256;
+                    if (e < elems) *reinterpret_cast<float4*>(s_do + (size_t)e * 4) = v[u];
+                }
             }
+        }
         }
         __syncthreads();
-        const int nq = npad / KP;
-        // Software pipeline, pinned with sched_barrier (hipcc otherwise sinks every ds_read next to its MFMA and waits
-        // lgkmcnt(0) per instruction): while step q's TG MFMAs issue, the fragments of step q+WLP are in flight from
-        // LDS and the pixel-table entry of step q+2*WLP is being fetched.
-        float av[TG], bv[TG];
-        int2 e_next;
-        bool pv_next;
-        {
-            const int p = wpix * KP + lk;
-            const int2 e = s_tab[p];
-            const bool pv = p < npix;
-#pragma unroll
-            for (int t = 0; t < TG; ++t) {
-                av[t] = s_in[e.x + tin[t]];
-                const float b = s_do[e.y + tout[t]];
-                bv[t] = pv ? b : 0.f;
-            }
-            const int p1 = (wpix + WLP) * KP + lk;          // table is padded by two extra steps
-            e_next = s_tab[p1];
-            pv_next = p1 < npix;
+        // Software pipeline pinned with sched_barrier (hipcc otherwise sinks every ds_read next to its MFMA and waits
+        // lgkmcnt(0) per instruction).  Two register sets ping-pong (no copy moves): while one set's TG MFMAs issue, the
+        // other set's fragments are in flight from LDS and the pixel-table entry of the step after is being fetched.
+        constexpr int NB = SHB ? 1 : TG;
+        const int nsteps = npad / (KP * WLP);          // even
+        float a0[TG], b0[NB], a1[TG], b1[NB];
+        bool pv0 = true, pv1 = true;
+        (void)pv0; (void)pv1;
+        int2 e_nxt;
+#define RD_WG_LOAD(AV, BV, PV, STEP)                                          \
+        {                                                                         \
+            const int2 e_ = e_nxt;                                                \
+            _Pragma("unroll") for (int t = 0; t < TG; ++t) AV[t] = s_in[e_.x + tin[t]]; \
+            _Pragma("unroll") for (int t = 0; t < NB; ++t) BV[t] = s_do[e_.y + tout[t]]; \
+            const int pn_ = (((STEP) + 1) * WLP + wpix) * KP + lk;                \
+            if (!SHB) PV = (((STEP)) * WLP + wpix) * KP + lk < npix;              \
+            e_nxt = s_tab[pn_];                                                   \
         }
-        for (int q = wpix; q < nq; q += WLP) {
-            float na[TG], nb[TG];
-#pragma unroll
-            for (int t = 0; t < TG; ++t) {
-                na[t] = s_in[e_next.x + tin[t]];
-                nb[t] = s_do[e_next.y + tout[t]];
-            }
-            const bool pv_cur = pv_next;
-            const int p2 = (q + 2 * WLP) * KP + lk;
-            e_next = s_tab[p2];
-            pv_next = p2 < npix;
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int t = 0; t < TG; ++t) {
-                if constexpr (MF == 32)
-                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[t], bv[t], acc[t], 0, 0, 0);
-                else
-                    acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[t], bv[t], acc[t], 0, 0, 0);
-            }
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int t = 0; t < TG; ++t) { av[t] = na[t]; bv[t] = pv_cur ? nb[t] : 0.f; }
+#define RD_WG_MFMA(AV, BV, PV)                                                \
+        _Pragma("unroll") for (int t = 0; t < TG; ++t) {                          \
+            const float bsel_ = SHB ? BV[0] : (PV ? BV[t < NB ? t : 0] : 0.f);    \
+            if constexpr (MF == 32)                                               \
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(AV[t], bsel_, acc[t], 0, 0, 0); \
+            else                                                                  \
+                acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(AV[t], bsel_, acc[t], 0, 0, 0); \
         }
+        e_nxt = s_tab[wpix * KP + lk];
+        RD_WG_LOAD(a0, b0, pv0, 0)
+        for (int st = 0; st < ((a.debug & 2) ? 0 : nsteps); st += 2) {
+            RD_WG_LOAD(a1, b1, pv1, st + 1)
+            __builtin_amdgcn_sched_barrier(0);
+            RD_WG_MFMA(a0, b0, pv0)
+            __builtin_amdgcn_sched_barrier(0);
+            RD_WG_LOAD(a0, b0, pv0, st + 2)
+            __builtin_amdgcn_sched_barrier(0);
+            RD_WG_MFMA(a1, b1, pv1)
+            __builtin_amdgcn_sched_barrier(0);
+        }
+#undef RD_WG_LOAD
+#undef RD_WG_MFMA
     }
 
     // ---- write this workgroup's partial slab
@@ -279,7 +301,7 @@ int launch_slab_reduce(const float* slabs, int n_splits, int64_t E, float* tmp, 
 struct WgradPlan {
     int TG, MF, layoutA;
     int TH, TW, tiles_h, tiles_w, total_tiles, tiles_per_split, n_splits, slab_splits;
-    int n_cib, n_cob, n_tg, S, J;
+    int n_cib, n_cob, n_tg, S, J, shb;
     size_t lds;
 };
 
@@ -299,6 +321,7 @@ static int plan_wgrad(const RdConvDesc& d, WgradPlan& pl, WgradArgs* out) {
     }
     RD_CHECK_ARG(ntaps == 1 || ntaps == 9 || ntaps == 25, "wgrad: %d taps unsupported", ntaps);
     RD_CHECK_ARG(d.Cin % 4 == 0 && d.Cout % 4 == 0 && d.ldi % 4 == 0 && d.ldo % 4 == 0, "wgrad: channels must be multiples of 4");
+    pl.shb = d.n_phases == 1;   // single phase: every tap pairs with the same dout pixel
     pl.TG = ntaps == 25 ? 5 : ntaps;
     pl.n_tg = ntaps == 25 ? 5 : 1;
     const int cmax = d.Cin > d.Cout ? d.Cin : d.Cout;
@@ -318,8 +341,8 @@ static int plan_wgrad(const RdConvDesc& d, WgradPlan& pl, WgradArgs* out) {
             if (TH * TW > WG_MAX_PIX) break;
             const int PH = (TH - 1) * d.in_stride + (dh_max - dh_min) + 1;
             const int PW = (TW - 1) * d.in_stride + (dw_max - dw_min) + 1;
-            const size_t lds = (size_t)2 * (WG_MAX_PIX + 32) * 4 + (size_t)PH * PW * CIB * 4 +
-                               ((size_t)TH * d.out_stride * TW * d.out_stride) * COB * 4;
+            const size_t lds = (size_t)2 * (WG_MAX_PIX + 64) * 4 + (size_t)PH * PW * CIB * 4 +
+                               ((size_t)TH * d.out_stride * TW * d.out_stride + 1) * COB * 4;
             if (lds > budget) break;
             const double useful = (double)P0.lh * P0.lw / ((double)cdiv(P0.lh, TH) * TH * cdiv(P0.lw, TW) * TW);
             const double halo = (double)PH * PW / ((double)TH * TW * d.in_stride * d.in_stride);
@@ -369,10 +392,10 @@ static int plan_wgrad(const RdConvDesc& d, WgradPlan& pl, WgradArgs* out) {
     return RD_OK;
 }
 
-template <int TG, int MF, bool LA>
+template <int TG, int MF, bool LA, bool SHB>
 static int launch_wgrad(const WgradArgs& a, int grid, size_t lds, hipStream_t s) {
     static bool attr_set = false;
-    auto k = wgrad_kernel<TG, MF, LA>;
+    auto k = wgrad_kernel<TG, MF, LA, SHB>;
     if (!attr_set) {
         RD_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr_set = true;
@@ -399,23 +422,25 @@ extern "C" int rd_wgrad(const RdConvDesc* d, const float* in, const float* dout,
     int rc = plan_wgrad(*d, pl, &a);
     if (rc != RD_OK) return rc;
     a.in = in; a.dout = dout; a.slabs = slabs;
+    { static const char* dbg = getenv("RD_WGRAD_DEBUG"); a.debug = dbg ? atoi(dbg) : 0; }
     hipStream_t s = static_cast<hipStream_t>(stream);
     for (int gi = 0; gi < pl.n_tg; ++gi) RD_CHECK_ARG(a.tg[gi].n == pl.TG, "wgrad: tap group %d has %d taps, expected %d", gi, a.tg[gi].n, pl.TG);
     // layout-B epilogue reuses the head of LDS for its cross-wave reduction
     if (!pl.layoutA && pl.lds < (size_t)4 * 16 * 64 * 4) pl.lds = (size_t)4 * 16 * 64 * 4;
     const int grid = pl.n_cib * pl.n_cob * pl.n_tg * pl.n_splits;
-#define RD_W(TG_, MF_, LA_) \
-    if (pl.TG == TG_ && pl.MF == MF_ && (pl.layoutA != 0) == LA_) return launch_wgrad<TG_, MF_, LA_>(a, grid, pl.lds, s);
-    RD_W(9, 32, true)
-    RD_W(9, 32, false)
-    RD_W(9, 16, false)
-    RD_W(5, 32, true)
-    RD_W(5, 32, false)
-    RD_W(1, 32, true)
-    RD_W(1, 32, false)
-    RD_W(1, 16, false)
+#define RD_W(TG_, MF_, LA_, SHB_) \
+    if (pl.TG == TG_ && pl.MF == MF_ && (pl.layoutA != 0) == LA_ && (pl.shb != 0) == SHB_) \
+        return launch_wgrad<TG_, MF_, LA_, SHB_>(a, grid, pl.lds, s);
+    RD_W(9, 32, true, true)
+    RD_W(9, 32, false, true)
+    RD_W(9, 16, false, true)
+    RD_W(5, 32, true, false)
+    RD_W(5, 32, false, false)
+    RD_W(1, 32, true, true)
+    RD_W(1, 32, false, true)
+    RD_W(1, 16, false, true)
 #undef RD_W
-    set_error("wgrad: unsupported plan TG=%d MF=%d layoutA=%d", pl.TG, pl.MF, pl.layoutA);
+    set_error("wgrad: unsupported plan TG=%d MF=%d layoutA=%d shb=%d", pl.TG, pl.MF, pl.layoutA, pl.shb);
     return RD_EINVAL;
 }
 
