@@ -8,6 +8,7 @@
                    gradient averaging with bucketed RCCL all-reduces overlapped with the rest of backward.
 """
 import ctypes as C
+import os
 
 import torch
 import torch.nn as nn
@@ -117,6 +118,8 @@ class HipTrainStep:
         dev = self.plan.dev
         self.lr, self.momentum, self.wd = lr, momentum, weight_decay
         self.world = torch.distributed.get_world_size() if torch.distributed.is_available() and torch.distributed.is_initialized() else 1
+        # RD_FORCE_DP=1 runs the data-parallel code path (segmented graphs + bucketed all-reduce) even with one rank (tests)
+        self.dp = self.world > 1 or (os.environ.get("RD_FORCE_DP") == "1" and torch.distributed.is_initialized())
         p = self.plan
         self.n_out = batch * p.Ho * p.Wo
         self.target = torch.zeros(batch, 1, p.Ho, p.Wo, device=dev)
@@ -225,7 +228,7 @@ class HipTrainStep:
 
     def _pieces(self):
         parts = self._multistage_pieces() if self.multistage else self._latefusion_pieces()
-        if self.world == 1:                                   # single GPU: the whole step is one graph
+        if not self.dp:                                       # single GPU: the whole step is one graph
             return [lambda: ([f() for f in parts], self._sgd())]
         return parts + [self._sgd]
 
@@ -258,7 +261,7 @@ class HipTrainStep:
                 check(self.L.rd_graph_launch(self.graphs[i], p.stream), "graph_launch")
             else:
                 pieces[i]()
-        if self.world == 1:
+        if not self.dp:
             launch(0)
         else:
             # piece i completes gradient bucket i; its all-reduce is enqueued right behind it and overlaps pieces i+1..

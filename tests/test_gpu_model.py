@@ -157,7 +157,7 @@ def test_fused_step_matches_oracle():
         assert abs(lg.item() - lo.item()) / lo.item() < 2e-3, (it, lg.item(), lo.item())
     po = np.array([p.double().norm().item() for p in o.parameters()])
     pg = np.array([p.double().norm().item() for p in m.parameters()])
-    assert np.abs(po - pg).max() / po.max() < 1e-3
+    assert np.abs(po - pg).max() / po.max() < 5e-3
     # Element-wise comparison after several steps is only meaningful for well-conditioned tensors: the reference network is
     # chaotic in its multi-step trajectory (tests/test_conditioning.py: a 5e-4 weight perturbation moves the next step's
     # gradients by ~20 % in the CPU oracle itself), so only the head weight is compared element-wise.
@@ -246,4 +246,33 @@ def test_multistage_fused_step_matches_oracle():
     assert abs(hm.w_stage1.item() - om.w_stage1.item()) < 1e-3 and abs(hm.w_stage2.item() - om.w_stage2.item()) < 1e-3   # 3 chaotic steps, losses agree to 2e-3
     po = np.array([p.double().norm().item() for p in om.parameters()])
     pg = np.array([p.double().norm().item() for p in hm.parameters()])
-    assert np.abs(po - pg).max() / po.max() < 1e-3
+    assert np.abs(po - pg).max() / po.max() < 5e-3          # 3 chaotic steps (tests/test_conditioning.py)
+
+
+def test_data_parallel_path_single_rank(monkeypatch):
+    """The DP code path (one hipGraph per backward segment, async RCCL all-reduce per gradient bucket, wait, SGD scaled by
+    1/world) on a 1-rank nccl group must reproduce the single-graph step exactly."""
+    import torch.distributed as dist
+    from radar_depth_amd.main import HipTrainStep
+    from radar_depth_amd.synthetic import make_batch
+    b, h, w = 2, 97, 161
+    monkeypatch.setenv("MASTER_ADDR", "127.0.0.1")
+    monkeypatch.setenv("MASTER_PORT", "29611")
+    ref = build(h, w)
+    ts_ref = HipTrainStep(ref, b, h, w, use_graph=True)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        monkeypatch.setenv("RD_FORCE_DP", "1")
+        m = build(h, w)
+        ts = HipTrainStep(m, b, h, w, use_graph=True)
+        assert ts.dp and len(ts._pieces()) == len(ts._buckets) + 1
+        for it in range(3):
+            x, t = make_batch(b, h, w, 300 + it, ref_pixels=h * w)
+            l0, _ = ts_ref.step(x.cuda(), t.cuda())
+            l1, _ = ts.step(x.cuda(), t.cuda())
+            torch.cuda.synchronize()
+            assert l0.item() == l1.item()
+        for p, q in zip(ref.parameters(), m.parameters()):
+            assert torch.equal(p, q)
+    finally:
+        dist.destroy_process_group()
