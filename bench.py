@@ -43,7 +43,7 @@ def kernel_identity(L, kind, d):
     if kind == "gconv":
         info = (C.c_int32 * 10)()
         L.rd_gconv_plan_info(C.byref(d), info)
-        return "gconv_kernel<%d,%d,%d,%d,%d>" % tuple(info[:5])
+        return "gconv_kernel<%d,%d,%d,%d,%d>" % (info[0], info[1], info[2], info[3], info[4] % 100)   # info[4] = ksplit*100 + CKW
     ntaps = sum(d.phase[i].n_taps for i in range(d.n_phases))
     tg = 5 if ntaps == 25 else ntaps
     cmax = max(d.Cin, d.Cout)

@@ -82,7 +82,15 @@ typedef struct {
 int rd_gconv(const RdConvDesc* d, const float* in, const float* w_packed, float* out,
              const float* addend, int32_t ld_add, float* stat_partial, void* stream);
 int rd_gconv_stat_tiles(const RdConvDesc* d);
-/* diagnostics: out[0..9] = MT, NT, WM, WN, CKW, CKP, TH, TW, lds_bytes, workgroups chosen for d */
+/* Same convolution with a caller-provided workspace: lets the library split the input channels of small-spatial /
+ * many-channel layers over several workgroups per tile (split-K; partials in ws are combined, the addend added and
+ * the BN partial sums produced by a second kernel).  ws: rd_gconv_workspace_floats(d) floats (0 -> no split, ws may
+ * be NULL); the stat buffer then holds rd_gconv_stat_tiles_ws(d) tiles. */
+int64_t rd_gconv_workspace_floats(const RdConvDesc* d);
+int rd_gconv_stat_tiles_ws(const RdConvDesc* d);
+int rd_gconv_ws(const RdConvDesc* d, const float* in, const float* w_packed, float* out,
+                const float* addend, int32_t ld_add, float* stat_partial, float* ws, void* stream);
+/* diagnostics: out[0..9] = MT, NT, WM, WN, ksplit*100+CKW, CKP, TH, TW, lds_bytes, workgroups chosen for d (workspace plan) */
 int rd_gconv_plan_info(const RdConvDesc* d, int32_t* out);
 /* diagnostics: workgroups per CU the HIP occupancy API reports for that plan (-1 without a GPU) */
 int rd_gconv_occupancy(const RdConvDesc* d);

@@ -36,6 +36,8 @@ struct GconvArgs {
     int n_cotiles;
     int taps_max;      // max taps over phases (sizes the LDS weight slab)
     int WSD;           // input channels per weight slab staged in LDS (multiple of CKW, divides CKP)
+    int ksplit;        // split-K: number of input-channel slices (each writes its own partial output)
+    long long split_stride;  // floats between consecutive partial outputs
     int debug;         // ablation bits (RD_GCONV_DEBUG env): 1 skip patch staging, 2 skip weight staging, 4 skip MFMA loop
 };
 
@@ -49,7 +51,9 @@ __global__ __launch_bounds__(256) void gconv_kernel(const GconvArgs a) {
     const int l31 = lane & 31, hh = lane >> 5;
     const RdConvDesc& D = a.d;
 
-    const int vid = xcd_remap(blockIdx.x, gridDim.x);
+    const int vid0 = xcd_remap(blockIdx.x, gridDim.x);
+    const int ksl = vid0 % a.ksplit;              // split-K slice (slices of one tile are neighbours: same XCD, shared patch)
+    const int vid = vid0 / a.ksplit;
     const int cot = vid % a.n_cotiles;
     const int pt = vid / a.n_cotiles;
     const int n = pt / a.tiles_total;
@@ -107,12 +111,15 @@ __global__ __launch_bounds__(256) void gconv_kernel(const GconvArgs a) {
     const int patch_elems = PH * PW * q4;
     const float* in_n = a.in + (size_t)n * D.Hi * D.Wi * D.ldi;
 
-    for (int cb = 0; cb < D.Cin; cb += CKP) {
+    const int cin_per = D.Cin / a.ksplit;
+    const int cb_lo = ksl * cin_per, cb_hi = cb_lo + cin_per;
+    float* const outp = a.out + (size_t)ksl * a.split_stride;
+    for (int cb = cb_lo; cb < cb_hi; cb += CKP) {
         __syncthreads();
         // ---- stage the halo patch chunk [PH*PW][CKP] (zero outside the image / beyond Cin).  Batched: U independent
         // global loads per thread are in flight before the first LDS write (a load-wait-store loop exposes every latency).
         constexpr int U = 8;
-        for (int base = tid; base < ((a.debug & 1) && cb > 0 ? 0 : patch_elems); base += 256 * U) {
+        for (int base = tid; base < ((a.debug & 1) && cb > cb_lo ? 0 : patch_elems); base += 256 * U) {
             float4 v[U];
 #pragma unroll
             for (int u = 0; u < U; ++u) {
@@ -135,12 +142,12 @@ __global__ __launch_bounds__(256) void gconv_kernel(const GconvArgs a) {
             }
         }
         const int WSD = a.WSD;
-        const int nsub = min(CKP, D.Cin - cb) / WSD;
+        const int nsub = min(CKP, cb_hi - cb) / WSD;
         for (int ks = 0; ks < nsub; ++ks) {
             if (ks > 0) __syncthreads();
             // ---- stage weights [taps][WSD][BN] for input channels cb+ks*WSD .. +WSD
             const int welems = ntaps * WSD * (BN / 4);
-            for (int base = tid; base < ((a.debug & 2) && (cb > 0 || ks > 0) ? 0 : welems); base += 256 * U) {
+            for (int base = tid; base < ((a.debug & 2) && (cb > cb_lo || ks > 0) ? 0 : welems); base += 256 * U) {
                 float4 v[U];
 #pragma unroll
                 for (int u = 0; u < U; ++u) {
@@ -169,15 +176,18 @@ __global__ __launch_bounds__(256) void gconv_kernel(const GconvArgs a) {
             const int nsteps = (a.debug & 4) ? 0 : nq * ntaps;
             float ca[KK][MT], cb_[KK][NT];
             int t_n = 0, kq_n = 0;         // (tap, k-quantum) of the step whose fragments are loaded next
+            int st_ld = 0;
             int toff_n = s_tapoff[0];
 #define RD_GC_LOAD(AV, BV)                                                                     \
             {                                                                                  \
                 const int toff = toff_n + ks * WSD + kq_n * CKW + hh;                          \
                 const float* wt = s_w + ((t_n * WSD + kq_n * CKW + hh) * BN + bcol);           \
+                if (!(a.debug & 8) || st_ld == 0) {                                            \
                 _Pragma("unroll") for (int kk = 0; kk < KK; ++kk) {                            \
                     _Pragma("unroll") for (int mt = 0; mt < MT; ++mt) AV[kk][mt] = s_patch[abase[mt] + toff + kk * 2]; \
                     _Pragma("unroll") for (int nt = 0; nt < NT; ++nt) BV[kk][nt] = wt[kk * 2 * BN + nt * 32];          \
-                }                                                                              \
+                } }                                                                            \
+                ++st_ld;                                                                       \
                 if (++t_n == ntaps) { t_n = 0; ++kq_n; }                                       \
                 toff_n = s_tapoff[t_n];                                                        \
             }
@@ -188,7 +198,7 @@ __global__ __launch_bounds__(256) void gconv_kernel(const GconvArgs a) {
                         acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(AV[kk][mt], BV[kk][nt], acc[mt][nt], 0, 0, 0);
             RD_GC_LOAD(ca, cb_)
             for (int st = 0; st < nsteps; st += 2) {
-                float na[KK][MT], nb[KK][NT];
+                float na[KK][MT] = {}, nb[KK][NT] = {};
                 // (the step after the last one re-reads in-bounds LDS: kq_n may reach nq, still inside the patch/slab rows
                 //  because one extra quantum is reserved by the host-side LDS sizing)
                 RD_GC_LOAD(na, nb)
@@ -224,7 +234,7 @@ __global__ __launch_bounds__(256) void gconv_kernel(const GconvArgs a) {
                     if (co < D.Cout) {
                         float v = acc[mt][nt][i];
                         if (a.addend) v += a.addend[(size_t)op * a.ld_add + co];
-                        a.out[(size_t)op * D.ldo + co] = v;
+                        outp[(size_t)op * D.ldo + co] = v;
                         ssum[nt] += v;
                         ssq[nt] += v * v;
                     }
@@ -256,9 +266,57 @@ __global__ __launch_bounds__(256) void gconv_kernel(const GconvArgs a) {
     }
 }
 
+// split-K combine: out[r][c] = sum_s part[s][r][c] (+ addend[r][c]); optional BN partial sums per row block.
+// Rows are the output tensor's pixels; thread = (channel quad, row lane) like the BN reductions in norm_act.hip.
+__global__ __launch_bounds__(256) void gconv_combine_kernel(const float* __restrict__ part, long long split_stride, int S,
+                                                            float* __restrict__ out, int ldo, const float* __restrict__ addend,
+                                                            int ld_add, long long M, int C, int RPB, float* __restrict__ stat) {
+    extern __shared__ float sm[];
+    const int Q = C >> 2, RL = 256 / Q;
+    const int q = threadIdx.x % Q, rl = threadIdx.x / Q;
+    const bool active = rl < RL;
+    const long long r0 = (long long)blockIdx.x * RPB, r1 = r0 + RPB < M ? r0 + RPB : M;
+    float4 s1 = make_float4(0, 0, 0, 0), s2 = make_float4(0, 0, 0, 0);
+    if (active) {
+        const int c = q * 4;
+        for (long long r = r0 + rl; r < r1; r += RL) {
+            float4 v = *reinterpret_cast<const float4*>(part + r * ldo + c);
+            for (int k = 1; k < S; ++k) {
+                const float4 u = *reinterpret_cast<const float4*>(part + k * split_stride + r * ldo + c);
+                v.x += u.x; v.y += u.y; v.z += u.z; v.w += u.w;
+            }
+            if (addend) {
+                const float4 u = *reinterpret_cast<const float4*>(addend + r * ld_add + c);
+                v.x += u.x; v.y += u.y; v.z += u.z; v.w += u.w;
+            }
+            *reinterpret_cast<float4*>(out + r * ldo + c) = v;
+            s1.x += v.x; s1.y += v.y; s1.z += v.z; s1.w += v.w;
+            s2.x += v.x * v.x; s2.y += v.y * v.y; s2.z += v.z * v.z; s2.w += v.w * v.w;
+        }
+    }
+    if (stat) {
+        // sm: [RL][2][C]
+        if (active) {
+            *reinterpret_cast<float4*>(sm + ((size_t)(rl * 2 + 0) * Q + q) * 4) = s1;
+            *reinterpret_cast<float4*>(sm + ((size_t)(rl * 2 + 1) * Q + q) * 4) = s2;
+        }
+        __syncthreads();
+        for (int e = threadIdx.x; e < 2 * C; e += blockDim.x) {
+            const int w = e / C, c = e - w * C;
+            float v = 0.f;
+            for (int r = 0; r < RL; ++r) v += sm[(size_t)(r * 2 + w) * C + c];
+            stat[((size_t)blockIdx.x * 2 + w) * C + c] = v;
+        }
+    }
+}
+static inline int combine_rows_per_block(long long M) {
+    long long r = (M + 1023) / 1024;
+    return (int)(r < 16 ? 16 : r);
+}
+
 // ------------------------------------------------------------------------------------------ host
 struct GconvPlan {
-    int MT, NT, WM, WN, CKW, CKP, TH, TW, PP, tiles_total, n_cotiles, taps_max, WSD;
+    int MT, NT, WM, WN, CKW, CKP, TH, TW, PP, tiles_total, n_cotiles, taps_max, WSD, ksplit;
     size_t lds_bytes;
 };
 
@@ -283,7 +341,7 @@ static size_t lds_need(int BM, int BN, int CKW, int CKP, int PP, int taps_max) {
 
 // Choose wave tiling + pixel tile for a descriptor.  Heuristic: maximise useful-MAC fraction of the
 // BM x BN tile, penalise halo re-reads, prefer <= 80 KB of LDS (two workgroups per CU).
-static bool plan_gconv(const RdConvDesc& d, GconvPlan& best) {
+static bool plan_gconv(const RdConvDesc& d, GconvPlan& best, bool allow_split = false) {
     // prior = measured relative efficiency of the register tile on large layers (tools/sweep_gconv.py, B=16 layer1/layer2);
     // the WN=2 tilings never won a shape and carry a low prior.
     struct Cfg { int MT, NT, WM, WN; double prior; };
@@ -328,13 +386,25 @@ static bool plan_gconv(const RdConvDesc& d, GconvPlan& best) {
                 double score = c.prior * m_util * n_util / (1.0 + 0.04 * (halo - 1.0));
                 if (lds > 80 * 1024) score *= 0.85;          // one workgroup per CU only
                 if (ckp == 16 && d.Cin >= 32) score *= 0.97;  // half-line loads
-                // CU load balance: the kernel is MFMA-bound, so the time is set by the CU that owns the most workgroups
-                const double wgs = (double)d.N * cdiv(P.lh, TH) * cdiv(P.lw, TW) * n_cot * d.n_phases;
+                // CU load balance: the kernel is MFMA-bound, so the time is set by the CU that owns the most workgroups.
+                // Small-spatial / many-channel layers do not produce enough large tiles: split the input channels over
+                // KS workgroups per tile (partials combined by gconv_combine_kernel).  Only single-phase, hole-free,
+                // unit-stride-output descriptors with a dense output buffer qualify.
+                const double wgs1 = (double)d.N * cdiv(P.lh, TH) * cdiv(P.lw, TW) * n_cot * d.n_phases;
                 const double ncu = (double)num_cus();
-                score *= wgs / (ncu * ceil(wgs / ncu));
-                if (score > best_score) {
-                    best_score = score;
-                    best = GconvPlan{c.MT, c.NT, c.WM, c.WN, CKW, ckp, TH, TW, PP, 0, n_cot, taps_max, pick_wsd(taps_max, BN, CKW, ckp), lds};
+                static const char* nosplit = getenv("RD_GCONV_NOSPLIT");
+                const bool can_split = !nosplit && allow_split && d.n_phases == 1 && d.out_stride == 1 && d.ldo == d.Cout && d.Cout <= 1024;
+                double base = score;
+                for (int ksp = 1; ksp <= (can_split ? 4 : 1); ksp *= 2) {
+                    if (d.Cin % (ksp * ckp) != 0) continue;
+                    const double wgs = wgs1 * ksp;
+                    // fewer than two workgroups per CU leaves staging/epilogue phases uncovered
+                    score = base * (wgs / (ncu * ceil(wgs / ncu))) * (ksp == 1 ? 1.0 : (ksp == 2 ? 0.95 : 0.91)) *
+                            (wgs < 2 * ncu ? 0.9 : 1.0);
+                    if (score > best_score) {
+                        best_score = score;
+                        best = GconvPlan{c.MT, c.NT, c.WM, c.WN, CKW, ckp, TH, TW, PP, 0, n_cot, taps_max, pick_wsd(taps_max, BN, CKW, ckp), ksp, lds};
+                    }
                 }
             }
         }
@@ -390,9 +460,11 @@ extern "C" int rd_gconv_plan_info(const RdConvDesc* d, int32_t* out) {
     if (validate_desc(d) != RD_OK) return RD_EINVAL;
     GconvPlan pl;
     RdConvDesc dd = *d;
-    if (!plan_gconv(dd, pl)) { set_error("gconv: no feasible tiling"); return RD_EINVAL; }
+    if (!plan_gconv(dd, pl, true)) { set_error("gconv: no feasible tiling"); return RD_EINVAL; }
     fill_tiles(dd, pl);
-    const int v[10] = {pl.MT, pl.NT, pl.WM, pl.WN, pl.CKW, pl.CKP, pl.TH, pl.TW, (int)pl.lds_bytes, d->N * pl.tiles_total * pl.n_cotiles};
+    // (reports the plan used WITH a workspace; CKW slot carries ksplit*100 + CKW)
+    const int v[10] = {pl.MT, pl.NT, pl.WM, pl.WN, pl.ksplit * 100 + pl.CKW, pl.CKP, pl.TH, pl.TW, (int)pl.lds_bytes,
+                       d->N * pl.tiles_total * pl.n_cotiles * pl.ksplit};
     for (int i = 0; i < 10; ++i) out[i] = v[i];
     return RD_OK;
 }
@@ -419,36 +491,62 @@ extern "C" int rd_gconv_occupancy(const RdConvDesc* d) {
     return -1;
 }
 
-extern "C" int rd_gconv_stat_tiles(const RdConvDesc* d) {
-    if (validate_desc(d) != RD_OK) return RD_EINVAL;
-    GconvPlan pl;
-    RdConvDesc dd = *d;
-    if (!plan_gconv(dd, pl)) { set_error("gconv: no feasible tiling"); return RD_EINVAL; }
+static int plan_query(const RdConvDesc* d, bool allow_split, GconvPlan& pl, RdConvDesc& dd) {
+    int rc = validate_desc(d);
+    if (rc != RD_OK) return rc;
+    dd = *d;
+    if (!plan_gconv(dd, pl, allow_split)) { set_error("gconv: no feasible tiling"); return RD_EINVAL; }
     fill_tiles(dd, pl);
+    return RD_OK;
+}
+
+extern "C" int rd_gconv_stat_tiles(const RdConvDesc* d) {
+    GconvPlan pl; RdConvDesc dd;
+    if (plan_query(d, false, pl, dd) != RD_OK) return RD_EINVAL;
     return d->N * pl.tiles_total;
 }
 
-extern "C" int rd_gconv(const RdConvDesc* d, const float* in, const float* w_packed, float* out, const float* addend,
-                        int32_t ld_add, float* stat_partial, void* stream) {
-    int rc = validate_desc(d);
-    if (rc != RD_OK) return rc;
+// with a workspace the planner may split the input channels over several workgroups per tile (split-K)
+extern "C" int64_t rd_gconv_workspace_floats(const RdConvDesc* d) {
+    GconvPlan pl; RdConvDesc dd;
+    if (plan_query(d, true, pl, dd) != RD_OK) return RD_EINVAL;
+    return pl.ksplit > 1 ? (int64_t)pl.ksplit * d->N * d->Ho * d->Wo * d->ldo : 0;
+}
+extern "C" int rd_gconv_stat_tiles_ws(const RdConvDesc* d) {
+    GconvPlan pl; RdConvDesc dd;
+    if (plan_query(d, true, pl, dd) != RD_OK) return RD_EINVAL;
+    if (pl.ksplit == 1) return d->N * pl.tiles_total;
+    const long long M = (long long)d->N * d->Ho * d->Wo;
+    return (int)((M + combine_rows_per_block(M) - 1) / combine_rows_per_block(M));
+}
+
+static int gconv_impl(const RdConvDesc* d, const float* in, const float* w_packed, float* out, const float* addend,
+                      int32_t ld_add, float* stat_partial, float* ws, void* stream) {
     RD_CHECK_ARG(in && w_packed && out, "gconv: null tensor");
     GconvArgs a;
-    a.d = *d;
     GconvPlan pl;
-    if (!plan_gconv(a.d, pl)) { set_error("gconv: no feasible tiling"); return RD_EINVAL; }
-    fill_tiles(a.d, pl);
-    a.in = in; a.w = w_packed; a.out = out; a.addend = addend; a.stat = stat_partial;
+    int rc = plan_query(d, ws != nullptr, pl, a.d);
+    if (rc != RD_OK) return rc;
+    const bool split = pl.ksplit > 1;
+    a.in = in; a.w = w_packed;
+    a.out = split ? ws : out;
+    a.addend = split ? nullptr : addend;
+    a.stat = split ? nullptr : stat_partial;
     a.ld_add = ld_add; a.ldw = d->Cout;
     a.TH = pl.TH; a.TW = pl.TW; a.PP = pl.PP; a.CKP = pl.CKP;
     a.tiles_total = pl.tiles_total; a.n_cotiles = pl.n_cotiles; a.taps_max = pl.taps_max; a.WSD = pl.WSD;
+    a.ksplit = pl.ksplit;
+    a.split_stride = (long long)d->N * d->Ho * d->Wo * d->ldo;
     { static const char* dbg = getenv("RD_GCONV_DEBUG"); a.debug = dbg ? atoi(dbg) : 0; }
-    const int grid = d->N * pl.tiles_total * pl.n_cotiles;
+    const int grid = d->N * pl.tiles_total * pl.n_cotiles * pl.ksplit;
     hipStream_t s = static_cast<hipStream_t>(stream);
+    rc = RD_EINVAL;
+    bool launched = false;
 #define RD_TRY(MT_, NT_, WM_, WN_)                                                                  \
-    if (pl.MT == MT_ && pl.NT == NT_ && pl.WM == WM_ && pl.WN == WN_) {                             \
-        if (pl.CKW == 8) return launch_cfg<MT_, NT_, WM_, WN_, 8>(a, grid, pl.lds_bytes, s);        \
-        return launch_cfg<MT_, NT_, WM_, WN_, 4>(a, grid, pl.lds_bytes, s);                         \
+    if (!launched && pl.MT == MT_ && pl.NT == NT_ && pl.WM == WM_ && pl.WN == WN_) {                \
+        launched = true;                                                                            \
+        rc = pl.CKW == 8 ? launch_cfg<MT_, NT_, WM_, WN_, 8>(a, grid, pl.lds_bytes, s)              \
+                         : launch_cfg<MT_, NT_, WM_, WN_, 4>(a, grid, pl.lds_bytes, s);             \
     }
     RD_TRY(2, 2, 4, 1)
     RD_TRY(2, 1, 4, 1)
@@ -458,6 +556,24 @@ extern "C" int rd_gconv(const RdConvDesc* d, const float* in, const float* w_pac
     RD_TRY(4, 2, 2, 2)
     RD_TRY(1, 1, 4, 1)
 #undef RD_TRY
-    set_error("gconv: unsupported plan");
-    return RD_EINVAL;
+    if (!launched) { set_error("gconv: unsupported plan"); return RD_EINVAL; }
+    if (rc != RD_OK || !split) return rc;
+    const long long M = (long long)d->N * d->Ho * d->Wo;
+    const int RPB = combine_rows_per_block(M), blocks = (int)((M + RPB - 1) / RPB);
+    const int Q = d->Cout / 4, RL = 256 / Q;
+    RD_CHECK_ARG(Q >= 1 && Q <= 256, "gconv: split-K combine needs Cout <= 1024");
+    hipLaunchKernelGGL(gconv_combine_kernel, dim3(blocks), dim3(256), (size_t)RL * 2 * d->Cout * sizeof(float), s, ws, a.split_stride,
+                       pl.ksplit, out, d->ldo, addend, ld_add, M, d->Cout, RPB, stat_partial);
+    RD_CHECK_LAUNCH("gconv_combine_kernel");
+    return RD_OK;
+}
+
+extern "C" int rd_gconv(const RdConvDesc* d, const float* in, const float* w_packed, float* out, const float* addend,
+                        int32_t ld_add, float* stat_partial, void* stream) {
+    return gconv_impl(d, in, w_packed, out, addend, ld_add, stat_partial, nullptr, stream);
+}
+
+extern "C" int rd_gconv_ws(const RdConvDesc* d, const float* in, const float* w_packed, float* out, const float* addend,
+                           int32_t ld_add, float* stat_partial, float* ws, void* stream) {
+    return gconv_impl(d, in, w_packed, out, addend, ld_add, stat_partial, ws, stream);
 }

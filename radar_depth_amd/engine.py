@@ -114,6 +114,13 @@ class LateFusionPlan:
         return self.m._grad_view(param)
 
     # ------------------------------------------------------------------ convolution (gconv family)
+    def _gconv_ws(self, d, name):
+        """Split-K workspace of a descriptor (None when the library's plan does not split)."""
+        n = self.L.rd_gconv_workspace_floats(C.byref(d))
+        if n < 0:
+            check(int(n), "rd_gconv_workspace_floats(%s)" % name)
+        return self.buf(int(n)) if n > 0 else None
+
     def conv_fwd(self, name, x, weights, k, stride, pad, out=None, upproj=False, lst=None):
         """weights: list of (param OIHW, column offset).  Returns (raw Act, ctx)."""
         lst = self.fwd if lst is None else lst
@@ -134,12 +141,13 @@ class LateFusionPlan:
             o, i, kh, kw = w.shape
             self.op(self.prep, name + ".pack", self.L.rd_pack_weights, _p(w), _p(wp), o, i, kh, kw, cout, off, i, 0, self.stream)
             self.op(self.prep, name + ".packT", self.L.rd_pack_weights, _p(w), _p(wd), o, i, kh, kw, cin, off, cout, 1, self.stream)
-        tiles = self.L.rd_gconv_stat_tiles(C.byref(d))
+        tiles = self.L.rd_gconv_stat_tiles_ws(C.byref(d))
         if tiles < 0:
-            check(tiles, "rd_gconv_stat_tiles(%s)" % name)
+            check(tiles, "rd_gconv_stat_tiles_ws(%s)" % name)
         stat = self.buf(tiles, 2, cout) if self.train else None
+        ws = self._gconv_ws(d, name)
         self.keep.append(d)
-        self.op(lst, name, self.L.rd_gconv, C.byref(d), x.ptr, _p(wp), out.ptr, C.c_void_p(0), 0, _p(stat), self.stream)
+        self.op(lst, name, self.L.rd_gconv_ws, C.byref(d), x.ptr, _p(wp), out.ptr, C.c_void_p(0), 0, _p(stat), _p(ws), self.stream)
         self.taps[name] = out
         self.meta[name] = ("gconv", d)
         ctx = dict(name=name, d=d, x=x, out=out, weights=weights, wd=wd, k=k, stride=stride, pad=pad, upproj=upproj,
@@ -180,9 +188,9 @@ class LateFusionPlan:
             if addend is not None:
                 raise NotImplementedError("addend with a zero-filled stride-2 dgrad")
         self.meta[name + ".dgrad"] = ("gconv", dd)
-        self.op(self.bwd, name + ".dgrad", self.L.rd_gconv, C.byref(dd), dout.ptr, _p(ctx["wd"]), dx.ptr,
+        self.op(self.bwd, name + ".dgrad", self.L.rd_gconv_ws, C.byref(dd), dout.ptr, _p(ctx["wd"]), dx.ptr,
                 addend.ptr if addend is not None else C.c_void_p(0), addend.ld if addend is not None else 0,
-                C.c_void_p(0), self.stream)
+                C.c_void_p(0), _p(self._gconv_ws(dd, name + ".dgrad")), self.stream)
         return dx
 
     # ------------------------------------------------------------------ batch norm

@@ -32,15 +32,27 @@ def pack_weights(w_oihw, transpose=False, out=None, ldc=None, off=0, rows_total=
 
 
 def gconv_stat_tiles(desc):
-    n = lib().rd_gconv_stat_tiles(C.byref(desc))
+    n = lib().rd_gconv_stat_tiles_ws(C.byref(desc))
     if n < 0:
-        check(n, "rd_gconv_stat_tiles")
+        check(n, "rd_gconv_stat_tiles_ws")
     return n
 
 
+_WS = {}
+
+
 def gconv(desc, x, w_packed, out, addend=None, ld_add=0, stat=None):
-    check(lib().rd_gconv(C.byref(desc), ptr(x), ptr(w_packed), ptr(out), ptr(addend), ld_add, ptr(stat),
-                         current_stream()), "rd_gconv")
+    """Runs through rd_gconv_ws (split-K allowed); the workspace is cached per size on the tensor's device."""
+    n = int(lib().rd_gconv_workspace_floats(C.byref(desc)))
+    if n < 0:
+        check(n, "rd_gconv_workspace_floats")
+    ws = None
+    if n > 0:
+        ws = _WS.get((n, out.device))
+        if ws is None:
+            ws = _WS[(n, out.device)] = torch.empty(n, dtype=torch.float32, device=out.device)
+    check(lib().rd_gconv_ws(C.byref(desc), ptr(x), ptr(w_packed), ptr(out), ptr(addend), ld_add, ptr(stat), ptr(ws),
+                            current_stream()), "rd_gconv_ws")
     return out
 
 

@@ -50,6 +50,9 @@ def _run_fwd(n, ci, co, k, s, p, h, w, seed=0):
     (2, 32, 32, 3, 1, 1, 120, 200),   # decoder.layer3 conv2
     (1, 16, 16, 3, 1, 1, 240, 400),   # decoder.layer4 conv2
     (3, 32, 48, 3, 1, 1, 9, 7),       # tiny / ragged
+    (16, 512, 512, 3, 1, 1, 15, 25),  # B=16: the planner splits the input channels (split-K + combine kernel)
+    (16, 512, 256, 1, 1, 0, 15, 25),
+    (16, 128, 128, 3, 1, 1, 15, 25),
 ])
 def test_gconv_forward(cfg):
     _run_fwd(*cfg)
@@ -61,6 +64,7 @@ def test_gconv_forward(cfg):
     (2, 64, 128, 1, 2, 0, 113, 200),
     (2, 256, 512, 3, 2, 1, 29, 50),
     (2, 16, 32, 3, 2, 1, 57, 101),
+    (16, 512, 512, 3, 1, 1, 15, 25),  # split-K dgrad with the residual addend applied by the combine kernel
 ])
 def test_gconv_dgrad(cfg):
     from radar_depth_amd import convdesc as cd, ops
