@@ -114,6 +114,13 @@ int rd_wgrad_reduce(const RdConvDesc* d, const float* slabs, float* grad_oihw, i
 int rd_pack_weights(const float* w_oihw, float* packed, int32_t O, int32_t I, int32_t KH, int32_t KW,
                     int32_t ldc, int32_t co_off, int32_t rows_total, int32_t transpose, void* stream);
 
+/* All weight tensors of a network in ONE launch.  jobs_dev: device array of
+ *   struct { const float* src; float* dst; int32_t O, I, T(=KH*KW), ldc, off, rows_total, transpose, first_block; }
+ * (same meaning as rd_pack_weights' arguments); block_job_dev[b] = job index of block b, where job j owns blocks
+ * [first_block, first_block + ceil(O*I*T / rd_pack_chunk())).  Both arrays are built once by the host plan. */
+int rd_pack_chunk(void);
+int rd_pack_weights_batched(const void* jobs_dev, const int32_t* block_job_dev, int32_t n_blocks, void* stream);
+
 /* ---------------------------------------------------------------------------------------
  * Stem convolutions: 7x7 stride 2 pad 3 read straight from the network's NCHW input
  * (models.py:539,559,633,643; multistage_model.py:163-164,236-241).  The Cin (1..3) input

@@ -26,6 +26,36 @@ __global__ void pack_weights_kernel(const float* __restrict__ w, float* __restri
     }
 }
 
+// One launch for every weight tensor of the network: block b works on chunk (b - job.first_block) of job block_job[b].
+// Same index mapping as pack_weights_kernel.
+struct PackJob {
+    const float* src;
+    float* dst;
+    int O, I, T, ldc, off, rows_total, transpose, first_block;
+};
+constexpr int PACK_CHUNK = 2048;
+__global__ __launch_bounds__(256) void pack_weights_batched_kernel(const PackJob* __restrict__ jobs, const int* __restrict__ block_job) {
+    const PackJob j = jobs[block_job[blockIdx.x]];
+    const int64_t total = (int64_t)j.O * j.I * j.T;
+    const int64_t base = (int64_t)(blockIdx.x - j.first_block) * PACK_CHUNK;
+#pragma unroll
+    for (int u = 0; u < PACK_CHUNK / 256; ++u) {
+        const int64_t e = base + u * 256 + threadIdx.x;
+        if (e >= total) break;
+        if (!j.transpose) {
+            const int o = (int)(e % j.O);
+            const int64_t r = e / j.O;
+            const int i = (int)(r % j.I), t = (int)(r / j.I);
+            j.dst[((int64_t)t * j.I + i) * j.ldc + j.off + o] = j.src[((int64_t)o * j.I + i) * j.T + t];
+        } else {
+            const int i = (int)(e % j.I);
+            const int64_t r = e / j.I;
+            const int o = (int)(r % j.O), t = (int)(r / j.O);
+            j.dst[((int64_t)t * j.rows_total + j.off + o) * j.ldc + i] = j.src[((int64_t)o * j.I + i) * j.T + t];
+        }
+    }
+}
+
 __global__ void fill_kernel(float* __restrict__ p, int64_t n, float v) {
     for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (int64_t)gridDim.x * blockDim.x) p[e] = v;
 }
@@ -64,6 +94,16 @@ extern "C" int rd_pack_weights(const float* w_oihw, float* packed, int32_t O, in
     hipLaunchKernelGGL(pack_weights_kernel, dim3(grid_for(total, 256)), dim3(256), 0, static_cast<hipStream_t>(stream),
                        w_oihw, packed, O, I, KH * KW, ldc, co_off, rows_total, transpose);
     RD_CHECK_LAUNCH("pack_weights_kernel");
+    return RD_OK;
+}
+
+extern "C" int rd_pack_chunk(void) { return PACK_CHUNK; }
+
+extern "C" int rd_pack_weights_batched(const void* jobs_dev, const int32_t* block_job_dev, int32_t n_blocks, void* stream) {
+    RD_CHECK_ARG(jobs_dev && block_job_dev && n_blocks > 0, "pack_weights_batched: bad arguments");
+    hipLaunchKernelGGL(pack_weights_batched_kernel, dim3(n_blocks), dim3(256), 0, static_cast<hipStream_t>(stream),
+                       static_cast<const PackJob*>(jobs_dev), block_job_dev);
+    RD_CHECK_LAUNCH("pack_weights_batched_kernel");
     return RD_OK;
 }
 

@@ -33,16 +33,17 @@ __global__ __launch_bounds__(256) void stem_fwd_kernel(const StemArgs a) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, hh = lane >> 5;
     const int K = 49 * a.Cin, Kp = (K + 1) & ~1;
     const int PLANE = PH * ST_PW;
-    int* s_koff = reinterpret_cast<int*>(smem);        // [Kp]
-    float* s_w = smem + ((Kp + 3) & ~3);               // [Kp][BN]
-    float* s_patch = s_w + (size_t)Kp * BN;            // [Cin][PH][PW]
+    const int Kq = Kp + 4;                              // slack rows: the pipelined loop prefetches up to two steps past the end
+    int* s_koff = reinterpret_cast<int*>(smem);        // [Kq]
+    float* s_w = smem + ((Kq + 3) & ~3);               // [Kq][BN]
+    float* s_patch = s_w + (size_t)Kq * BN;            // [Cin][PH][PW]
 
     const int bid = xcd_remap(blockIdx.x, gridDim.x);
     const int n = bid / (a.tiles_h * a.tiles_w);
     const int trem = bid - n * (a.tiles_h * a.tiles_w);
     const int r0 = (trem / a.tiles_w) * TH, c0 = (trem % a.tiles_w) * ST_TW;
 
-    for (int k = tid; k < Kp; k += 256) {
+    for (int k = tid; k < Kq; k += 256) {
         int off = 0;
         if (k < K) {
             const int t = k / a.Cin, ci = k - t * a.Cin;
@@ -50,7 +51,7 @@ __global__ __launch_bounds__(256) void stem_fwd_kernel(const StemArgs a) {
         }
         s_koff[k] = off;
     }
-    for (int e = tid; e < Kp * (BN / 4); e += 256) {
+    for (int e = tid; e < Kq * (BN / 4); e += 256) {
         const int k = e / (BN / 4), j = (e - k * (BN / 4)) * 4;
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
         if (k < K && j < a.Cout) v = *reinterpret_cast<const float4*>(a.w + (size_t)k * a.Cout + j);
@@ -79,21 +80,37 @@ __global__ __launch_bounds__(256) void stem_fwd_kernel(const StemArgs a) {
 #pragma unroll
             for (int i = 0; i < 16; ++i) acc[mt][nt][i] = 0.f;
 
-#pragma unroll 2
-    for (int kk = 0; kk < Kp; kk += 2) {
-        const int k = kk + hh;
-        const int ko = s_koff[k];
-        float av[MT], bv[NT];
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt) av[mt] = s_patch[abase[mt] + ko];
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt) bv[nt] = s_w[(size_t)k * BN + nt * 32 + l31];
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-            for (int nt = 0; nt < NT; ++nt)
-                acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[mt], bv[nt], acc[mt][nt], 0, 0, 0);
+    // K walk, two k per MFMA.  Software pipeline pinned with sched_barrier (see gconv.hip): two register sets ping-pong;
+    // while one step's MT*NT MFMAs issue, the next step's fragments and the k->offset entry after that are in flight.
+    const int nst = Kp / 2;              // Kp is even; s_koff / s_w have >= 4 slack entries past Kp (host LDS sizing)
+    float a0[MT], b0[NT], a1[MT], b1[NT];
+    int ko_n = s_koff[hh];
+#define RD_ST_LOAD(AV, BV, STEP)                                                             \
+    {                                                                                        \
+        const int k_ = 2 * (STEP) + hh;                                                      \
+        _Pragma("unroll") for (int mt = 0; mt < MT; ++mt) AV[mt] = s_patch[abase[mt] + ko_n]; \
+        _Pragma("unroll") for (int nt = 0; nt < NT; ++nt) BV[nt] = s_w[(size_t)k_ * BN + nt * 32 + l31]; \
+        ko_n = s_koff[k_ + 2];                                                               \
     }
+#define RD_ST_MFMA(AV, BV)                                                                   \
+    _Pragma("unroll") for (int mt = 0; mt < MT; ++mt)                                        \
+        _Pragma("unroll") for (int nt = 0; nt < NT; ++nt)                                    \
+            acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(AV[mt], BV[nt], acc[mt][nt], 0, 0, 0);
+    RD_ST_LOAD(a0, b0, 0)
+    for (int st = 0; st < nst; st += 2) {
+        RD_ST_LOAD(a1, b1, st + 1)
+        __builtin_amdgcn_sched_barrier(0);
+        RD_ST_MFMA(a0, b0)
+        __builtin_amdgcn_sched_barrier(0);
+        if (st + 1 < nst) {
+            RD_ST_LOAD(a0, b0, st + 2)
+            __builtin_amdgcn_sched_barrier(0);
+            RD_ST_MFMA(a1, b1)
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+#undef RD_ST_LOAD
+#undef RD_ST_MFMA
 
     float ssum[NT], ssq[NT];
 #pragma unroll
@@ -196,19 +213,33 @@ __global__ __launch_bounds__(256) void stem_wgrad_kernel(const StemArgs a, float
             *reinterpret_cast<float4*>(s_do + (size_t)p * BN + j) = v;
         }
         __syncthreads();
-        for (int q = wave; q < NPIX / 2; q += 4) {
-            const int p = 2 * q + hh;
-            const int aoff = (2 * (p >> 5)) * ST_PW + 2 * (p & 31);
-            float av[MTK], bv[NT];
-#pragma unroll
-            for (int mt = 0; mt < MTK; ++mt) av[mt] = s_patch[aoff + koff[mt]];
-#pragma unroll
-            for (int nt = 0; nt < NT; ++nt) bv[nt] = s_do[(size_t)p * BN + nt * 32 + l31];
-#pragma unroll
-            for (int mt = 0; mt < MTK; ++mt)
-#pragma unroll
-                for (int nt = 0; nt < NT; ++nt)
-                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[mt], bv[nt], acc[mt][nt], 0, 0, 0);
+        // pixel walk (two pixels per MFMA), pipelined like the forward K walk; NPIX/2/4 = 16 steps per wave (even)
+        {
+            float a0[MTK], b0[NT], a1[MTK], b1[NT];
+#define RD_SW_LOAD(AV, BV, Q)                                                                    \
+            {                                                                                        \
+                const int p_ = 2 * (Q) + hh;                                                         \
+                const int aoff_ = (2 * (p_ >> 5)) * ST_PW + 2 * (p_ & 31);                           \
+                _Pragma("unroll") for (int mt = 0; mt < MTK; ++mt) AV[mt] = s_patch[aoff_ + koff[mt]]; \
+                _Pragma("unroll") for (int nt = 0; nt < NT; ++nt) BV[nt] = s_do[(size_t)p_ * BN + nt * 32 + l31]; \
+            }
+#define RD_SW_MFMA(AV, BV)                                                                       \
+            _Pragma("unroll") for (int mt = 0; mt < MTK; ++mt)                                       \
+                _Pragma("unroll") for (int nt = 0; nt < NT; ++nt)                                    \
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(AV[mt], BV[nt], acc[mt][nt], 0, 0, 0);
+            RD_SW_LOAD(a0, b0, wave)
+            for (int q = wave; q < NPIX / 2; q += 8) {
+                RD_SW_LOAD(a1, b1, q + 4)
+                __builtin_amdgcn_sched_barrier(0);
+                RD_SW_MFMA(a0, b0)
+                __builtin_amdgcn_sched_barrier(0);
+                RD_SW_LOAD(a0, b0, (q + 8 < NPIX / 2 ? q + 8 : wave))
+                __builtin_amdgcn_sched_barrier(0);
+                RD_SW_MFMA(a1, b1)
+                __builtin_amdgcn_sched_barrier(0);
+            }
+#undef RD_SW_LOAD
+#undef RD_SW_MFMA
         }
     }
     // combine the four waves through LDS, one accumulator tile at a time; slab layout [K][Cout]
@@ -307,7 +338,8 @@ extern "C" int rd_stem_fwd(const float* const* planes, const int64_t* strides, i
     const int grid = N * a.tiles_h * a.tiles_w;
     const int NT = Cout > 32 ? 2 : 1, BN = NT * 32;
     const int Kp = (49 * Cin + 1) & ~1;
-    const size_t lds = ((size_t)((Kp + 3) & ~3) + (size_t)Kp * BN + (size_t)Cin * 21 * ST_PW) * 4;
+    const int Kq = Kp + 4;
+    const size_t lds = ((size_t)((Kq + 3) & ~3) + (size_t)Kq * BN + (size_t)Cin * 21 * ST_PW) * 4;
     hipStream_t s = static_cast<hipStream_t>(stream);
     static bool attr = false;
     if (!attr) {

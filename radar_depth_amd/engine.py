@@ -88,6 +88,7 @@ class LateFusionPlan:
         self.stream = C.c_void_p(0)
         self.fwd, self.bwd = [], []
         self.prep = []
+        self.pack_jobs = []    # (src, dst, O, I, T, ldc, off, rows_total, transpose): packed in ONE launch per forward
         self.taps = {}         # name -> Act of intermediate tensors (tests / debugging)
         self.meta = {}         # op name -> (kernel family, descriptor) for the conv launches (bench roofline accounting)
         self.keep = []         # keep ctypes descriptors and tensors alive
@@ -139,8 +140,8 @@ class LateFusionPlan:
         wd = self.buf(S, cout, cin)
         for w, off in weights:
             o, i, kh, kw = w.shape
-            self.op(self.prep, name + ".pack", self.L.rd_pack_weights, _p(w), _p(wp), o, i, kh, kw, cout, off, i, 0, self.stream)
-            self.op(self.prep, name + ".packT", self.L.rd_pack_weights, _p(w), _p(wd), o, i, kh, kw, cin, off, cout, 1, self.stream)
+            self.pack_jobs.append((w, wp, o, i, kh * kw, cout, off, i, 0))
+            self.pack_jobs.append((w, wd, o, i, kh * kw, cin, off, cout, 1))
         tiles = self.L.rd_gconv_stat_tiles_ws(C.byref(d))
         if tiles < 0:
             check(tiles, "rd_gconv_stat_tiles_ws(%s)" % name)
@@ -255,7 +256,7 @@ class LateFusionPlan:
         Hc, Wc = (H - 1) // 2 + 1, (W - 1) // 2 + 1
         raw = self.act(N, Hc, Wc, cout)
         wp = self.buf(49, cin, cout)
-        self.op(self.prep, name + ".pack", self.L.rd_pack_weights, _p(conv.weight), _p(wp), cout, cin, 7, 7, cout, 0, cin, 0, self.stream)
+        self.pack_jobs.append((conv.weight, wp, cout, cin, 49, cout, 0, cin, 0))
         tiles = self.L.rd_stem_stat_tiles(N, H, W)
         stat = self.buf(tiles, 2, cout) if self.train else None
         pl = (C.c_void_p * 3)(*([p for p in planes] + [None] * (3 - len(planes))))
@@ -427,8 +428,31 @@ class LateFusionPlan:
         self.op(self.fwd, "conv3", self.L.rd_head_conv_fwd, z.ptr, z.ld, _p(m.conv3.weight), N, z.H, z.W, z.C, _p(self.dmap), self.stream)
         self.pred = self.buf(N, 1, self.Ho, self.Wo)
         self.op(self.fwd, "bilinear", self.L.rd_bilinear_fwd, _p(self.dmap), N, z.H, z.W, _p(self.pred), self.Ho, self.Wo, self.stream)
+        self._finish_pack_jobs()
         if self.train:
             self._build_backward()
+
+    def _finish_pack_jobs(self):
+        """Upload the job table of rd_pack_weights_batched: one launch refreshes every packed weight copy."""
+        import numpy as np
+
+        class Job(C.Structure):
+            _fields_ = [("src", C.c_void_p), ("dst", C.c_void_p), ("O", C.c_int32), ("I", C.c_int32), ("T", C.c_int32),
+                        ("ldc", C.c_int32), ("off", C.c_int32), ("rows_total", C.c_int32), ("transpose", C.c_int32),
+                        ("first_block", C.c_int32)]
+        chunk = self.L.rd_pack_chunk()
+        jobs = (Job * len(self.pack_jobs))()
+        block_job, nb = [], 0
+        for k, (src, dst, o, i, t, ldc, off, rows, tr) in enumerate(self.pack_jobs):
+            n = -(-(o * i * t) // chunk)
+            jobs[k] = Job(src.data_ptr(), dst.data_ptr(), o, i, t, ldc, off, rows, tr, nb)
+            block_job += [k] * n
+            nb += n
+        raw = np.frombuffer(bytes(jobs), dtype=np.uint8).copy()
+        self.pack_table = torch.from_numpy(raw).to(self.dev)
+        self.pack_blocks = torch.tensor(block_job, dtype=torch.int32, device=self.dev)
+        self.keep += [self.pack_table, self.pack_blocks]
+        self.op(self.prep, "pack_all", self.L.rd_pack_weights_batched, _p(self.pack_table), _p(self.pack_blocks), nb, self.stream)
 
     def _build_backward(self):
         m, N = self.m, self.N
