@@ -216,6 +216,10 @@ int rd_loss_tiles(int64_t n);
 /* dpred (+)= coef_dev[0] * (-sign(t-p)) / count on valid pixels; coef read on device */
 int rd_masked_l1_bwd(const float* pred, const float* target, int64_t n, const double* sums,
                      const float* coef, float* dpred, int32_t accumulate, void* stream);
+/* Result.evaluate (evaluation/metrics.py:34-58) as ONE masked reduction instead of ~12 blocking float() syncs:
+ * sums[10] = count, sum d^2, sum |d|, sum |log10 o - log10 t|, sum |d|/t, #(r<1.25), #(r<1.25^2), #(r<1.25^3),
+ * sum (1/o-1/t)^2, sum |1/o-1/t| over pixels with target > 0.  ws: 10*rd_loss_tiles(n) doubles. */
+int rd_depth_metrics(const float* output, const float* target, int64_t n, float* ws, double* sums, void* stream);
 /* SmoothnessLoss (:8-28) on pred [N,1,H,W] and image [N,C,H,W] (NCHW).  out[0] = loss.
  * ws: rd_smooth_workspace_floats(N,H,W) floats, 8-byte aligned; rd_smooth_bwd reuses what fwd left there. */
 int64_t rd_smooth_workspace_floats(int32_t N, int32_t H, int32_t W);

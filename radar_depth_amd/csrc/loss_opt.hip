@@ -65,6 +65,39 @@ __global__ __launch_bounds__(256) void l1_bwd_kernel(const float* __restrict__ p
     }
 }
 
+// ---------------------------------------------------------------- evaluation metrics (evaluation/metrics.py:34-58)
+// part[block][10]: count, sum d^2, sum |d|, sum |log10 o - log10 t|, sum |d|/t, #(r<1.25), #(r<1.25^2), #(r<1.25^3),
+// sum (1/o-1/t)^2, sum |1/o-1/t|   over pixels with t > 0, d = o - t, r = max(o/t, t/o)
+__global__ __launch_bounds__(256) void metrics_partial_kernel(const float* __restrict__ out, const float* __restrict__ target,
+                                                              int64_t n, double* __restrict__ part) {
+    __shared__ double sh[4];
+    double acc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    const float inv_ln10 = 0.4342944819032518f;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (int64_t)gridDim.x * blockDim.x) {
+        const float t = target[e];
+        if (t > 0.f) {
+            const float o = out[e];
+            const float ad = fabsf(o - t);
+            acc[0] += 1.0;
+            acc[1] += (double)(ad * ad);
+            acc[2] += (double)ad;
+            acc[3] += (double)fabsf(logf(o) * inv_ln10 - logf(t) * inv_ln10);
+            acc[4] += (double)(ad / t);
+            const float r = fmaxf(o / t, t / o);
+            if (r < 1.25f) acc[5] += 1.0;
+            if (r < 1.25f * 1.25f) acc[6] += 1.0;
+            if (r < 1.25f * 1.25f * 1.25f) acc[7] += 1.0;
+            const float id = fabsf(1.f / o - 1.f / t);
+            acc[8] += (double)(id * id);
+            acc[9] += (double)id;
+        }
+    }
+    for (int k = 0; k < 10; ++k) {
+        const double s = block_sum_d(acc[k], sh);
+        if (threadIdx.x == 0) part[(size_t)blockIdx.x * 10 + k] = s;
+    }
+}
+
 // ---------------------------------------------------------------- smoothness
 // pass 1: per-sample sum of pred -> part[n][block]
 __global__ __launch_bounds__(256) void smooth_sum_kernel(const float* __restrict__ pred, int64_t hw, double* __restrict__ part) {
@@ -258,6 +291,19 @@ extern "C" int rd_masked_l1_sums(const float* pred, const float* target, int64_t
     hipLaunchKernelGGL(l1_partial_kernel, dim3(g), dim3(256), 0, s, pred, target, n, part);
     RD_CHECK_LAUNCH("l1_partial_kernel");
     hipLaunchKernelGGL(pair_final_kernel, dim3(1), dim3(256), 0, s, part, g, 2, sums);
+    RD_CHECK_LAUNCH("pair_final_kernel");
+    return RD_OK;
+}
+
+// sums[10] as listed above; ws: 10*rd_loss_tiles(n) doubles
+extern "C" int rd_depth_metrics(const float* output, const float* target, int64_t n, float* ws, double* sums, void* stream) {
+    RD_CHECK_ARG(output && target && ws && sums && n > 0 && ((uintptr_t)ws & 7) == 0, "depth_metrics: bad arguments");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const int g = red_grid(n);
+    double* part = reinterpret_cast<double*>(ws);
+    hipLaunchKernelGGL(metrics_partial_kernel, dim3(g), dim3(256), 0, s, output, target, n, part);
+    RD_CHECK_LAUNCH("metrics_partial_kernel");
+    hipLaunchKernelGGL(pair_final_kernel, dim3(1), dim3(256), 0, s, part, g, 10, sums);
     RD_CHECK_LAUNCH("pair_final_kernel");
     return RD_OK;
 }

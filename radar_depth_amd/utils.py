@@ -1,6 +1,10 @@
 """Counterpart of the reference's utils.py for the hot path: the argparse flag surface (utils.py:16-74) and the
-learning-rate schedule (utils.py:85-89).  Checkpoint / visualisation helpers are outside the path."""
+learning-rate schedule (utils.py:85-89).  save_checkpoint (utils.py:77-82) keeps the wire format; visualisation helpers are outside the path."""
 import argparse
+import os
+import shutil
+
+import torch
 
 from .model.models import Decoder
 
@@ -43,6 +47,16 @@ def parse_command(argv=None):
         print("max depth is forced to be 0.0 when input modality is rgb/rgbd")
         args.max_depth = 0.0
     return args
+
+
+def save_checkpoint(state, is_best, epoch, output_directory):
+    """Reference wire format (utils.py:77-82, main.py:358-374): torch.save of {args, epoch, arch, model_state_dict,
+    best_result, optimizer_state_dict} as checkpoint-<epoch>.pth.tar (+ model_best.pth.tar)."""
+    checkpoint_filename = os.path.join(output_directory, 'checkpoint-' + str(epoch) + '.pth.tar')
+    torch.save(state, checkpoint_filename)
+    if is_best:
+        shutil.copyfile(checkpoint_filename, os.path.join(output_directory, 'model_best.pth.tar'))
+    return checkpoint_filename
 
 
 def adjust_learning_rate(optimizer, epoch, lr_init):

@@ -66,3 +66,36 @@ def test_plugin_surface():
         m(torch.zeros(1, 4, 450, 800))
     opt = torch.optim.SGD(m.parameters(), 0.01)
     assert utils.adjust_learning_rate(opt, 7, 0.01) == pytest.approx(0.001) and opt.param_groups[0]["lr"] == pytest.approx(0.001)
+
+
+def test_checkpoint_wire_format(tmp_path):
+    """the reference's .pth.tar payload round-trips between the HIP-backed modules and the
+    reference-shaped (oracle) modules: identical keys, shapes and values, multistage shape filtering included."""
+    from oracle.models import ResNet_latefusion as ORef
+    from oracle.multistage_model import ResNet_multistage as OMulti
+    from radar_depth_amd import utils
+    from radar_depth_amd.model.models import ResNet_latefusion
+    from radar_depth_amd.model.multistage_model import ResNet_multistage
+    from radar_depth_amd.synthetic import procedural_fill_
+    src = ORef(18, "upproj", [97, 161], 4, False)
+    procedural_fill_(src)
+    opt = torch.optim.SGD(src.parameters(), 0.01, momentum=0.9, weight_decay=1e-4)
+    path = utils.save_checkpoint({"args": None, "epoch": 3, "arch": "resnet18_latefusion", "model_state_dict": src.state_dict(),
+                                  "best_result": None, "optimizer_state_dict": opt.state_dict()}, True, 3, str(tmp_path))
+    assert os.path.exists(os.path.join(str(tmp_path), "model_best.pth.tar"))
+    ck = torch.load(path, map_location="cpu", weights_only=False)
+    m = ResNet_latefusion(18, "upproj", [97, 161], 4, False)
+    missing, unexpected = m.load_state_dict(ck["model_state_dict"], strict=False)     # main.py:208,251 use strict=False
+    assert not missing and not unexpected
+    for (k, a), (k2, b) in zip(m.state_dict().items(), src.state_dict().items()):
+        assert k == k2 and torch.equal(a, b)
+    # multistage: stage 1 loads the late-fusion checkpoint directly, stage 2 drops the shape-mismatched depth stem
+    ms = ResNet_multistage(18, "upproj", [97, 161], False)
+    ms.stage1.load_state_dict(ck["model_state_dict"])
+    filt = ms.filter_state_dict(dict(ck["model_state_dict"]), ms.stage2.state_dict())
+    assert "conv1_depth.weight" not in filt and len(filt) == 324
+    ms.stage2.load_state_dict(filt, strict=False)
+    assert torch.equal(ms.stage2.conv3.weight, src.conv3.weight)
+    # and back: a HIP-module checkpoint loads into the reference-shaped module
+    om = OMulti(18, "upproj", [97, 161], False)
+    om.load_state_dict(ms.state_dict())

@@ -276,3 +276,22 @@ def test_data_parallel_path_single_rank(monkeypatch):
             assert torch.equal(p, q)
     finally:
         dist.destroy_process_group()
+
+
+def test_checkpoint_loads_and_eval_forward_matches_oracle():
+    """A reference-format state_dict loaded into the HIP module reproduces the oracle's eval-mode forward (running-stat BN)."""
+    from oracle.models import ResNet_latefusion as ORef
+    from radar_depth_amd.model.models import ResNet_latefusion
+    from radar_depth_amd.synthetic import make_batch, procedural_fill_
+    h, w = 97, 161
+    o = ORef(18, "upproj", [h, w], 4, False)
+    procedural_fill_(o)
+    o.eval()
+    m = ResNet_latefusion(18, "upproj", [h, w], 4, False)
+    m.load_state_dict(o.state_dict())
+    m = m.cuda().eval()
+    x, _ = make_batch(1, h, w, 5, ref_pixels=h * w)          # validate() uses batch size 1 (main.py:636)
+    with torch.no_grad():
+        want = o(x)
+        got = m(x.cuda())
+    assert rel(got.cpu().numpy(), want.numpy()) < 1e-3

@@ -193,3 +193,27 @@ def test_losses_filter_sgd(golden_dir):
                                 current_stream()), "sgd")
     torch.cuda.synchronize()
     assert _rel(P[:1003].cpu(), ref.detach()) < 1e-6
+
+
+def test_depth_metrics(golden_dir):
+    """Result.evaluate / AverageMeter (evaluation/metrics.py:34-58,179-216) against vectors from the real reference."""
+    import os
+
+    import numpy as np
+
+    from radar_depth_amd.evaluation.metrics import AverageMeter, Result
+    want = np.load(os.path.join(golden_dir, "metrics.npz"))
+    out, tgt = torch.tensor(want["out"]).cuda(), torch.tensor(want["target"]).cuda()
+    names = [str(n) for n in want["names"]]
+    r1, r2 = Result(), Result()
+    r1.evaluate(out, tgt)
+    r2.evaluate(out * 1.1 + 0.3, tgt)
+    for r, key in ((r1, "r1"), (r2, "r2")):
+        got = np.array([getattr(r, n) for n in names])
+        assert np.abs(got - want[key]).max() / np.abs(want[key]).max() < 2e-5, (key, got, want[key])
+    m = AverageMeter()
+    m.update(r1, 0.5, 0.1, 2)
+    m.update(r2, 0.7, 0.2, 3)
+    a = m.average()
+    got = np.array([getattr(a, n) for n in names] + [a.gpu_time, a.data_time])
+    assert np.abs(got - want["avg"]).max() / np.abs(want["avg"]).max() < 2e-5

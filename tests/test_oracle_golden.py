@@ -94,3 +94,10 @@ def test_state_dict_contract():
         models.choose_decoder("nope", 256)
     with pytest.raises(ValueError):
         multistage_model.ResNet_multistage(18, "upproj", [450, 800], True)
+
+
+def test_metrics_oracle(golden_dir):
+    from oracle import metrics
+    want = np.load(os.path.join(golden_dir, "metrics.npz"))
+    got = metrics.evaluate(torch.tensor(want["out"]), torch.tensor(want["target"]))
+    assert rel(got, want["r1"]) < 1e-6
