@@ -329,8 +329,10 @@ static int patch_pixels(const RdConvDesc& d, const RdPhase& p, int TH, int TW) {
 
 // weight-slab depth: as many input channels as fit ~40 KB (fewer barriers), at least one CKW quantum
 static int pick_wsd(int taps_max, int BN, int CKW, int CKP) {
+    static const char* cap = getenv("RD_GCONV_WSD_KB");   // diagnostics: slab budget in KB (default 40)
+    const size_t budget = (size_t)(cap ? atoi(cap) : 40) * 1024;
     int w = CKP;
-    while (w > CKW && (size_t)taps_max * w * BN * 4 > 40 * 1024) w >>= 1;
+    while (w > CKW && (size_t)taps_max * w * BN * 4 > budget) w >>= 1;
     return w < CKW ? CKW : w;
 }
 static size_t lds_need(int BM, int BN, int CKW, int CKP, int PP, int taps_max) {
@@ -364,7 +366,9 @@ static bool plan_gconv(const RdConvDesc& d, GconvPlan& best, bool allow_split = 
         const int BM = c.WM * c.MT * 32, BN = c.WN * c.NT * 32;
         const int n_cot = cdiv(d.Cout, BN);
         const double n_util = (double)d.Cout / (n_cot * BN);
+        static const char* force_ckp = getenv("RD_GCONV_CKP");   // diagnostics
         for (int ckp = 32; ckp >= 16; ckp -= 16) {
+            if (force_ckp && atoi(force_ckp) != ckp && d.Cin >= 32) continue;
             if (ckp > d.Cin && ckp != 16) continue;
             if (d.Cin % ckp != 0 && !(ckp == 16 && d.Cin % 16 == 0)) continue;
             for (int twt = 1; twt <= cdiv(P.lw, 4); ++twt) {

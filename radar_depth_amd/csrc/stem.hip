@@ -51,20 +51,41 @@ __global__ __launch_bounds__(256) void stem_fwd_kernel(const StemArgs a) {
         }
         s_koff[k] = off;
     }
-    for (int e = tid; e < Kq * (BN / 4); e += 256) {
-        const int k = e / (BN / 4), j = (e - k * (BN / 4)) * 4;
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (k < K && j < a.Cout) v = *reinterpret_cast<const float4*>(a.w + (size_t)k * a.Cout + j);
-        *reinterpret_cast<float4*>(s_w + (size_t)k * BN + j) = v;
+    // staging is batched (U independent loads per thread in flight before the first LDS write)
+    constexpr int U = 8;
+    for (int base = tid; base < Kq * (BN / 4); base += 256 * U) {
+        float4 v[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int e = base + u * 256;
+            const int k = e / (BN / 4), j = (e - k * (BN / 4)) * 4;
+            v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (e < Kq * (BN / 4) && k < K && j < a.Cout) v[u] = *reinterpret_cast<const float4*>(a.w + (size_t)k * a.Cout + j);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int e = base + u * 256;
+            if (e < Kq * (BN / 4)) *reinterpret_cast<float4*>(s_w + (size_t)e * 4) = v[u];
+        }
     }
     const int ih0 = 2 * r0 - 3, iw0 = 2 * c0 - 3;
-    for (int e = tid; e < a.Cin * PLANE; e += 256) {
-        const int ci = e / PLANE, rem = e - ci * PLANE;
-        const int py = rem / ST_PW, px = rem - py * ST_PW;
-        const int ih = ih0 + py, iw = iw0 + px;
-        float v = 0.f;
-        if (ih >= 0 && ih < a.H && iw >= 0 && iw < a.W) v = a.plane[ci][(size_t)n * a.stride[ci] + (size_t)ih * a.W + iw];
-        s_patch[e] = v;
+    for (int base = tid; base < a.Cin * PLANE; base += 256 * U) {
+        float v[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int e = base + u * 256;
+            const int ci = min(e / PLANE, a.Cin - 1), rem = e - (e / PLANE) * PLANE;
+            const int py = rem / ST_PW, px = rem - py * ST_PW;
+            const int ih = ih0 + py, iw = iw0 + px;
+            v[u] = 0.f;
+            if (e < a.Cin * PLANE && ih >= 0 && ih < a.H && iw >= 0 && iw < a.W)
+                v[u] = a.plane[ci][(size_t)n * a.stride[ci] + (size_t)ih * a.W + iw];
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int e = base + u * 256;
+            if (e < a.Cin * PLANE) s_patch[e] = v[u];
+        }
     }
     __syncthreads();
 
@@ -196,21 +217,41 @@ __global__ __launch_bounds__(256) void stem_wgrad_kernel(const StemArgs a, float
         const int r0 = (trem / a.tiles_w) * TH, c0 = (trem % a.tiles_w) * ST_TW;
         __syncthreads();
         const int ih0 = 2 * r0 - 3, iw0 = 2 * c0 - 3;
-        for (int e = tid; e < a.Cin * PLANE; e += 256) {
-            const int ci = e / PLANE, rem = e - ci * PLANE;
-            const int py = rem / ST_PW, px = rem - py * ST_PW;
-            const int ih = ih0 + py, iw = iw0 + px;
-            float v = 0.f;
-            if (ih >= 0 && ih < a.H && iw >= 0 && iw < a.W) v = a.plane[ci][(size_t)n * a.stride[ci] + (size_t)ih * a.W + iw];
-            s_patch[e] = v;
+        constexpr int U = 8;
+        for (int base = tid; base < a.Cin * PLANE; base += 256 * U) {
+            float v[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int e = base + u * 256;
+                const int ci = min(e / PLANE, a.Cin - 1), rem = e - (e / PLANE) * PLANE;
+                const int py = rem / ST_PW, px = rem - py * ST_PW;
+                const int ih = ih0 + py, iw = iw0 + px;
+                v[u] = 0.f;
+                if (e < a.Cin * PLANE && ih >= 0 && ih < a.H && iw >= 0 && iw < a.W)
+                    v[u] = a.plane[ci][(size_t)n * a.stride[ci] + (size_t)ih * a.W + iw];
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int e = base + u * 256;
+                if (e < a.Cin * PLANE) s_patch[e] = v[u];
+            }
         }
-        for (int e = tid; e < NPIX * (BN / 4); e += 256) {
-            const int p = e / (BN / 4), j = (e - p * (BN / 4)) * 4;
-            const int oh = r0 + (p >> 5), ow = c0 + (p & 31);
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (oh < a.Ho && ow < a.Wo && j < a.Cout)
-                v = *reinterpret_cast<const float4*>(a.dout + (((size_t)n * a.Ho + oh) * a.Wo + ow) * a.Cout + j);
-            *reinterpret_cast<float4*>(s_do + (size_t)p * BN + j) = v;
+        for (int base = tid; base < NPIX * (BN / 4); base += 256 * U) {
+            float4 v[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int e = base + u * 256;
+                const int p = e / (BN / 4), j = (e - p * (BN / 4)) * 4;
+                const int oh = r0 + (p >> 5), ow = c0 + (p & 31);
+                v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (e < NPIX * (BN / 4) && oh < a.Ho && ow < a.Wo && j < a.Cout)
+                    v[u] = *reinterpret_cast<const float4*>(a.dout + (((size_t)n * a.Ho + oh) * a.Wo + ow) * a.Cout + j);
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int e = base + u * 256;
+                if (e < NPIX * (BN / 4)) *reinterpret_cast<float4*>(s_do + (size_t)e * 4) = v[u];
+            }
         }
         __syncthreads();
         // pixel walk (two pixels per MFMA), pipelined like the forward K walk; NPIX/2/4 = 16 steps per wave (even)
