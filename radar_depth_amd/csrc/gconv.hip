@@ -217,24 +217,57 @@ __global__ __launch_bounds__(256) void gconv_kernel(const GconvArgs a) {
         }
     }
 
-    // ---- epilogue
+    // ---- epilogue.  Row validity is uniform per half-wave and almost always true, so full M-tiles take a wave-uniform
+    // fast path: no exec masking, one row pointer per accumulator row with the N-tile as an immediate offset, and the
+    // residual-gradient addend gathered before its first use (a load-wait-add-store chain per element exposes every latency).
     float ssum[NT], ssq[NT];
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) ssum[nt] = ssq[nt] = 0.f;
+    const bool has_add = a.addend != nullptr;
+    const int cob = co0 + wn * NT * 32 + l31;
+    const bool cols_full = co0 + wn * NT * 32 + NT * 32 <= D.Cout;       // wave-uniform
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
+        int ro[16];
+        bool rows_ok = true;
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
-            const int m = (wm * MT + mt) * 32 + (i & 3) + 8 * (i >> 2) + 4 * hh;
-            const int op = s_opix[m];
-            if (op >= 0) {
+            ro[i] = s_opix[(wm * MT + mt) * 32 + (i & 3) + 8 * (i >> 2) + 4 * hh];   // -1: no such pixel
+            rows_ok = rows_ok && ro[i] >= 0;
+        }
+        if (cols_full && __all(rows_ok)) {
+            float addv[NT][16];
+            if (has_add) {
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    const float* ap = a.addend + (size_t)ro[i] * a.ld_add + cob;
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt) addv[nt][i] = ap[nt * 32];
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                float* rp = outp + (size_t)ro[i] * D.ldo + cob;
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt) {
-                    const int co = co0 + wn * NT * 32 + nt * 32 + l31;
-                    if (co < D.Cout) {
+                    float v = acc[mt][nt][i];
+                    if (has_add) v += addv[nt][i];
+                    rp[nt * 32] = v;
+                    ssum[nt] += v;
+                    ssq[nt] += v * v;
+                }
+            }
+        } else {
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                const int co = cob + nt * 32;
+                const bool cok = co < D.Cout;
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    if (cok && ro[i] >= 0) {
                         float v = acc[mt][nt][i];
-                        if (a.addend) v += a.addend[(size_t)op * a.ld_add + co];
-                        outp[(size_t)op * D.ldo + co] = v;
+                        if (has_add) v += a.addend[(size_t)ro[i] * a.ld_add + co];
+                        outp[(size_t)ro[i] * D.ldo + co] = v;
                         ssum[nt] += v;
                         ssq[nt] += v * v;
                     }
