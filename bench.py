@@ -59,7 +59,7 @@ def instrumented_pass(ts):
     L = ts.L
     agg, fam = {}, {}
     with torch.cuda.stream(ts.side):
-        plan.set_stream()
+        plan.set_stream(serialize=True)      # all plan streams -> this stream, so per-op event pairs bracket the op
         recs = []
         for lst in (plan.prep, plan.fwd, plan.bwd):
             for name, fn, args in lst:
@@ -74,6 +74,8 @@ def instrumented_pass(ts):
         for name, e0, e1 in recs:
             ms = e0.elapsed_time(e1)
             tag = name.rsplit(".", 1)[-1]
+            if tag in ("record", "wait"):
+                continue
             family = {"wgrad": "wgrad", "dgrad": "dgrad", "wreduce": "wgrad_reduce", "pack": "pack", "packT": "pack"}.get(tag)
             if family is None:
                 family = "conv_fwd" if name in plan.meta else ("bn/act/pool/head" if True else "other")

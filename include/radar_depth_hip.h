@@ -249,6 +249,13 @@ int rd_fill(float* p, int64_t n, float v, void* stream);
 int rd_nchw_to_nhwc(const float* src, float* dst, int32_t N, int32_t C, int32_t H, int32_t W, void* stream);
 int rd_nhwc_to_nchw(const float* src, float* dst, int32_t N, int32_t C, int32_t H, int32_t W, void* stream);
 
+/* Fork/join between the caller's streams (the plan runs the depth encoder and the weight-gradient chains on side streams);
+ * record/wait pairs are captured as graph edges when the main stream is being captured. */
+int rd_event_create(void** event);
+int rd_event_destroy(void* event);
+int rd_event_record(void* event, void* stream);
+int rd_stream_wait_event(void* stream, void* event);
+
 /* hipGraph capture helpers so a whole step replays without host launch cost */
 int rd_graph_begin(void* stream);
 int rd_graph_end(void* stream, void** graph_exec);

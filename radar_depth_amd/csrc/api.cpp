@@ -64,3 +64,24 @@ extern "C" int rd_graph_destroy(void* graph_exec) {
     if (graph_exec) RD_CHECK_HIP(hipGraphExecDestroy(static_cast<hipGraphExec_t>(graph_exec)));
     return RD_OK;
 }
+
+// Events for fork/join between the plan's streams (captured as graph edges under hipStreamBeginCapture)
+extern "C" int rd_event_create(void** ev) {
+    RD_CHECK_ARG(ev != nullptr, "rd_event_create: null out pointer");
+    hipEvent_t e = nullptr;
+    RD_CHECK_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    *ev = e;
+    return RD_OK;
+}
+extern "C" int rd_event_destroy(void* ev) {
+    if (ev) RD_CHECK_HIP(hipEventDestroy(static_cast<hipEvent_t>(ev)));
+    return RD_OK;
+}
+extern "C" int rd_event_record(void* ev, void* stream) {
+    RD_CHECK_HIP(hipEventRecord(static_cast<hipEvent_t>(ev), static_cast<hipStream_t>(stream)));
+    return RD_OK;
+}
+extern "C" int rd_stream_wait_event(void* stream, void* ev) {
+    RD_CHECK_HIP(hipStreamWaitEvent(static_cast<hipStream_t>(stream), static_cast<hipEvent_t>(ev), 0));
+    return RD_OK;
+}

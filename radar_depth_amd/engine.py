@@ -16,7 +16,9 @@ outputs (ReLU masks are re-derived from them) and the max-pool argmax bytes.
 Forward structure follows model/models.py:627-664 (ResNet_latefusion.forward); the training-mode BatchNorm,
 ReLU / LeakyReLU, residual joins and max-pool follow models.py:96-112,203-208,633-650.
 """
+import contextlib
 import ctypes as C
+import os
 
 import torch
 
@@ -85,7 +87,15 @@ class LateFusionPlan:
         assert dry_run or self.dev.type == "cuda", "the HIP path needs the module on a GPU"
         self.dry_run = dry_run
         self.L = lib()
-        self.stream = C.c_void_p(0)
+        # three streams: 0 = main chain (caller's stream), 1 = depth encoder, 2 = weight-gradient chains.  self._s is the
+        # stream object the op builders attach to the ops they create (see on()).
+        self.streams = [C.c_void_p(0), C.c_void_p(0), C.c_void_p(0)]
+        self._s = self.streams[0]
+        self._side = None            # torch streams backing streams[1:], created on first run
+        self.events = []
+        self.multi_stream = os.environ.get("RD_SINGLE_STREAM") != "1"
+        # diagnostics: RD_STREAM_MASK bit0 = depth encoder on stream 1, bit1 = weight-gradient chains on stream 2 (default 3)
+        self.stream_mask = int(os.environ.get("RD_STREAM_MASK", "3"))
         self.fwd, self.bwd = [], []
         self.prep = []
         self.pack_jobs = []    # (src, dst, O, I, T, ldc, off, rows_total, transpose): packed in ONE launch per forward
@@ -109,6 +119,40 @@ class LateFusionPlan:
 
     def op(self, lst, name, fn, *args):
         lst.append((name, fn, args))
+
+    @property
+    def stream(self):
+        """Stream object attached to the ops being built (the C ABI reads its value at call time)."""
+        return self._s
+
+    @contextlib.contextmanager
+    def on(self, k):
+        prev = self._s
+        if not self.multi_stream or not (self.stream_mask >> (k - 1)) & 1 if k else False:
+            k = 0
+        self._s = self.streams[k]
+        try:
+            yield
+        finally:
+            self._s = prev
+
+    def _event(self):
+        ev = C.c_void_p(0)
+        if not self.dry_run:
+            check(self.L.rd_event_create(C.byref(ev)), "rd_event_create")
+        self.events.append(ev)
+        return ev
+
+    def edge(self, lst, name, src, dst):
+        """Make stream `dst` wait for everything enqueued so far on stream `src` (fork or join)."""
+        for q in (1, 2):
+            if not (self.stream_mask >> (q - 1)) & 1:
+                src, dst = (0 if src == q else src), (0 if dst == q else dst)
+        if not self.multi_stream or src == dst:
+            return
+        ev = self._event()
+        self.op(lst, name + ".record", self.L.rd_event_record, ev, self.streams[src])
+        self.op(lst, name + ".wait", self.L.rd_stream_wait_event, self.streams[dst], ev)
 
     def grad_of(self, param):
         """fp32 gradient buffer of a parameter (the module's flat gradient arena view)."""
@@ -168,12 +212,18 @@ class LateFusionPlan:
         if nws < 0:
             check(int(nws), "rd_wgrad_workspace_floats(%s)" % name)
         ws = self.buf(int(nws))
-        self.op(self.bwd, name + ".wgrad", self.L.rd_wgrad, C.byref(dwd), x.ptr, dout.ptr, _p(ws), self.stream)
-        self.meta[name + ".wgrad"] = ("wgrad", dwd)
-        for w, off in sorted(ctx["weights"], key=lambda t: t[1]):
-            o, i, kh, kw = w.shape
-            self.op(self.bwd, name + ".wreduce", self.L.rd_wgrad_reduce, C.byref(dwd), _p(ws), _p(self.grad_of(w)), o, i, kh, kw,
-                    off, 0, self.stream)
+        # the weight-gradient chain (wgrad + its slab reductions) gates nothing until the bucket boundary: it runs on the
+        # wgrad stream, concurrently with the dgrad / BatchNorm chain that continues on the current stream
+        cur = self.streams.index(self._s) if self._s in self.streams else 0
+        wst = 2 if cur == 0 else cur
+        self.edge(self.bwd, name + ".fork_wgrad", cur, wst)
+        with self.on(wst):
+            self.op(self.bwd, name + ".wgrad", self.L.rd_wgrad, C.byref(dwd), x.ptr, dout.ptr, _p(ws), self.stream)
+            self.meta[name + ".wgrad"] = ("wgrad", dwd)
+            for w, off in sorted(ctx["weights"], key=lambda t: t[1]):
+                o, i, kh, kw = w.shape
+                self.op(self.bwd, name + ".wreduce", self.L.rd_wgrad_reduce, C.byref(dwd), _p(ws), _p(self.grad_of(w)), o, i, kh, kw,
+                        off, 0, self.stream)
         if not need_dx:
             return None
         if dx is None:
@@ -283,8 +333,12 @@ class LateFusionPlan:
         dx, _ = self.bn_join_bwd(ctx["name"] + ".bn", g, None, ACT_NONE, raw, co)
         nws = self.L.rd_stem_wgrad_workspace_floats(N, H, W, cin, cout)
         ws = self.buf(int(nws))
-        self.op(self.bwd, ctx["name"] + ".wgrad", self.L.rd_stem_wgrad, ctx["pl"], ctx["st"], cin, N, H, W, dx.ptr, cout,
-                _p(self.grad_of(ctx["conv"].weight)), _p(ws), self.stream)
+        cur = self.streams.index(self._s) if self._s in self.streams else 0
+        wst = 2 if cur == 0 else cur
+        self.edge(self.bwd, ctx["name"] + ".fork_wgrad", cur, wst)
+        with self.on(wst):
+            self.op(self.bwd, ctx["name"] + ".wgrad", self.L.rd_stem_wgrad, ctx["pl"], ctx["st"], cin, N, H, W, dx.ptr, cout,
+                    _p(self.grad_of(ctx["conv"].weight)), _p(ws), self.stream)
         if dgrad_channel is not None:
             ci, dst = dgrad_channel
             self.op(self.bwd, ctx["name"] + ".dgrad_ch", self.L.rd_stem_dgrad_channel, dx.ptr, _p(ctx["wp"]), N, H, W, cin, ci, cout,
@@ -383,9 +437,11 @@ class LateFusionPlan:
         else:
             dep_planes = [t.data_ptr() for t in self.depth_planes]
             dep_strides = [hw] * len(dep_planes)
-        # encoders
+        # encoders: RGB on the main stream, the (small-channel, low-occupancy) depth encoder concurrently on stream 1
+        self.edge(self.fwd, "fork_depth", 0, 1)
         a, self.c_stem_rgb = self._stem("conv1", rgb_planes, rgb_strides, m.conv1, m.bn1, ACT_RELU, "maxpool")
-        d_, self.c_stem_d = self._stem("conv1_depth", dep_planes, dep_strides, m.conv1_depth, m.bn1_depth, ACT_LEAKY02, "maxpool_depth")
+        with self.on(1):
+            d_, self.c_stem_d = self._stem("conv1_depth", dep_planes, dep_strides, m.conv1_depth, m.bn1_depth, ACT_LEAKY02, "maxpool_depth")
         self.blocks_rgb, self.blocks_d = [], []
         layers_rgb = [("layer1", m.layer1), ("layer2", m.layer2), ("layer3", m.layer3), ("layer4", m.layer4)]
         layers_d = [("layer1_depth", m.layer1_depth), ("layer2_depth", m.layer2_depth), ("layer3_depth", m.layer3_depth),
@@ -397,18 +453,20 @@ class LateFusionPlan:
         c_rgb = m.layer4[1].conv2.weight.shape[0]
         c_dep = m.layer4_depth[1].conv2.weight.shape[0]
         self.cat = self.act(N, hh, ww, c_rgb + c_dep)
-        x = a
-        for li, (lname, layer) in enumerate(layers_rgb):
+        x, xd = a, d_
+        for li in range(4):                      # emission interleaved per stage (host order only matters in eager mode)
+            lname, layer = layers_rgb[li]
             for bi, blk in enumerate(layer):
                 last = li == 3 and bi == len(layer) - 1
                 x, ctx = self._block("%s.%d" % (lname, bi), blk, x, out=self.cat.chan(0, c_rgb) if last else None)
                 self.blocks_rgb.append(ctx)
-        x = d_
-        for li, (lname, layer) in enumerate(layers_d):
-            for bi, blk in enumerate(layer):
-                last = li == 3 and bi == len(layer) - 1
-                x, ctx = self._block("%s.%d" % (lname, bi), blk, x, out=self.cat.chan(c_rgb, c_dep) if last else None)
-                self.blocks_d.append(ctx)
+            lname, layer = layers_d[li]
+            with self.on(1):
+                for bi, blk in enumerate(layer):
+                    last = li == 3 and bi == len(layer) - 1
+                    xd, ctx = self._block("%s.%d" % (lname, bi), blk, xd, out=self.cat.chan(c_rgb, c_dep) if last else None)
+                    self.blocks_d.append(ctx)
+        self.edge(self.fwd, "join_depth", 1, 0)
         # fusion 1x1 convs (no activation, models.py:652-657)
         rf, self.c_fus = self.conv_fwd("conv_fusion", self.cat, [(m.conv_fusion.weight, 0)], 1, 1, 0)
         self.co_fus = self.bn_coeffs("bn_fusion", m.bn_fusion, self.c_fus["stat"], self.c_fus["tiles"], rf.C, 0, rf.M)
@@ -455,10 +513,24 @@ class LateFusionPlan:
         self.op(self.prep, "pack_all", self.L.rd_pack_weights_batched, _p(self.pack_table), _p(self.pack_blocks), nb, self.stream)
 
     def _build_backward(self):
+        """Backward as four bucket-aligned segments (self.bwd_segments): every segment ends with all streams joined, so
+        it can be captured as its own hipGraph and its gradient bucket all-reduced while the next segment runs:
+          0: head, decoder, bn2/conv2, bn_fusion/conv_fusion      1: layer4 || layer4_depth
+          2: layer3 || layer3_depth                               3: layer2, layer1, stem || their depth counterparts
+        Inside a segment the RGB chain runs on stream 0, the depth chain on stream 1 and every weight-gradient chain of
+        the main stream on stream 2."""
         m, N = self.m, self.N
         z = self.z
         self.dpred = self.buf(N, 1, self.Ho, self.Wo)
         self.dx_dense = None
+        self.bwd_segments = []
+
+        def end_segment(prefixes):
+            self.edge(self.bwd, "join1", 1, 0)
+            self.edge(self.bwd, "join2", 2, 0)
+            begin = self.bwd_segments[-1][1] if self.bwd_segments else 0
+            self.bwd_segments.append((begin, len(self.bwd), prefixes))
+
         ddm = self.buf(N, z.H, z.W)
         self.op(self.bwd, "bilinear.bwd", self.L.rd_bilinear_bwd, _p(self.dpred), N, self.Ho, self.Wo, _p(ddm), z.H, z.W, self.stream)
         dz = self.act(N, z.H, z.W, z.C)
@@ -472,19 +544,33 @@ class LateFusionPlan:
         drf, _ = self.bn_join_bwd("bn_fusion", dyf, None, ACT_NONE, self.rf, self.co_fus)
         dcat = self.act(N, self.cat.H, self.cat.W, self.cat.C)
         self.conv_bwd(self.c_fus, drf, dx=dcat)
+        end_segment(("conv_fusion", "bn_fusion", "conv2", "bn2", "decoder", "conv3"))
+
         c_rgb = self.blocks_rgb[-1]["y"].C
         g = dcat.chan(0, c_rgb)
-        for ctx in reversed(self.blocks_rgb):
-            g = self._block_bwd(ctx, g)
-        self._stem_bwd(self.c_stem_rgb, g)
-        g = dcat.chan(c_rgb, dcat.C - c_rgb)
-        for ctx in reversed(self.blocks_d):
-            g = self._block_bwd(ctx, g)
+        gd = dcat.chan(c_rgb, dcat.C - c_rgb)
         dense = None
         if self.depth_planes is not None and len(self.depth_planes) == 2:
             self.dx_dense = self.dense_grad_dst if self.dense_grad_dst is not None else self.buf(N, self.H, self.W)
             dense = (1, self.dx_dense)
-        self._stem_bwd(self.c_stem_d, g, dgrad_channel=dense)
+        # blocks come in pairs per ResNet stage: indices (6,7)=layer4, (4,5)=layer3, (2,3)=layer2, (0,1)=layer1
+        for stage in (3, 2):
+            self.edge(self.bwd, "fork_depth", 0, 1)
+            for ctx in reversed(self.blocks_rgb[2 * stage:2 * stage + 2]):
+                g = self._block_bwd(ctx, g)
+            with self.on(1):
+                for ctx in reversed(self.blocks_d[2 * stage:2 * stage + 2]):
+                    gd = self._block_bwd(ctx, gd)
+            end_segment(("layer%d" % (stage + 1), "layer%d_depth" % (stage + 1)))
+        self.edge(self.bwd, "fork_depth", 0, 1)
+        for ctx in reversed(self.blocks_rgb[0:4]):
+            g = self._block_bwd(ctx, g)
+        self._stem_bwd(self.c_stem_rgb, g)
+        with self.on(1):
+            for ctx in reversed(self.blocks_d[0:4]):
+                gd = self._block_bwd(ctx, gd)
+            self._stem_bwd(self.c_stem_d, gd, dgrad_channel=dense)
+        end_segment(("conv1", "bn1", "layer1", "layer2", "conv1_depth", "bn1_depth", "layer1_depth", "layer2_depth"))
 
     # ------------------------------------------------------------------ execution
     def _run(self, ops):
@@ -495,8 +581,18 @@ class LateFusionPlan:
             if rc != 0:
                 check(rc, name)
 
-    def set_stream(self):
-        self.stream.value = torch.cuda.current_stream().cuda_stream
+    def set_stream(self, serialize=False):
+        """Bind stream 0 to torch's current stream and streams 1/2 to the plan's side streams (serialize=True binds all
+        three to the current stream: used by the instrumented timing pass of bench.py)."""
+        cur = torch.cuda.current_stream().cuda_stream
+        self.streams[0].value = cur
+        if serialize or not self.multi_stream:
+            self.streams[1].value = self.streams[2].value = cur
+            return
+        if self._side is None:
+            self._side = [torch.cuda.Stream(device=self.dev), torch.cuda.Stream(device=self.dev)]
+        self.streams[1].value = self._side[0].cuda_stream
+        self.streams[2].value = self._side[1].cuda_stream
 
     def run_forward(self, x=None):
         """x: [N,>=4,H,W] fp32 CUDA tensor (copied into the plan's static input buffer) or None if already there."""

@@ -44,13 +44,6 @@ def create_model(args, output_size):
     return model
 
 
-# backward-op name prefixes whose gradients are complete once the last op carrying the prefix has run, in the order
-# backward finishes them; each bucket is one contiguous slice of the flat gradient arena (named_parameters order)
-_BUCKETS = (("conv_fusion", "bn_fusion", "conv2", "bn2", "decoder", "conv3"), ("layer4",), ("layer3",),
-            ("conv1", "bn1", "layer1", "layer2"),
-            ("conv1_depth", "bn1_depth", "layer1_depth", "layer2_depth", "layer3_depth", "layer4_depth"))
-
-
 def _param_offsets(root):
     """name -> (begin, end) element offsets in the flat arenas (16-byte aligned slots, named_parameters order)."""
     offs, off = {}, 0
@@ -60,31 +53,34 @@ def _param_offsets(root):
     return offs
 
 
-def bucket_segments(op_names, param_offsets, prefix=""):
-    """Split one plan's backward op list into gradient buckets.  Returns [(op_begin, op_end, lo, hi)]: after ops
-    [op_begin, op_end) have run, arena elements [lo, hi) (parameters `prefix`+bucket names) are final."""
-    segs, start = [], 0
-    for names in _BUCKETS:
-        idx = [i for i, nm in enumerate(op_names) if nm.split(".")[0] in names]
-        sl = [v for k, v in param_offsets.items() if k.startswith(prefix) and k[len(prefix):].split(".")[0] in names]
-        if not idx or not sl:
-            continue
-        end = max(idx) + 1
-        segs.append([start, end, min(s[0] for s in sl), (max(s[1] for s in sl) + 3) // 4 * 4])
-        start = end
-    segs[-1][1] = len(op_names)
-    assert all(a[1] == b[0] for a, b in zip(segs, segs[1:])) and segs[0][0] == 0, "backward ops are not ordered by bucket"
-    return [tuple(s) for s in segs]
+def bucket_segments(plan, param_offsets, prefix=""):
+    """Gradient buckets of a LateFusionPlan: its backward is built as segments that end with all streams joined
+    (engine.LateFusionPlan._build_backward).  Returns [(op_begin, op_end, [(lo, hi), ...])]: after ops [op_begin, op_end)
+    the listed arena slices (parameters whose top-level name is in the segment's prefix list) are final."""
+    out = []
+    for begin, end, names in plan.bwd_segments:
+        sl = sorted((v[0], (v[1] + 3) // 4 * 4) for k, v in param_offsets.items()
+                    if k.startswith(prefix) and k[len(prefix):].split(".")[0] in names)
+        merged = []
+        for lo, hi in sl:
+            if merged and lo == merged[-1][1]:
+                merged[-1][1] = hi
+            else:
+                merged.append([lo, hi])
+        out.append((begin, end, [tuple(m) for m in merged]))
+    return out
 
 
-def reduce_gradient_buckets(grads, buckets, done_after=None):
-    """Sum-all-reduce the arena slices `buckets` = [(lo, hi)] of the flat gradient tensor across the default process
-    group.  Generator form: yields before each bucket so the caller can enqueue the backward segment that completes it;
-    all collectives are asynchronous and waited for at the end (RCCL over xGMI on the GPU, gloo in the CPU tests)."""
+def reduce_gradient_buckets(grads, buckets):
+    """Sum-all-reduce the gradient buckets (each a list of arena slices [(lo, hi), ...]) of the flat gradient tensor
+    across the default process group.  Generator form: yields before each bucket so the caller can enqueue the backward
+    segment that completes it; all collectives are asynchronous and waited for at the end (RCCL over xGMI on the GPU,
+    gloo in the CPU tests)."""
     works = []
-    for lo, hi in buckets:
-        yield (lo, hi)
-        works.append(torch.distributed.all_reduce(grads[lo:hi], async_op=True))
+    for slices in buckets:
+        yield slices
+        for lo, hi in slices:
+            works.append(torch.distributed.all_reduce(grads[lo:hi], async_op=True))
     for wk in works:
         wk.wait()
 
@@ -148,16 +144,16 @@ class HipTrainStep:
         self.graphs = None
         self.steps = 0
         # hipGraph capture is illegal on the legacy default stream: the step owns a stream and fences it against the caller's
-        self.side = torch.cuda.Stream(device=dev)
+        self.side = torch.cuda.Stream(device=dev)   # default priority: raising any stream's priority measured 17-29 % slower
         offs = _param_offsets(model)
         if self.multistage:
             s1 = [v for k, v in offs.items() if not k.startswith("stage2.")]
             s2 = [v for k, v in offs.items() if k.startswith("stage2.")]
-            self._buckets = [(min(v[0] for v in s2), (max(v[1] for v in s2) + 3) // 4 * 4),
-                             (min(v[0] for v in s1), (max(v[1] for v in s1) + 3) // 4 * 4)]
+            self._buckets = [[(min(v[0] for v in s2), (max(v[1] for v in s2) + 3) // 4 * 4)],
+                             [(min(v[0] for v in s1), (max(v[1] for v in s1) + 3) // 4 * 4)]]
         else:
-            self._segments = bucket_segments([nm for nm, _, _ in self.plan.bwd], offs)
-            self._buckets = [(lo, hi) for _, _, lo, hi in self._segments]
+            self._segments = bucket_segments(self.plan, offs)
+            self._buckets = [sl for _, _, sl in self._segments]
 
     def set_lr(self, lr):
         if lr != self.lr:

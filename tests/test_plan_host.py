@@ -26,20 +26,32 @@ def test_dry_run_plan_structure():
     with pytest.raises(RuntimeError):
         plan.run_forward()
     offs = _param_offsets(m)
-    segs = bucket_segments(names, offs)
+    segs = bucket_segments(plan, offs)
+    assert len(segs) == 4 and segs[0][0] == 0 and segs[-1][1] == len(names)
+    assert all(a[1] == b[0] for a, b in zip(segs, segs[1:]))
     # buckets tile the whole arena exactly once
-    cover = sorted((lo, hi) for _, _, lo, hi in segs)
+    cover = sorted(sl for _, _, sls in segs for sl in sls)
     assert cover[0][0] == 0 and all(a[1] == b[0] for a, b in zip(cover, cover[1:]))
     assert cover[-1][1] == m._ensure_arenas()["total"]
+    # every segment ends with the side streams joined back (hipGraph capture requirement), and an op that writes a
+    # gradient of bucket k never appears after segment k
+    for begin, end, sls in segs:
+        assert names[end - 1].endswith(".wait")
+    seg_of = {}
+    for k, (begin, end, sls) in enumerate(segs):
+        for n in names[begin:end]:
+            seg_of.setdefault(n.split(".")[0] + "|" + n, k)
+    for k, (begin, end, prefixes) in enumerate(plan.bwd_segments):
+        for n in names[begin:end]:
+            if n.endswith((".wreduce", ".bwd_apply")) or n.endswith(".wgrad"):
+                assert n.split(".")[0] in prefixes, (n, prefixes)
     # every conv weight has a wgrad reduce and every BN a backward apply
     n_w = sum(1 for n, p in m.named_parameters() if p.dim() == 4)
     n_reduce = sum(1 for n in names if n.endswith(".wreduce")) + 2 + 1      # + two stems + conv3 (own kernels)
     assert n_reduce == n_w
     n_bn = sum(1 for n, p in m.named_parameters() if n.endswith(".bias"))
     assert sum(1 for n in names if n.endswith(".bwd_apply")) == n_bn
-    # an op never belongs to an earlier bucket than the one being completed
-    for a, b, _, _ in segs:
-        assert a < b
+
 
 
 def _dp_worker(rank, world, port, q):
@@ -51,13 +63,13 @@ def _dp_worker(rank, world, port, q):
         m = _model()
         plan = LateFusionPlan(m, 2, 97, 161, train=True, dry_run=True)
         st = m._ensure_arenas()
-        segs = bucket_segments([n for n, _, _ in plan.bwd], _param_offsets(m))
+        segs = bucket_segments(plan, _param_offsets(m))
         g = torch.Generator().manual_seed(100 + rank)
         st["grads"].copy_(torch.randn(st["total"], generator=g))
         mine = st["grads"].clone()
         order = []
-        for lo, hi in reduce_gradient_buckets(st["grads"], [(lo, hi) for _, _, lo, hi in segs]):
-            order.append((lo, hi))
+        for slices in reduce_gradient_buckets(st["grads"], [sl for _, _, sl in segs]):
+            order.append(slices)
         other = torch.randn(st["total"], generator=torch.Generator().manual_seed(100 + (1 - rank)))
         ok = torch.allclose(st["grads"], mine + other, atol=1e-6) and len(order) == len(segs)
         # the per-parameter views see the reduced values (what the SGD kernel reads, scaled by 1/world)
