@@ -123,6 +123,9 @@ def main():
     ap.add_argument("--batch", type=int, default=16, help="per-GPU batch (weak scaling)")
     ap.add_argument("--height", type=int, default=450)
     ap.add_argument("--width", type=int, default=800)
+    ap.add_argument("--arch", default="resnet18_latefusion",
+                    choices=["resnet18_latefusion", "resnet18_multistage_uncertainty_fixs"],
+                    help="headline = resnet18_latefusion (BASELINE configs[1]); the multistage arch is configs[3] (use --batch 8)")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
@@ -139,14 +142,18 @@ def main():
         torch.distributed.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
     assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node %d (WORLD_SIZE=%d)" % (args.gpus, world)
 
-    from radar_depth_amd.main import HipTrainStep
-    from radar_depth_amd.model.models import ResNet_latefusion
+    import types
+
+    from radar_depth_amd.main import HipTrainStep, create_model
     from radar_depth_amd.synthetic import make_batch
 
     torch.manual_seed(0)                                     # identical random init on every rank
-    model = ResNet_latefusion(18, "upproj", [args.height, args.width], 4, False).cuda()
+    made = create_model(types.SimpleNamespace(arch=args.arch, decoder="upproj", modality="rgbd", pretrained=False),
+                        [args.height, args.width])
+    model, loss_weights = made if isinstance(made, tuple) else (made, None)
+    model = model.cuda()
     ts = HipTrainStep(model, args.batch, args.height, args.width, lr=0.01, momentum=0.9, weight_decay=1e-4,
-                      use_graph=not args.no_graph)
+                      loss_weights=loss_weights, use_graph=not args.no_graph)
     x, t = make_batch(args.batch, args.height, args.width, 1234 + 1000 * rank)
     x, t = x.cuda(), t.cuda()
 
@@ -173,12 +180,13 @@ def main():
         "metric": METRIC, "value": round(world * args.batch * args.steps / dt, 2), "unit": "samples/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 3),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "config": {"workload": "resnet18_latefusion --decoder upproj --modality rgbd, b=%d/GPU %dx%d fp32, full step "
-                               "(fwd + MaskedL1 + bwd + SGD momentum .9 wd 1e-4), random init" % (args.batch, args.height, args.width),
+        "config": {"workload": "%s --decoder upproj --modality rgbd, b=%d/GPU %dx%d fp32, full step "
+                               "(fwd + loss + bwd + SGD momentum .9 wd 1e-4), random init" % (args.arch, args.batch, args.height, args.width),
                    "global_batch": world * args.batch, "parallelism": "dp%d" % world if world > 1 else "single",
                    "hipgraph": not args.no_graph, "final_loss": round(final_loss, 5)},
     }
-    if rank == 0 and not args.no_roofline:
+    multistage = args.arch != "resnet18_latefusion"
+    if rank == 0 and not args.no_roofline and not multistage:
         agg, fam = instrumented_pass(ts)
         name, (ms, n, flops) = max(agg.items(), key=lambda kv: kv[1][0])
         achieved = flops / (ms * 1e-3) / 1e12
@@ -197,7 +205,11 @@ def main():
     if world > 1:
         torch.distributed.barrier()
     if rank == 0:
-        if world == 1 and not args.no_cpu_baseline:
+        if multistage:
+            out["metric"] = "training samples/sec, %s b=%d %dx%d rgbd" % (args.arch, args.batch, args.height, args.width)
+            out["roofline_note"] = "algorithmic work 209.57 GFLOP/sample at 450x800 (SURVEY 8d): %.1f%% of the fp32 peak" % (
+                100 * 209.57e9 * (args.height * args.width / 360000.0) * out["value"] / 157.3e12)
+        if world == 1 and not args.no_cpu_baseline and not multistage:
             out["cpu_baseline"] = cpu_baseline(args.height, args.width)
         print(json.dumps(out), flush=True)
     if world > 1:

@@ -295,3 +295,29 @@ def test_checkpoint_loads_and_eval_forward_matches_oracle():
         want = o(x)
         got = m(x.cuda())
     assert rel(got.cpu().numpy(), want.numpy()) < 1e-3
+
+
+def test_large_geometry_900x1600():
+    """configs[4] geometry (900x1600, 4x the activations of 450x800): forward + loss + gradient norms vs the CPU oracle, b=1."""
+    from oracle.criteria import MaskedL1Loss as OL1
+    from oracle.models import ResNet_latefusion as ORef
+    from radar_depth_amd.evaluation.criteria_new import MaskedL1Loss
+    from radar_depth_amd.synthetic import make_batch, procedural_fill_
+    h, w = 900, 1600
+    m = build(h, w).train()
+    torch.manual_seed(0)
+    o = ORef(18, "upproj", [h, w], 4, False)
+    procedural_fill_(o)
+    o.train()
+    x, t = make_batch(1, h, w, 31)
+    yo = o(x)
+    lo = OL1()(yo, t)
+    lo.backward()
+    y = m(x.cuda())
+    lg = MaskedL1Loss()(y, t.cuda())
+    lg.backward()
+    assert rel(y.detach().cpu().numpy(), yo.detach().numpy()) < 1e-3
+    assert abs(lg.item() - lo.item()) / lo.item() < 1e-4
+    go = np.array([p.grad.double().norm().item() for p in o.parameters()])
+    gg = np.array([p.grad.double().norm().item() for p in m.parameters()])
+    assert np.abs(go - gg).max() / go.max() < 2e-2
