@@ -193,9 +193,19 @@ def main():
         # algorithmic work of one training sample (UpProj zero-skipped, stem dgrads omitted): 104.57 GFLOP at 450x800
         alg_gflop = 104.57 * (args.height * args.width) / (450.0 * 800.0)
         step_flops = alg_gflop * 1e9 * args.batch
+        # HBM bytes per launch of that kernel from the committed rocprofv3 --pmc passes (FETCH_SIZE x2 + WRITE_SIZE,
+        # profiles/r01_pmc_traffic.json; collected with tools described in DESIGN.md, not re-measured on every run)
+        traffic = None
+        try:
+            tj = json.load(open(os.path.join(REPO, "profiles", "r01_pmc_traffic.json")))["kernels"]
+            key = name.replace(" ", "")
+            if key in tj:
+                traffic = tj[key]["hbm_read_bytes_per_launch"] + tj[key]["hbm_write_bytes_per_launch"]
+        except (OSError, KeyError, ValueError):
+            pass
         out["roofline"] = {"bound": "mfma", "kernel": name, "launches_per_step": n, "avg_launch_us": round(1e3 * ms / n, 2),
                            "achieved": round(achieved, 2), "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
-                           "frac": round(achieved / PEAK_FP32_TFLOPS, 4), "traffic": None,
+                           "frac": round(achieved / PEAK_FP32_TFLOPS, 4), "traffic": traffic,
                            "algorithmic_gflop_per_sample": round(alg_gflop, 2),
                            "step_conv_tflops": round(step_flops * args.steps / dt / 1e12, 2),
                            "step_frac_of_peak": round(step_flops * args.steps / dt / 1e12 / PEAK_FP32_TFLOPS, 4),
