@@ -332,7 +332,8 @@ static int plan_wgrad(const RdConvDesc& d, WgradPlan& pl, WgradArgs* out) {
     pl.n_cob = cdiv(d.Cout, COB);
     pl.S = S;
     // tile: largest pixel count within the LDS budget, preferring full-width rows
-    const size_t budget = 78 * 1024;
+    static const char* bud = getenv("RD_WGRAD_LDS_KB");   // diagnostics (default 78: two workgroups per CU)
+    const size_t budget = (size_t)(bud ? atoi(bud) : 78) * 1024;
     double best = -1;
     pl.TH = pl.TW = 0;
     for (int twt = 1; twt <= P0.lw; ++twt) {
