@@ -90,6 +90,11 @@ int64_t rd_gconv_workspace_floats(const RdConvDesc* d);
 int rd_gconv_stat_tiles_ws(const RdConvDesc* d);
 int rd_gconv_ws(const RdConvDesc* d, const float* in, const float* w_packed, float* out,
                 const float* addend, int32_t ld_add, float* stat_partial, float* ws, void* stream);
+/* Inference form (validate() body main.py:564-595):
+ *   out = act_{co < act_cols}( conv(in, w) + bias[co] + addend )
+ * with the eval-mode BatchNorm folded in: scale into the packed weights, shift = bias.  bias / addend / ws may be NULL. */
+int rd_gconv_fused(const RdConvDesc* d, const float* in, const float* w_packed, float* out, const float* bias,
+                   int32_t act, int32_t act_cols, const float* addend, int32_t ld_add, float* ws, void* stream);
 /* diagnostics: out[0..9] = MT, NT, WM, WN, ksplit*100+CKW, CKP, TH, TW, lds_bytes, workgroups chosen for d (workspace plan) */
 int rd_gconv_plan_info(const RdConvDesc* d, int32_t* out);
 /* diagnostics: workgroups per CU the HIP occupancy API reports for that plan (-1 without a GPU) */
@@ -115,7 +120,8 @@ int rd_pack_weights(const float* w_oihw, float* packed, int32_t O, int32_t I, in
                     int32_t ldc, int32_t co_off, int32_t rows_total, int32_t transpose, void* stream);
 
 /* All weight tensors of a network in ONE launch.  jobs_dev: device array of
- *   struct { const float* src; float* dst; int32_t O, I, T(=KH*KW), ldc, off, rows_total, transpose, first_block; }
+ *   struct { const float* src; float* dst; const float* scale; int32_t O, I, T(=KH*KW), ldc, off, rows_total,
+ *            transpose, first_block; }      scale (nullable): per-output-channel factor = folded BatchNorm scale (eval mode)
  * (same meaning as rd_pack_weights' arguments); block_job_dev[b] = job index of block b, where job j owns blocks
  * [first_block, first_block + ceil(O*I*T / rd_pack_chunk())).  Both arrays are built once by the host plan. */
 int rd_pack_chunk(void);

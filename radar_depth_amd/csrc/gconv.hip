@@ -27,6 +27,8 @@ struct GconvArgs {
     float* out;
     const float* addend;
     float* stat;
+    const float* bias;   // optional per-output-channel bias (eval mode: folded BatchNorm shift)
+    int act, act_cols;   // activation applied to output channels < act_cols (RD_ACT_*), after bias and addend
     int ld_add;
     int ldw;           // packed weight row length (>= Cout)
     int TH, TW;        // tile in logical output pixels
@@ -224,7 +226,11 @@ __global__ __launch_bounds__(256) void gconv_kernel(const GconvArgs a) {
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) ssum[nt] = ssq[nt] = 0.f;
     const bool has_add = a.addend != nullptr;
+    const bool has_bias = a.bias != nullptr;
     const int cob = co0 + wn * NT * 32 + l31;
+    float biasv[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) biasv[nt] = (has_bias && cob + nt * 32 < D.Cout) ? a.bias[cob + nt * 32] : 0.f;
     const bool cols_full = co0 + wn * NT * 32 + NT * 32 <= D.Cout;       // wave-uniform
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
@@ -251,7 +257,9 @@ __global__ __launch_bounds__(256) void gconv_kernel(const GconvArgs a) {
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt) {
                     float v = acc[mt][nt][i];
+                    if (has_bias) v += biasv[nt];
                     if (has_add) v += addv[nt][i];
+                    if (cob + nt * 32 < a.act_cols) v = act_fwd(v, a.act);
                     rp[nt * 32] = v;
                     ssum[nt] += v;
                     ssq[nt] += v * v;
@@ -266,7 +274,9 @@ __global__ __launch_bounds__(256) void gconv_kernel(const GconvArgs a) {
                 for (int i = 0; i < 16; ++i) {
                     if (cok && ro[i] >= 0) {
                         float v = acc[mt][nt][i];
+                        if (has_bias) v += biasv[nt];
                         if (has_add) v += a.addend[(size_t)ro[i] * a.ld_add + co];
+                        if (co < a.act_cols) v = act_fwd(v, a.act);
                         outp[(size_t)ro[i] * D.ldo + co] = v;
                         ssum[nt] += v;
                         ssq[nt] += v * v;
@@ -303,7 +313,8 @@ __global__ __launch_bounds__(256) void gconv_kernel(const GconvArgs a) {
 // Rows are the output tensor's pixels; thread = (channel quad, row lane) like the BN reductions in norm_act.hip.
 __global__ __launch_bounds__(256) void gconv_combine_kernel(const float* __restrict__ part, long long split_stride, int S,
                                                             float* __restrict__ out, int ldo, const float* __restrict__ addend,
-                                                            int ld_add, long long M, int C, int RPB, float* __restrict__ stat) {
+                                                            int ld_add, long long M, int C, int RPB, float* __restrict__ stat,
+                                                            const float* __restrict__ bias, int act, int act_cols) {
     extern __shared__ float sm[];
     const int Q = C >> 2, RL = 256 / Q;
     const int q = threadIdx.x % Q, rl = threadIdx.x / Q;
@@ -318,9 +329,19 @@ __global__ __launch_bounds__(256) void gconv_combine_kernel(const float* __restr
                 const float4 u = *reinterpret_cast<const float4*>(part + k * split_stride + r * ldo + c);
                 v.x += u.x; v.y += u.y; v.z += u.z; v.w += u.w;
             }
+            if (bias) {
+                const float4 u = *reinterpret_cast<const float4*>(bias + c);
+                v.x += u.x; v.y += u.y; v.z += u.z; v.w += u.w;
+            }
             if (addend) {
                 const float4 u = *reinterpret_cast<const float4*>(addend + r * ld_add + c);
                 v.x += u.x; v.y += u.y; v.z += u.z; v.w += u.w;
+            }
+            if (act != RD_ACT_NONE) {
+                if (c + 0 < act_cols) v.x = act_fwd(v.x, act);
+                if (c + 1 < act_cols) v.y = act_fwd(v.y, act);
+                if (c + 2 < act_cols) v.z = act_fwd(v.z, act);
+                if (c + 3 < act_cols) v.w = act_fwd(v.w, act);
             }
             *reinterpret_cast<float4*>(out + r * ldo + c) = v;
             s1.x += v.x; s1.y += v.y; s1.z += v.z; s1.w += v.w;
@@ -558,7 +579,8 @@ extern "C" int rd_gconv_stat_tiles_ws(const RdConvDesc* d) {
 }
 
 static int gconv_impl(const RdConvDesc* d, const float* in, const float* w_packed, float* out, const float* addend,
-                      int32_t ld_add, float* stat_partial, float* ws, void* stream) {
+                      int32_t ld_add, float* stat_partial, float* ws, void* stream, const float* bias = nullptr,
+                      int act = RD_ACT_NONE, int act_cols = 0) {
     RD_CHECK_ARG(in && w_packed && out, "gconv: null tensor");
     GconvArgs a;
     GconvPlan pl;
@@ -569,6 +591,9 @@ static int gconv_impl(const RdConvDesc* d, const float* in, const float* w_packe
     a.out = split ? ws : out;
     a.addend = split ? nullptr : addend;
     a.stat = split ? nullptr : stat_partial;
+    a.bias = split ? nullptr : bias;
+    a.act = split ? RD_ACT_NONE : act;
+    a.act_cols = split ? 0 : act_cols;
     a.ld_add = ld_add; a.ldw = d->Cout;
     a.TH = pl.TH; a.TW = pl.TW; a.PP = pl.PP; a.CKP = pl.CKP;
     a.tiles_total = pl.tiles_total; a.n_cotiles = pl.n_cotiles; a.taps_max = pl.taps_max; a.WSD = pl.WSD;
@@ -600,7 +625,7 @@ static int gconv_impl(const RdConvDesc* d, const float* in, const float* w_packe
     const int Q = d->Cout / 4, RL = 256 / Q;
     RD_CHECK_ARG(Q >= 1 && Q <= 256, "gconv: split-K combine needs Cout <= 1024");
     hipLaunchKernelGGL(gconv_combine_kernel, dim3(blocks), dim3(256), (size_t)RL * 2 * d->Cout * sizeof(float), s, ws, a.split_stride,
-                       pl.ksplit, out, d->ldo, addend, ld_add, M, d->Cout, RPB, stat_partial);
+                       pl.ksplit, out, d->ldo, addend, ld_add, M, d->Cout, RPB, stat_partial, bias, act, act_cols);
     RD_CHECK_LAUNCH("gconv_combine_kernel");
     return RD_OK;
 }
@@ -613,4 +638,12 @@ extern "C" int rd_gconv(const RdConvDesc* d, const float* in, const float* w_pac
 extern "C" int rd_gconv_ws(const RdConvDesc* d, const float* in, const float* w_packed, float* out, const float* addend,
                            int32_t ld_add, float* stat_partial, float* ws, void* stream) {
     return gconv_impl(d, in, w_packed, out, addend, ld_add, stat_partial, ws, stream);
+}
+
+// Inference form: out = act_{co < act_cols}(conv(in, w) + bias[co] + addend).  With the BatchNorm scale
+// folded into w (rd_pack_weights_batched with a per-channel scale) and bias = the folded shift this is conv+BN+ReLU(+residual)
+// in one kernel (validate() body, main.py:564-595).
+extern "C" int rd_gconv_fused(const RdConvDesc* d, const float* in, const float* w_packed, float* out, const float* bias,
+                              int32_t act, int32_t act_cols, const float* addend, int32_t ld_add, float* ws, void* stream) {
+    return gconv_impl(d, in, w_packed, out, addend, ld_add, nullptr, ws, stream, bias, act, act_cols);
 }

@@ -31,6 +31,7 @@ __global__ void pack_weights_kernel(const float* __restrict__ w, float* __restri
 struct PackJob {
     const float* src;
     float* dst;
+    const float* scale;   // optional per-output-channel factor (eval mode: folded BatchNorm scale), may be null
     int O, I, T, ldc, off, rows_total, transpose, first_block;
 };
 constexpr int PACK_CHUNK = 2048;
@@ -46,12 +47,16 @@ __global__ __launch_bounds__(256) void pack_weights_batched_kernel(const PackJob
             const int o = (int)(e % j.O);
             const int64_t r = e / j.O;
             const int i = (int)(r % j.I), t = (int)(r / j.I);
-            j.dst[((int64_t)t * j.I + i) * j.ldc + j.off + o] = j.src[((int64_t)o * j.I + i) * j.T + t];
+            float v = j.src[((int64_t)o * j.I + i) * j.T + t];
+            if (j.scale) v *= j.scale[o];
+            j.dst[((int64_t)t * j.I + i) * j.ldc + j.off + o] = v;
         } else {
             const int i = (int)(e % j.I);
             const int64_t r = e / j.I;
             const int o = (int)(r % j.O), t = (int)(r / j.O);
-            j.dst[((int64_t)t * j.rows_total + j.off + o) * j.ldc + i] = j.src[((int64_t)o * j.I + i) * j.T + t];
+            float v = j.src[((int64_t)o * j.I + i) * j.T + t];
+            if (j.scale) v *= j.scale[o];
+            j.dst[((int64_t)t * j.rows_total + j.off + o) * j.ldc + i] = v;
         }
     }
 }

@@ -184,8 +184,8 @@ class LateFusionPlan:
         wd = self.buf(S, cout, cin)
         for w, off in weights:
             o, i, kh, kw = w.shape
-            self.pack_jobs.append((w, wp, o, i, kh * kw, cout, off, i, 0))
-            self.pack_jobs.append((w, wd, o, i, kh * kw, cin, off, cout, 1))
+            self.pack_jobs.append((w, wp, o, i, kh * kw, cout, off, i, 0, None))
+            self.pack_jobs.append((w, wd, o, i, kh * kw, cin, off, cout, 1, None))
         tiles = self.L.rd_gconv_stat_tiles_ws(C.byref(d))
         if tiles < 0:
             check(tiles, "rd_gconv_stat_tiles_ws(%s)" % name)
@@ -243,6 +243,34 @@ class LateFusionPlan:
                 addend.ptr if addend is not None else C.c_void_p(0), addend.ld if addend is not None else 0,
                 C.c_void_p(0), _p(self._gconv_ws(dd, name + ".dgrad")), self.stream)
         return dx
+
+    # ------------------------------------------------------------------ inference: conv + folded BatchNorm (+ReLU, +residual)
+    def conv_bn_eval(self, name, x, parts, k, stride, pad, act, act_cols=None, addend=None, out=None, upproj=False):
+        """Eval-mode conv+BN(+act)(+residual) as ONE kernel: the BatchNorm scale gamma/sqrt(var+eps)
+        is folded into the packed weights, its shift is the epilogue bias.  parts: [(conv weight, column offset, bn)]."""
+        N, H, W, cin = x.N, x.H, x.W, x.C
+        cout = sum(w.shape[0] for w, _, _ in parts)
+        d = cd.upproj_fwd(N, H, W, cin, cout, ldi=x.ld) if upproj else cd.conv_fwd(N, H, W, cin, cout, k, stride, pad, ldi=x.ld)
+        if out is None:
+            out = self.act(N, d.Ho, d.Wo, cout)
+        d.ldo = out.ld
+        wp = self.buf(k * k, cin, cout)
+        bias = self.buf(cout)
+        scale = self.buf(cout)
+        for w, off, bn in parts:
+            o, i, kh, kw = w.shape
+            sc = C.c_void_p(scale.data_ptr() + 4 * off)
+            sh = C.c_void_p(bias.data_ptr() + 4 * off)
+            self.op(self.prep, name + ".evalcoef", self.L.rd_bn_eval_coeffs, o, _p(bn.weight), _p(bn.bias), _p(bn.running_mean),
+                    _p(bn.running_var), C.c_float(BN_EPS), sc, sh, self.streams[0])
+            self.pack_jobs.append((w, wp, o, i, kh * kw, cout, off, i, 0, scale[off:off + o]))
+        ws = self._gconv_ws(d, name)
+        self.keep += [d, scale]
+        self.op(self.fwd, name, self.L.rd_gconv_fused, C.byref(d), x.ptr, _p(wp), out.ptr, _p(bias), act,
+                cout if act_cols is None else act_cols, addend.ptr if addend is not None else C.c_void_p(0),
+                addend.ld if addend is not None else 0, _p(ws), self.stream)
+        self.meta[name] = ("gconv", d)
+        return out
 
     # ------------------------------------------------------------------ batch norm
     def bn_coeffs(self, name, bn, stat, tiles, ld, c0, count, lst=None):
@@ -306,7 +334,7 @@ class LateFusionPlan:
         Hc, Wc = (H - 1) // 2 + 1, (W - 1) // 2 + 1
         raw = self.act(N, Hc, Wc, cout)
         wp = self.buf(49, cin, cout)
-        self.pack_jobs.append((conv.weight, wp, cout, cin, 49, cout, 0, cin, 0))
+        self.pack_jobs.append((conv.weight, wp, cout, cin, 49, cout, 0, cin, 0, None))
         tiles = self.L.rd_stem_stat_tiles(N, H, W)
         stat = self.buf(tiles, 2, cout) if self.train else None
         pl = (C.c_void_p * 3)(*([p for p in planes] + [None] * (3 - len(planes))))
@@ -347,6 +375,15 @@ class LateFusionPlan:
     def _block(self, name, blk, x, out=None):
         """BasicBlock forward (models.py:96-112)."""
         stride = blk.stride
+        if not self.train:
+            y1 = self.conv_bn_eval(name + ".conv1", x, [(blk.conv1.weight, 0, blk.bn1)], 3, stride, 1, ACT_RELU)
+            skip = x
+            if blk.downsample is not None:
+                skip = self.conv_bn_eval(name + ".downsample.0", x, [(blk.downsample[0].weight, 0, blk.downsample[1])], 1, stride, 0,
+                                         ACT_NONE)
+            y = self.conv_bn_eval(name + ".conv2", y1, [(blk.conv2.weight, 0, blk.bn2)], 3, 1, 1, ACT_RELU, addend=skip, out=out)
+            self.taps[name] = y
+            return y, None
         r1, c1 = self.conv_fwd(name + ".conv1", x, [(blk.conv1.weight, 0)], 3, stride, 1)
         co1 = self.bn_coeffs(name + ".bn1", blk.bn1, c1["stat"], c1["tiles"], r1.C, 0, r1.M)
         y1 = self.bn_act(name + ".relu1", r1, co1, ACT_RELU)
@@ -387,6 +424,13 @@ class LateFusionPlan:
         Cc = x.C
         half = Cc // 2
         ub, bb = mod.upper_branch, mod.bottom_branch
+        if not self.train:
+            R = self.conv_bn_eval(name + ".conv5x5", x, [(ub.conv1.weight, 0, ub.batchnorm1), (bb.conv.weight, half, bb.batchnorm)], 5, 1, 2,
+                                  ACT_RELU, act_cols=half, upproj=True)
+            y = self.conv_bn_eval(name + ".upper_branch.conv2", R.chan(0, half), [(ub.conv2.weight, 0, ub.batchnorm2)], 3, 1, 1, ACT_RELU,
+                                  addend=R.chan(half, half))
+            self.taps[name] = y
+            return y, None
         R, cR = self.conv_fwd(name + ".conv5x5", x, [(ub.conv1.weight, 0), (bb.conv.weight, half)], 5, 1, 2, upproj=True)
         M = R.M
         co_u1 = self.bn_coeffs(name + ".upper_branch.batchnorm1", ub.batchnorm1, cR["stat"], cR["tiles"], Cc, 0, M)
@@ -468,6 +512,15 @@ class LateFusionPlan:
                     self.blocks_d.append(ctx)
         self.edge(self.fwd, "join_depth", 1, 0)
         # fusion 1x1 convs (no activation, models.py:652-657)
+        if not self.train:
+            yf = self.conv_bn_eval("conv_fusion", self.cat, [(m.conv_fusion.weight, 0, m.bn_fusion)], 1, 1, 0, ACT_NONE)
+            z = self.conv_bn_eval("conv2", yf, [(m.conv2.weight, 0, m.bn2)], 1, 1, 0, ACT_NONE)
+            self.taps["bn_fusion"], self.taps["bn2"] = yf, z
+            for i, mod in enumerate((m.decoder.layer1, m.decoder.layer2, m.decoder.layer3, m.decoder.layer4), 1):
+                z, _ = self._upproj("decoder.layer%d" % i, mod, z)
+            self._head(z)
+            self._finish_pack_jobs()
+            return
         rf, self.c_fus = self.conv_fwd("conv_fusion", self.cat, [(m.conv_fusion.weight, 0)], 1, 1, 0)
         self.co_fus = self.bn_coeffs("bn_fusion", m.bn_fusion, self.c_fus["stat"], self.c_fus["tiles"], rf.C, 0, rf.M)
         self.yf = self.bn_act("bn_fusion", rf, self.co_fus, ACT_NONE)
@@ -480,30 +533,33 @@ class LateFusionPlan:
         for i, mod in enumerate((m.decoder.layer1, m.decoder.layer2, m.decoder.layer3, m.decoder.layer4), 1):
             z, ctx = self._upproj("decoder.layer%d" % i, mod, z)
             self.ups.append(ctx)
-        # head
+        self._head(z)
+        self._finish_pack_jobs()
+        if self.train:
+            self._build_backward()
+
+    def _head(self, z):
+        m, N = self.m, self.N
         self.z = z
         self.dmap = self.buf(N, z.H, z.W)
         self.op(self.fwd, "conv3", self.L.rd_head_conv_fwd, z.ptr, z.ld, _p(m.conv3.weight), N, z.H, z.W, z.C, _p(self.dmap), self.stream)
         self.pred = self.buf(N, 1, self.Ho, self.Wo)
         self.op(self.fwd, "bilinear", self.L.rd_bilinear_fwd, _p(self.dmap), N, z.H, z.W, _p(self.pred), self.Ho, self.Wo, self.stream)
-        self._finish_pack_jobs()
-        if self.train:
-            self._build_backward()
 
     def _finish_pack_jobs(self):
         """Upload the job table of rd_pack_weights_batched: one launch refreshes every packed weight copy."""
         import numpy as np
 
         class Job(C.Structure):
-            _fields_ = [("src", C.c_void_p), ("dst", C.c_void_p), ("O", C.c_int32), ("I", C.c_int32), ("T", C.c_int32),
+            _fields_ = [("src", C.c_void_p), ("dst", C.c_void_p), ("scale", C.c_void_p), ("O", C.c_int32), ("I", C.c_int32), ("T", C.c_int32),
                         ("ldc", C.c_int32), ("off", C.c_int32), ("rows_total", C.c_int32), ("transpose", C.c_int32),
                         ("first_block", C.c_int32)]
         chunk = self.L.rd_pack_chunk()
         jobs = (Job * len(self.pack_jobs))()
         block_job, nb = [], 0
-        for k, (src, dst, o, i, t, ldc, off, rows, tr) in enumerate(self.pack_jobs):
+        for k, (src, dst, o, i, t, ldc, off, rows, tr, scale) in enumerate(self.pack_jobs):
             n = -(-(o * i * t) // chunk)
-            jobs[k] = Job(src.data_ptr(), dst.data_ptr(), o, i, t, ldc, off, rows, tr, nb)
+            jobs[k] = Job(src.data_ptr(), dst.data_ptr(), scale.data_ptr() if scale is not None else None, o, i, t, ldc, off, rows, tr, nb)
             block_job += [k] * n
             nb += n
         raw = np.frombuffer(bytes(jobs), dtype=np.uint8).copy()

@@ -265,3 +265,59 @@ class HipTrainStep:
                 launch(i)
             launch(len(self._buckets))                        # SGD, after every bucket has been waited for
         self.steps += 1
+
+
+class HipInference:
+    """Eval-mode forward of the validate() body (main.py:564-595: model.eval(), no_grad, batch 1) as one hipGraph:
+    BatchNorm folded into the convolutions (scale in the packed weights, shift/ReLU/residual in the conv epilogue)."""
+
+    def __init__(self, model, batch, height, width, use_graph=True):
+        from .model.multistage_model import ResNet_multistage
+        self.L = lib()
+        model.eval()
+        self.multistage = isinstance(model, ResNet_multistage)
+        if self.multistage:
+            self.mp = model._plans(batch, height, width, False)
+            self.plans = [self.mp.p1, self.mp.p2]
+        else:
+            self.mp = None
+            self.plans = [model._plan(batch, height, width, False)]
+        self.use_graph = use_graph
+        self.graph = None
+        self.calls = 0
+        self.side = torch.cuda.Stream(device=self.plans[0].dev)
+
+    def _run(self):
+        p1 = self.plans[0]
+        p1._run(p1.prep)
+        p1._run(p1.fwd)
+        if self.multistage:
+            self.mp.filter_op()
+            p2 = self.plans[1]
+            p2._run(p2.prep)
+            p2._run(p2.fwd)
+
+    def __call__(self, x):
+        """x [B,>=4,H,W] CUDA fp32 -> prediction(s) (plan-owned tensors, valid until the next call)."""
+        caller = torch.cuda.current_stream()
+        self.side.wait_stream(caller)
+        with torch.cuda.stream(self.side):
+            p = self.plans[0]
+            for pl in self.plans:
+                pl.set_stream()
+            p.x_in.copy_(x[:, :p.x_in.shape[1]])
+            if self.use_graph and self.calls >= 1 and self.graph is None:
+                check(self.L.rd_graph_begin(p.streams[0]), "graph_begin")
+                self._run()
+                g = C.c_void_p(0)
+                check(self.L.rd_graph_end(p.streams[0], C.byref(g)), "graph_end")
+                self.graph = g
+            if self.graph is not None:
+                check(self.L.rd_graph_launch(self.graph, p.streams[0]), "graph_launch")
+            else:
+                self._run()
+            self.calls += 1
+        caller.wait_stream(self.side)
+        if self.multistage:
+            return {"stage1": self.mp.p1.pred, "stage2": self.mp.p2.pred, "mask": self.mp.mask, "radar_filtered": self.mp.kept}
+        return self.plans[0].pred

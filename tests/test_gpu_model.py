@@ -321,3 +321,25 @@ def test_large_geometry_900x1600():
     go = np.array([p.grad.double().norm().item() for p in o.parameters()])
     gg = np.array([p.grad.double().norm().item() for p in m.parameters()])
     assert np.abs(go - gg).max() / go.max() < 2e-2
+
+
+def test_inference_graph_matches_module_forward():
+    """HipInference (graph-captured eval forward, folded BatchNorm) == module.eval()(x) == oracle eval forward."""
+    from oracle.models import ResNet_latefusion as ORef
+    from radar_depth_amd.main import HipInference
+    from radar_depth_amd.synthetic import make_batch, procedural_fill_
+    h, w = 97, 161
+    m = build(h, w).eval()
+    o = ORef(18, "upproj", [h, w], 4, False)
+    procedural_fill_(o)
+    o.eval()
+    inf = HipInference(m, 2, h, w)
+    for it in range(3):
+        x, _ = make_batch(2, h, w, 40 + it, ref_pixels=h * w)
+        got = inf(x.cuda()).clone()
+        with torch.no_grad():
+            want = o(x)
+            direct = m(x.cuda())
+        torch.cuda.synchronize()
+        assert rel(got.cpu().numpy(), want.numpy()) < 1e-3, it
+        assert torch.equal(got, direct)

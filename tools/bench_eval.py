@@ -1,0 +1,21 @@
+#!/usr/bin/env python3
+"""Eval-mode (validate(), main.py:564-595) latency of the HIP inference path: batch 1 and 16, 450x800, hipGraph replay."""
+import sys, time, torch
+sys.path.insert(0, ".")
+from radar_depth_amd.main import HipInference
+from radar_depth_amd.model.models import ResNet_latefusion
+from radar_depth_amd.synthetic import make_batch
+torch.manual_seed(0)
+m = ResNet_latefusion(18, "upproj", [450, 800], 4, False).cuda()
+for b in (1, 16):
+    inf = HipInference(m, b, 450, 800)
+    x, _ = make_batch(b, 450, 800, 1)
+    x = x.cuda()
+    for _ in range(5): inf(x)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    n = 50
+    for _ in range(n): inf(x)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / n
+    print("eval forward b=%d: %.3f ms/call  %.1f samples/s  (35.47 GFLOP/sample algorithmic -> %.1f TFLOP/s)" % (b, dt * 1e3, b / dt, 35.47e9 * b / dt / 1e12))
