@@ -44,7 +44,7 @@ struct GconvArgs {
 };
 
 template <int MT, int NT, int WM, int WN, int CKW>
-__global__ __launch_bounds__(256) void gconv_kernel(const GconvArgs a) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MT * NT <= 6 ? 2 : 1))) void gconv_kernel(const GconvArgs a) {
     constexpr int BM = WM * MT * 32;
     constexpr int BN = WN * NT * 32;
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -227,6 +227,9 @@ __global__ __launch_bounds__(256) void gconv_kernel(const GconvArgs a) {
     for (int nt = 0; nt < NT; ++nt) ssum[nt] = ssq[nt] = 0.f;
     const bool has_add = a.addend != nullptr;
     const bool has_bias = a.bias != nullptr;
+    // inference form (bias / activation in the epilogue, rd_gconv_fused) takes the general path below; the training
+    // fast path stays free of it (adding it there cost 80 VGPRs and ~20 % on the big training kernels)
+    const bool fused = has_bias || a.act != RD_ACT_NONE;
     const int cob = co0 + wn * NT * 32 + l31;
     float biasv[NT];
 #pragma unroll
@@ -234,6 +237,7 @@ __global__ __launch_bounds__(256) void gconv_kernel(const GconvArgs a) {
     const bool cols_full = co0 + wn * NT * 32 + NT * 32 <= D.Cout;       // wave-uniform
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
+        __builtin_amdgcn_sched_barrier(0);   // keep one M-tile's row offsets / addends live at a time
         int ro[16];
         bool rows_ok = true;
 #pragma unroll
@@ -241,29 +245,33 @@ __global__ __launch_bounds__(256) void gconv_kernel(const GconvArgs a) {
             ro[i] = s_opix[(wm * MT + mt) * 32 + (i & 3) + 8 * (i >> 2) + 4 * hh];   // -1: no such pixel
             rows_ok = rows_ok && ro[i] >= 0;
         }
-        if (cols_full && __all(rows_ok)) {
-            float addv[NT][16];
-            if (has_add) {
+        if (!fused && cols_full && __all(rows_ok)) {
+            // two batches of 8 accumulator rows: enough loads in flight to hide the addend latency without pushing the
+            // kernel past 256 registers (arch + accumulation), which would halve the waves per SIMD
 #pragma unroll
-                for (int i = 0; i < 16; ++i) {
-                    const float* ap = a.addend + (size_t)ro[i] * a.ld_add + cob;
+            for (int h8 = 0; h8 < 16; h8 += 8) {
+                float addv[NT][8];
+                if (has_add) {
 #pragma unroll
-                    for (int nt = 0; nt < NT; ++nt) addv[nt][i] = ap[nt * 32];
+                    for (int i = 0; i < 8; ++i) {
+                        const float* ap = a.addend + (size_t)ro[h8 + i] * a.ld_add + cob;
+#pragma unroll
+                        for (int nt = 0; nt < NT; ++nt) addv[nt][i] = ap[nt * 32];
+                    }
                 }
-            }
 #pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                float* rp = outp + (size_t)ro[i] * D.ldo + cob;
+                for (int i = 0; i < 8; ++i) {
+                    float* rp = outp + (size_t)ro[h8 + i] * D.ldo + cob;
 #pragma unroll
-                for (int nt = 0; nt < NT; ++nt) {
-                    float v = acc[mt][nt][i];
-                    if (has_bias) v += biasv[nt];
-                    if (has_add) v += addv[nt][i];
-                    if (cob + nt * 32 < a.act_cols) v = act_fwd(v, a.act);
-                    rp[nt * 32] = v;
-                    ssum[nt] += v;
-                    ssq[nt] += v * v;
+                    for (int nt = 0; nt < NT; ++nt) {
+                        float v = acc[mt][nt][h8 + i];
+                        if (has_add) v += addv[nt][i];
+                        rp[nt * 32] = v;
+                        ssum[nt] += v;
+                        ssq[nt] += v * v;
+                    }
                 }
+                __builtin_amdgcn_sched_barrier(0);
             }
         } else {
 #pragma unroll

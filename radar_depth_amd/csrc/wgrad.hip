@@ -43,7 +43,7 @@ struct WgradArgs {
 // waves take interleaved pixel groups and each writes its own slab.
 // SHB: every tap of the group reads the same dout pixel (stride-1/2 k x k convs) -> one shared B fragment per step.
 template <int TG, int MF, bool LAYOUT_A, bool SHB>
-__global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs a) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void wgrad_kernel(const WgradArgs a) {
     constexpr int CIB = LAYOUT_A ? 64 : MF;
     constexpr int COB = LAYOUT_A ? 64 : MF;
     constexpr int KP = MF == 32 ? 2 : 4;   // pixels per MFMA
