@@ -61,6 +61,12 @@ def instrumented_pass(ts):
     with torch.cuda.stream(ts.side):
         plan.set_stream(serialize=True)      # all plan streams -> this stream, so per-op event pairs bracket the op
         recs = []
+        # three un-instrumented passes first, back to back with the measured one: the device is then at its sustained
+        # (power-managed) clock like in the timed region, not at the boost clock it reaches after an idle gap
+        for _ in range(3):
+            for lst in (plan.prep, plan.fwd, plan.bwd):
+                for name, fn, args in lst:
+                    assert fn(*args) == 0, name
         for lst in (plan.prep, plan.fwd, plan.bwd):
             for name, fn, args in lst:
                 e0 = torch.cuda.Event(enable_timing=True)

@@ -466,7 +466,7 @@ static bool plan_gconv(const RdConvDesc& d, GconvPlan& best, bool allow_split = 
                     const double wgs = wgs1 * ksp;
                     // fewer than two workgroups per CU leaves staging/epilogue phases uncovered
                     score = base * (wgs / (ncu * ceil(wgs / ncu))) * (ksp == 1 ? 1.0 : (ksp == 2 ? 0.95 : 0.91)) *
-                            (wgs < 2 * ncu ? 0.9 : 1.0);
+                            (wgs < 2 * ncu && lds <= 80 * 1024 ? 0.9 : 1.0);   // (a > 80 KB tile already paid for single residency)
                     if (score > best_score) {
                         best_score = score;
                         best = GconvPlan{c.MT, c.NT, c.WM, c.WN, CKW, ckp, TH, TW, PP, 0, n_cot, taps_max, pick_wsd(taps_max, BN, CKW, ckp), ksp, lds};
