@@ -52,7 +52,8 @@ int rd_device_info(int* n_cu, char* name, int name_len);
  *   - Unpool + 5x5 conv of an UpProj module    : 4 phases, 9/6/6/4 taps on the LOW-RES input,
  *     both branches fused along co             (models.py:13-27,181-209; zero-skipping identity)
  *   - every input-gradient (dgrad) of the above: same form with transposed weights
- * Weights are the packed layout produced by rd_pack_weights: [slab][cin][cout], cout fastest.
+ * Weights are the packed layout produced by rd_pack_weights: logical [slab][cin][cout], stored with the
+ * reduction rows interleaved by four: element (slab, ci, co) at ((slab*Cin/4 + ci/4)*ld + co)*4 + ci%4.
  * ------------------------------------------------------------------------------------- */
 typedef struct {
     int32_t n_taps;
@@ -112,16 +113,20 @@ int rd_wgrad(const RdConvDesc* d, const float* in, const float* dout, float* sla
 int rd_wgrad_reduce(const RdConvDesc* d, const float* slabs, float* grad_oihw, int32_t O, int32_t I,
                     int32_t KH, int32_t KW, int32_t co_off, int32_t accumulate, void* stream);
 
-/* OIHW -> packed [slab][I][ldc] at column offset co_off (forward operand), or, with
+/* OIHW -> packed logical [slab][I][ldc] at column offset co_off (forward operand), or, with
  * transpose != 0, -> packed [slab][O.. as rows][I as columns] (dgrad operand: rows are the
  * forward output channels at row offset co_off, ldc >= I).  flip != 0 reverses the slab order
- * (kh,kw -> KH-1-kh, KW-1-kw).  Replaces nothing in the reference (layout glue). */
+ * (kh,kw -> KH-1-kh, KW-1-kw).  The physical order interleaves the rows by four (see the
+ * descriptor comment above); the row count must be a multiple of 4.  Replaces nothing in the
+ * reference (layout glue). */
 int rd_pack_weights(const float* w_oihw, float* packed, int32_t O, int32_t I, int32_t KH, int32_t KW,
                     int32_t ldc, int32_t co_off, int32_t rows_total, int32_t transpose, void* stream);
 
 /* All weight tensors of a network in ONE launch.  jobs_dev: device array of
  *   struct { const float* src; float* dst; const float* scale; int32_t O, I, T(=KH*KW), ldc, off, rows_total,
- *            transpose, first_block; }      scale (nullable): per-output-channel factor = folded BatchNorm scale (eval mode)
+ *            transpose, first_block, quad, pad; }
+ *   scale (nullable): per-output-channel factor = folded BatchNorm scale (eval mode); quad != 0: row-interleaved gconv
+ *   operand layout, 0: plain [slab][row][col] (the 7x7 stem kernels)
  * (same meaning as rd_pack_weights' arguments); block_job_dev[b] = job index of block b, where job j owns blocks
  * [first_block, first_block + ceil(O*I*T / rd_pack_chunk())).  Both arrays are built once by the host plan. */
 int rd_pack_chunk(void);

@@ -6,11 +6,14 @@
 // Structure per workgroup (256 threads = 4 waves, WM x WN wave grid):
 //   * a TH x TW tile of logical output pixels (BM = WM*MT*32 rows of the implicit GEMM) times
 //     BN = WN*NT*32 output channels;
-//   * the input halo patch of the tile is staged ONCE per 32-channel chunk in LDS and reused by every
+//   * the input halo patch of the tile is staged ONCE per 16/32-channel chunk in LDS and reused by every
 //     tap (direct convolution: no im2col buffer, input read once from HBM/L2);
-//   * weights stream through LDS in [taps][CKW][BN] slabs;
-//   * each wave keeps MT x NT accumulator tiles of 32x32 in registers; A fragments are ds_read_b32 with
-//     an odd pixel stride (conflict-free), B fragments are contiguous in cout;
+//   * weights stream through LDS in [taps][WSD/4][BN][4] slabs (rows interleaved by four, the layout
+//     rd_pack_weights writes to HBM); patch and slab loads of a chunk are issued as one batch: one
+//     memory round trip per chunk;
+//   * each wave keeps MT x NT accumulator tiles of 32x32 in registers; a lane's A and B fragments for the
+//     CKW/2 MFMAs of a step are one ds_read_b128 (b64 for CKW=4) each: padded or XOR-swizzled pixel
+//     layout keeps the A reads conflict-free;
 //   * epilogue: optional addend (residual-gradient merge), NHWC store through an output stride/offset
 //     (UpProj phases, stride-2 dgrad), and per-tile partial BatchNorm sums for the fused statistics.
 #include <math.h>
@@ -43,7 +46,7 @@ struct GconvArgs {
     int debug;         // ablation bits (RD_GCONV_DEBUG env): 1 skip patch staging, 2 skip weight staging, 4 skip MFMA loop
 };
 
-template <int MT, int NT, int WM, int WN, int CKW>
+template <int MT, int NT, int WM, int WN, int CKW, bool SWZ>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MT * NT <= 6 ? 2 : 1))) void gconv_kernel(const GconvArgs a) {
     constexpr int BM = WM * MT * 32;
     constexpr int BN = WN * NT * 32;
@@ -72,17 +75,25 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MT * NT <= 
     const int PW = (a.TW - 1) * IS + (P.dw_max - P.dw_min) + 1;
     const int PH = (th_n - 1) * IS + (P.dh_max - P.dh_min) + 1;
     const int ih0 = r0 * IS + P.dh_min, iw0 = c0 * IS + P.dw_min;
-    const int CKP = a.CKP, PS = CKP + 1;
+    const int CKP = a.CKP;
+    // Patch pixel layout in LDS, two forms (float offset of channel cq of patch pixel px = paddr(px, cq)):
+    //  padded   (unit input stride): pixel stride CKP+4 floats -- 16-byte aligned with an odd quad count, so the 16 lanes of
+    //           a b128 read pass (consecutive pixels) hit 16 distinct bank groups;
+    //  swizzled (input stride 2, whose 4x larger halo patch has no LDS to spare for padding): pixel stride CKP, quad q of
+    //           pixel p stored in slot q ^ ((p >> SWS) & (QP-1)).
+    const int PS = SWZ ? CKP : CKP + 4;
+    const int QPM = (CKP >> 2) - 1, SWS = CKP == 16 ? 2 : 1;
+    auto paddr = [&](int px, int cq) { return SWZ ? ((px * CKP + (((px >> SWS) & QPM) << 2)) ^ cq) : px * PS + cq; };
     const int ntaps = P.n_taps;
     const int co0 = cot * BN;
 
     // LDS carve-up
     int* s_opix = reinterpret_cast<int*>(smem);          // [BM] output pixel index or -1
     int* s_apix = s_opix + BM;                           // [BM] patch pixel index of tap (0,0)
-    int* s_tapoff = s_apix + BM;                         // [32] patch float offset per tap
+    int* s_tapoff = s_apix + BM;                         // [32] patch pixel offset per tap
     int* s_widx = s_tapoff + 32;                         // [32]
-    float* s_w = reinterpret_cast<float*>(s_widx + 32);  // [taps][WSD][BN]
-    float* s_patch = s_w + a.taps_max * a.WSD * BN;      // [PP][PS]
+    float* s_w = reinterpret_cast<float*>(s_widx + 32);  // [taps][WSD/4][BN][4]  (quad layout, see layout.hip)
+    float* s_patch = s_w + a.taps_max * a.WSD * BN;      // [PP][CKP], quads swizzled
 
     for (int m = tid; m < BM; m += 256) {
         const int r = m / a.TW, c = m - r * a.TW;
@@ -91,14 +102,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MT * NT <= 
         s_apix[m] = ok ? ((r * IS) * PW + c * IS) : 0;
     }
     if (tid < ntaps) {
-        s_tapoff[tid] = ((P.dh[tid] - P.dh_min) * PW + (P.dw[tid] - P.dw_min)) * PS;
+        s_tapoff[tid] = (P.dh[tid] - P.dh_min) * PW + (P.dw[tid] - P.dw_min);
         s_widx[tid] = P.widx[tid];
     }
     __syncthreads();
 
     int abase[MT];
 #pragma unroll
-    for (int mt = 0; mt < MT; ++mt) abase[mt] = s_apix[(wm * MT + mt) * 32 + l31] * PS;
+    for (int mt = 0; mt < MT; ++mt) abase[mt] = s_apix[(wm * MT + mt) * 32 + l31];
     const int bcol = wn * NT * 32 + l31;
 
     f32x16 acc[MT][NT];
@@ -118,56 +129,85 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MT * NT <= 
     float* const outp = a.out + (size_t)ksl * a.split_stride;
     for (int cb = cb_lo; cb < cb_hi; cb += CKP) {
         __syncthreads();
-        // ---- stage the halo patch chunk [PH*PW][CKP] (zero outside the image / beyond Cin).  Batched: U independent
-        // global loads per thread are in flight before the first LDS write (a load-wait-store loop exposes every latency).
-        constexpr int U = 8;
-        for (int base = tid; base < ((a.debug & 1) && cb > cb_lo ? 0 : patch_elems); base += 256 * U) {
-            float4 v[U];
+        // ---- stage the halo patch chunk [PH*PW][CKP] (zero outside the image / beyond Cin) and the first weight slab
+        // [taps][WSD/4][BN] quads (a straight copy: the packed operand in HBM has the same quad layout).  All global loads
+        // of both are issued before the first LDS write, so a chunk pays ONE memory round trip (a load-wait-store loop
+        // exposes every latency; separate patch / weight batches expose two or three).
+        // (batch sizes: the large register tiles run two waves per SIMD whatever the staging needs; the small ones keep
+        //  their higher occupancy with shorter batches)
+        constexpr int UP = MT * NT >= 4 ? 8 : 4, UW = MT * NT >= 4 ? 9 : 5;
+        const int WSD = a.WSD, W4 = WSD >> 2;
+        const int nsub = min(CKP, cb_hi - cb) / WSD;
+        const int welems = ntaps * W4 * BN;
+        const int cinq = D.Cin >> 2;
+        const int pe = ((a.debug & 1) && cb > cb_lo) ? 0 : patch_elems;
+        auto patch_load = [&](int base, auto& v) {
+            constexpr int N = sizeof(v) / sizeof(v[0]);
 #pragma unroll
-            for (int u = 0; u < U; ++u) {
+            for (int u = 0; u < N; ++u) {
                 const int e = base + u * 256;
                 const int pix = e / q4, qq = e - pix * q4;
                 const int py = pix / PW, px = pix - py * PW;
                 const int ih = ih0 + py, iw = iw0 + px, c = cb + qq * 4;
                 v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (e < patch_elems && ih >= 0 && ih < D.Hi && iw >= 0 && iw < D.Wi && c < D.Cin)
+                if (e < pe && ih >= 0 && ih < D.Hi && iw >= 0 && iw < D.Wi && c < D.Cin)
                     v[u] = *reinterpret_cast<const float4*>(in_n + ((size_t)ih * D.Wi + iw) * D.ldi + c);
             }
+        };
+        auto patch_store = [&](int base, auto& v) {
+            constexpr int N = sizeof(v) / sizeof(v[0]);
 #pragma unroll
-            for (int u = 0; u < U; ++u) {
+            for (int u = 0; u < N; ++u) {
                 const int e = base + u * 256;
-                if (e < patch_elems) {
+                if (e < pe) {
                     const int pix = e / q4, qq = e - pix * q4;
-                    float* dst = s_patch + pix * PS + qq * 4;
-                    dst[0] = v[u].x; dst[1] = v[u].y; dst[2] = v[u].z; dst[3] = v[u].w;
+                    *reinterpret_cast<float4*>(s_patch + paddr(pix, qq * 4)) = v[u];
                 }
             }
+        };
+        auto w_load = [&](int base, int ks, auto& v) {
+            constexpr int N = sizeof(v) / sizeof(v[0]);
+            const int we = ((a.debug & 2) && (cb > cb_lo || ks > 0)) ? 0 : welems;
+            const int cq0 = (cb + ks * WSD) >> 2;
+#pragma unroll
+            for (int u = 0; u < N; ++u) {
+                const int e = base + u * 256;
+                const int j = e % BN;
+                const int tk = e / BN;
+                const int k4 = tk % W4, t = min(tk / W4, ntaps - 1);
+                const int co = co0 + j;
+                v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (e < we && co < D.Cout)
+                    v[u] = *reinterpret_cast<const float4*>(a.w + (((size_t)s_widx[t] * cinq + cq0 + k4) * a.ldw + co) * 4);
+            }
+        };
+        auto w_store = [&](int base, int ks, auto& v) {
+            constexpr int N = sizeof(v) / sizeof(v[0]);
+            const int we = ((a.debug & 2) && (cb > cb_lo || ks > 0)) ? 0 : welems;
+#pragma unroll
+            for (int u = 0; u < N; ++u) {
+                const int e = base + u * 256;
+                if (e < we) *reinterpret_cast<float4*>(s_w + (size_t)e * 4) = v[u];   // [t][k4][BN] is linear in e
+            }
+        };
+        {
+            float4 vp[UP], vw[UW];
+            patch_load(tid, vp);
+            w_load(tid, 0, vw);
+            patch_store(tid, vp);
+            w_store(tid, 0, vw);
         }
-        const int WSD = a.WSD;
-        const int nsub = min(CKP, cb_hi - cb) / WSD;
+        for (int base = tid + 256 * UP; base < pe; base += 256 * UP) {
+            float4 vp[UP];
+            patch_load(base, vp);
+            patch_store(base, vp);
+        }
         for (int ks = 0; ks < nsub; ++ks) {
             if (ks > 0) __syncthreads();
-            // ---- stage weights [taps][WSD][BN] for input channels cb+ks*WSD .. +WSD
-            const int welems = ntaps * WSD * (BN / 4);
-            for (int base = tid; base < ((a.debug & 2) && (cb > cb_lo || ks > 0) ? 0 : welems); base += 256 * U) {
-                float4 v[U];
-#pragma unroll
-                for (int u = 0; u < U; ++u) {
-                    const int e = base + u * 256;
-                    const int j4 = e % (BN / 4);
-                    const int tk = e / (BN / 4);
-                    const int k = tk % WSD, t = min(tk / WSD, ntaps - 1);
-                    const int co = co0 + j4 * 4;
-                    const int ci = cb + ks * WSD + k;
-                    v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
-                    if (e < welems && co < D.Cout)  // Cout is a multiple of 4 (checked on the host)
-                        v[u] = *reinterpret_cast<const float4*>(a.w + ((size_t)s_widx[t] * D.Cin + ci) * a.ldw + co);
-                }
-#pragma unroll
-                for (int u = 0; u < U; ++u) {
-                    const int e = base + u * 256;
-                    if (e < welems) *reinterpret_cast<float4*>(s_w + (size_t)e * 4) = v[u];   // [tk][BN] is linear in e
-                }
+            for (int base = ks > 0 ? tid : tid + 256 * UW; base < welems; base += 256 * UW) {
+                float4 vw[UW];
+                w_load(base, ks, vw);
+                w_store(base, ks, vw);
             }
             __syncthreads();
             // ---- MFMA over (k-quantum, tap) steps.  One step = CKW input channels of one tap = KK*MT*NT MFMAs.  Software
@@ -176,19 +216,24 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MT * NT <= 
             constexpr int KK = CKW / 2;
             const int nq = WSD / CKW;
             const int nsteps = (a.debug & 4) ? 0 : nq * ntaps;
-            float ca[KK][MT], cb_[KK][NT];
+            typedef float fK __attribute__((ext_vector_type(KK)));   // KK consecutive channels per lane: one LDS read
+            fK ca[MT], cb_[NT];
             int t_n = 0, kq_n = 0;         // (tap, k-quantum) of the step whose fragments are loaded next
             int st_ld = 0;
             int toff_n = s_tapoff[0];
+            // lane (row|col = l31, hh) feeds channel kq*CKW + hh*KK + kk to the kk-th MFMA of the step (any bijection of the
+            // CKW channels onto (kk, hh) is a valid reduction order as long as A and B agree)
 #define RD_GC_LOAD(AV, BV)                                                                     \
             {                                                                                  \
-                const int toff = toff_n + ks * WSD + kq_n * CKW + hh;                          \
-                const float* wt = s_w + ((t_n * WSD + kq_n * CKW + hh) * BN + bcol);           \
+                const int cq = ks * WSD + kq_n * CKW + hh * KK;    /* first channel of this lane's fragment */ \
+                const float* wt = s_w + ((t_n * W4 + ((kq_n * CKW + hh * KK) >> 2)) * BN + bcol) * 4 + ((hh * KK) & 3); \
                 if (!(a.debug & 8) || st_ld == 0) {                                            \
-                _Pragma("unroll") for (int kk = 0; kk < KK; ++kk) {                            \
-                    _Pragma("unroll") for (int mt = 0; mt < MT; ++mt) AV[kk][mt] = s_patch[abase[mt] + toff + kk * 2]; \
-                    _Pragma("unroll") for (int nt = 0; nt < NT; ++nt) BV[kk][nt] = wt[kk * 2 * BN + nt * 32];          \
-                } }                                                                            \
+                    _Pragma("unroll") for (int mt = 0; mt < MT; ++mt) {                        \
+                        const int px = abase[mt] + toff_n;                                     \
+                        AV[mt] = *reinterpret_cast<const fK*>(s_patch + paddr(px, cq));            \
+                    }                                                                          \
+                    _Pragma("unroll") for (int nt = 0; nt < NT; ++nt) BV[nt] = *reinterpret_cast<const fK*>(wt + nt * 32 * 4);          \
+                }                                                                              \
                 ++st_ld;                                                                       \
                 if (++t_n == ntaps) { t_n = 0; ++kq_n; }                                       \
                 toff_n = s_tapoff[t_n];                                                        \
@@ -197,10 +242,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MT * NT <= 
             _Pragma("unroll") for (int kk = 0; kk < KK; ++kk)                                  \
                 _Pragma("unroll") for (int mt = 0; mt < MT; ++mt)                              \
                     _Pragma("unroll") for (int nt = 0; nt < NT; ++nt)                          \
-                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(AV[kk][mt], BV[kk][nt], acc[mt][nt], 0, 0, 0);
+                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(AV[mt][kk], BV[nt][kk], acc[mt][nt], 0, 0, 0);
             RD_GC_LOAD(ca, cb_)
             for (int st = 0; st < nsteps; st += 2) {
-                float na[KK][MT] = {}, nb[KK][NT] = {};
+                fK na[MT], nb[NT];
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) na[mt] = 0.f;
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) nb[nt] = 0.f;
                 // (the step after the last one re-reads in-bounds LDS: kq_n may reach nq, still inside the patch/slab rows
                 //  because one extra quantum is reserved by the host-side LDS sizing)
                 RD_GC_LOAD(na, nb)
@@ -397,20 +446,19 @@ static int pick_wsd(int taps_max, int BN, int CKW, int CKP) {
     while (w > CKW && (size_t)taps_max * w * BN * 4 > budget) w >>= 1;
     return w < CKW ? CKW : w;
 }
-static size_t lds_need(int BM, int BN, int CKW, int CKP, int PP, int taps_max) {
+static size_t lds_need(int BM, int BN, int CKW, int CKP, int PP, int taps_max, bool swz) {
     // + one CKW quantum of slab rows and one patch pixel row of slack: the pipelined loop prefetches one step past the end
     return (size_t)(2 * BM + 64) * 4 + ((size_t)taps_max * pick_wsd(taps_max, BN, CKW, CKP) + CKW) * BN * 4 +
-           (size_t)(PP + 1) * (CKP + 1) * 4 + 64;
+            (size_t)(PP + 2) * (swz ? CKP : CKP + 4) * 4 + 64;
 }
 
 // Choose wave tiling + pixel tile for a descriptor.  Heuristic: maximise useful-MAC fraction of the
 // BM x BN tile, penalise halo re-reads, prefer <= 80 KB of LDS (two workgroups per CU).
 static bool plan_gconv(const RdConvDesc& d, GconvPlan& best, bool allow_split = false) {
     // prior = measured relative efficiency of the register tile on large layers (tools/sweep_gconv.py, B=16 layer1/layer2);
-    // the WN=2 tilings never won a shape and carry a low prior.
+    // WN=2 tilings (2,2,2,2), (4,2,2,2) never won a shape and were dropped.
     struct Cfg { int MT, NT, WM, WN; double prior; };
-    static const Cfg cfgs[] = {{2, 2, 4, 1, 0.93}, {2, 1, 4, 1, 0.82}, {3, 2, 4, 1, 1.0}, {1, 2, 4, 1, 0.78},
-                               {2, 2, 2, 2, 0.6}, {4, 2, 2, 2, 0.5}, {1, 1, 4, 1, 0.76}};
+    static const Cfg cfgs[] = {{2, 2, 4, 1, 0.93}, {2, 1, 4, 1, 0.82}, {3, 2, 4, 1, 1.0}, {1, 2, 4, 1, 0.78}, {1, 1, 4, 1, 0.76}};
     int taps_max = 0;
     for (int i = 0; i < d.n_phases; ++i) taps_max = taps_max > d.phase[i].n_taps ? taps_max : d.phase[i].n_taps;
     const int CKW = taps_max > 9 ? 4 : 8;
@@ -445,7 +493,7 @@ static bool plan_gconv(const RdConvDesc& d, GconvPlan& best, bool allow_split = 
                     const int pp = patch_pixels(d, d.phase[i], TH, TW);
                     PP = PP > pp ? PP : pp;
                 }
-                const size_t lds = lds_need(BM, BN, CKW, ckp, PP, taps_max);
+                const size_t lds = lds_need(BM, BN, CKW, ckp, PP, taps_max, d.in_stride == 2);
                 if (lds > 160 * 1024 - 512) continue;
                 const double m_util = (double)P.lh * P.lw / ((double)cdiv(P.lh, TH) * cdiv(P.lw, TW) * BM);
                 const double halo = (double)PP / (TH * TW * d.in_stride * d.in_stride);
@@ -478,10 +526,10 @@ static bool plan_gconv(const RdConvDesc& d, GconvPlan& best, bool allow_split = 
     return best_score > 0;
 }
 
-template <int MT, int NT, int WM, int WN, int CKW>
+template <int MT, int NT, int WM, int WN, int CKW, bool SWZ>
 static int launch_cfg(const GconvArgs& a, int grid, size_t lds, hipStream_t s) {
     static bool attr_set = false;
-    auto k = gconv_kernel<MT, NT, WM, WN, CKW>;
+    auto k = gconv_kernel<MT, NT, WM, WN, CKW, SWZ>;
     if (!attr_set) {
         RD_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr_set = true;
@@ -535,11 +583,11 @@ extern "C" int rd_gconv_plan_info(const RdConvDesc* d, int32_t* out) {
     return RD_OK;
 }
 
-template <int MT, int NT, int WM, int WN, int CKW>
+template <int MT, int NT, int WM, int WN, int CKW, bool SWZ>
 static int occ_cfg(size_t lds) {
     int n = -1;
-    auto k = gconv_kernel<MT, NT, WM, WN, CKW>;
-    hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    auto k = gconv_kernel<MT, NT, WM, WN, CKW, SWZ>;
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k, 256, lds) != hipSuccess) n = -1;
     return n;
 }
@@ -551,8 +599,10 @@ extern "C" int rd_gconv_occupancy(const RdConvDesc* d) {
     if (!plan_gconv(dd, pl)) return RD_EINVAL;
 #define RD_OCC(MT_, NT_, WM_, WN_) \
     if (pl.MT == MT_ && pl.NT == NT_ && pl.WM == WM_ && pl.WN == WN_) \
-        return pl.CKW == 8 ? occ_cfg<MT_, NT_, WM_, WN_, 8>(pl.lds_bytes) : occ_cfg<MT_, NT_, WM_, WN_, 4>(pl.lds_bytes);
-    RD_OCC(2, 2, 4, 1) RD_OCC(2, 1, 4, 1) RD_OCC(3, 2, 4, 1) RD_OCC(1, 2, 4, 1) RD_OCC(2, 2, 2, 2) RD_OCC(4, 2, 2, 2) RD_OCC(1, 1, 4, 1)
+        return swz ? (pl.CKW == 8 ? occ_cfg<MT_, NT_, WM_, WN_, 8, true>(pl.lds_bytes) : occ_cfg<MT_, NT_, WM_, WN_, 4, true>(pl.lds_bytes)) \
+                   : (pl.CKW == 8 ? occ_cfg<MT_, NT_, WM_, WN_, 8, false>(pl.lds_bytes) : occ_cfg<MT_, NT_, WM_, WN_, 4, false>(pl.lds_bytes));
+    const bool swz = d->in_stride == 2;
+    RD_OCC(2, 2, 4, 1) RD_OCC(2, 1, 4, 1) RD_OCC(3, 2, 4, 1) RD_OCC(1, 2, 4, 1) RD_OCC(1, 1, 4, 1)
 #undef RD_OCC
     return -1;
 }
@@ -615,15 +665,16 @@ static int gconv_impl(const RdConvDesc* d, const float* in, const float* w_packe
 #define RD_TRY(MT_, NT_, WM_, WN_)                                                                  \
     if (!launched && pl.MT == MT_ && pl.NT == NT_ && pl.WM == WM_ && pl.WN == WN_) {                \
         launched = true;                                                                            \
-        rc = pl.CKW == 8 ? launch_cfg<MT_, NT_, WM_, WN_, 8>(a, grid, pl.lds_bytes, s)              \
-                         : launch_cfg<MT_, NT_, WM_, WN_, 4>(a, grid, pl.lds_bytes, s);             \
+        rc = swz ? (pl.CKW == 8 ? launch_cfg<MT_, NT_, WM_, WN_, 8, true>(a, grid, pl.lds_bytes, s)                \
+                                : launch_cfg<MT_, NT_, WM_, WN_, 4, true>(a, grid, pl.lds_bytes, s))               \
+                 : (pl.CKW == 8 ? launch_cfg<MT_, NT_, WM_, WN_, 8, false>(a, grid, pl.lds_bytes, s)               \
+                                : launch_cfg<MT_, NT_, WM_, WN_, 4, false>(a, grid, pl.lds_bytes, s));             \
     }
+    const bool swz = d->in_stride == 2;
     RD_TRY(2, 2, 4, 1)
     RD_TRY(2, 1, 4, 1)
     RD_TRY(3, 2, 4, 1)
     RD_TRY(1, 2, 4, 1)
-    RD_TRY(2, 2, 2, 2)
-    RD_TRY(4, 2, 2, 2)
     RD_TRY(1, 1, 4, 1)
 #undef RD_TRY
     if (!launched) { set_error("gconv: unsupported plan"); return RD_EINVAL; }

@@ -3,7 +3,12 @@
 
 namespace rd {
 
-// packed[slab][row][col]: transpose==0 -> row=i (I rows), col=co_off+o ; transpose!=0 -> row=co_off+o, col=i
+// Logical packed[slab][row][col]: transpose==0 -> row=i (I rows), col=co_off+o ; transpose!=0 -> row=co_off+o, col=i.
+// gconv reads its operand with the reduction rows interleaved by four ("quad" layout): element (slab, row, col) lives at
+// ((slab * R/4 + row/4) * ldc + col) * 4 + row%4, so that one 16-byte LDS read feeds four consecutive MFMAs.
+__device__ __forceinline__ int64_t packed_index(int quad, int64_t t, int64_t rows, int64_t row, int64_t ldc, int64_t col) {
+    return quad ? ((t * (rows >> 2) + (row >> 2)) * ldc + col) * 4 + (row & 3) : (t * rows + row) * ldc + col;
+}
 __global__ void pack_weights_kernel(const float* __restrict__ w, float* __restrict__ packed, int O, int I, int T,
                                     int ldc, int off, int rows_total, int transpose) {
     const int64_t total = (int64_t)O * I * T;
@@ -15,13 +20,13 @@ __global__ void pack_weights_kernel(const float* __restrict__ w, float* __restri
             const int64_t r = e / O;
             i = (int)(r % I);
             t = (int)(r / I);
-            packed[((int64_t)t * I + i) * ldc + off + o] = w[((int64_t)o * I + i) * T + t];
+            packed[packed_index(1, t, I, i, ldc, off + o)] = w[((int64_t)o * I + i) * T + t];
         } else {
             i = (int)(e % I);
             const int64_t r = e / I;
             o = (int)(r % O);
             t = (int)(r / O);
-            packed[((int64_t)t * rows_total + off + o) * ldc + i] = w[((int64_t)o * I + i) * T + t];
+            packed[packed_index(1, t, rows_total, off + o, ldc, i)] = w[((int64_t)o * I + i) * T + t];
         }
     }
 }
@@ -33,6 +38,7 @@ struct PackJob {
     float* dst;
     const float* scale;   // optional per-output-channel factor (eval mode: folded BatchNorm scale), may be null
     int O, I, T, ldc, off, rows_total, transpose, first_block;
+    int quad, pad_;       // quad != 0: gconv operand layout (rows interleaved by four); 0: plain [slab][row][col] (stem kernels)
 };
 constexpr int PACK_CHUNK = 2048;
 __global__ __launch_bounds__(256) void pack_weights_batched_kernel(const PackJob* __restrict__ jobs, const int* __restrict__ block_job) {
@@ -49,14 +55,14 @@ __global__ __launch_bounds__(256) void pack_weights_batched_kernel(const PackJob
             const int i = (int)(r % j.I), t = (int)(r / j.I);
             float v = j.src[((int64_t)o * j.I + i) * j.T + t];
             if (j.scale) v *= j.scale[o];
-            j.dst[((int64_t)t * j.I + i) * j.ldc + j.off + o] = v;
+            j.dst[packed_index(j.quad, t, j.I, i, j.ldc, j.off + o)] = v;
         } else {
             const int i = (int)(e % j.I);
             const int64_t r = e / j.I;
             const int o = (int)(r % j.O), t = (int)(r / j.O);
             float v = j.src[((int64_t)o * j.I + i) * j.T + t];
             if (j.scale) v *= j.scale[o];
-            j.dst[((int64_t)t * j.rows_total + j.off + o) * j.ldc + i] = v;
+            j.dst[packed_index(j.quad, t, j.rows_total, j.off + o, j.ldc, i)] = v;
         }
     }
 }
@@ -95,6 +101,7 @@ using namespace rd;
 extern "C" int rd_pack_weights(const float* w_oihw, float* packed, int32_t O, int32_t I, int32_t KH, int32_t KW,
                                int32_t ldc, int32_t co_off, int32_t rows_total, int32_t transpose, void* stream) {
     RD_CHECK_ARG(w_oihw && packed && O > 0 && I > 0 && KH > 0 && KW > 0, "pack_weights: bad arguments");
+    RD_CHECK_ARG((transpose ? rows_total : I) % 4 == 0, "pack_weights: the reduction dimension must be a multiple of 4");
     const int64_t total = (int64_t)O * I * KH * KW;
     hipLaunchKernelGGL(pack_weights_kernel, dim3(grid_for(total, 256)), dim3(256), 0, static_cast<hipStream_t>(stream),
                        w_oihw, packed, O, I, KH * KW, ldc, co_off, rows_total, transpose);

@@ -98,7 +98,7 @@ class LateFusionPlan:
         self.stream_mask = int(os.environ.get("RD_STREAM_MASK", "3"))
         self.fwd, self.bwd = [], []
         self.prep = []
-        self.pack_jobs = []    # (src, dst, O, I, T, ldc, off, rows_total, transpose): packed in ONE launch per forward
+        self.pack_jobs = []    # (src, dst, O, I, T, ldc, off, rows_total, transpose, scale, quad): packed in ONE launch per forward
         self.taps = {}         # name -> Act of intermediate tensors (tests / debugging)
         self.meta = {}         # op name -> (kernel family, descriptor) for the conv launches (bench roofline accounting)
         self.keep = []         # keep ctypes descriptors and tensors alive
@@ -184,8 +184,8 @@ class LateFusionPlan:
         wd = self.buf(S, cout, cin)
         for w, off in weights:
             o, i, kh, kw = w.shape
-            self.pack_jobs.append((w, wp, o, i, kh * kw, cout, off, i, 0, None))
-            self.pack_jobs.append((w, wd, o, i, kh * kw, cin, off, cout, 1, None))
+            self.pack_jobs.append((w, wp, o, i, kh * kw, cout, off, i, 0, None, 1))
+            self.pack_jobs.append((w, wd, o, i, kh * kw, cin, off, cout, 1, None, 1))
         tiles = self.L.rd_gconv_stat_tiles_ws(C.byref(d))
         if tiles < 0:
             check(tiles, "rd_gconv_stat_tiles_ws(%s)" % name)
@@ -263,7 +263,7 @@ class LateFusionPlan:
             sh = C.c_void_p(bias.data_ptr() + 4 * off)
             self.op(self.prep, name + ".evalcoef", self.L.rd_bn_eval_coeffs, o, _p(bn.weight), _p(bn.bias), _p(bn.running_mean),
                     _p(bn.running_var), C.c_float(BN_EPS), sc, sh, self.streams[0])
-            self.pack_jobs.append((w, wp, o, i, kh * kw, cout, off, i, 0, scale[off:off + o]))
+            self.pack_jobs.append((w, wp, o, i, kh * kw, cout, off, i, 0, scale[off:off + o], 1))
         ws = self._gconv_ws(d, name)
         self.keep += [d, scale]
         self.op(self.fwd, name, self.L.rd_gconv_fused, C.byref(d), x.ptr, _p(wp), out.ptr, _p(bias), act,
@@ -334,7 +334,7 @@ class LateFusionPlan:
         Hc, Wc = (H - 1) // 2 + 1, (W - 1) // 2 + 1
         raw = self.act(N, Hc, Wc, cout)
         wp = self.buf(49, cin, cout)
-        self.pack_jobs.append((conv.weight, wp, cout, cin, 49, cout, 0, cin, 0, None))
+        self.pack_jobs.append((conv.weight, wp, cout, cin, 49, cout, 0, cin, 0, None, 0))   # stem kernels read the plain layout
         tiles = self.L.rd_stem_stat_tiles(N, H, W)
         stat = self.buf(tiles, 2, cout) if self.train else None
         pl = (C.c_void_p * 3)(*([p for p in planes] + [None] * (3 - len(planes))))
@@ -553,13 +553,13 @@ class LateFusionPlan:
         class Job(C.Structure):
             _fields_ = [("src", C.c_void_p), ("dst", C.c_void_p), ("scale", C.c_void_p), ("O", C.c_int32), ("I", C.c_int32), ("T", C.c_int32),
                         ("ldc", C.c_int32), ("off", C.c_int32), ("rows_total", C.c_int32), ("transpose", C.c_int32),
-                        ("first_block", C.c_int32)]
+                        ("first_block", C.c_int32), ("quad", C.c_int32), ("pad_", C.c_int32)]
         chunk = self.L.rd_pack_chunk()
         jobs = (Job * len(self.pack_jobs))()
         block_job, nb = [], 0
-        for k, (src, dst, o, i, t, ldc, off, rows, tr, scale) in enumerate(self.pack_jobs):
+        for k, (src, dst, o, i, t, ldc, off, rows, tr, scale, quad) in enumerate(self.pack_jobs):
             n = -(-(o * i * t) // chunk)
-            jobs[k] = Job(src.data_ptr(), dst.data_ptr(), scale.data_ptr() if scale is not None else None, o, i, t, ldc, off, rows, tr, nb)
+            jobs[k] = Job(src.data_ptr(), dst.data_ptr(), scale.data_ptr() if scale is not None else None, o, i, t, ldc, off, rows, tr, nb, quad, 0)
             block_job += [k] * n
             nb += n
         raw = np.frombuffer(bytes(jobs), dtype=np.uint8).copy()

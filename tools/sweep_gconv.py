@@ -1,5 +1,5 @@
 """Sweep the wave-tiling configs of gconv per layer shape (RD_GCONV_FORCE) -> time per config; run as
-   for c in 0..6: RD_GCONV_FORCE=$c python tools/sweep_gconv.py"""
+   for c in 0..4: RD_GCONV_FORCE=$c python tools/sweep_gconv.py"""
 import ctypes as C, os, sys, torch
 sys.path.insert(0, ".")
 from radar_depth_amd import convdesc as cd, ops
