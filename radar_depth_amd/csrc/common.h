@@ -53,6 +53,15 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
     return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
 }
 
+// Asynchronous 16-byte global -> LDS copy (global_load_lds_dwordx4).  The LDS destination is NOT per lane: the hardware
+// writes lane l's 16 bytes to wave_base + 16 * l, so `lds_wave_base` must be the same value in every lane of the wave (the
+// address lane 0 would write) and the LDS image must be lane-linear.  Lanes masked out by a branch write nothing.  Completion
+// is tracked by vmcnt; __syncthreads() waits for it.
+__device__ __forceinline__ void glds16(const float* gsrc, float* lds_wave_base) {
+    __builtin_amdgcn_global_load_lds(gsrc, reinterpret_cast<__attribute__((address_space(3))) void*>(
+                                               (unsigned)(size_t)lds_wave_base), 16, 0, 0);
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

@@ -43,6 +43,9 @@ struct GconvArgs {
     int WSD;           // input channels per weight slab staged in LDS (multiple of CKW, divides CKP)
     int ksplit;        // split-K: number of input-channel slices (each writes its own partial output)
     long long split_stride;  // floats between consecutive partial outputs
+    // per phase and tap: offset of the tap inside the LDS halo patch -- bytes for the padded layout, pixels for the swizzled
+    // one.  Read through the scalar unit (s_load_dword), so the per-step address arithmetic costs no VALU issue.
+    int tapoff[RD_MAX_PHASES][RD_MAX_TAPS + 1];
     int debug;         // ablation bits (RD_GCONV_DEBUG env): 1 skip patch staging, 2 skip weight staging, 4 skip MFMA loop
 };
 
@@ -111,6 +114,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MT * NT <= 
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) abase[mt] = s_apix[(wm * MT + mt) * 32 + l31];
     const int bcol = wn * NT * 32 + l31;
+    // lane-constant byte offsets of the A (padded layout) and B fragments; the per-step part is wave-uniform (SGPR)
+    constexpr int KKc = CKW / 2;
+    int aoffB[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) aoffB[mt] = (abase[mt] * PS + hh * KKc) * 4;
+    const int boffB = (((hh * KKc) >> 2) * BN + bcol) * 16 + ((hh * KKc) & 3) * 4;
 
     f32x16 acc[MT][NT];
 #pragma unroll
@@ -217,54 +226,71 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MT * NT <= 
             const int nq = WSD / CKW;
             const int nsteps = (a.debug & 4) ? 0 : nq * ntaps;
             typedef float fK __attribute__((ext_vector_type(KK)));   // KK consecutive channels per lane: one LDS read
-            fK ca[MT], cb_[NT];
-            int t_n = 0, kq_n = 0;         // (tap, k-quantum) of the step whose fragments are loaded next
-            int st_ld = 0;
-            int toff_n = s_tapoff[0];
             // lane (row|col = l31, hh) feeds channel kq*CKW + hh*KK + kk to the kk-th MFMA of the step (any bijection of the
-            // CKW channels onto (kk, hh) is a valid reduction order as long as A and B agree)
+            // CKW channels onto (kk, hh) is a valid reduction order as long as A and B agree).
+            //
+            // Cost model (tools/micro/mfma_mix.hip): fp32 MFMAs execute on the SIMD's fp32 lanes, so a VALU instruction
+            // in this loop is NOT free -- it costs ~8 clk of MFMA time -- and an LDS read costs ~10 clk when issued in a
+            // block but ~3.5 clk when issued between two MFMAs.  Hence: every address = lane-constant VGPR + wave-uniform
+            // SGPR term (one v_add per fragment, no multiplies), tap offsets come from the kernel arguments through the
+            // scalar unit, and the LDS reads of step s+1 are interleaved with the MFMAs of step s (sched_group_barrier).
+            fK ca[MT], cb_[NT], na[MT], nb[NT];
+            // (tap, k-quantum) of the step whose fragments are loaded next: wave-uniform, kept in SGPRs.  tap_nxt is fetched
+            // one step early so that its s_load is covered by the wait the MFMAs need anyway.
+            int t_n = 0, kqA = 0, kqB = 0;
+            int tap_cur = a.tapoff[ph][0], tap_nxt = a.tapoff[ph][ntaps > 1 ? 1 : 0];
+            const char* const wbase = reinterpret_cast<const char*>(s_w) + boffB;
+            const char* const pbase = reinterpret_cast<const char*>(s_patch);
 #define RD_GC_LOAD(AV, BV)                                                                     \
             {                                                                                  \
-                const int cq = ks * WSD + kq_n * CKW + hh * KK;    /* first channel of this lane's fragment */ \
-                const float* wt = s_w + ((t_n * W4 + ((kq_n * CKW + hh * KK) >> 2)) * BN + bcol) * 4 + ((hh * KK) & 3); \
-                if (!(a.debug & 8) || st_ld == 0) {                                            \
-                    _Pragma("unroll") for (int mt = 0; mt < MT; ++mt) {                        \
-                        const int px = abase[mt] + toff_n;                                     \
-                        AV[mt] = *reinterpret_cast<const fK*>(s_patch + paddr(px, cq));            \
-                    }                                                                          \
-                    _Pragma("unroll") for (int nt = 0; nt < NT; ++nt) BV[nt] = *reinterpret_cast<const fK*>(wt + nt * 32 * 4);          \
+                if constexpr (SWZ) {                                                           \
+                    const int cq = ks * WSD + (kqA >> 2) + hh * KK;                            \
+                    _Pragma("unroll") for (int mt = 0; mt < MT; ++mt)                          \
+                        AV[mt] = *reinterpret_cast<const fK*>(s_patch + paddr(abase[mt] + tap_cur, cq)); \
+                } else {                                                                       \
+                    const int sA = tap_cur + ks * WSD * 4 + kqA;                               \
+                    _Pragma("unroll") for (int mt = 0; mt < MT; ++mt)                          \
+                        AV[mt] = *reinterpret_cast<const fK*>(pbase + (aoffB[mt] + sA));       \
                 }                                                                              \
-                ++st_ld;                                                                       \
-                if (++t_n == ntaps) { t_n = 0; ++kq_n; }                                       \
-                toff_n = s_tapoff[t_n];                                                        \
+                const int sB = t_n * (W4 * BN * 16) + kqB;                                     \
+                _Pragma("unroll") for (int nt = 0; nt < NT; ++nt) BV[nt] = *reinterpret_cast<const fK*>(wbase + sB + nt * 512); \
+                ++t_n;                                                                         \
+                if (t_n == ntaps) { t_n = 0; kqA += CKW * 4; kqB += (CKW >> 2) * BN * 16; }    \
+                tap_cur = tap_nxt;                                                             \
+                tap_nxt = a.tapoff[ph][t_n + 1 == ntaps ? 0 : t_n + 1];                        \
             }
 #define RD_GC_MFMA(AV, BV)                                                                     \
             _Pragma("unroll") for (int kk = 0; kk < KK; ++kk)                                  \
                 _Pragma("unroll") for (int mt = 0; mt < MT; ++mt)                              \
                     _Pragma("unroll") for (int nt = 0; nt < NT; ++nt)                          \
                         acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(AV[mt][kk], BV[nt][kk], acc[mt][nt], 0, 0, 0);
+            // schedule of one half-iteration: the address VALU ops, then MFMAs with one LDS read slotted after every
+            // KK*NT of them (MT+NT reads in all), then the remaining MFMAs
+#define RD_GC_SCHED()                                                                          \
+            __builtin_amdgcn_sched_group_barrier(0x002, SWZ ? 8 * MT : MT + 1, 0);             \
+            _Pragma("unroll") for (int i = 0; i < MT + NT; ++i) {                              \
+                __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);                             \
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                             \
+            }                                                                                  \
+            __builtin_amdgcn_sched_group_barrier(0x008, KK * MT * NT - 2 * (MT + NT), 0);      \
+            __builtin_amdgcn_sched_barrier(0);
             RD_GC_LOAD(ca, cb_)
+            __builtin_amdgcn_sched_barrier(0);
             for (int st = 0; st < nsteps; st += 2) {
-                fK na[MT], nb[NT];
-#pragma unroll
-                for (int mt = 0; mt < MT; ++mt) na[mt] = 0.f;
-#pragma unroll
-                for (int nt = 0; nt < NT; ++nt) nb[nt] = 0.f;
                 // (the step after the last one re-reads in-bounds LDS: kq_n may reach nq, still inside the patch/slab rows
                 //  because one extra quantum is reserved by the host-side LDS sizing)
                 RD_GC_LOAD(na, nb)
-                __builtin_amdgcn_sched_barrier(0);
                 RD_GC_MFMA(ca, cb_)
-                __builtin_amdgcn_sched_barrier(0);
+                RD_GC_SCHED()
                 if (st + 1 < nsteps) {
                     RD_GC_LOAD(ca, cb_)
-                    __builtin_amdgcn_sched_barrier(0);
                     RD_GC_MFMA(na, nb)
-                    __builtin_amdgcn_sched_barrier(0);
+                    RD_GC_SCHED()
                 }
             }
 #undef RD_GC_LOAD
 #undef RD_GC_MFMA
+#undef RD_GC_SCHED
         }
     }
 
@@ -656,6 +682,18 @@ static int gconv_impl(const RdConvDesc* d, const float* in, const float* w_packe
     a.TH = pl.TH; a.TW = pl.TW; a.PP = pl.PP; a.CKP = pl.CKP;
     a.tiles_total = pl.tiles_total; a.n_cotiles = pl.n_cotiles; a.taps_max = pl.taps_max; a.WSD = pl.WSD;
     a.ksplit = pl.ksplit;
+    {
+        const bool swz_ = d->in_stride == 2;
+        const int PS_ = swz_ ? pl.CKP : pl.CKP + 4;
+        for (int i = 0; i < d->n_phases; ++i) {
+            const RdPhase& p = d->phase[i];
+            const int PW_ = (pl.TW - 1) * d->in_stride + (p.dw_max - p.dw_min) + 1;
+            for (int t = 0; t < p.n_taps; ++t) {
+                const int pix = (p.dh[t] - p.dh_min) * PW_ + (p.dw[t] - p.dw_min);
+                a.tapoff[i][t] = swz_ ? pix : pix * PS_ * 4;
+            }
+        }
+    }
     a.split_stride = (long long)d->N * d->Ho * d->Wo * d->ldo;
     { static const char* dbg = getenv("RD_GCONV_DEBUG"); a.debug = dbg ? atoi(dbg) : 0; }
     const int grid = d->N * pl.tiles_total * pl.n_cotiles * pl.ksplit;

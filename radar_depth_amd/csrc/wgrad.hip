@@ -107,32 +107,24 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void w
             }
             s_tab[p] = e;
         }
-        // Staging is batched: U independent global loads per thread are issued before any LDS write, otherwise every
-        // load's full L2/HBM latency is exposed (measured: 100 us of a 390 us kernel).
-        constexpr int U = 8;
+        // Staging goes global -> LDS directly (global_load_lds_dwordx4: wave-uniform LDS base + lane * 16 B, which is
+        // exactly the [pixel][channel] order both tiles have), so no registers are held and every load of the tile is in
+        // flight at once: one memory round trip per tile.  Elements outside the image / tile / channel range are written
+        // as zeros by their (exec-masked-out) lanes with an ordinary ds_write.
         {   // input halo patch
             const int PH = (th_n - 1) * a.IS + (a.dh_max - a.dh_min) + 1;
             const int ih0 = r0 * a.IS + a.dh_min, iw0 = c0 * a.IS + a.dw_min;
             const float* in_n = a.in + (size_t)n * a.Hi * a.Wi * a.ldi;
             constexpr int q4 = CIB / 4;
             const int elems = PH * PWmax * q4;
-            for (int base = tid; base < elems; base += 256 * U) {
-                float4 v[U];
-#pragma unroll
-                for (int u = 0; u < U; ++u) {
-                    const int e = base + u * 256;
-                    const int pix = e / q4, qq = e - pix * q4;
-                    const int py = pix / PWmax, px = pix - py * PWmax;
-                    const int ih = ih0 + py, iw = iw0 + px, c = cib0 + qq * 4;
-                    v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
-                    if (e < elems && ih >= 0 && ih < a.Hi && iw >= 0 && iw < a.Wi && c < a.Cin)
-                        v[u] = *reinterpret_cast<const float4*>(in_n + ((size_t)ih * a.Wi + iw) * a.ldi + c);
-                }
-#pragma unroll
-                for (int u = 0; u < U; ++u) {
-                    const int e = base + u * 256;
-                    if (e < elems) *reinterpret_cast<float4*>(s_in + (size_t)e * 4) = v[u];   // [pix][CIB] is linear in e
-                }
+            for (int e = tid; e < elems; e += 256) {
+                const int pix = e / q4, qq = e - pix * q4;
+                const int py = pix / PWmax, px = pix - py * PWmax;
+                const int ih = ih0 + py, iw = iw0 + px, c = cib0 + qq * 4;
+                if (ih >= 0 && ih < a.Hi && iw >= 0 && iw < a.Wi && c < a.Cin)
+                    glds16(in_n + ((size_t)ih * a.Wi + iw) * a.ldi + c, s_in + (size_t)(e - lane) * 4);
+                else
+                    *reinterpret_cast<float4*>(s_in + (size_t)e * 4) = make_float4(0.f, 0.f, 0.f, 0.f);   // [pix][CIB] is linear in e
             }
         }
         {   // dout tile (rows/cols beyond the image or beyond the tile's valid extent are zero)
@@ -142,23 +134,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void w
             constexpr int q4 = COB / 4;
             const int elems = DH * DW * q4;
             const int ow_lim = min(a.Wo, ow0 + tw_n * a.OS);
-            for (int base = tid; base < elems; base += 256 * U) {
-                float4 v[U];
-#pragma unroll
-                for (int u = 0; u < U; ++u) {
-                    const int e = base + u * 256;
-                    const int pix = e / q4, qq = e - pix * q4;
-                    const int py = pix / DW, px = pix - py * DW;
-                    const int oh = oh0 + py, ow = ow0 + px, c = cob0 + qq * 4;
-                    v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
-                    if (e < elems && oh < a.Ho && ow < ow_lim && c < a.Cout)
-                        v[u] = *reinterpret_cast<const float4*>(do_n + ((size_t)oh * a.Wo + ow) * a.ldo + c);
-                }
-#pragma unroll
-                for (int u = 0; u < U; ++u) {
-                    const int e = base + u * 256;
-                    if (e < elems) *reinterpret_cast<float4*>(s_do + (size_t)e * 4) = v[u];
-                }
+            for (int e = tid; e < elems; e += 256) {
+                const int pix = e / q4, qq = e - pix * q4;
+                const int py = pix / DW, px = pix - py * DW;
+                const int oh = oh0 + py, ow = ow0 + px, c = cob0 + qq * 4;
+                if (oh < a.Ho && ow < ow_lim && c < a.Cout)
+                    glds16(do_n + ((size_t)oh * a.Wo + ow) * a.ldo + c, s_do + (size_t)(e - lane) * 4);
+                else
+                    *reinterpret_cast<float4*>(s_do + (size_t)e * 4) = make_float4(0.f, 0.f, 0.f, 0.f);
             }
         }
         }
