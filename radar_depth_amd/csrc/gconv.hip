@@ -46,6 +46,8 @@ struct GconvArgs {
     // per phase and tap: offset of the tap inside the LDS halo patch -- bytes for the padded layout, pixels for the swizzled
     // one.  Read through the scalar unit (s_load_dword), so the per-step address arithmetic costs no VALU issue.
     int tapoff[RD_MAX_PHASES][RD_MAX_TAPS + 1];
+    int lds_floats;              // floats of LDS in use before the trace stamps
+    unsigned long long* trace;   // diagnostics (RD_GCONV_TRACE=1): per-workgroup cycle-counter stamps, 64 per workgroup
     int debug;         // ablation bits (RD_GCONV_DEBUG env): 1 skip patch staging, 2 skip weight staging, 4 skip MFMA loop
 };
 
@@ -59,6 +61,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MT * NT <= 
     const int l31 = lane & 31, hh = lane >> 5;
     const RdConvDesc& D = a.d;
 
+    // diagnostics: thread 0 stamps the cycle counter into LDS at the phase boundaries and dumps them when the workgroup ends
+    int n_stamp = 0;
+    unsigned long long* s_stamp = reinterpret_cast<unsigned long long*>(smem + a.lds_floats);   // [64], after everything else
+#define RD_STAMP()                                                                                      \
+    if (a.trace && tid == 0 && n_stamp < 63) s_stamp[n_stamp++] = __builtin_readcyclecounter();
+    RD_STAMP()
+    const unsigned long long rt0 = a.trace ? __builtin_amdgcn_s_memrealtime() : 0;   // 100 MHz constant clock
     const int vid0 = xcd_remap(blockIdx.x, gridDim.x);
     const int ksl = vid0 % a.ksplit;              // split-K slice (slices of one tile are neighbours: same XCD, shared patch)
     const int vid = vid0 / a.ksplit;
@@ -109,6 +118,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MT * NT <= 
         s_widx[tid] = P.widx[tid];
     }
     __syncthreads();
+    RD_STAMP()
 
     int abase[MT];
 #pragma unroll
@@ -219,6 +229,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MT * NT <= 
                 w_store(base, ks, vw);
             }
             __syncthreads();
+            RD_STAMP()
             // ---- MFMA over (k-quantum, tap) steps.  One step = CKW input channels of one tap = KK*MT*NT MFMAs.  Software
             // pipeline pinned with sched_barrier: the A/B fragments of step s+1 (and the patch offset of step s+2) are in
             // flight from LDS while step s's MFMAs issue.
@@ -291,12 +302,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MT * NT <= 
 #undef RD_GC_LOAD
 #undef RD_GC_MFMA
 #undef RD_GC_SCHED
+            RD_STAMP()
         }
     }
 
     // ---- epilogue.  Row validity is uniform per half-wave and almost always true, so full M-tiles take a wave-uniform
     // fast path: no exec masking, one row pointer per accumulator row with the N-tile as an immediate offset, and the
     // residual-gradient addend gathered before its first use (a load-wait-add-store chain per element exposes every latency).
+    RD_STAMP()
     float ssum[NT], ssq[NT];
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) ssum[nt] = ssq[nt] = 0.f;
@@ -390,6 +403,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MT * NT <= 
             if (co < D.Cout) a.stat[((size_t)pt * 2 + which) * D.Cout + co] = s;
         }
     }
+    RD_STAMP()
+    if (a.trace && tid == 0) {
+        a.trace[(size_t)blockIdx.x * 64] = n_stamp;
+        a.trace[(size_t)blockIdx.x * 64 + 62] = __builtin_amdgcn_s_memrealtime() - rt0;
+        // where it ran: HW_REG_XCC_ID (id 20) and HW_REG_HW_ID (id 4); counters are only comparable within one CU
+        a.trace[(size_t)blockIdx.x * 64 + 63] = ((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 32) |
+                                                 __builtin_amdgcn_s_getreg((31 << 11) | 4);
+        for (int i = 0; i < n_stamp; ++i) a.trace[(size_t)blockIdx.x * 64 + 1 + i] = s_stamp[i];
+    }
+#undef RD_STAMP
 }
 
 // split-K combine: out[r][c] = sum_s part[s][r][c] (+ addend[r][c]); optional BN partial sums per row block.
@@ -662,6 +685,14 @@ extern "C" int rd_gconv_stat_tiles_ws(const RdConvDesc* d) {
     return (int)((M + combine_rows_per_block(M) - 1) / combine_rows_per_block(M));
 }
 
+static unsigned long long* g_trace_buf = nullptr;
+// diagnostics: copy the stamps of the last traced launch (64 per workgroup) to the host
+extern "C" int rd_gconv_trace_read(unsigned long long* host, int n_wg) {
+    if (!g_trace_buf) return RD_EINVAL;
+    RD_CHECK_HIP(hipMemcpy(host, g_trace_buf, (size_t)n_wg * 64 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    return RD_OK;
+}
+
 static int gconv_impl(const RdConvDesc* d, const float* in, const float* w_packed, float* out, const float* addend,
                       int32_t ld_add, float* stat_partial, float* ws, void* stream, const float* bias = nullptr,
                       int act = RD_ACT_NONE, int act_cols = 0) {
@@ -696,6 +727,17 @@ static int gconv_impl(const RdConvDesc* d, const float* in, const float* w_packe
     }
     a.split_stride = (long long)d->N * d->Ho * d->Wo * d->ldo;
     { static const char* dbg = getenv("RD_GCONV_DEBUG"); a.debug = dbg ? atoi(dbg) : 0; }
+    a.trace = nullptr;
+    a.lds_floats = (int)((pl.lds_bytes + 7) / 8) * 2;
+    {
+        static const char* tr = getenv("RD_GCONV_TRACE");
+        if (tr && atoi(tr)) {
+            static unsigned long long* buf = nullptr;
+            if (!buf) RD_CHECK_HIP(hipMalloc(&buf, (size_t)65536 * 64 * sizeof(unsigned long long)));
+            g_trace_buf = buf;
+            a.trace = buf;
+        }
+    }
     const int grid = d->N * pl.tiles_total * pl.n_cotiles * pl.ksplit;
     hipStream_t s = static_cast<hipStream_t>(stream);
     rc = RD_EINVAL;
@@ -703,12 +745,13 @@ static int gconv_impl(const RdConvDesc* d, const float* in, const float* w_packe
 #define RD_TRY(MT_, NT_, WM_, WN_)                                                                  \
     if (!launched && pl.MT == MT_ && pl.NT == NT_ && pl.WM == WM_ && pl.WN == WN_) {                \
         launched = true;                                                                            \
-        rc = swz ? (pl.CKW == 8 ? launch_cfg<MT_, NT_, WM_, WN_, 8, true>(a, grid, pl.lds_bytes, s)                \
-                                : launch_cfg<MT_, NT_, WM_, WN_, 4, true>(a, grid, pl.lds_bytes, s))               \
-                 : (pl.CKW == 8 ? launch_cfg<MT_, NT_, WM_, WN_, 8, false>(a, grid, pl.lds_bytes, s)               \
-                                : launch_cfg<MT_, NT_, WM_, WN_, 4, false>(a, grid, pl.lds_bytes, s));             \
+        rc = swz ? (pl.CKW == 8 ? launch_cfg<MT_, NT_, WM_, WN_, 8, true>(a, grid, lds_launch, s)                \
+                                : launch_cfg<MT_, NT_, WM_, WN_, 4, true>(a, grid, lds_launch, s))               \
+                 : (pl.CKW == 8 ? launch_cfg<MT_, NT_, WM_, WN_, 8, false>(a, grid, lds_launch, s)               \
+                                : launch_cfg<MT_, NT_, WM_, WN_, 4, false>(a, grid, lds_launch, s));             \
     }
     const bool swz = d->in_stride == 2;
+    const size_t lds_launch = (size_t)a.lds_floats * 4 + (a.trace ? 512 : 0);
     RD_TRY(2, 2, 4, 1)
     RD_TRY(2, 1, 4, 1)
     RD_TRY(3, 2, 4, 1)

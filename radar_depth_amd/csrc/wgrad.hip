@@ -19,6 +19,7 @@ namespace rd {
 constexpr int WG_MAX_TG = 9;     // taps per group
 constexpr int WG_MAX_GROUPS = 5;
 constexpr int WG_MAX_PIX = 512;  // logical pixels per tile
+constexpr int WG_PITCH = 27;     // patch pitch of the immediate-offset 3x3 kernel: 25-wide tiles (stride 1), 13-wide (stride 2)
 
 struct WgTapGroup {
     int n;
@@ -42,7 +43,11 @@ struct WgradArgs {
 // LAYOUT_A: waves arranged 2 (ci) x 2 (co), all see every pixel.  Otherwise: one (ci,co) block, the four
 // waves take interleaved pixel groups and each writes its own slab.
 // SHB: every tap of the group reads the same dout pixel (stride-1/2 k x k convs) -> one shared B fragment per step.
-template <int TG, int MF, bool LAYOUT_A, bool SHB>
+// PITCH > 0: the group is a full 3x3 stencil (taps in row-major order) and the LDS patch row pitch is the compile-time
+// PITCH, so the nine tap offsets are instruction immediates: the walk then costs 2 VALU instructions per 9 MFMAs instead of
+// 16 (fp32 MFMAs share the SIMD's fp32 lanes with the VALU: every VALU instruction in the walk is lost MFMA time, see
+// tools/micro/mfma_mix.hip).
+template <int TG, int MF, bool LAYOUT_A, bool SHB, int PITCH>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void wgrad_kernel(const WgradArgs a) {
     constexpr int CIB = LAYOUT_A ? 64 : MF;
     constexpr int COB = LAYOUT_A ? 64 : MF;
@@ -63,7 +68,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void w
     const int cib0 = (g / (a.n_tg * a.n_cob)) * CIB;
     const WgTapGroup& G = a.tg[tgi];
 
-    const int PWmax = (a.TW - 1) * a.IS + (a.dw_max - a.dw_min) + 1;
+    const int PWmax = PITCH > 0 ? PITCH : (a.TW - 1) * a.IS + (a.dw_max - a.dw_min) + 1;
     const int PHmax = (a.TH - 1) * a.IS + (a.dh_max - a.dh_min) + 1;
     const int DW = a.TW * a.OS, DHmax = a.TH * a.OS;
     int2* s_tab = reinterpret_cast<int2*>(smem);                        // [WG_MAX_PIX + 64]
@@ -76,7 +81,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void w
     int tin[TG], tout[TG];
 #pragma unroll
     for (int t = 0; t < TG; ++t) {
-        tin[t] = ((G.dh[t] - a.dh_min) * PWmax + (G.dw[t] - a.dw_min)) * CIB + wci * 32 + lm;
+        tin[t] = (PITCH > 0 ? ((t / 3) * PITCH + (t % 3)) * CIB : ((G.dh[t] - a.dh_min) * PWmax + (G.dw[t] - a.dw_min)) * CIB) + wci * 32 + lm;
         tout[t] = (G.oh[t] * DW + G.ow[t]) * COB + wco * 32 + lm;
     }
 
@@ -158,7 +163,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void w
 #define RD_WG_LOAD(AV, BV, PV, STEP)                                          \
         {                                                                         \
             const int2 e_ = e_nxt;                                                \
-            _Pragma("unroll") for (int t = 0; t < TG; ++t) AV[t] = s_in[e_.x + tin[t]]; \
+            if constexpr (PITCH > 0) {                                            \
+                const float* pa_ = s_in + (e_.x + wci * 32 + lm);                 \
+                _Pragma("unroll") for (int t = 0; t < TG; ++t) AV[t] = pa_[((t / 3) * PITCH + (t % 3)) * CIB]; \
+            } else {                                                              \
+                _Pragma("unroll") for (int t = 0; t < TG; ++t) AV[t] = s_in[e_.x + tin[t]]; \
+            }                                                                     \
             _Pragma("unroll") for (int t = 0; t < NB; ++t) BV[t] = s_do[e_.y + tout[t]]; \
             const int pn_ = (((STEP) + 1) * WLP + wpix) * KP + lk;                \
             if (!SHB) PV = (((STEP)) * WLP + wpix) * KP + lk < npix;              \
@@ -172,20 +182,46 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void w
             else                                                                  \
                 acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(AV[t], bsel_, acc[t], 0, 0, 0); \
         }
+        // one half-iteration: address VALU first, then MFMAs with the LDS reads of the next step slotted between them
+        // (an LDS read issued between two MFMAs costs ~3.5 clk of MFMA time, ~10 clk when issued in a block)
+#define RD_WG_SCHED()                                                         \
+        if constexpr (PITCH > 0) {                                                \
+            __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);                    \
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                    \
+            __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);                    \
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                    \
+            __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);                    \
+            _Pragma("unroll") for (int i = 2; i < TG; ++i) {                      \
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                \
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                \
+            }                                                                     \
+        }                                                                         \
+        __builtin_amdgcn_sched_barrier(0);
         e_nxt = s_tab[wpix * KP + lk];
         RD_WG_LOAD(a0, b0, pv0, 0)
+        __builtin_amdgcn_sched_barrier(0);
         for (int st = 0; st < ((a.debug & 2) ? 0 : nsteps); st += 2) {
-            RD_WG_LOAD(a1, b1, pv1, st + 1)
-            __builtin_amdgcn_sched_barrier(0);
-            RD_WG_MFMA(a0, b0, pv0)
-            __builtin_amdgcn_sched_barrier(0);
-            RD_WG_LOAD(a0, b0, pv0, st + 2)
-            __builtin_amdgcn_sched_barrier(0);
-            RD_WG_MFMA(a1, b1, pv1)
-            __builtin_amdgcn_sched_barrier(0);
+            if constexpr (PITCH > 0) {
+                RD_WG_LOAD(a1, b1, pv1, st + 1)
+                RD_WG_MFMA(a0, b0, pv0)
+                RD_WG_SCHED()
+                RD_WG_LOAD(a0, b0, pv0, st + 2)
+                RD_WG_MFMA(a1, b1, pv1)
+                RD_WG_SCHED()
+            } else {
+                RD_WG_LOAD(a1, b1, pv1, st + 1)
+                __builtin_amdgcn_sched_barrier(0);
+                RD_WG_MFMA(a0, b0, pv0)
+                __builtin_amdgcn_sched_barrier(0);
+                RD_WG_LOAD(a0, b0, pv0, st + 2)
+                __builtin_amdgcn_sched_barrier(0);
+                RD_WG_MFMA(a1, b1, pv1)
+                __builtin_amdgcn_sched_barrier(0);
+            }
         }
 #undef RD_WG_LOAD
 #undef RD_WG_MFMA
+#undef RD_WG_SCHED
     }
 
     // ---- write this workgroup's partial slab
@@ -285,6 +321,7 @@ struct WgradPlan {
     int TG, MF, layoutA;
     int TH, TW, tiles_h, tiles_w, total_tiles, tiles_per_split, n_splits, slab_splits;
     int n_cib, n_cob, n_tg, S, J, shb;
+    int pitch;      // > 0: fixed LDS patch pitch with immediate tap offsets (full 3x3 stencil)
     size_t lds;
 };
 
@@ -317,6 +354,12 @@ static int plan_wgrad(const RdConvDesc& d, WgradPlan& pl, WgradArgs* out) {
     // tile: largest pixel count within the LDS budget, preferring full-width rows
     static const char* bud = getenv("RD_WGRAD_LDS_KB");   // diagnostics (default 78: two workgroups per CU)
     const size_t budget = (size_t)(bud ? atoi(bud) : 78) * 1024;
+    // full 3x3 stencil in row-major tap order -> the immediate-offset kernel, whose patch pitch is fixed at WG_PITCH
+    bool k3 = ntaps == 9 && d.n_phases == 1 && dh_max - dh_min == 2 && dw_max - dw_min == 2;
+    for (int t = 0; k3 && t < 9; ++t) k3 = P0.dh[t] - dh_min == t / 3 && P0.dw[t] - dw_min == t % 3;
+    static const char* nok3 = getenv("RD_WGRAD_NOK3");
+    if (nok3) k3 = false;
+    pl.pitch = 0;
     double best = -1;
     pl.TH = pl.TW = 0;
     for (int twt = 1; twt <= P0.lw; ++twt) {
@@ -324,7 +367,11 @@ static int plan_wgrad(const RdConvDesc& d, WgradPlan& pl, WgradArgs* out) {
         for (int TH = 1; TH <= P0.lh; ++TH) {
             if (TH * TW > WG_MAX_PIX) break;
             const int PH = (TH - 1) * d.in_stride + (dh_max - dh_min) + 1;
-            const int PW = (TW - 1) * d.in_stride + (dw_max - dw_min) + 1;
+            int PW = (TW - 1) * d.in_stride + (dw_max - dw_min) + 1;
+            if (k3) {
+                if (PW > WG_PITCH) break;
+                PW = WG_PITCH;
+            }
             const size_t lds = (size_t)2 * (WG_MAX_PIX + 64) * 4 + (size_t)PH * PW * CIB * 4 +
                                ((size_t)TH * d.out_stride * TW * d.out_stride + 1) * COB * 4;
             if (lds > budget) break;
@@ -334,6 +381,7 @@ static int plan_wgrad(const RdConvDesc& d, WgradPlan& pl, WgradArgs* out) {
             if (score > best) {
                 best = score;
                 pl.TH = TH; pl.TW = TW; pl.lds = lds;
+                pl.pitch = k3 ? WG_PITCH : 0;
             }
         }
         if (TW <= 4) break;
@@ -376,10 +424,10 @@ static int plan_wgrad(const RdConvDesc& d, WgradPlan& pl, WgradArgs* out) {
     return RD_OK;
 }
 
-template <int TG, int MF, bool LA, bool SHB>
+template <int TG, int MF, bool LA, bool SHB, int PITCH = 0>
 static int launch_wgrad(const WgradArgs& a, int grid, size_t lds, hipStream_t s) {
     static bool attr_set = false;
-    auto k = wgrad_kernel<TG, MF, LA, SHB>;
+    auto k = wgrad_kernel<TG, MF, LA, SHB, PITCH>;
     if (!attr_set) {
         RD_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr_set = true;
@@ -415,6 +463,11 @@ extern "C" int rd_wgrad(const RdConvDesc* d, const float* in, const float* dout,
 #define RD_W(TG_, MF_, LA_, SHB_) \
     if (pl.TG == TG_ && pl.MF == MF_ && (pl.layoutA != 0) == LA_ && (pl.shb != 0) == SHB_) \
         return launch_wgrad<TG_, MF_, LA_, SHB_>(a, grid, pl.lds, s);
+    if (pl.pitch > 0) {
+        if (pl.MF == 32 && pl.layoutA) return launch_wgrad<9, 32, true, true, WG_PITCH>(a, grid, pl.lds, s);
+        if (pl.MF == 32) return launch_wgrad<9, 32, false, true, WG_PITCH>(a, grid, pl.lds, s);
+        return launch_wgrad<9, 16, false, true, WG_PITCH>(a, grid, pl.lds, s);
+    }
     RD_W(9, 32, true, true)
     RD_W(9, 32, false, true)
     RD_W(9, 16, false, true)

@@ -1,0 +1,69 @@
+"""Per-workgroup timeline of one gconv launch (RD_GCONV_TRACE=1): s_memtime stamps at start, after the prologue, around every
+chunk's MFMA loop, at the epilogue.  Prints the mean duration of each phase and the workgroup start/end distribution.
+   RD_GCONV_TRACE=1 python tools/trace_gconv.py [layer1|layer2|layer3|layer4|up64]"""
+import ctypes as C, os, sys
+import numpy as np, torch
+sys.path.insert(0, ".")
+os.environ.setdefault("RD_GCONV_TRACE", "1")
+from radar_depth_amd import convdesc as cd, ops
+from radar_depth_amd._lib import lib
+B, dev = 16, "cuda"
+SH = {"layer1": (64, 64, 3, 113, 200), "layer2": (128, 128, 3, 57, 100), "layer3": (256, 256, 3, 29, 50), "layer4": (512, 512, 3, 15, 25)}
+name = sys.argv[1] if len(sys.argv) > 1 else "layer2"
+ci, co, k, h, w = SH[name]
+d = cd.conv_fwd(B, h, w, ci, co, k, 1, k // 2)
+L = lib()
+info = (C.c_int32 * 10)()
+L.rd_gconv_plan_info(C.byref(d), info)
+nwg = info[9]
+x = torch.randn(B, h, w, ci, device=dev); wp = torch.randn(k * k, ci, co, device=dev); y = torch.empty(B, d.Ho, d.Wo, co, device=dev)
+for _ in range(3): ops.gconv(d, x, wp, y)
+torch.cuda.synchronize()
+e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+e0.record(); ops.gconv(d, x, wp, y); e1.record(); torch.cuda.synchronize()
+kernel_us = e0.elapsed_time(e1) * 1e3
+buf = np.zeros((nwg, 64), dtype=np.uint64)
+L.rd_gconv_trace_read.argtypes = [C.c_void_p, C.c_int]
+assert L.rd_gconv_trace_read(buf.ctypes.data, nwg) == 0
+n = int(buf[0, 0]); st = buf[:, 1:1 + n].astype(np.int64)
+print("kernel %.1f us by events (= %.0fk cycles at 2.4 GHz)" % (kernel_us, kernel_us * 2.4))
+hw = buf[:, 63]
+xcc = (hw >> np.uint64(32)) & np.uint64(0xF); hwid = hw & np.uint64(0xFFFFFFFF)
+cu = (hwid >> np.uint64(8)) & np.uint64(0xF); sh = (hwid >> np.uint64(12)) & np.uint64(1); se = (hwid >> np.uint64(13)) & np.uint64(7)
+key = (xcc * np.uint64(64) + se * np.uint64(16) + sh * np.uint64(8)).astype(np.int64) * 16 + cu.astype(np.int64)
+keys = np.unique(key)
+print("  %d distinct CUs seen" % len(keys))
+spans, starts2 = [], []
+for kk in keys[:6]:
+    x = st[key == kk]
+    b0 = x[:, 0].min()
+    order = np.argsort(x[:, 0])
+    print("  CU %d: " % kk + "  ".join("[%d..%d]" % ((x[i, 0] - b0) // 1000, (x[i, -1] - b0) // 1000) for i in order) + " kcyc")
+for kk in keys:
+    x = st[key == kk]
+    spans.append(x[:, -1].max() - x[:, 0].min())
+rt = buf[:, 62].astype(np.float64) / 100e6      # workgroup lifetime by the 100 MHz real-time clock, seconds
+cyc = (st[:, -1] - st[:, 0]).astype(np.float64)
+print("  effective shader clock (cycle counter / real time): mean %.0f MHz  min %.0f  max %.0f" % (
+    np.mean(cyc / rt) / 1e6, np.min(cyc / rt) / 1e6, np.max(cyc / rt) / 1e6))
+print("  per-CU busy span: mean %dk max %dk cycles" % (np.mean(spans) / 1000, np.max(spans) / 1000))
+t0 = st[:, 0].min()
+st = st - t0
+CLK = 100e6   # s_memtime ticks at the constant 100 MHz reference on gfx9xx
+us = st / CLK * 1e6
+print("%s: %d workgroups, %d stamps each, plan MT,NT=%d,%d tile %dx%d CKP %d ksplit*100+CKW %d" % (name, nwg, n, info[0], info[1], info[6], info[7], info[5], info[4]))
+print("kernel span %.1f us; workgroup start: min %.1f p50 %.1f max %.1f; end: min %.1f p50 %.1f max %.1f" % (
+    us.max(), us[:, 0].min(), np.median(us[:, 0]), us[:, 0].max(), us[:, -1].min(), np.median(us[:, -1]), us[:, -1].max()))
+dur = np.diff(us, axis=1)
+labels = ["prologue"]
+nch = (n - 4) // 2
+for c in range(nch): labels += ["stage%d" % c, "mfma%d" % c]
+labels += ["(epi stamp)", "epilogue"]
+first = us[:, 0] < 5.0
+for sel, tag in ((first, "first-round"), (~first, "later-rounds")):
+    if sel.sum() == 0: continue
+    m = dur[sel].mean(axis=0)
+    print("%s (%d wgs): lifetime %.1f us" % (tag, sel.sum(), (us[sel, -1] - us[sel, 0]).mean()))
+    print("   " + "  ".join("%s %.1f" % (l, v) for l, v in zip(labels, m)))
+    stg = m[1:1 + 2 * nch:2].sum(); mf = m[2:2 + 2 * nch:2].sum()
+    print("   totals (cycles/100): prologue %.1f  staging %.1f  mfma %.1f  epilogue %.1f" % (m[0], stg, mf, m[-1]))
