@@ -36,6 +36,9 @@ struct WgradArgs {
     int dh_min, dh_max, dw_min, dw_max;
     int n_cib, n_cob, n_tg;
     int S;  // slabs (= kernel taps) per split
+    // compact != 0: one phase of a strided-output stencil (UpProj): only this phase's dout pixels (oh*OS+off_h, ow*OS+off_w)
+    // are staged, densely, in LDS
+    int compact, off_h, off_w;
     int debug;  // ablation bits (RD_WGRAD_DEBUG): 1 skip staging after the first tile, 2 skip the MFMA walk
     WgTapGroup tg[WG_MAX_GROUPS];
 };
@@ -43,11 +46,12 @@ struct WgradArgs {
 // LAYOUT_A: waves arranged 2 (ci) x 2 (co), all see every pixel.  Otherwise: one (ci,co) block, the four
 // waves take interleaved pixel groups and each writes its own slab.
 // SHB: every tap of the group reads the same dout pixel (stride-1/2 k x k convs) -> one shared B fragment per step.
-// PITCH > 0: the group is a full 3x3 stencil (taps in row-major order) and the LDS patch row pitch is the compile-time
+// PITCH > 0: the group is a full rectangular stencil, RW taps per row (taps in row-major order: 3x3, or the 3x2 / 2x3 / 2x2
+// sub-stencils of the UpProj phases) and the LDS patch row pitch is the compile-time
 // PITCH, so the nine tap offsets are instruction immediates: the walk then costs 2 VALU instructions per 9 MFMAs instead of
 // 16 (fp32 MFMAs share the SIMD's fp32 lanes with the VALU: every VALU instruction in the walk is lost MFMA time, see
 // tools/micro/mfma_mix.hip).
-template <int TG, int MF, bool LAYOUT_A, bool SHB, int PITCH>
+template <int TG, int MF, bool LAYOUT_A, bool SHB, int PITCH, int RW>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void wgrad_kernel(const WgradArgs a) {
     constexpr int CIB = LAYOUT_A ? 64 : MF;
     constexpr int COB = LAYOUT_A ? 64 : MF;
@@ -70,7 +74,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void w
 
     const int PWmax = PITCH > 0 ? PITCH : (a.TW - 1) * a.IS + (a.dw_max - a.dw_min) + 1;
     const int PHmax = (a.TH - 1) * a.IS + (a.dh_max - a.dh_min) + 1;
-    const int DW = a.TW * a.OS, DHmax = a.TH * a.OS;
+    const int LOS = a.compact ? 1 : a.OS;          // dout pixel stride inside LDS
+    const int DW = a.TW * LOS, DHmax = a.TH * LOS;
     int2* s_tab = reinterpret_cast<int2*>(smem);                        // [WG_MAX_PIX + 64]
     float* s_in = smem + 2 * (WG_MAX_PIX + 64);                         // [PHmax*PWmax][CIB]
     float* s_do = s_in + (size_t)PHmax * PWmax * CIB;                    // [DHmax*DW + 1][COB], last row zero (SHB padding)
@@ -81,7 +86,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void w
     int tin[TG], tout[TG];
 #pragma unroll
     for (int t = 0; t < TG; ++t) {
-        tin[t] = (PITCH > 0 ? ((t / 3) * PITCH + (t % 3)) * CIB : ((G.dh[t] - a.dh_min) * PWmax + (G.dw[t] - a.dw_min)) * CIB) + wci * 32 + lm;
+        tin[t] = (PITCH > 0 ? ((t / RW) * PITCH + (t % RW)) * CIB : ((G.dh[t] - a.dh_min) * PWmax + (G.dw[t] - a.dw_min)) * CIB) + wci * 32 + lm;
         tout[t] = (G.oh[t] * DW + G.ow[t]) * COB + wco * 32 + lm;
     }
 
@@ -108,7 +113,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void w
             if (p < npix) {
                 const int r = p / tw_n, c = p - r * tw_n;
                 e.x = ((r * a.IS) * PWmax + c * a.IS) * CIB;
-                e.y = ((r * a.OS) * DW + c * a.OS) * COB;
+                e.y = ((r * LOS) * DW + c * LOS) * COB;
             }
             s_tab[p] = e;
         }
@@ -133,17 +138,18 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void w
             }
         }
         {   // dout tile (rows/cols beyond the image or beyond the tile's valid extent are zero)
-            const int DH = th_n * a.OS;
-            const int oh0 = r0 * a.OS, ow0 = c0 * a.OS;
+            const int DH = th_n * LOS;
+            const int gst = a.compact ? a.OS : 1;          // global pixel step per LDS pixel
+            const int oh0 = r0 * a.OS + (a.compact ? a.off_h : 0), ow0 = c0 * a.OS + (a.compact ? a.off_w : 0);
             const float* do_n = a.dout + (size_t)n * a.Ho * a.Wo * a.ldo;
             constexpr int q4 = COB / 4;
             const int elems = DH * DW * q4;
-            const int ow_lim = min(a.Wo, ow0 + tw_n * a.OS);
+            const int px_lim = tw_n * LOS;
             for (int e = tid; e < elems; e += 256) {
                 const int pix = e / q4, qq = e - pix * q4;
                 const int py = pix / DW, px = pix - py * DW;
-                const int oh = oh0 + py, ow = ow0 + px, c = cob0 + qq * 4;
-                if (oh < a.Ho && ow < ow_lim && c < a.Cout)
+                const int oh = oh0 + py * gst, ow = ow0 + px * gst, c = cob0 + qq * 4;
+                if (oh < a.Ho && ow < a.Wo && px < px_lim && c < a.Cout)
                     glds16(do_n + ((size_t)oh * a.Wo + ow) * a.ldo + c, s_do + (size_t)(e - lane) * 4);
                 else
                     *reinterpret_cast<float4*>(s_do + (size_t)e * 4) = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -165,7 +171,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void w
             const int2 e_ = e_nxt;                                                \
             if constexpr (PITCH > 0) {                                            \
                 const float* pa_ = s_in + (e_.x + wci * 32 + lm);                 \
-                _Pragma("unroll") for (int t = 0; t < TG; ++t) AV[t] = pa_[((t / 3) * PITCH + (t % 3)) * CIB]; \
+                _Pragma("unroll") for (int t = 0; t < TG; ++t) AV[t] = pa_[((t / RW) * PITCH + (t % RW)) * CIB]; \
             } else {                                                              \
                 _Pragma("unroll") for (int t = 0; t < TG; ++t) AV[t] = s_in[e_.x + tin[t]]; \
             }                                                                     \
@@ -321,11 +327,22 @@ struct WgradPlan {
     int TG, MF, layoutA;
     int TH, TW, tiles_h, tiles_w, total_tiles, tiles_per_split, n_splits, slab_splits;
     int n_cib, n_cob, n_tg, S, J, shb;
-    int pitch;      // > 0: fixed LDS patch pitch with immediate tap offsets (full 3x3 stencil)
+    int pitch;      // > 0: fixed LDS patch pitch with immediate tap offsets (full rectangular stencil)
+    int rw;         // taps per stencil row (pitch > 0)
+    int per_phase;  // UpProj: one launch per output phase (each a rectangular sub-stencil with a shared dout pixel)
     size_t lds;
 };
 
-static int plan_wgrad(const RdConvDesc& d, WgradPlan& pl, WgradArgs* out) {
+// ph >= 0: plan one phase of a multi-phase descriptor on its own (compact dout staging); tile: reuse this plan's tile.
+static int plan_wgrad(const RdConvDesc& d_in, WgradPlan& pl, WgradArgs* out, int ph = -1, const WgradPlan* tile = nullptr) {
+    RdConvDesc d = d_in;
+    int S_all = 0;
+    for (int i = 0; i < d_in.n_phases; ++i)
+        for (int t = 0; t < d_in.phase[i].n_taps; ++t) S_all = S_all > d_in.phase[i].widx[t] + 1 ? S_all : d_in.phase[i].widx[t] + 1;
+    if (ph >= 0) {
+        d.n_phases = 1;
+        d.phase[0] = d_in.phase[ph];
+    }
     const RdPhase& P0 = d.phase[0];
     int ntaps = 0, S = 0;
     int dh_min = 127, dh_max = -127, dw_min = 127, dw_max = -127;
@@ -339,7 +356,16 @@ static int plan_wgrad(const RdConvDesc& d, WgradPlan& pl, WgradArgs* out) {
         dw_min = dw_min < p.dw_min ? dw_min : p.dw_min;
         dw_max = dw_max > p.dw_max ? dw_max : p.dw_max;
     }
-    RD_CHECK_ARG(ntaps == 1 || ntaps == 9 || ntaps == 25, "wgrad: %d taps unsupported", ntaps);
+    S = S_all;
+    // rectangular stencil in row-major tap order -> the immediate-offset kernel, whose patch pitch is fixed at WG_PITCH
+    const int rw = dw_max - dw_min + 1;
+    bool k3 = d.n_phases == 1 && ntaps == rw * (dh_max - dh_min + 1) && (ntaps == 9 || (ph >= 0 && (ntaps == 6 || ntaps == 4)));
+    for (int t = 0; k3 && t < ntaps; ++t) k3 = P0.dh[t] - dh_min == t / rw && P0.dw[t] - dw_min == t % rw;
+    static const char* nok3 = getenv("RD_WGRAD_NOK3");
+    if (nok3) k3 = false;
+    RD_CHECK_ARG(ntaps == 1 || ntaps == 9 || ntaps == 25 || k3, "wgrad: %d taps unsupported", ntaps);
+    pl.rw = rw;
+    pl.per_phase = 0;
     RD_CHECK_ARG(d.Cin % 4 == 0 && d.Cout % 4 == 0 && d.ldi % 4 == 0 && d.ldo % 4 == 0, "wgrad: channels must be multiples of 4");
     pl.shb = d.n_phases == 1;   // single phase: every tap pairs with the same dout pixel
     pl.TG = ntaps == 25 ? 5 : ntaps;
@@ -354,12 +380,8 @@ static int plan_wgrad(const RdConvDesc& d, WgradPlan& pl, WgradArgs* out) {
     // tile: largest pixel count within the LDS budget, preferring full-width rows
     static const char* bud = getenv("RD_WGRAD_LDS_KB");   // diagnostics (default 78: two workgroups per CU)
     const size_t budget = (size_t)(bud ? atoi(bud) : 78) * 1024;
-    // full 3x3 stencil in row-major tap order -> the immediate-offset kernel, whose patch pitch is fixed at WG_PITCH
-    bool k3 = ntaps == 9 && d.n_phases == 1 && dh_max - dh_min == 2 && dw_max - dw_min == 2;
-    for (int t = 0; k3 && t < 9; ++t) k3 = P0.dh[t] - dh_min == t / 3 && P0.dw[t] - dw_min == t % 3;
-    static const char* nok3 = getenv("RD_WGRAD_NOK3");
-    if (nok3) k3 = false;
     pl.pitch = 0;
+    const int los = ph >= 0 ? 1 : d.out_stride;      // dout pixel stride inside LDS (compact per-phase staging: 1)
     double best = -1;
     pl.TH = pl.TW = 0;
     for (int twt = 1; twt <= P0.lw; ++twt) {
@@ -373,8 +395,9 @@ static int plan_wgrad(const RdConvDesc& d, WgradPlan& pl, WgradArgs* out) {
                 PW = WG_PITCH;
             }
             const size_t lds = (size_t)2 * (WG_MAX_PIX + 64) * 4 + (size_t)PH * PW * CIB * 4 +
-                               ((size_t)TH * d.out_stride * TW * d.out_stride + 1) * COB * 4;
-            if (lds > budget) break;
+                               ((size_t)TH * los * TW * los + 1) * COB * 4;
+            if (tile && (TH != tile->TH || TW != tile->TW)) continue;
+            if (lds > budget) { if (tile) continue; break; }
             const double useful = (double)P0.lh * P0.lw / ((double)cdiv(P0.lh, TH) * TH * cdiv(P0.lw, TW) * TW);
             const double halo = (double)PH * PW / ((double)TH * TW * d.in_stride * d.in_stride);
             const double score = useful * (TH * TW >= 64 ? 1.0 : TH * TW / 64.0) / (1.0 + 0.15 * (halo - 1.0));
@@ -406,6 +429,7 @@ static int plan_wgrad(const RdConvDesc& d, WgradPlan& pl, WgradArgs* out) {
         a.total_tiles = pl.total_tiles; a.tiles_per_split = pl.tiles_per_split; a.n_splits = pl.n_splits;
         a.dh_min = dh_min; a.dh_max = dh_max; a.dw_min = dw_min; a.dw_max = dw_max;
         a.n_cib = pl.n_cib; a.n_cob = pl.n_cob; a.n_tg = pl.n_tg; a.S = S;
+        a.compact = ph >= 0; a.off_h = P0.out_off_h; a.off_w = P0.out_off_w;
         // distribute taps over groups: 25 taps -> one kernel row (5 taps) per group; else a single group
         for (int gi = 0; gi < WG_MAX_GROUPS; ++gi) a.tg[gi].n = 0;
         for (int i = 0; i < d.n_phases; ++i) {
@@ -415,7 +439,7 @@ static int plan_wgrad(const RdConvDesc& d, WgradPlan& pl, WgradArgs* out) {
                 WgTapGroup& G = a.tg[gi];
                 RD_CHECK_ARG(G.n < pl.TG, "wgrad: tap grouping overflow");
                 G.dh[G.n] = p.dh[t]; G.dw[G.n] = p.dw[t];
-                G.oh[G.n] = (int8_t)p.out_off_h; G.ow[G.n] = (int8_t)p.out_off_w;
+                G.oh[G.n] = ph >= 0 ? 0 : (int8_t)p.out_off_h; G.ow[G.n] = ph >= 0 ? 0 : (int8_t)p.out_off_w;
                 G.widx[G.n] = p.widx[t];
                 ++G.n;
             }
@@ -424,10 +448,10 @@ static int plan_wgrad(const RdConvDesc& d, WgradPlan& pl, WgradArgs* out) {
     return RD_OK;
 }
 
-template <int TG, int MF, bool LA, bool SHB, int PITCH = 0>
+template <int TG, int MF, bool LA, bool SHB, int PITCH = 0, int RW = 3>
 static int launch_wgrad(const WgradArgs& a, int grid, size_t lds, hipStream_t s) {
     static bool attr_set = false;
-    auto k = wgrad_kernel<TG, MF, LA, SHB, PITCH>;
+    auto k = wgrad_kernel<TG, MF, LA, SHB, PITCH, RW>;
     if (!attr_set) {
         RD_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr_set = true;
@@ -437,13 +461,50 @@ static int launch_wgrad(const WgradArgs& a, int grid, size_t lds, hipStream_t s)
     return RD_OK;
 }
 
+// UpProj forward form (4 output phases of a 5x5 stencil on the low-res input): one launch per phase, each a rectangular
+// 3x3 / 3x2 / 2x3 / 2x2 sub-stencil whose taps share one dout pixel -> the immediate-offset kernel with a shared B fragment,
+// instead of one launch of 5-tap row groups that needs a B fragment per tap.  All phases use phase 0's tile and split count,
+// so that they fill disjoint slabs of one workspace.
+static bool upproj_split(const RdConvDesc& d) {
+    static const char* fused = getenv("RD_WGRAD_FUSEDPH");   // diagnostics: keep the single fused launch
+    if (fused || d.n_phases != 4 || d.out_stride != 2 || d.in_stride != 1) return false;
+    int nt = 0;
+    for (int i = 0; i < 4; ++i) nt += d.phase[i].n_taps;
+    return nt == 25 && d.phase[0].n_taps == 9;
+}
+static int plan_any(const RdConvDesc& d, WgradPlan& pl) {
+    if (upproj_split(d)) {
+        bool ok = plan_wgrad(d, pl, nullptr, 0) == RD_OK && pl.pitch > 0;
+        for (int ph = 1; ok && ph < 4; ++ph) {
+            WgradPlan q;
+            ok = plan_wgrad(d, q, nullptr, ph, &pl) == RD_OK && q.pitch > 0 && q.n_splits == pl.n_splits;
+        }
+        if (ok) { pl.per_phase = 1; return RD_OK; }
+    }
+    return plan_wgrad(d, pl, nullptr);
+}
+
+// immediate-offset kernels: (taps, taps per row) = (9,3) (6,3) (6,2) (4,2)
+static int launch_pitch(const WgradPlan& pl, const WgradArgs& a, int grid, hipStream_t s) {
+#define RD_WP(TG_, RW_)                                                                                              \
+    if (pl.TG == TG_ && pl.rw == RW_) {                                                                              \
+        if (pl.MF == 32 && pl.layoutA) return launch_wgrad<TG_, 32, true, true, WG_PITCH, RW_>(a, grid, pl.lds, s);  \
+        if (pl.MF == 32) return launch_wgrad<TG_, 32, false, true, WG_PITCH, RW_>(a, grid, pl.lds, s);               \
+        return launch_wgrad<TG_, 16, false, true, WG_PITCH, RW_>(a, grid, pl.lds, s);                                \
+    }
+    RD_WP(9, 3) RD_WP(6, 3) RD_WP(6, 2) RD_WP(4, 2)
+#undef RD_WP
+    set_error("wgrad: no immediate-offset kernel for %d taps, %d per row", pl.TG, pl.rw);
+    return RD_EINVAL;
+}
+
 }  // namespace rd
 using namespace rd;
 
 extern "C" int64_t rd_wgrad_workspace_floats(const RdConvDesc* d) {
     if (!d) return RD_EINVAL;
     WgradPlan pl;
-    if (plan_wgrad(*d, pl, nullptr) != RD_OK) return RD_EINVAL;
+    if (plan_any(*d, pl) != RD_OK) return RD_EINVAL;
     return (int64_t)(pl.slab_splits + pl.J) * pl.S * d->Cin * d->Cout;
 }
 
@@ -451,11 +512,25 @@ extern "C" int rd_wgrad(const RdConvDesc* d, const float* in, const float* dout,
     RD_CHECK_ARG(d && in && dout && slabs, "wgrad: null argument");
     WgradPlan pl;
     WgradArgs a;
-    int rc = plan_wgrad(*d, pl, &a);
-    if (rc != RD_OK) return rc;
-    a.in = in; a.dout = dout; a.slabs = slabs;
-    { static const char* dbg = getenv("RD_WGRAD_DEBUG"); a.debug = dbg ? atoi(dbg) : 0; }
     hipStream_t s = static_cast<hipStream_t>(stream);
+    static const char* dbg = getenv("RD_WGRAD_DEBUG");
+    int rc = plan_any(*d, pl);
+    if (rc != RD_OK) return rc;
+    if (pl.per_phase) {
+        const WgradPlan pl0 = pl;
+        for (int ph = 0; ph < 4; ++ph) {
+            rc = plan_wgrad(*d, pl, &a, ph, &pl0);
+            if (rc != RD_OK) return rc;
+            a.in = in; a.dout = dout; a.slabs = slabs; a.debug = dbg ? atoi(dbg) : 0;
+            if (!pl.layoutA && pl.lds < (size_t)4 * 16 * 64 * 4) pl.lds = (size_t)4 * 16 * 64 * 4;
+            rc = launch_pitch(pl, a, pl.n_cib * pl.n_cob * pl.n_splits, s);
+            if (rc != RD_OK) return rc;
+        }
+        return RD_OK;
+    }
+    rc = plan_wgrad(*d, pl, &a);
+    if (rc != RD_OK) return rc;
+    a.in = in; a.dout = dout; a.slabs = slabs; a.debug = dbg ? atoi(dbg) : 0;
     for (int gi = 0; gi < pl.n_tg; ++gi) RD_CHECK_ARG(a.tg[gi].n == pl.TG, "wgrad: tap group %d has %d taps, expected %d", gi, a.tg[gi].n, pl.TG);
     // layout-B epilogue reuses the head of LDS for its cross-wave reduction
     if (!pl.layoutA && pl.lds < (size_t)4 * 16 * 64 * 4) pl.lds = (size_t)4 * 16 * 64 * 4;
@@ -463,11 +538,7 @@ extern "C" int rd_wgrad(const RdConvDesc* d, const float* in, const float* dout,
 #define RD_W(TG_, MF_, LA_, SHB_) \
     if (pl.TG == TG_ && pl.MF == MF_ && (pl.layoutA != 0) == LA_ && (pl.shb != 0) == SHB_) \
         return launch_wgrad<TG_, MF_, LA_, SHB_>(a, grid, pl.lds, s);
-    if (pl.pitch > 0) {
-        if (pl.MF == 32 && pl.layoutA) return launch_wgrad<9, 32, true, true, WG_PITCH>(a, grid, pl.lds, s);
-        if (pl.MF == 32) return launch_wgrad<9, 32, false, true, WG_PITCH>(a, grid, pl.lds, s);
-        return launch_wgrad<9, 16, false, true, WG_PITCH>(a, grid, pl.lds, s);
-    }
+    if (pl.pitch > 0) return launch_pitch(pl, a, grid, s);
     RD_W(9, 32, true, true)
     RD_W(9, 32, false, true)
     RD_W(9, 16, false, true)
@@ -485,7 +556,7 @@ extern "C" int rd_wgrad_reduce(const RdConvDesc* d, const float* slabs, float* g
                                int32_t KW, int32_t co_off, int32_t accumulate, void* stream) {
     RD_CHECK_ARG(d && slabs && grad_oihw, "wgrad_reduce: null argument");
     WgradPlan pl;
-    int rc = plan_wgrad(*d, pl, nullptr);
+    int rc = plan_any(*d, pl);
     if (rc != RD_OK) return rc;
     RD_CHECK_ARG(KH * KW == pl.S && I == d->Cin && co_off + O <= d->Cout, "wgrad_reduce: shape mismatch");
     const int64_t E = (int64_t)pl.S * d->Cin * d->Cout;
