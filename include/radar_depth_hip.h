@@ -100,6 +100,9 @@ int rd_gconv_fused(const RdConvDesc* d, const float* in, const float* w_packed, 
 int rd_gconv_plan_info(const RdConvDesc* d, int32_t* out);
 /* diagnostics: workgroups per CU the HIP occupancy API reports for that plan (-1 without a GPU) */
 int rd_gconv_occupancy(const RdConvDesc* d);
+/* diagnostics: with RD_GCONV_TRACE=1 every workgroup of rd_gconv records cycle-counter stamps at its phase boundaries;
+ * copies the 64 slots per workgroup of the last traced launch to the host (tools/trace_gconv.py). */
+int rd_gconv_trace_read(unsigned long long* host, int n_wg);
 
 /* Weight gradient of the same descriptor: dw[slab][ci][co] = sum_pixels in(...) * dout(...).
  * `d` is the FORWARD descriptor (in = forward input, "out" geometry = dout).  slabs is a
@@ -183,6 +186,11 @@ int rd_bn_bwd_reduce(const float* dy, int32_t lddy, const float* y, int32_t ldy,
                      const float* x2, int32_t ldx2, const float* mean2,
                      float* g, int32_t ldg, int64_t M, int32_t C, int32_t act,
                      float* red_partial, void* stream);
+/* Same for out = act(scale1 * x1 + shift1) with no second operand: the activation's sign is recomputed from x1 (with the
+ * forward kernel's own fmaf), so the activation tensor is not read -- one HBM pass less. */
+int rd_bn_bwd_reduce_x(const float* dy, int32_t lddy, const float* x1, int32_t ldx1, const float* mean1,
+                       const float* scale1, const float* shift1, float* g, int32_t ldg, int64_t M, int32_t C,
+                       int32_t act, float* red_partial, void* stream);
 int rd_bn_bwd_tiles(int64_t M);
 /* backward pass 2 (per BN): finishes the reduction, writes dgamma/dbeta (overwrite) and
  * dx = gamma*invstd*(g - mean(g) - xhat*mean(g*xhat)).  which = 1 or 2 selects the x1 / x2 sums. */

@@ -124,12 +124,15 @@ __global__ __launch_bounds__(256) void bn_act_kernel(const float* __restrict__ x
     }
 }
 
-// backward pass 1: g = dy * act'(y); sums of g, g*(x1-m1), g*(x2-m2)
+// backward pass 1: g = dy * act'(y); sums of g, g*(x1-m1), g*(x2-m2).
+// y == nullptr with an activation: the output was act(s1*x1 + t1) alone (no second operand), so its sign is recomputed from
+// x1 -- which the kernel reads anyway -- with the forward kernel's own fmaf, instead of reading the activation tensor.
 __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restrict__ dy, int lddy, const float* __restrict__ y,
                                                             int ldy, const float* __restrict__ x1, int ldx1,
                                                             const float* __restrict__ m1, const float* __restrict__ x2, int ldx2,
                                                             const float* __restrict__ m2, float* __restrict__ g, int ldg,
-                                                            int64_t M, int C, int act, int RPB, float* __restrict__ part) {
+                                                            int64_t M, int C, int act, int RPB, float* __restrict__ part,
+                                                            const float* __restrict__ s1, const float* __restrict__ t1) {
     extern __shared__ float sm[];
     const int Q = C >> 2, RL = 256 / Q;
     const int q = threadIdx.x % Q, rl = threadIdx.x / Q;
@@ -140,17 +143,23 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restr
         const int c = q * 4;
         const float4 mu1 = x1 ? *reinterpret_cast<const float4*>(m1 + c) : make_float4(0, 0, 0, 0);
         const float4 mu2 = x2 ? *reinterpret_cast<const float4*>(m2 + c) : make_float4(0, 0, 0, 0);
+        const bool from_x = act != RD_ACT_NONE && !y;
+        const float4 sa = from_x ? *reinterpret_cast<const float4*>(s1 + c) : make_float4(0, 0, 0, 0);
+        const float4 sb = from_x ? *reinterpret_cast<const float4*>(t1 + c) : make_float4(0, 0, 0, 0);
         for (int64_t r = r0 + rl; r < r1; r += RL) {
             float4 gv = *reinterpret_cast<const float4*>(dy + r * lddy + c);
+            float4 v = make_float4(0, 0, 0, 0);
+            if (x1) v = *reinterpret_cast<const float4*>(x1 + r * ldx1 + c);
             if (act != RD_ACT_NONE) {
-                const float4 yv = *reinterpret_cast<const float4*>(y + r * ldy + c);
+                float4 yv;
+                if (from_x) yv = make_float4(fmaf(sa.x, v.x, sb.x), fmaf(sa.y, v.y, sb.y), fmaf(sa.z, v.z, sb.z), fmaf(sa.w, v.w, sb.w));
+                else yv = *reinterpret_cast<const float4*>(y + r * ldy + c);
                 gv.x *= act_grad_from_out(yv.x, act); gv.y *= act_grad_from_out(yv.y, act);
                 gv.z *= act_grad_from_out(yv.z, act); gv.w *= act_grad_from_out(yv.w, act);
             }
             if (g) *reinterpret_cast<float4*>(g + r * ldg + c) = gv;
             acc[0].x += gv.x; acc[0].y += gv.y; acc[0].z += gv.z; acc[0].w += gv.w;
             if (x1) {
-                const float4 v = *reinterpret_cast<const float4*>(x1 + r * ldx1 + c);
                 acc[1].x += gv.x * (v.x - mu1.x); acc[1].y += gv.y * (v.y - mu1.y);
                 acc[1].z += gv.z * (v.z - mu1.z); acc[1].w += gv.w * (v.w - mu1.w);
             }
@@ -359,19 +368,31 @@ extern "C" int rd_bn_act(const float* x1, int32_t ldx1, const float* scale1, con
     return RD_OK;
 }
 
-extern "C" int rd_bn_bwd_reduce(const float* dy, int32_t lddy, const float* y, int32_t ldy, const float* x1, int32_t ldx1,
-                                const float* mean1, const float* x2, int32_t ldx2, const float* mean2, float* g, int32_t ldg,
-                                int64_t M, int32_t C, int32_t act, float* red_partial, void* stream) {
+static int bn_bwd_reduce_impl(const float* dy, int32_t lddy, const float* y, int32_t ldy, const float* x1, int32_t ldx1,
+                              const float* mean1, const float* x2, int32_t ldx2, const float* mean2, float* g, int32_t ldg,
+                              int64_t M, int32_t C, int32_t act, float* red_partial, const float* scale1, const float* shift1,
+                              void* stream) {
     RD_CHECK_ARG(dy && red_partial && M > 0 && C >= 4 && C % 4 == 0 && C <= 1024, "bn_bwd_reduce: bad arguments");
-    RD_CHECK_ARG(act == RD_ACT_NONE || y, "bn_bwd_reduce: activation needs y");
+    RD_CHECK_ARG(act == RD_ACT_NONE || y || (scale1 && shift1 && x1 && !x2), "bn_bwd_reduce: activation needs y (or scale/shift of a lone x1)");
     RD_CHECK_ARG((!x1 || mean1) && (!x2 || mean2), "bn_bwd_reduce: x without mean");
     const int RPB = rows_per_block(M), grid = (int)cdiv64(M, RPB);
     const int Q = C / 4, RL = 256 / Q;
     hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(grid), dim3(256), (size_t)RL * 3 * C * sizeof(float),
                        static_cast<hipStream_t>(stream), dy, lddy, y, ldy, x1, ldx1, mean1, x2, ldx2, mean2, g, ldg, M, C, act, RPB,
-                       red_partial);
+                       red_partial, scale1, shift1);
     RD_CHECK_LAUNCH("bn_bwd_reduce_kernel");
     return RD_OK;
+}
+extern "C" int rd_bn_bwd_reduce(const float* dy, int32_t lddy, const float* y, int32_t ldy, const float* x1, int32_t ldx1,
+                                const float* mean1, const float* x2, int32_t ldx2, const float* mean2, float* g, int32_t ldg,
+                                int64_t M, int32_t C, int32_t act, float* red_partial, void* stream) {
+    return bn_bwd_reduce_impl(dy, lddy, y, ldy, x1, ldx1, mean1, x2, ldx2, mean2, g, ldg, M, C, act, red_partial, nullptr, nullptr, stream);
+}
+// out = act(scale1 * x1 + shift1): the activation's sign is recomputed from x1 (one tensor read less than rd_bn_bwd_reduce)
+extern "C" int rd_bn_bwd_reduce_x(const float* dy, int32_t lddy, const float* x1, int32_t ldx1, const float* mean1,
+                                  const float* scale1, const float* shift1, float* g, int32_t ldg, int64_t M, int32_t C,
+                                  int32_t act, float* red_partial, void* stream) {
+    return bn_bwd_reduce_impl(dy, lddy, nullptr, 0, x1, ldx1, mean1, nullptr, 0, nullptr, g, ldg, M, C, act, red_partial, scale1, shift1, stream);
 }
 
 extern "C" int rd_bn_bwd_apply(const float* g, int32_t ldg, const float* x, int32_t ldx, const float* red_partial, int32_t n_tiles,

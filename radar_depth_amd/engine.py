@@ -298,18 +298,24 @@ class LateFusionPlan:
         self.taps[name] = out
         return out
 
-    def bn_join_bwd(self, name, dy, y, act, x1, co1, x2=None, co2=None, dx2=None):
-        """Backward of out = act(bn1(x1) [+ bn2(x2) | + x2]).  Returns (dx1, dx2 or g-if-identity-residual)."""
+    def bn_join_bwd(self, name, dy, y, act, x1, co1, x2=None, co2=None, dx2=None, lone=False):
+        """Backward of out = act(bn1(x1) [+ bn2(x2) | + x2]).  Returns (dx1, dx2 or g-if-identity-residual).
+        lone: out is act(bn1(x1)) with nothing added (callers with an identity residual pass x2=None too, hence the flag)."""
         M, Cc = x1.M, x1.C
         tiles = self.L.rd_bn_bwd_tiles(C.c_int64(M))
         red = self.buf(tiles, 3, Cc)
         # with no activation g == dy: skip the copy and let the apply pass read dy directly
         g = self.act(x1.N, x1.H, x1.W, Cc) if act != ACT_NONE else dy
-        self.op(self.bwd, name + ".bwd_reduce", self.L.rd_bn_bwd_reduce, dy.ptr, dy.ld, y.ptr if y is not None else C.c_void_p(0),
-                y.ld if y is not None else 0, x1.ptr, x1.ld, _p(co1["mean"]),
-                x2.ptr if co2 is not None else C.c_void_p(0), x2.ld if co2 is not None else 0,
-                _p(co2["mean"]) if co2 is not None else C.c_void_p(0), g.ptr if act != ACT_NONE else C.c_void_p(0), g.ld,
-                C.c_int64(M), Cc, act, _p(red), self.stream)
+        if lone and x2 is None and act != ACT_NONE:
+            # lone act(bn(x1)): the activation's sign is recomputed from x1 in the kernel, y is not read
+            self.op(self.bwd, name + ".bwd_reduce", self.L.rd_bn_bwd_reduce_x, dy.ptr, dy.ld, x1.ptr, x1.ld, _p(co1["mean"]),
+                    _p(co1["scale"]), _p(co1["shift"]), g.ptr, g.ld, C.c_int64(M), Cc, act, _p(red), self.stream)
+        else:
+            self.op(self.bwd, name + ".bwd_reduce", self.L.rd_bn_bwd_reduce, dy.ptr, dy.ld, y.ptr if y is not None else C.c_void_p(0),
+                    y.ld if y is not None else 0, x1.ptr, x1.ld, _p(co1["mean"]),
+                    x2.ptr if co2 is not None else C.c_void_p(0), x2.ld if co2 is not None else 0,
+                    _p(co2["mean"]) if co2 is not None else C.c_void_p(0), g.ptr if act != ACT_NONE else C.c_void_p(0), g.ld,
+                    C.c_int64(M), Cc, act, _p(red), self.stream)
         dx1 = self.act(x1.N, x1.H, x1.W, Cc)
         self._bn_apply(name + ".bn1", g, x1, red, tiles, 1, co1, dx1)
         if co2 is not None:
@@ -409,7 +415,7 @@ class LateFusionPlan:
         else:
             dr2, g = self.bn_join_bwd(name, dy, ctx["y"], ACT_RELU, ctx["r2"], ctx["co2"])
         dy1 = self.conv_bwd(ctx["c2"], dr2)
-        dr1, _ = self.bn_join_bwd(name + ".relu1", dy1, ctx["y1"], ACT_RELU, ctx["r1"], ctx["co1"])
+        dr1, _ = self.bn_join_bwd(name + ".relu1", dy1, ctx["y1"], ACT_RELU, ctx["r1"], ctx["co1"], lone=True)
         self.taps["grad_out:" + name] = dy
         if ctx["ds"] is not None:
             dx_part = self.conv_bwd(ctx["ds"]["c"], drd)          # 1x1 stride-2 dgrad (zero-filled odd pixels)
@@ -451,8 +457,8 @@ class LateFusionPlan:
         red = self.buf(tiles, 3, half)
         g = self.act(R.N, R.H, R.W, half)
         y1, x1, co = ctx["y1"], R.chan(0, half), ctx["co_u1"]
-        self.op(self.bwd, name + ".bn1.bwd_reduce", self.L.rd_bn_bwd_reduce, dy1.ptr, dy1.ld, y1.ptr, y1.ld, x1.ptr, x1.ld,
-                _p(co["mean"]), C.c_void_p(0), 0, C.c_void_p(0), g.ptr, g.ld, C.c_int64(M), half, ACT_RELU, _p(red), self.stream)
+        self.op(self.bwd, name + ".bn1.bwd_reduce", self.L.rd_bn_bwd_reduce_x, dy1.ptr, dy1.ld, x1.ptr, x1.ld, _p(co["mean"]),
+                _p(co["scale"]), _p(co["shift"]), g.ptr, g.ld, C.c_int64(M), half, ACT_RELU, _p(red), self.stream)
         self._bn_apply(name + ".bn1", g, x1, red, tiles, 1, co, dR.chan(0, half))
         dx = self.conv_bwd(ctx["cR"], dR)
         self.taps["grad_out:" + name] = dy

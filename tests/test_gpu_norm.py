@@ -73,6 +73,13 @@ def test_bn_forward_backward(M, Cc, act, res):
     Gt = torch.empty(M, Cc, device=dev)
     check(L.rd_bn_bwd_reduce(ptr(DY), Cc, ptr(Y), Cc, ptr(X1), Cc, ptr(mean1), ptr(X2) if res == "bn" else None, Cc if res == "bn" else 0,
                              ptr(mean2) if res == "bn" else None, ptr(Gt), Cc, C.c_int64(M), Cc, act, ptr(red), current_stream()), "reduce")
+    if not res and act != 0:
+        # lone act(bn(x1)): the variant that recomputes the activation's sign from x1 must agree bit for bit
+        red_x, Gx = torch.zeros(tiles, 3, Cc, device=dev), torch.empty(M, Cc, device=dev)
+        check(L.rd_bn_bwd_reduce_x(ptr(DY), Cc, ptr(X1), Cc, ptr(mean1), ptr(sc1), ptr(sh1), ptr(Gx), Cc, C.c_int64(M), Cc, act,
+                                   ptr(red_x), current_stream()), "reduce_x")
+        torch.cuda.synchronize()
+        assert torch.equal(Gx, Gt) and torch.equal(red_x[:, :2], red[:, :2])
     dG, dB, coef, DX = (torch.empty(Cc, device=dev), torch.empty(Cc, device=dev), torch.empty(3 * Cc, device=dev), torch.empty(M, Cc, device=dev))
     check(L.rd_bn_bwd_apply(ptr(Gt), Cc, ptr(X1), Cc, ptr(red), tiles, 1, ptr(G1), ptr(mean1), ptr(inv1), ptr(dG), ptr(dB), ptr(coef), ptr(DX),
                             Cc, C.c_int64(M), Cc, current_stream()), "apply1")

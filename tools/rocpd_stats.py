@@ -20,6 +20,12 @@ for name, st, en in rows:
     a = agg.setdefault(name, [0, 0])
     a[0] += 1
     a[1] += en - st
+if "--top" in sys.argv:      # longest single dispatches of the kernels whose name contains the given substring
+    sub = sys.argv[sys.argv.index("--top") + 1]
+    sel = sorted(((en - st) / 1e3, re.sub(r"\(.*$", "", name)) for name, st, en in rows if sub in name)
+    print("# %d dispatches matching %r; durations (us), descending" % (len(sel), sub))
+    print(" ".join("%.1f" % d for d, _ in sel[::-1][:80]))
+    sys.exit(0)
 tot = sum(a[1] for a in agg.values())
 print("# rocprofv3 --kernel-trace summary of %s (%d dispatches, %.3f ms of kernel time)" % (sys.argv[1], len(rows), tot / 1e6))
 print("%-72s %8s %12s %10s %7s" % ("kernel", "calls", "total_ms", "avg_us", "share"))
