@@ -198,6 +198,12 @@ int rd_bn_bwd_apply(const float* g, int32_t ldg, const float* x, int32_t ldx, co
                     int32_t n_tiles, int32_t which, const float* gamma, const float* mean,
                     const float* invstd, float* dgamma, float* dbeta, float* coef_ws /* 3*C floats */,
                     float* dx, int32_t lddx, int64_t M, int32_t C, void* stream);
+/* Apply pass paired with rd_bn_bwd_reduce_x(g = NULL): dy is the raw output gradient of act(scale*x + shift); the activation
+ * factor is recomputed from x here, so the masked gradient is never written to HBM. */
+int rd_bn_bwd_apply_x(const float* dy, int32_t lddy, const float* x, int32_t ldx, const float* red_partial, int32_t n_tiles,
+                      const float* gamma, const float* mean, const float* invstd, const float* scale, const float* shift,
+                      int32_t act, float* dgamma, float* dbeta, float* coef_ws, float* dx, int32_t lddx, int64_t M, int32_t C,
+                      void* stream);
 
 /* MaxPool2d(3,2,1) fused with the stem's BN affine + activation (models.py:634-636,644-646):
  * y = maxpool(act(scale*x+shift)); idx = argmax position 0..8 in the window. */

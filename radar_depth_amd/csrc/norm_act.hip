@@ -203,16 +203,24 @@ __global__ __launch_bounds__(256) void bn_bwd_coeffs_kernel(const float* __restr
     }
 }
 
+// s1 != nullptr: g is the raw output gradient dy of act(s1*x + t1); the activation factor is applied here (the reduce pass then
+// does not have to write the masked gradient)
 __global__ __launch_bounds__(256) void bn_bwd_dx_kernel(const float* __restrict__ g, int ldg, const float* __restrict__ x, int ldx,
                                                         const float* __restrict__ mean, const float* __restrict__ coef,
-                                                        float* __restrict__ dx, int lddx, int64_t M, int C) {
+                                                        float* __restrict__ dx, int lddx, int64_t M, int C,
+                                                        const float* __restrict__ s1, const float* __restrict__ t1, int act) {
     const int Q = C >> 2;
     const int64_t total = M * Q;
     for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
         const int64_t r = e / Q;
         const int c = (int)(e - r * Q) * 4;
-        const float4 gv = *reinterpret_cast<const float4*>(g + r * ldg + c);
+        float4 gv = *reinterpret_cast<const float4*>(g + r * ldg + c);
         const float4 xv = *reinterpret_cast<const float4*>(x + r * ldx + c);
+        if (s1) {
+            const float4 sa = *reinterpret_cast<const float4*>(s1 + c), sb = *reinterpret_cast<const float4*>(t1 + c);
+            gv.x *= act_grad_from_out(fmaf(sa.x, xv.x, sb.x), act); gv.y *= act_grad_from_out(fmaf(sa.y, xv.y, sb.y), act);
+            gv.z *= act_grad_from_out(fmaf(sa.z, xv.z, sb.z), act); gv.w *= act_grad_from_out(fmaf(sa.w, xv.w, sb.w), act);
+        }
         const float4 mu = *reinterpret_cast<const float4*>(mean + c);
         const float4 A = *reinterpret_cast<const float4*>(coef + c);
         const float4 B = *reinterpret_cast<const float4*>(coef + C + c);
@@ -404,7 +412,25 @@ extern "C" int rd_bn_bwd_apply(const float* g, int32_t ldg, const float* x, int3
     hipLaunchKernelGGL(bn_bwd_coeffs_kernel, dim3(C), dim3(256), 0, s, red_partial, n_tiles, C, which, (double)M, gamma, invstd,
                        dgamma, dbeta, coef_ws);
     RD_CHECK_LAUNCH("bn_bwd_coeffs_kernel");
-    hipLaunchKernelGGL(bn_bwd_dx_kernel, dim3(ew_grid(M * (C / 4))), dim3(256), 0, s, g, ldg, x, ldx, mean, coef_ws, dx, lddx, M, C);
+    hipLaunchKernelGGL(bn_bwd_dx_kernel, dim3(ew_grid(M * (C / 4))), dim3(256), 0, s, g, ldg, x, ldx, mean, coef_ws, dx, lddx, M, C,
+                       (const float*)nullptr, (const float*)nullptr, RD_ACT_NONE);
+    RD_CHECK_LAUNCH("bn_bwd_dx_kernel");
+    return RD_OK;
+}
+
+// Apply pass paired with rd_bn_bwd_reduce_x(g = NULL): dy is the raw output gradient, the activation factor is recomputed from x.
+extern "C" int rd_bn_bwd_apply_x(const float* dy, int32_t lddy, const float* x, int32_t ldx, const float* red_partial, int32_t n_tiles,
+                                 const float* gamma, const float* mean, const float* invstd, const float* scale, const float* shift,
+                                 int32_t act, float* dgamma, float* dbeta, float* coef_ws, float* dx, int32_t lddx, int64_t M, int32_t C,
+                                 void* stream) {
+    RD_CHECK_ARG(dy && x && red_partial && gamma && mean && invstd && scale && shift && coef_ws && dx && M > 0 && C % 4 == 0,
+                 "bn_bwd_apply_x: bad arguments");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    hipLaunchKernelGGL(bn_bwd_coeffs_kernel, dim3(C), dim3(256), 0, s, red_partial, n_tiles, C, 1, (double)M, gamma, invstd, dgamma,
+                       dbeta, coef_ws);
+    RD_CHECK_LAUNCH("bn_bwd_coeffs_kernel");
+    hipLaunchKernelGGL(bn_bwd_dx_kernel, dim3(ew_grid(M * (C / 4))), dim3(256), 0, s, dy, lddy, x, ldx, mean, coef_ws, dx, lddx, M, C,
+                       scale, shift, act);
     RD_CHECK_LAUNCH("bn_bwd_dx_kernel");
     return RD_OK;
 }

@@ -304,13 +304,17 @@ class LateFusionPlan:
         M, Cc = x1.M, x1.C
         tiles = self.L.rd_bn_bwd_tiles(C.c_int64(M))
         red = self.buf(tiles, 3, Cc)
+        if lone and x2 is None and act != ACT_NONE:
+            # lone act(bn(x1)): the activation's sign is recomputed from x1 in both passes -- y is not read and the masked
+            # gradient is never materialised
+            self.op(self.bwd, name + ".bwd_reduce", self.L.rd_bn_bwd_reduce_x, dy.ptr, dy.ld, x1.ptr, x1.ld, _p(co1["mean"]),
+                    _p(co1["scale"]), _p(co1["shift"]), C.c_void_p(0), 0, C.c_int64(M), Cc, act, _p(red), self.stream)
+            dx1 = self.act(x1.N, x1.H, x1.W, Cc)
+            self._bn_apply_x(name + ".bn1", dy, x1, red, tiles, co1, act, dx1)
+            return dx1, None
         # with no activation g == dy: skip the copy and let the apply pass read dy directly
         g = self.act(x1.N, x1.H, x1.W, Cc) if act != ACT_NONE else dy
-        if lone and x2 is None and act != ACT_NONE:
-            # lone act(bn(x1)): the activation's sign is recomputed from x1 in the kernel, y is not read
-            self.op(self.bwd, name + ".bwd_reduce", self.L.rd_bn_bwd_reduce_x, dy.ptr, dy.ld, x1.ptr, x1.ld, _p(co1["mean"]),
-                    _p(co1["scale"]), _p(co1["shift"]), g.ptr, g.ld, C.c_int64(M), Cc, act, _p(red), self.stream)
-        else:
+        if True:
             self.op(self.bwd, name + ".bwd_reduce", self.L.rd_bn_bwd_reduce, dy.ptr, dy.ld, y.ptr if y is not None else C.c_void_p(0),
                     y.ld if y is not None else 0, x1.ptr, x1.ld, _p(co1["mean"]),
                     x2.ptr if co2 is not None else C.c_void_p(0), x2.ld if co2 is not None else 0,
@@ -331,6 +335,13 @@ class LateFusionPlan:
         self.op(self.bwd, name + ".bwd_apply", self.L.rd_bn_bwd_apply, g.ptr, g.ld, x.ptr, x.ld, _p(red), tiles, which,
                 _p(bn.weight), _p(co["mean"]), _p(co["invstd"]), _p(self.grad_of(bn.weight)), _p(self.grad_of(bn.bias)),
                 _p(coef), dx.ptr, dx.ld, C.c_int64(x.M), co["C"], self.stream)
+
+    def _bn_apply_x(self, name, dy, x, red, tiles, co, act, dx):
+        bn = co["bn"]
+        coef = self.buf(3 * co["C"])
+        self.op(self.bwd, name + ".bwd_apply", self.L.rd_bn_bwd_apply_x, dy.ptr, dy.ld, x.ptr, x.ld, _p(red), tiles,
+                _p(bn.weight), _p(co["mean"]), _p(co["invstd"]), _p(co["scale"]), _p(co["shift"]), act,
+                _p(self.grad_of(bn.weight)), _p(self.grad_of(bn.bias)), _p(coef), dx.ptr, dx.ld, C.c_int64(x.M), co["C"], self.stream)
 
     # ------------------------------------------------------------------ network pieces
     def _stem(self, name, planes, strides, conv, bn, act, out_name):
@@ -455,11 +466,10 @@ class LateFusionPlan:
         dy1 = self.conv_bwd(ctx["c2"], dr2)
         M, tiles = R.M, self.L.rd_bn_bwd_tiles(C.c_int64(R.M))
         red = self.buf(tiles, 3, half)
-        g = self.act(R.N, R.H, R.W, half)
-        y1, x1, co = ctx["y1"], R.chan(0, half), ctx["co_u1"]
+        x1, co = R.chan(0, half), ctx["co_u1"]
         self.op(self.bwd, name + ".bn1.bwd_reduce", self.L.rd_bn_bwd_reduce_x, dy1.ptr, dy1.ld, x1.ptr, x1.ld, _p(co["mean"]),
-                _p(co["scale"]), _p(co["shift"]), g.ptr, g.ld, C.c_int64(M), half, ACT_RELU, _p(red), self.stream)
-        self._bn_apply(name + ".bn1", g, x1, red, tiles, 1, co, dR.chan(0, half))
+                _p(co["scale"]), _p(co["shift"]), C.c_void_p(0), 0, C.c_int64(M), half, ACT_RELU, _p(red), self.stream)
+        self._bn_apply_x(name + ".bn1", dy1, x1, red, tiles, co, ACT_RELU, dR.chan(0, half))
         dx = self.conv_bwd(ctx["cR"], dR)
         self.taps["grad_out:" + name] = dy
         self.taps["grad_in:" + name] = dx

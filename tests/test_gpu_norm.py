@@ -80,6 +80,16 @@ def test_bn_forward_backward(M, Cc, act, res):
                                    ptr(red_x), current_stream()), "reduce_x")
         torch.cuda.synchronize()
         assert torch.equal(Gx, Gt) and torch.equal(red_x[:, :2], red[:, :2])
+        # ... and the pair that never materialises the masked gradient (g = NULL, apply_x) must give the same dx, dgamma, dbeta
+        red_n = torch.zeros(tiles, 3, Cc, device=dev)
+        check(L.rd_bn_bwd_reduce_x(ptr(DY), Cc, ptr(X1), Cc, ptr(mean1), ptr(sc1), ptr(sh1), None, 0, C.c_int64(M), Cc, act,
+                                   ptr(red_n), current_stream()), "reduce_x(g=NULL)")
+        dGx, dBx, coefx, DXx = (torch.empty(Cc, device=dev), torch.empty(Cc, device=dev), torch.empty(3 * Cc, device=dev),
+                                torch.empty(M, Cc, device=dev))
+        check(L.rd_bn_bwd_apply_x(ptr(DY), Cc, ptr(X1), Cc, ptr(red_n), tiles, ptr(G1), ptr(mean1), ptr(inv1), ptr(sc1), ptr(sh1), act,
+                                  ptr(dGx), ptr(dBx), ptr(coefx), ptr(DXx), Cc, C.c_int64(M), Cc, current_stream()), "apply_x")
+        torch.cuda.synchronize()
+        assert _rel(dBx.cpu(), bet1.grad) < 2e-5 and _rel(dGx.cpu(), gam1.grad) < 5e-5 and _rel(DXx.cpu(), x1.grad) < 5e-5
     dG, dB, coef, DX = (torch.empty(Cc, device=dev), torch.empty(Cc, device=dev), torch.empty(3 * Cc, device=dev), torch.empty(M, Cc, device=dev))
     check(L.rd_bn_bwd_apply(ptr(Gt), Cc, ptr(X1), Cc, ptr(red), tiles, 1, ptr(G1), ptr(mean1), ptr(inv1), ptr(dG), ptr(dB), ptr(coef), ptr(DX),
                             Cc, C.c_int64(M), Cc, current_stream()), "apply1")
