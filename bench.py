@@ -40,16 +40,17 @@ def desc_flops(d):
 
 
 def kernel_identity(L, kind, d):
+    """Kernel name as rocprofv3 prints it (spaces removed), from the library's own plan for the descriptor."""
     if kind == "gconv":
         info = (C.c_int32 * 10)()
-        L.rd_gconv_plan_info(C.byref(d), info)
-        return "gconv_kernel<%d,%d,%d,%d,%d>" % (info[0], info[1], info[2], info[3], info[4] % 100)   # info[4] = ksplit*100 + CKW
-    ntaps = sum(d.phase[i].n_taps for i in range(d.n_phases))
-    tg = 5 if ntaps == 25 else ntaps
-    cmax = max(d.Cin, d.Cout)
-    la = cmax >= 64
-    mf = 16 if (not la and cmax <= 16) else 32
-    return "wgrad_kernel<%d,%d,%s>" % (tg, mf, "true" if la else "false")
+        L.rd_gconv_plan_info(C.byref(d), info)                 # info[4] = ksplit*100 + CKW
+        return "gconv_kernel<%d,%d,%d,%d,%d,%s>" % (info[0], info[1], info[2], info[3], info[4] % 100, "true" if d.in_stride == 2 else "false")
+    w = (C.c_int32 * 8)()
+    L.rd_wgrad_plan_info(C.byref(d), w)
+    tb = lambda v: "true" if v else "false"
+    if w[6]:       # UpProj: four launches (9/6/6/4-tap sub-stencils) inside one op
+        return "wgrad_kernel<9|6|6|4,%d,%s,true,%d,3|2> (4 UpProj phase launches)" % (w[1], tb(w[2]), w[4])
+    return "wgrad_kernel<%d,%d,%s,%s,%d,%d>" % (w[0], w[1], tb(w[2]), tb(w[3]), w[4], 3 if w[4] == 0 else w[5])
 
 
 def instrumented_pass(ts):

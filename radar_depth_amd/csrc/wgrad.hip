@@ -501,6 +501,16 @@ static int launch_pitch(const WgradPlan& pl, const WgradArgs& a, int grid, hipSt
 }  // namespace rd
 using namespace rd;
 
+// diagnostics: out[0..7] = TG, MF, layoutA, shb, pitch, taps per row, per_phase (4 launches), n_splits
+extern "C" int rd_wgrad_plan_info(const RdConvDesc* d, int32_t* out) {
+    if (!d || !out) return RD_EINVAL;
+    WgradPlan pl;
+    if (plan_any(*d, pl) != RD_OK) return RD_EINVAL;
+    const int v[8] = {pl.TG, pl.MF, pl.layoutA, pl.shb, pl.pitch, pl.rw, pl.per_phase, pl.n_splits};
+    for (int i = 0; i < 8; ++i) out[i] = v[i];
+    return RD_OK;
+}
+
 extern "C" int64_t rd_wgrad_workspace_floats(const RdConvDesc* d) {
     if (!d) return RD_EINVAL;
     WgradPlan pl;
