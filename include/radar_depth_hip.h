@@ -272,6 +272,16 @@ int rd_l1_total(const double* sums, float* loss, float* coef, void* stream);
 int rd_sgd_step(float* p, const float* g, float* buf, int64_t n, float lr, float momentum, float wd,
                 float grad_scale, int32_t first_step, void* stream);
 int rd_fill(float* p, int64_t n, float v, void* stream);
+/* Input staging from the exported .h5 frames.  Replaces the depth decompression of
+ * nuscenes_dataset_torch.get_data (dataset/nuscenes_dataset_torch_new.py:191-195) and the CenterCrop -> /255 -> ToTensor ->
+ * max-depth clamp -> cat of transform_val (same file :415-455, :503-512; CenterCrop dataset/transforms.py:332-385):
+ *   inputs [B,4,H,W] fp32 NCHW = (rgb/255, radar/256 with values > max_depth zeroed), labels [B,1,H,W] = lidar/256,
+ * both cropped at (i0, j0) out of the H0 x W0 frames.  rgb: uint8 [B,H0,W0,3]; lidar, radar: int16 [B,H0,W0] (depth*256).
+ * Bit-exact with the reference arithmetic.  max_depth = +inf disables the clamp (main.py:71). */
+int rd_stage_frames(const uint8_t* rgb_hwc, const int16_t* lidar, const int16_t* radar, int32_t B, int32_t H0, int32_t W0,
+                    int32_t i0, int32_t j0, int32_t H, int32_t W, float max_depth, float* inputs_nchw4, float* labels,
+                    void* stream);
+
 /* NCHW [N,C,H,W] (channel c0..c0+C of Ctot) <-> NHWC helpers for module-level tests */
 int rd_nchw_to_nhwc(const float* src, float* dst, int32_t N, int32_t C, int32_t H, int32_t W, void* stream);
 int rd_nhwc_to_nchw(const float* src, float* dst, int32_t N, int32_t C, int32_t H, int32_t W, void* stream);

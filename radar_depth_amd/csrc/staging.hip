@@ -1,0 +1,84 @@
+// Input staging from the exported frames: the deterministic part of the reference's DataLoader worker,
+// done on the GPU.  Replaces nuscenes_dataset_torch.get_data's depth decompression (dataset/nuscenes_dataset_torch_new.py:191-195)
+// and transform_val's CenterCrop -> /255 -> ToTensor -> max-depth clamp -> cat (same file :415-455,:503-512; CenterCrop
+// dataset/transforms.py:332-385):
+//   inputs[b, 0..2, y, x] = float(rgb[b, i0+y, j0+x, c]) / 255        (uint8 HWC -> fp32 planes)
+//   inputs[b, 3,    y, x] = r = float(radar[b, i0+y, j0+x]) / 256;  r > max_depth -> 0
+//   labels[b, 0,    y, x] = float(lidar[b, i0+y, j0+x]) / 256
+// Pure byte/integer traffic: 7 B read + 20 B written per output pixel, HBM-bound.  The uint8 -> fp32 /255 map is a 256-entry
+// table computed on the host with the IEEE division numpy uses, so the result is bit-identical whatever the device's
+// division lowering is; /256 is exact.
+#include "common.h"
+
+namespace rd {
+
+struct StageLut { float v[256]; };
+
+__global__ __launch_bounds__(256) void stage_frames_kernel(const uint8_t* __restrict__ rgb, const int16_t* __restrict__ lidar,
+                                                           const int16_t* __restrict__ radar, int B, int H0, int W0, int i0, int j0,
+                                                           int H, int W, float max_depth, float* __restrict__ inputs,
+                                                           float* __restrict__ labels, const StageLut lut) {
+    __shared__ float s_lut[256];
+    s_lut[threadIdx.x] = lut.v[threadIdx.x];
+    __syncthreads();
+    const int W4 = (W + 3) >> 2;                 // four consecutive output pixels per thread
+    const int64_t total = (int64_t)B * H * W4;
+    const int64_t plane = (int64_t)H * W;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+        const int xq = (int)(e % W4);
+        const int64_t r = e / W4;
+        const int y = (int)(r % H), b = (int)(r / H);
+        const int x0 = xq * 4, nx = min(4, W - x0);
+        const int64_t src = ((int64_t)b * H0 + i0 + y) * W0 + j0 + x0;
+        float o[5][4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            if (k < nx) {
+                const uint8_t* p = rgb + (src + k) * 3;
+                o[0][k] = s_lut[p[0]]; o[1][k] = s_lut[p[1]]; o[2][k] = s_lut[p[2]];
+                const float rd_ = (float)radar[src + k] * (1.0f / 256.0f);
+                o[3][k] = rd_ > max_depth ? 0.f : rd_;
+                o[4][k] = (float)lidar[src + k] * (1.0f / 256.0f);
+            }
+        }
+        const int64_t dst = (int64_t)y * W + x0;
+        float* in_b = inputs + (int64_t)b * 4 * plane + dst;
+        float* lb = labels + (int64_t)b * plane + dst;
+        if (nx == 4 && ((reinterpret_cast<uintptr_t>(in_b) | reinterpret_cast<uintptr_t>(lb) | (uintptr_t)(plane * 4)) & 15) == 0) {
+#pragma unroll
+            for (int c = 0; c < 4; ++c) *reinterpret_cast<float4*>(in_b + c * plane) = make_float4(o[c][0], o[c][1], o[c][2], o[c][3]);
+            *reinterpret_cast<float4*>(lb) = make_float4(o[4][0], o[4][1], o[4][2], o[4][3]);
+        } else {
+            for (int k = 0; k < nx; ++k) {
+#pragma unroll
+                for (int c = 0; c < 4; ++c) in_b[c * plane + k] = o[c][k];
+                lb[k] = o[4][k];
+            }
+        }
+    }
+}
+
+}  // namespace rd
+using namespace rd;
+
+extern "C" int rd_stage_frames(const uint8_t* rgb_hwc, const int16_t* lidar, const int16_t* radar, int32_t B, int32_t H0, int32_t W0,
+                               int32_t i0, int32_t j0, int32_t H, int32_t W, float max_depth, float* inputs_nchw4, float* labels,
+                               void* stream) {
+    RD_CHECK_ARG(rgb_hwc && lidar && radar && inputs_nchw4 && labels, "stage_frames: null argument");
+    RD_CHECK_ARG(B > 0 && H > 0 && W > 0 && i0 >= 0 && j0 >= 0 && i0 + H <= H0 && j0 + W <= W0,
+                 "stage_frames: crop %dx%d at (%d,%d) does not fit the %dx%d frame", H, W, i0, j0, H0, W0);
+    static StageLut lut;
+    static bool init = false;
+    if (!init) {
+        for (int v = 0; v < 256; ++v) lut.v[v] = (float)v / 255.0f;      // IEEE single division on the host == numpy float32 / 255.
+        init = true;
+    }
+    const int64_t total = (int64_t)B * H * ((W + 3) / 4);
+    int64_t g = cdiv64(total, 256);
+    const int64_t cap = (int64_t)num_cus() * 16;
+    if (g > cap) g = cap;
+    hipLaunchKernelGGL(stage_frames_kernel, dim3((int)g), dim3(256), 0, static_cast<hipStream_t>(stream), rgb_hwc, lidar, radar, B, H0, W0,
+                       i0, j0, H, W, max_depth, inputs_nchw4, labels, lut);
+    RD_CHECK_LAUNCH("stage_frames_kernel");
+    return RD_OK;
+}
