@@ -45,9 +45,11 @@ def kernel_identity(L, kind, d):
         info = (C.c_int32 * 10)()
         L.rd_gconv_plan_info(C.byref(d), info)                 # info[4] = ksplit*100 + CKW
         return "gconv_kernel<%d,%d,%d,%d,%d,%s>" % (info[0], info[1], info[2], info[3], info[4] % 100, "true" if d.in_stride == 2 else "false")
-    w = (C.c_int32 * 8)()
+    w = (C.c_int32 * 9)()
     L.rd_wgrad_plan_info(C.byref(d), w)
     tb = lambda v: "true" if v else "false"
+    if w[8]:       # column-strip kernel (one per UpProj phase when w[6])
+        return "wgrad_strip_kernel<%s>%s" % ("3,3|2,3|3,2|2,2" if w[6] else "%d,%d" % (w[0] // w[5], w[5]), " (4 UpProj phase launches)" if w[6] else "")
     if w[6]:       # UpProj: four launches (9/6/6/4-tap sub-stencils) inside one op
         return "wgrad_kernel<9|6|6|4,%d,%s,true,%d,3|2> (4 UpProj phase launches)" % (w[1], tb(w[2]), w[4])
     return "wgrad_kernel<%d,%d,%s,%s,%d,%d>" % (w[0], w[1], tb(w[2]), tb(w[3]), w[4], 3 if w[4] == 0 else w[5])

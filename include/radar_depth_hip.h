@@ -115,7 +115,8 @@ int rd_wgrad(const RdConvDesc* d, const float* in, const float* dout, float* sla
  * slab index of (kh,kw) is kh*KW+kw. */
 int rd_wgrad_reduce(const RdConvDesc* d, const float* slabs, float* grad_oihw, int32_t O, int32_t I,
                     int32_t KH, int32_t KW, int32_t co_off, int32_t accumulate, void* stream);
-/* diagnostics: out[0..7] = taps per group, MFMA size, layoutA, shared-B, LDS pitch, taps per row, per-phase launches, splits */
+/* diagnostics: out[0..8] = taps per group, MFMA size, layoutA, shared-B, LDS pitch, taps per row, per-phase launches, splits,
+ * column-strip kernel */
 int rd_wgrad_plan_info(const RdConvDesc* d, int32_t* out);
 
 /* OIHW -> packed logical [slab][I][ldc] at column offset co_off (forward operand), or, with

@@ -12,9 +12,20 @@
 // rd_wgrad_reduce sums in a fixed order (deterministic, no atomics) straight into OIHW gradients.
 #include <stdlib.h>
 
+#include <type_traits>
+
 #include "common.h"
 
 namespace rd {
+
+// compile-time loop: f(std::integral_constant<int, I>) for I = B, B+ST, ... < E
+template <int B, int E, int ST, typename F>
+__device__ __forceinline__ void static_for(F&& f) {
+    if constexpr (B < E) {
+        f(std::integral_constant<int, B>{});
+        static_for<B + ST, E, ST>(f);
+    }
+}
 
 constexpr int WG_MAX_TG = 9;     // taps per group
 constexpr int WG_MAX_GROUPS = 5;
@@ -267,6 +278,164 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void w
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// Strip kernel for rectangular RH x RW stencils at unit input stride on 64-channel blocks (every 3x3 conv with C >= 64 and
+// the UpProj phase sub-stencils): the workgroup walks DOWN a 25-pixel-wide column strip.  Input rows and dout rows live in
+// two LDS rings; while the MFMAs of output rows (2i, 2i+1) issue, the two input rows and two dout rows of iteration i+1 are
+// already in flight into their ring slots (global_load_lds: no staging registers), so the memory latency that cost the tiled
+// kernel 12 % of its time (RD_WGRAD_DEBUG=1 ablation) is covered, vertical halo rows are never re-staged, and there is one
+// barrier per 234 MFMAs.  All LDS offsets of the 26 steps of an iteration are instruction immediates relative to RH+1 row
+// base registers: the walk issues no VALU instruction at all besides those bases.
+struct WgradStripArgs {
+    int seg_rows, n_segs, n_strips, n_units, units_per_split;
+};
+template <int RH, int RW>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void wgrad_strip_kernel(const WgradArgs a, const WgradStripArgs sa) {
+    constexpr int TG = RH * RW, CIB = 64, COB = 64;
+    constexpr int TWS = 25, PW = WG_PITCH, DW = 26;        // strip width, patch row pixels, dout row slots (slot 25 stays zero)
+    constexpr int RP = 6, RD = 4;                          // ring depths in rows
+    constexpr int PROW = PW * CIB, DROW = DW * COB;        // floats per ring row
+    constexpr int STEPS = (TWS + 1) / 2;                   // 13 two-pixel steps per output row
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* s_in = smem;                                    // [RP][PW][CIB]
+    float* s_do = smem + RP * PROW;                        // [RD][DW][COB]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int lm = lane & 31, lk = lane >> 5;
+    const int wci = wave >> 1, wco = wave & 1;
+
+    const int vid = xcd_remap(blockIdx.x, gridDim.x);
+    const int n_groups = a.n_cib * a.n_cob;
+    const int g = vid % n_groups, split = vid / n_groups;
+    const int cob0 = (g % a.n_cob) * COB, cib0 = (g / a.n_cob) * CIB;
+    const WgTapGroup& G = a.tg[0];
+
+    typedef float accv __attribute__((ext_vector_type(16)));
+    accv acc[TG];
+#pragma unroll
+    for (int t = 0; t < TG; ++t)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
+
+    const int laneA = lk * CIB + wci * 32 + lm, laneB = lk * COB + wco * 32 + lm;
+    const int gst = a.compact ? a.OS : 1;                  // global dout pixel step per logical pixel
+    const int u_begin = split * sa.units_per_split, u_end = min(u_begin + sa.units_per_split, sa.n_units);
+    for (int unit = u_begin; unit < u_end; ++unit) {
+        const int seg = unit % sa.n_segs, uj = unit / sa.n_segs;
+        const int strip = uj % sa.n_strips, n = uj / sa.n_strips;
+        const int r_b = seg * sa.seg_rows, r_e = min(a.lh, r_b + sa.seg_rows);
+        const int c0 = strip * TWS, tw_n = min(TWS, a.lw - c0);
+        const int niter = (r_e - r_b + 1) >> 1;
+        const int ih_base = r_b + a.dh_min, iw_base = c0 + a.dw_min;
+        const float* in_n = a.in + (size_t)n * a.Hi * a.Wi * a.ldi;
+        const float* do_n = a.dout + (size_t)n * a.Ho * a.Wo * a.ldo;
+        // this thread's share of one staged row (fixed for the unit): element e = tid + k*256 -> (pixel, channel quad)
+        int p_off[2], d_off[2];        // float offset inside the global row, -1: write zeros
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const int e = tid + k * 256;
+            const int px = e >> 4, q = e & 15;
+            const int iw = iw_base + px, ci = cib0 + q * 4;
+            p_off[k] = (e < PW * 16 && iw >= 0 && iw < a.Wi && ci < a.Cin) ? iw * a.ldi + ci : -1;
+            const int ow = (c0 + px) * gst + (a.compact ? a.off_w : 0), co = cob0 + q * 4;
+            d_off[k] = (e < DW * 16 && px < tw_n && ow < a.Wo && co < a.Cout) ? ow * a.ldo + co : -1;
+        }
+        auto stage_patch_row = [&](int p) {                // p: patch row of the unit (0 = input row ih_base)
+            const int ih = ih_base + p;
+            const bool rowok = ih >= 0 && ih < a.Hi;
+            float* dst = s_in + (p % RP) * PROW;
+            const float* src = in_n + (size_t)ih * a.Wi * a.ldi;
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                const int e = tid + k * 256;
+                if (e < PW * 16) {
+                    if (rowok && p_off[k] >= 0) glds16(src + p_off[k], dst + (e - lane) * 4);
+                    else *reinterpret_cast<float4*>(dst + e * 4) = make_float4(0.f, 0.f, 0.f, 0.f);
+                }
+            }
+        };
+        auto stage_dout_row = [&](int q) {                 // q: output row of the unit (0 = logical row r_b)
+            const int r = r_b + q;
+            const int oh = r * gst + (a.compact ? a.off_h : 0);
+            const bool rowok = r < r_e && oh < a.Ho;
+            float* dst = s_do + (q % RD) * DROW;
+            const float* src = do_n + (size_t)oh * a.Wo * a.ldo;
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                const int e = tid + k * 256;
+                if (e < DW * 16) {
+                    if (rowok && d_off[k] >= 0) glds16(src + d_off[k], dst + (e - lane) * 4);
+                    else *reinterpret_cast<float4*>(dst + e * 4) = make_float4(0.f, 0.f, 0.f, 0.f);
+                }
+            }
+        };
+        __syncthreads();                                   // the previous unit's walk is over: the rings are free
+        for (int p = 0; p <= RH; ++p) stage_patch_row(p);
+        stage_dout_row(0);
+        stage_dout_row(1);
+        for (int it = 0; it < niter; ++it) {
+            __syncthreads();                               // rows of iteration `it` have landed; iteration it-1 is fully consumed
+            if (it + 1 < niter && !(a.debug & 1)) {
+                stage_patch_row(2 * it + RH + 1);
+                stage_patch_row(2 * it + RH + 2);
+                stage_dout_row(2 * it + 2);
+                stage_dout_row(2 * it + 3);
+            }
+            if (a.debug & 2) continue;
+            // row bases of the two output rows of this iteration
+            const float* ab[2][RH];
+            const float* bb[2];
+#pragma unroll
+            for (int rr = 0; rr < 2; ++rr) {
+#pragma unroll
+                for (int dh = 0; dh < RH; ++dh) ab[rr][dh] = s_in + ((2 * it + rr + dh) % RP) * PROW + laneA;
+                bb[rr] = s_do + ((2 * it + rr) % RD) * DROW + laneB;
+            }
+            float a0[TG], a1[TG], b0, b1;
+#define RD_WS_LOAD(AV, BV, S_)                                                                     \
+            {                                                                                          \
+                constexpr int rr_ = (S_) / STEPS, sc_ = (S_) % STEPS;                                  \
+                _Pragma("unroll") for (int t = 0; t < TG; ++t) AV[t] = ab[rr_][t / RW][((t % RW) + 2 * sc_) * CIB]; \
+                BV = bb[rr_][2 * sc_ * COB];                                                           \
+            }
+#define RD_WS_MFMA(AV, BV)                                                                         \
+            _Pragma("unroll") for (int t = 0; t < TG; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(AV[t], BV, acc[t], 0, 0, 0);
+#define RD_WS_SCHED()                                                                              \
+            _Pragma("unroll") for (int i = 0; i < TG; ++i) {                                           \
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                     \
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                                     \
+            }                                                                                          \
+            __builtin_amdgcn_sched_barrier(0);
+            RD_WS_LOAD(a0, b0, 0)
+            __builtin_amdgcn_sched_barrier(0);
+            static_for<0, 2 * STEPS, 2>([&](auto sc) {
+                constexpr int S = decltype(sc)::value;
+                RD_WS_LOAD(a1, b1, S + 1)
+                RD_WS_MFMA(a0, b0)
+                RD_WS_SCHED()
+                if constexpr (S + 2 < 2 * STEPS) { RD_WS_LOAD(a0, b0, S + 2) }
+                RD_WS_MFMA(a1, b1)
+                RD_WS_SCHED()
+            });
+#undef RD_WS_LOAD
+#undef RD_WS_MFMA
+#undef RD_WS_SCHED
+        }
+    }
+
+    // ---- write this workgroup's partial slab (same layout as the tiled kernel)
+    float* slab = a.slabs + (size_t)split * a.S * a.Cin * a.Cout;
+    const int co = cob0 + wco * 32 + lm;
+#pragma unroll
+    for (int t = 0; t < TG; ++t) {
+        float* dst = slab + (size_t)G.widx[t] * a.Cin * a.Cout;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int ci = cib0 + wci * 32 + (i & 3) + 8 * (i >> 2) + 4 * lk;
+            if (ci < a.Cin && co < a.Cout) dst[(size_t)ci * a.Cout + co] = acc[t][i];
+        }
+    }
+}
+
 // Deterministic two-stage reduction of the per-split slabs.
 // stage 1: tmp[j][e] = sum over splits k == j (mod J) of slabs[k][e]        (J partial sums, wide parallelism)
 // stage 2: grad[o][i][t] (+)= sum_j tmp[j][(t*Cin+i)*Cout + co_off + o]
@@ -330,9 +499,12 @@ struct WgradPlan {
     int pitch;      // > 0: fixed LDS patch pitch with immediate tap offsets (full rectangular stencil)
     int rw;         // taps per stencil row (pitch > 0)
     int per_phase;  // UpProj: one launch per output phase (each a rectangular sub-stencil with a shared dout pixel)
+    int strip;      // column-strip kernel with LDS row rings (rectangular stencil, unit input stride, 64-channel blocks)
+    WgradStripArgs sa;
     size_t lds;
 };
 
+static inline bool tile_is_tiled(const struct WgradPlan* tile);
 // ph >= 0: plan one phase of a multi-phase descriptor on its own (compact dout staging); tile: reuse this plan's tile.
 static int plan_wgrad(const RdConvDesc& d_in, WgradPlan& pl, WgradArgs* out, int ph = -1, const WgradPlan* tile = nullptr) {
     RdConvDesc d = d_in;
@@ -381,6 +553,48 @@ static int plan_wgrad(const RdConvDesc& d_in, WgradPlan& pl, WgradArgs* out, int
     static const char* bud = getenv("RD_WGRAD_LDS_KB");   // diagnostics (default 78: two workgroups per CU)
     const size_t budget = (size_t)(bud ? atoi(bud) : 78) * 1024;
     pl.pitch = 0;
+    pl.strip = 0;
+    static const char* nostrip = getenv("RD_WGRAD_NOSTRIP");
+    // (short images do not amortise the ring fill of a strip: 15-row layers measured 3 % slower than tiled)
+    if (k3 && !nostrip && pl.layoutA && pl.MF == 32 && d.in_stride == 1 && (d.out_stride == 1 || ph >= 0) && P0.lh >= 24 && !tile_is_tiled(tile)) {
+        // column-strip kernel: 25-pixel strips, row segments sized so that every CU gets two workgroups
+        WgradStripArgs& sa = pl.sa;
+        const int groups = pl.n_cib * pl.n_cob;
+        int want = cdiv(2 * num_cus(), groups);
+        if (want < 1) want = 1;
+        sa.n_strips = cdiv(P0.lw, 25);
+        const int base_units = d.N * sa.n_strips;
+        int n_segs0 = cdiv(want, base_units);
+        if (n_segs0 < 1) n_segs0 = 1;
+        sa.seg_rows = 2 * cdiv(cdiv(P0.lh, n_segs0), 2);
+        sa.n_segs = cdiv(P0.lh, sa.seg_rows);
+        sa.n_units = base_units * sa.n_segs;
+        sa.units_per_split = cdiv(sa.n_units, want);
+        pl.n_splits = cdiv(sa.n_units, sa.units_per_split);
+        pl.slab_splits = pl.n_splits;
+        pl.J = pl.n_splits < 16 ? pl.n_splits : 16;
+        pl.strip = 1;
+        pl.pitch = WG_PITCH;
+        pl.TH = 2; pl.TW = 25; pl.tiles_h = pl.tiles_w = pl.total_tiles = pl.tiles_per_split = 0;
+        pl.lds = (size_t)(6 * WG_PITCH * 64 + 4 * 26 * 64) * 4;
+        if (out) {
+            WgradArgs& a = *out;
+            a.N = d.N; a.Hi = d.Hi; a.Wi = d.Wi; a.Cin = d.Cin; a.ldi = d.ldi;
+            a.Ho = d.Ho; a.Wo = d.Wo; a.Cout = d.Cout; a.ldo = d.ldo; a.IS = d.in_stride; a.OS = d.out_stride;
+            a.lh = P0.lh; a.lw = P0.lw; a.TH = pl.TH; a.TW = pl.TW; a.tiles_h = a.tiles_w = a.total_tiles = a.tiles_per_split = 0;
+            a.n_splits = pl.n_splits;
+            a.dh_min = dh_min; a.dh_max = dh_max; a.dw_min = dw_min; a.dw_max = dw_max;
+            a.n_cib = pl.n_cib; a.n_cob = pl.n_cob; a.n_tg = 1; a.S = S;
+            a.compact = ph >= 0; a.off_h = P0.out_off_h; a.off_w = P0.out_off_w;
+            for (int gi = 0; gi < WG_MAX_GROUPS; ++gi) a.tg[gi].n = 0;
+            WgTapGroup& G = a.tg[0];
+            for (int t = 0; t < P0.n_taps; ++t) {
+                G.dh[t] = P0.dh[t]; G.dw[t] = P0.dw[t]; G.oh[t] = 0; G.ow[t] = 0; G.widx[t] = P0.widx[t];
+            }
+            G.n = P0.n_taps;
+        }
+        return RD_OK;
+    }
     const int los = ph >= 0 ? 1 : d.out_stride;      // dout pixel stride inside LDS (compact per-phase staging: 1)
     double best = -1;
     pl.TH = pl.TW = 0;
@@ -448,6 +662,21 @@ static int plan_wgrad(const RdConvDesc& d_in, WgradPlan& pl, WgradArgs* out, int
     return RD_OK;
 }
 
+static inline bool tile_is_tiled(const WgradPlan* tile) { return tile != nullptr && !tile->strip; }
+
+template <int RH, int RW>
+static int launch_strip(const WgradPlan& pl, const WgradArgs& a, int grid, hipStream_t s) {
+    static bool attr_set = false;
+    auto k = wgrad_strip_kernel<RH, RW>;
+    if (!attr_set) {
+        RD_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(k, dim3(grid), dim3(256), pl.lds, s, a, pl.sa);
+    RD_CHECK_LAUNCH("wgrad_strip_kernel");
+    return RD_OK;
+}
+
 template <int TG, int MF, bool LA, bool SHB, int PITCH = 0, int RW = 3>
 static int launch_wgrad(const WgradArgs& a, int grid, size_t lds, hipStream_t s) {
     static bool attr_set = false;
@@ -486,6 +715,14 @@ static int plan_any(const RdConvDesc& d, WgradPlan& pl) {
 
 // immediate-offset kernels: (taps, taps per row) = (9,3) (6,3) (6,2) (4,2)
 static int launch_pitch(const WgradPlan& pl, const WgradArgs& a, int grid, hipStream_t s) {
+    if (pl.strip) {
+        if (pl.TG == 9 && pl.rw == 3) return launch_strip<3, 3>(pl, a, grid, s);
+        if (pl.TG == 6 && pl.rw == 3) return launch_strip<2, 3>(pl, a, grid, s);
+        if (pl.TG == 6 && pl.rw == 2) return launch_strip<3, 2>(pl, a, grid, s);
+        if (pl.TG == 4 && pl.rw == 2) return launch_strip<2, 2>(pl, a, grid, s);
+        set_error("wgrad: no strip kernel for %d taps, %d per row", pl.TG, pl.rw);
+        return RD_EINVAL;
+    }
 #define RD_WP(TG_, RW_)                                                                                              \
     if (pl.TG == TG_ && pl.rw == RW_) {                                                                              \
         if (pl.MF == 32 && pl.layoutA) return launch_wgrad<TG_, 32, true, true, WG_PITCH, RW_>(a, grid, pl.lds, s);  \
@@ -501,13 +738,13 @@ static int launch_pitch(const WgradPlan& pl, const WgradArgs& a, int grid, hipSt
 }  // namespace rd
 using namespace rd;
 
-// diagnostics: out[0..7] = TG, MF, layoutA, shb, pitch, taps per row, per_phase (4 launches), n_splits
+// diagnostics: out[0..8] = TG, MF, layoutA, shb, pitch, taps per row, per_phase (4 launches), n_splits, strip kernel
 extern "C" int rd_wgrad_plan_info(const RdConvDesc* d, int32_t* out) {
     if (!d || !out) return RD_EINVAL;
     WgradPlan pl;
     if (plan_any(*d, pl) != RD_OK) return RD_EINVAL;
-    const int v[8] = {pl.TG, pl.MF, pl.layoutA, pl.shb, pl.pitch, pl.rw, pl.per_phase, pl.n_splits};
-    for (int i = 0; i < 8; ++i) out[i] = v[i];
+    const int v[9] = {pl.TG, pl.MF, pl.layoutA, pl.shb, pl.pitch, pl.rw, pl.per_phase, pl.n_splits, pl.strip};
+    for (int i = 0; i < 9; ++i) out[i] = v[i];
     return RD_OK;
 }
 
