@@ -146,8 +146,11 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback for the HIP path)")
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    # RD_FORCE_DP=1 with one rank: run the data-parallel code path (segmented graphs + bucketed RCCL all-reduce) on a 1-rank
+    # group, to measure its host/launch overhead against the single-graph step on the same box
+    if world > 1 or os.environ.get("RD_FORCE_DP") == "1":
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
         torch.distributed.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
     assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node %d (WORLD_SIZE=%d)" % (args.gpus, world)
 
@@ -191,7 +194,7 @@ def main():
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": "%s --decoder upproj --modality rgbd, b=%d/GPU %dx%d fp32, full step "
                                "(fwd + loss + bwd + SGD momentum .9 wd 1e-4), random init" % (args.arch, args.batch, args.height, args.width),
-                   "global_batch": world * args.batch, "parallelism": "dp%d" % world if world > 1 else "single",
+                   "global_batch": world * args.batch, "parallelism": "dp%d" % world if world > 1 else ("dp1 (forced data-parallel code path)" if os.environ.get("RD_FORCE_DP") == "1" else "single"),
                    "hipgraph": not args.no_graph, "final_loss": round(final_loss, 5)},
     }
     multistage = args.arch != "resnet18_latefusion"
@@ -231,7 +234,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline and not multistage:
             out["cpu_baseline"] = cpu_baseline(args.height, args.width)
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if torch.distributed.is_available() and torch.distributed.is_initialized():
         torch.distributed.destroy_process_group()
 
 

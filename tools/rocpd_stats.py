@@ -26,6 +26,44 @@ if "--top" in sys.argv:      # longest single dispatches of the kernels whose na
     print("# %d dispatches matching %r; durations (us), descending" % (len(sel), sub))
     print(" ".join("%.1f" % d for d, _ in sel[::-1][:80]))
     sys.exit(0)
+if "--gaps" in sys.argv:       # which kernels end before / start after the idle gaps (steady-state part of the trace)
+    iv = sorted((st, en, re.sub(r"\(.*$", "", name).replace("void rd::", "").replace("rd::", "")) for name, st, en in rows)
+    t_lo = iv[0][0] + 0.4 * (iv[-1][1] - iv[0][0])
+    iv = [x for x in iv if x[0] >= t_lo]
+    pairs = {}
+    cur_end, cur_name = iv[0][1], iv[0][2]
+    for a, b, nm in iv[1:]:
+        if a > cur_end + 1500:
+            k = (cur_name[:40], nm[:40])
+            v = pairs.setdefault(k, [0, 0])
+            v[0] += 1; v[1] += a - cur_end
+        if b > cur_end:
+            cur_end, cur_name = b, nm
+    print("# idle gaps > 1.5 us: (kernel ending last before the gap -> kernel starting after it): count, total us")
+    for k, v in sorted(pairs.items(), key=lambda kv: -kv[1][1])[:25]:
+        print("%-42s -> %-42s %5d %9.1f" % (k[0], k[1], v[0], v[1] / 1e3))
+    sys.exit(0)
+if "--timeline" in sys.argv:   # how full is the device: union of kernel intervals vs wall span, over the last 60 % of the trace
+    iv = sorted((st, en) for _, st, en in rows)
+    t_lo = iv[0][0] + 0.4 * (iv[-1][1] - iv[0][0])
+    iv = [(a, b) for a, b in iv if a >= t_lo]
+    span = iv[-1][1] - iv[0][0]
+    busy, cur_a, cur_b = 0, iv[0][0], iv[0][1]
+    gaps = []
+    for a, b in iv[1:]:
+        if a > cur_b:
+            busy += cur_b - cur_a
+            gaps.append(a - cur_b)
+            cur_a, cur_b = a, b
+        else:
+            cur_b = max(cur_b, b)
+    busy += cur_b - cur_a
+    ssum = sum(b - a for a, b in iv)
+    print("# steady-state window: %.2f ms wall, %.2f ms with at least one kernel running (%.1f %%), %.2f ms summed kernel time "
+          "(average concurrency %.2f), %d idle gaps totalling %.3f ms (median %.2f us)" % (
+              span / 1e6, busy / 1e6, 100.0 * busy / span, ssum / 1e6, ssum / busy, len(gaps), sum(gaps) / 1e6,
+              sorted(gaps)[len(gaps) // 2] / 1e3 if gaps else 0.0))
+    sys.exit(0)
 tot = sum(a[1] for a in agg.values())
 print("# rocprofv3 --kernel-trace summary of %s (%d dispatches, %.3f ms of kernel time)" % (sys.argv[1], len(rows), tot / 1e6))
 print("%-72s %8s %12s %10s %7s" % ("kernel", "calls", "total_ms", "avg_us", "share"))
