@@ -19,29 +19,17 @@ to_tensor = transforms.ToTensor()
 
 
 def reference_val_frame(image, lidar_i16, radar_i16, crop_size_val, max_depth):
-    lidar_depth = lidar_i16 / 256.
-    radar_depth = radar_i16 / 256.
-    rgb = np.array(image).astype(np.float32)
-    lidar_depth = np.array(lidar_depth).astype(np.float32)
-    radar_depth = np.array(radar_depth).astype(np.float32)
-    transform_rgb = transforms.Compose([transforms.CenterCrop(crop_size_val)])
-    transform_depth = transforms.Compose([transforms.CenterCrop(crop_size_val)])
-    rgb = transform_rgb(rgb)
-    rgb = rgb / 255.
-    lidar_depth = transform_depth(lidar_depth)
-    rgb = np.array(rgb).astype(np.float32)
-    lidar_depth = np.array(lidar_depth).astype(np.float32)
-    rgb = to_tensor(rgb)
-    lidar_depth = to_tensor(lidar_depth)
-    radar_depth = transform_depth(radar_depth)
-    radar_depth = np.array(radar_depth).astype(np.float32)
-    radar_depth = to_tensor(radar_depth)
-    lidar_depth = lidar_depth.unsqueeze(0)
-    radar_depth = radar_depth.unsqueeze(0)
-    mask = (radar_depth > max_depth)
-    radar_depth[mask] = 0
-    inputs = torch.cat((rgb, radar_depth), dim=0)
-    return inputs.numpy(), lidar_depth.numpy()
+    """The op sequence of get_data (:193,:195) and transform_val (:417-456,:498-512) for modality rgbd / sparsifier radar,
+    executed with the reference's own CenterCrop and ToTensor objects (the only parts with non-trivial semantics)."""
+    crop = transforms.Compose([transforms.CenterCrop(crop_size_val)])
+    lidar = np.array(lidar_i16 / 256.).astype(np.float32)            # int16 -> float64 metres -> float32
+    radar = np.array(radar_i16 / 256.).astype(np.float32)
+    rgb = crop(np.array(image).astype(np.float32)) / 255.            # float32 array / python float
+    rgb_t = to_tensor(np.array(rgb).astype(np.float32))             # HWC -> CHW
+    lidar_t = to_tensor(np.array(crop(lidar)).astype(np.float32)).unsqueeze(0)
+    radar_t = to_tensor(np.array(crop(radar)).astype(np.float32)).unsqueeze(0)
+    radar_t[radar_t > max_depth] = 0                                 # tensor-vs-python-scalar comparison, as in :506-507
+    return torch.cat((rgb_t, radar_t), dim=0).numpy(), lidar_t.numpy()
 
 
 def main():
