@@ -24,6 +24,15 @@ def _rel(a, b):
     (2, 32, 32, 3, 1, 1, 57, 100),
     (1, 16, 16, 3, 1, 1, 240, 400),
     (3, 32, 48, 3, 1, 1, 9, 7),
+    # column-strip kernel edge cases: ragged last strip (26 = 25 + 1 columns), odd row counts, one-row segments, partial
+    # 64-channel blocks, a single image
+    (2, 64, 64, 3, 1, 1, 25, 26),
+    (1, 96, 160, 3, 1, 1, 31, 51),
+    (5, 128, 64, 3, 1, 1, 24, 3),
+    (2, 64, 64, 3, 1, 1, 29, 75),
+    # immediate-offset tiled kernel (short image -> no strip) with ragged tiles
+    (2, 64, 96, 3, 1, 1, 7, 33),
+    (2, 256, 64, 3, 2, 1, 21, 27),
 ])
 def test_wgrad_conv(cfg):
     from radar_depth_amd import convdesc as cd, ops
@@ -46,7 +55,7 @@ def test_wgrad_conv(cfg):
     assert _rel(grad.cpu(), 2 * wt.grad) < 5e-5
 
 
-@pytest.mark.parametrize("c,h,w", [(256, 15, 25), (64, 60, 100), (32, 13, 9)])
+@pytest.mark.parametrize("c,h,w", [(256, 15, 25), (64, 60, 100), (32, 13, 9), (64, 27, 26), (128, 25, 51), (64, 5, 3)])
 def test_wgrad_upproj(c, h, w):
     from radar_depth_amd import convdesc as cd, ops
     n = 2
