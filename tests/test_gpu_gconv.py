@@ -53,6 +53,14 @@ def _run_fwd(n, ci, co, k, s, p, h, w, seed=0):
     (16, 512, 512, 3, 1, 1, 15, 25),  # B=16: the planner splits the input channels (split-K + combine kernel)
     (16, 512, 256, 1, 1, 0, 15, 25),
     (16, 128, 128, 3, 1, 1, 15, 25),
+    # ragged geometry for the padded / swizzled LDS layouts and the quad-interleaved weight operand: output channels that do not
+    # fill a 32/64 block, 1-pixel-wide and single-pixel images, stride 2 on odd sizes, 48/80/96-channel reductions
+    (2, 48, 80, 3, 1, 1, 31, 17),
+    (1, 96, 36, 3, 2, 1, 33, 45),
+    (3, 64, 64, 3, 1, 1, 1, 1),
+    (2, 32, 16, 3, 1, 1, 40, 1),
+    (2, 80, 48, 1, 1, 0, 19, 23),
+    (4, 16, 64, 1, 2, 0, 7, 5),
 ])
 def test_gconv_forward(cfg):
     _run_fwd(*cfg)
@@ -65,6 +73,9 @@ def test_gconv_forward(cfg):
     (2, 256, 512, 3, 2, 1, 29, 50),
     (2, 16, 32, 3, 2, 1, 57, 101),
     (16, 512, 512, 3, 1, 1, 15, 25),  # split-K dgrad with the residual addend applied by the combine kernel
+    (2, 48, 80, 3, 1, 1, 31, 17),
+    (1, 96, 48, 3, 2, 1, 33, 45),
+    (3, 64, 64, 3, 1, 1, 1, 1),
 ])
 def test_gconv_dgrad(cfg):
     from radar_depth_amd import convdesc as cd, ops
