@@ -102,8 +102,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MT * NT <= 
     // LDS carve-up
     int* s_opix = reinterpret_cast<int*>(smem);          // [BM] output pixel index or -1
     int* s_apix = s_opix + BM;                           // [BM] patch pixel index of tap (0,0)
-    int* s_tapoff = s_apix + BM;                         // [32] patch pixel offset per tap
-    int* s_widx = s_tapoff + 32;                         // [32]
+    int* s_widx = s_apix + BM + 32;                      // [32] weight slab index of each tap ([32] ints before it are spare)
     float* s_w = reinterpret_cast<float*>(s_widx + 32);  // [taps][WSD/4][BN][4]  (quad layout, see layout.hip)
     float* s_patch = s_w + a.taps_max * a.WSD * BN;      // [PP][CKP], quads swizzled
 
@@ -114,7 +113,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MT * NT <= 
         s_apix[m] = ok ? ((r * IS) * PW + c * IS) : 0;
     }
     if (tid < ntaps) {
-        s_tapoff[tid] = (P.dh[tid] - P.dh_min) * PW + (P.dw[tid] - P.dw_min);
         s_widx[tid] = P.widx[tid];
     }
     __syncthreads();
