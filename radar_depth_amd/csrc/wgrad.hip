@@ -477,7 +477,9 @@ int launch_slab_reduce(const float* slabs, int n_splits, int64_t E, float* tmp, 
     RD_CHECK_ARG(E % 4 == 0, "slab_reduce: slab size must be a multiple of 4");
     const int J = n_splits < 16 ? n_splits : 16;
     const int64_t E4 = E / 4;
-    if (co_off == 0) {
+    // up to 16 splits stage 1 would be a plain copy (tmp[j] = slabs[j]): stage 2 reads the slabs themselves, same order, same bits
+    if (n_splits <= 16) tmp = const_cast<float*>(slabs);
+    else if (co_off == 0) {
         int64_t g1 = cdiv64(E4, 256);
         if (g1 > 2048) g1 = 2048;
         hipLaunchKernelGGL(wgrad_reduce1_kernel, dim3((int)g1, J), dim3(256), 0, s, slabs, tmp, n_splits, J, E4);
