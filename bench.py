@@ -135,7 +135,8 @@ def main():
     ap.add_argument("--arch", default="resnet18_latefusion",
                     choices=["resnet18_latefusion", "resnet18_multistage_uncertainty_fixs"],
                     help="headline = resnet18_latefusion (BASELINE configs[1]); the multistage arch is configs[3] (use --batch 8)")
-    ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--graph", action="store_true", help="replay the step as hipGraphs (slower than plain stream launches here)")
+    ap.add_argument("--no-graph", action="store_true", help="(default; kept for older command lines)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     args = ap.parse_args()
@@ -165,7 +166,7 @@ def main():
     model, loss_weights = made if isinstance(made, tuple) else (made, None)
     model = model.cuda()
     ts = HipTrainStep(model, args.batch, args.height, args.width, lr=0.01, momentum=0.9, weight_decay=1e-4,
-                      loss_weights=loss_weights, use_graph=not args.no_graph)
+                      loss_weights=loss_weights, use_graph=args.graph)
     x, t = make_batch(args.batch, args.height, args.width, 1234 + 1000 * rank)
     x, t = x.cuda(), t.cuda()
 
@@ -195,7 +196,7 @@ def main():
         "config": {"workload": "%s --decoder upproj --modality rgbd, b=%d/GPU %dx%d fp32, full step "
                                "(fwd + loss + bwd + SGD momentum .9 wd 1e-4), random init" % (args.arch, args.batch, args.height, args.width),
                    "global_batch": world * args.batch, "parallelism": "dp%d" % world if world > 1 else ("dp1 (forced data-parallel code path)" if os.environ.get("RD_FORCE_DP") == "1" else "single"),
-                   "hipgraph": not args.no_graph, "final_loss": round(final_loss, 5)},
+                   "hipgraph": args.graph, "final_loss": round(final_loss, 5)},
     }
     multistage = args.arch != "resnet18_latefusion"
     if rank == 0 and not args.no_roofline and not multistage:

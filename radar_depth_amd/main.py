@@ -94,9 +94,14 @@ class HipTrainStep:
 
     followed by zero_grad / backward / SGD(momentum, weight decay) (main.py:443-445).  With torch.distributed initialised
     (one process per GPU, backend nccl = RCCL) gradients are averaged with bucketed all-reduces launched as soon as each
-    bucket's last backward kernel has been enqueued, overlapping the rest of backward."""
+    bucket's last backward kernel has been enqueued, overlapping the rest of backward.
 
-    def __init__(self, model, batch, height, width, lr=0.01, momentum=0.9, weight_decay=1e-4, loss_weights=None, use_graph=True):
+    use_graph: replay the step as hipGraphs from the second call on.  Off by default: the step keeps ~650 kernels on three
+    streams in flight from a few ms of host time, and on this stack the graph executor's handling of the cross-stream edges is
+    slower than the plain stream launches (661 vs 679 samples/s for latefusion b=16, 272 vs 288 for multistage b=8, and the
+    data-parallel path loses 2.5 % as five graphs but nothing as plain launches)."""
+
+    def __init__(self, model, batch, height, width, lr=0.01, momentum=0.9, weight_decay=1e-4, loss_weights=None, use_graph=False):
         from .model.multistage_model import ResNet_multistage
         self.model = model
         self.L = lib()

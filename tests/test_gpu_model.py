@@ -263,17 +263,19 @@ def test_data_parallel_path_single_rank(monkeypatch):
     dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
     try:
         monkeypatch.setenv("RD_FORCE_DP", "1")
-        m = build(h, w)
-        ts = HipTrainStep(m, b, h, w, use_graph=True)
-        assert ts.dp and len(ts._pieces()) == len(ts._buckets) + 1
+        m, m2 = build(h, w), build(h, w)
+        ts = HipTrainStep(m, b, h, w, use_graph=True)         # data-parallel path as segment graphs
+        ts2 = HipTrainStep(m2, b, h, w)                       # ... and as plain stream launches (the default)
+        assert ts.dp and ts2.dp and len(ts._pieces()) == len(ts._buckets) + 1
         for it in range(3):
             x, t = make_batch(b, h, w, 300 + it, ref_pixels=h * w)
             l0, _ = ts_ref.step(x.cuda(), t.cuda())
             l1, _ = ts.step(x.cuda(), t.cuda())
+            l2, _ = ts2.step(x.cuda(), t.cuda())
             torch.cuda.synchronize()
-            assert l0.item() == l1.item()
-        for p, q in zip(ref.parameters(), m.parameters()):
-            assert torch.equal(p, q)
+            assert l0.item() == l1.item() == l2.item()
+        for p, q, r in zip(ref.parameters(), m.parameters(), m2.parameters()):
+            assert torch.equal(p, q) and torch.equal(p, r)
     finally:
         dist.destroy_process_group()
 

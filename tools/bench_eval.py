@@ -7,8 +7,8 @@ from radar_depth_amd.model.models import ResNet_latefusion
 from radar_depth_amd.synthetic import make_batch
 torch.manual_seed(0)
 m = ResNet_latefusion(18, "upproj", [450, 800], 4, False).cuda()
-for b in (1, 16):
-    inf = HipInference(m, b, 450, 800)
+for b, g in ((1, True), (1, False), (16, True), (16, False)):
+    inf = HipInference(m, b, 450, 800, use_graph=g)
     x, _ = make_batch(b, 450, 800, 1)
     x = x.cuda()
     for _ in range(5): inf(x)
@@ -18,4 +18,4 @@ for b in (1, 16):
     for _ in range(n): inf(x)
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / n
-    print("eval forward b=%d: %.3f ms/call  %.1f samples/s  (35.47 GFLOP/sample algorithmic -> %.1f TFLOP/s)" % (b, dt * 1e3, b / dt, 35.47e9 * b / dt / 1e12))
+    print(("hipGraph " if g else "eager    ") + "eval forward b=%d: %.3f ms/call  %.1f samples/s  (35.47 GFLOP/sample algorithmic -> %.1f TFLOP/s)" % (b, dt * 1e3, b / dt, 35.47e9 * b / dt / 1e12))
