@@ -19,6 +19,10 @@
 #include <math.h>
 #include <stdlib.h>
 
+#include <mutex>
+#include <string>
+#include <unordered_map>
+
 #include "common.h"
 
 namespace rd {
@@ -654,12 +658,27 @@ extern "C" int rd_gconv_occupancy(const RdConvDesc* d) {
     return -1;
 }
 
+// Plans are a pure function of the descriptor: cached, because the step is issued as ~650 plain launches per iteration and the
+// tile search (tens of microseconds) would otherwise be repeated on every one of them.
 static int plan_query(const RdConvDesc* d, bool allow_split, GconvPlan& pl, RdConvDesc& dd) {
+    struct Entry { GconvPlan pl; RdConvDesc dd; };
+    static std::mutex mu;
+    static std::unordered_map<std::string, Entry> cache;
+    RD_CHECK_ARG(d != nullptr, "gconv: null descriptor");
+    std::string key(reinterpret_cast<const char*>(d), sizeof(RdConvDesc));
+    key.push_back(allow_split ? 1 : 0);
+    {
+        std::lock_guard<std::mutex> lk(mu);
+        auto it = cache.find(key);
+        if (it != cache.end()) { pl = it->second.pl; dd = it->second.dd; return RD_OK; }
+    }
     int rc = validate_desc(d);
     if (rc != RD_OK) return rc;
     dd = *d;
     if (!plan_gconv(dd, pl, allow_split)) { set_error("gconv: no feasible tiling"); return RD_EINVAL; }
     fill_tiles(dd, pl);
+    std::lock_guard<std::mutex> lk(mu);
+    cache.emplace(std::move(key), Entry{pl, dd});
     return RD_OK;
 }
 

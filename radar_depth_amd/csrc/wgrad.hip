@@ -12,7 +12,11 @@
 // rd_wgrad_reduce sums in a fixed order (deterministic, no atomics) straight into OIHW gradients.
 #include <stdlib.h>
 
+#include <mutex>
+#include <string>
 #include <type_traits>
+#include <unordered_map>
+#include <vector>
 
 #include "common.h"
 
@@ -703,7 +707,24 @@ static bool upproj_split(const RdConvDesc& d) {
     for (int i = 0; i < 4; ++i) nt += d.phase[i].n_taps;
     return nt == 25 && d.phase[0].n_taps == 9;
 }
+static int plan_any_uncached(const RdConvDesc& d, WgradPlan& pl);
+// plans are a pure function of the descriptor: cached (the tile search would otherwise run on every launch of every step)
 static int plan_any(const RdConvDesc& d, WgradPlan& pl) {
+    static std::mutex mu;
+    static std::unordered_map<std::string, WgradPlan> cache;
+    std::string key(reinterpret_cast<const char*>(&d), sizeof(RdConvDesc));
+    {
+        std::lock_guard<std::mutex> lk(mu);
+        auto it = cache.find(key);
+        if (it != cache.end()) { pl = it->second; return RD_OK; }
+    }
+    const int rc = plan_any_uncached(d, pl);
+    if (rc != RD_OK) return rc;
+    std::lock_guard<std::mutex> lk(mu);
+    cache.emplace(std::move(key), pl);
+    return RD_OK;
+}
+static int plan_any_uncached(const RdConvDesc& d, WgradPlan& pl) {
     if (upproj_split(d)) {
         bool ok = plan_wgrad(d, pl, nullptr, 0) == RD_OK && pl.pitch > 0;
         for (int ph = 1; ok && ph < 4; ++ph) {
@@ -765,11 +786,40 @@ extern "C" int rd_wgrad(const RdConvDesc* d, const float* in, const float* dout,
     static const char* dbg = getenv("RD_WGRAD_DEBUG");
     int rc = plan_any(*d, pl);
     if (rc != RD_OK) return rc;
-    if (pl.per_phase) {
-        const WgradPlan pl0 = pl;
-        for (int ph = 0; ph < 4; ++ph) {
-            rc = plan_wgrad(*d, pl, &a, ph, &pl0);
+    // the launch records (plan + kernel arguments minus the tensor pointers) are cached per descriptor like the plans
+    struct Launch { WgradPlan pl; WgradArgs a; };
+    static std::mutex mu;
+    static std::unordered_map<std::string, std::vector<Launch>> cache;
+    const std::string key(reinterpret_cast<const char*>(d), sizeof(RdConvDesc));
+    const std::vector<Launch>* recs = nullptr;
+    {
+        std::lock_guard<std::mutex> lk(mu);
+        auto it = cache.find(key);
+        if (it != cache.end()) recs = &it->second;      // (references into an unordered_map stay valid across inserts)
+    }
+    if (!recs) {
+        std::vector<Launch> v;
+        if (pl.per_phase) {
+            const WgradPlan pl0 = pl;
+            for (int ph = 0; ph < 4; ++ph) {
+                Launch L;
+                rc = plan_wgrad(*d, L.pl, &L.a, ph, &pl0);
+                if (rc != RD_OK) return rc;
+                v.push_back(L);
+            }
+        } else {
+            Launch L;
+            rc = plan_wgrad(*d, L.pl, &L.a);
             if (rc != RD_OK) return rc;
+            L.pl.per_phase = 0;
+            v.push_back(L);
+        }
+        std::lock_guard<std::mutex> lk(mu);
+        recs = &cache.emplace(key, std::move(v)).first->second;
+    }
+    if (pl.per_phase) {
+        for (const Launch& L : *recs) {
+            pl = L.pl; a = L.a;
             a.in = in; a.dout = dout; a.slabs = slabs; a.debug = dbg ? atoi(dbg) : 0;
             if (!pl.layoutA && pl.lds < (size_t)4 * 16 * 64 * 4) pl.lds = (size_t)4 * 16 * 64 * 4;
             rc = launch_pitch(pl, a, pl.n_cib * pl.n_cob * pl.n_splits, s);
@@ -777,8 +827,7 @@ extern "C" int rd_wgrad(const RdConvDesc* d, const float* in, const float* dout,
         }
         return RD_OK;
     }
-    rc = plan_wgrad(*d, pl, &a);
-    if (rc != RD_OK) return rc;
+    pl = (*recs)[0].pl; a = (*recs)[0].a;
     a.in = in; a.dout = dout; a.slabs = slabs; a.debug = dbg ? atoi(dbg) : 0;
     for (int gi = 0; gi < pl.n_tg; ++gi) RD_CHECK_ARG(a.tg[gi].n == pl.TG, "wgrad: tap group %d has %d taps, expected %d", gi, a.tg[gi].n, pl.TG);
     // layout-B epilogue reuses the head of LDS for its cross-wave reduction
