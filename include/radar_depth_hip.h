@@ -218,6 +218,13 @@ int rd_bnact_maxpool_fwd(const float* x, const float* scale, const float* shift,
 int rd_bnact_maxpool_bwd(const float* dy, int32_t lddy, const uint8_t* idx, const float* x,
                          const float* scale, const float* shift, int32_t act, int32_t N, int32_t H,
                          int32_t W, int32_t C, float* g, void* stream);
+/* Same pass, plus the stem BatchNorm's backward sums (sum g, sum g*(x - mean)) as per-block partials
+ * [rd_bnact_maxpool_bwd_tiles(N,H,W,C)][3][C] for rd_bn_bwd_apply(which = 1): g and x are in registers here, so the separate
+ * rd_bn_bwd_reduce pass over the two largest tensors of the network is not needed.  C/4 must divide 256. */
+int rd_bnact_maxpool_bwd_tiles(int32_t N, int32_t H, int32_t W, int32_t C);
+int rd_bnact_maxpool_bwd_stats(const float* dy, int32_t lddy, const uint8_t* idx, const float* x, const float* scale,
+                               const float* shift, int32_t act, int32_t N, int32_t H, int32_t W, int32_t C, float* g,
+                               const float* mean, float* red_partial, void* stream);
 
 /* ---------------------------------------------------------------------------------------
  * Head: conv3 (3x3, C->1, models.py:587,661) and bilinear align_corners=True resize

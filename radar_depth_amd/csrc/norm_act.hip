@@ -274,14 +274,21 @@ __global__ __launch_bounds__(256) void bnact_maxpool_fwd_kernel(const float* __r
     }
 }
 
-// g[n,h,w,c] = act'(scale*x+shift) * sum over windows whose argmax is (h,w) of dy
+// g[n,h,w,c] = act'(scale*x+shift) * sum over windows whose argmax is (h,w) of dy.
+// part != nullptr: also the BatchNorm-backward sums of the stem (sum g, sum g*(x - mean)) per block, [block][3][C] like
+// bn_bwd_reduce_kernel -- g and x are in registers here, so the separate reduce pass over both (the largest tensors of the
+// network) disappears.  Needs 256 % (C/4) == 0 so that a thread keeps its channel quad across the grid-stride loop.
 __global__ __launch_bounds__(256) void bnact_maxpool_bwd_kernel(const float* __restrict__ dy, int lddy,
                                                                 const uint8_t* __restrict__ idx, const float* __restrict__ x,
                                                                 const float* __restrict__ scale, const float* __restrict__ shift,
                                                                 int act, int N, int H, int W, int C, int Ho, int Wo,
-                                                                float* __restrict__ g) {
+                                                                float* __restrict__ g, const float* __restrict__ mean,
+                                                                float* __restrict__ part) {
+    extern __shared__ float sm[];
     const int Q = C >> 2;
     const int64_t total = (int64_t)N * H * W * Q;
+    float4 acc[3] = {make_float4(0, 0, 0, 0), make_float4(0, 0, 0, 0), make_float4(0, 0, 0, 0)};
+    const float4 mu = part ? *reinterpret_cast<const float4*>(mean + (threadIdx.x % Q) * 4) : make_float4(0, 0, 0, 0);
     for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
         const int c = (int)(e % Q) * 4;
         int64_t r = e / Q;
@@ -317,7 +324,13 @@ __global__ __launch_bounds__(256) void bnact_maxpool_bwd_kernel(const float* __r
         o4.z = s[2] * act_grad_from_out(fmaf(a.z, v.z, b.z), act);
         o4.w = s[3] * act_grad_from_out(fmaf(a.w, v.w, b.w), act);
         *reinterpret_cast<float4*>(g + i) = o4;
+        if (part) {
+            acc[0].x += o4.x; acc[0].y += o4.y; acc[0].z += o4.z; acc[0].w += o4.w;
+            acc[1].x += o4.x * (v.x - mu.x); acc[1].y += o4.y * (v.y - mu.y);
+            acc[1].z += o4.z * (v.z - mu.z); acc[1].w += o4.w * (v.w - mu.w);
+        }
     }
+    if (part) block_reduce_store<3>(acc, Q, 256 / Q, threadIdx.x % Q, threadIdx.x / Q, true, part + (size_t)blockIdx.x * 3 * C, C, sm);
 }
 
 static int ew_grid(int64_t elems) {
@@ -451,7 +464,28 @@ extern "C" int rd_bnact_maxpool_bwd(const float* dy, int32_t lddy, const uint8_t
     RD_CHECK_ARG(dy && idx && x && scale && shift && g && C % 4 == 0 && lddy % 4 == 0, "bnact_maxpool_bwd: bad arguments");
     const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
     hipLaunchKernelGGL(bnact_maxpool_bwd_kernel, dim3(ew_grid((int64_t)N * H * W * (C / 4))), dim3(256), 0,
-                       static_cast<hipStream_t>(stream), dy, lddy, idx, x, scale, shift, act, N, H, W, C, Ho, Wo, g);
+                       static_cast<hipStream_t>(stream), dy, lddy, idx, x, scale, shift, act, N, H, W, C, Ho, Wo, g,
+                       (const float*)nullptr, (float*)nullptr);
+    RD_CHECK_LAUNCH("bnact_maxpool_bwd_kernel");
+    return RD_OK;
+}
+
+// Same, and the stem BatchNorm's backward sums in the same pass: red_partial [rd_bnact_maxpool_bwd_tiles(...)][3][C]
+// (slot 0 = sum g, slot 1 = sum g*(x - mean)), consumed by rd_bn_bwd_apply(which = 1).
+extern "C" int rd_bnact_maxpool_bwd_tiles(int32_t N, int32_t H, int32_t W, int32_t C) {
+    return ew_grid((int64_t)N * H * W * (C / 4));
+}
+extern "C" int rd_bnact_maxpool_bwd_stats(const float* dy, int32_t lddy, const uint8_t* idx, const float* x, const float* scale,
+                                          const float* shift, int32_t act, int32_t N, int32_t H, int32_t W, int32_t C, float* g,
+                                          const float* mean, float* red_partial, void* stream) {
+    RD_CHECK_ARG(dy && idx && x && scale && shift && g && mean && red_partial && C % 4 == 0 && lddy % 4 == 0,
+                 "bnact_maxpool_bwd_stats: bad arguments");
+    RD_CHECK_ARG(C >= 4 && 256 % (C / 4) == 0, "bnact_maxpool_bwd_stats: C/4 = %d must divide 256", C / 4);
+    const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
+    const int Q = C / 4, RL = 256 / Q;
+    hipLaunchKernelGGL(bnact_maxpool_bwd_kernel, dim3(ew_grid((int64_t)N * H * W * (C / 4))), dim3(256),
+                       (size_t)RL * 3 * C * sizeof(float), static_cast<hipStream_t>(stream), dy, lddy, idx, x, scale, shift, act, N, H,
+                       W, C, Ho, Wo, g, mean, red_partial);
     RD_CHECK_LAUNCH("bnact_maxpool_bwd_kernel");
     return RD_OK;
 }

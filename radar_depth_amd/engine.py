@@ -383,10 +383,14 @@ class LateFusionPlan:
         N, H, W = self.N, self.H, self.W
         raw, co, cout, cin = ctx["raw"], ctx["co"], ctx["cout"], ctx["cin"]
         g = self.act(N, ctx["Hc"], ctx["Wc"], cout)
-        self.op(self.bwd, ctx["name"] + ".pool_bwd", self.L.rd_bnact_maxpool_bwd, dpooled.ptr, dpooled.ld, _p(ctx["idx"]), raw.ptr,
-                _p(co["scale"]), _p(co["shift"]), ctx["act"], N, ctx["Hc"], ctx["Wc"], cout, g.ptr, self.stream)
-        # BN backward on g (activation derivative already applied by the pooling gather)
-        dx, _ = self.bn_join_bwd(ctx["name"] + ".bn", g, None, ACT_NONE, raw, co)
+        # the pooling gather applies the activation derivative and, in the same pass, produces the BatchNorm-backward sums
+        # (g and x are in registers there): no separate reduce pass over the two largest tensors of the network
+        tiles = self.L.rd_bnact_maxpool_bwd_tiles(N, ctx["Hc"], ctx["Wc"], cout)
+        red = self.buf(tiles, 3, cout)
+        self.op(self.bwd, ctx["name"] + ".pool_bwd", self.L.rd_bnact_maxpool_bwd_stats, dpooled.ptr, dpooled.ld, _p(ctx["idx"]), raw.ptr,
+                _p(co["scale"]), _p(co["shift"]), ctx["act"], N, ctx["Hc"], ctx["Wc"], cout, g.ptr, _p(co["mean"]), _p(red), self.stream)
+        dx = self.act(raw.N, raw.H, raw.W, cout)
+        self._bn_apply(ctx["name"] + ".bn.bn1", g, raw, red, tiles, 1, co, dx)
         nws = self.L.rd_stem_wgrad_workspace_floats(N, H, W, cin, cout)
         ws = self.buf(int(nws))
         cur = self.streams.index(self._s) if self._s in self.streams else 0

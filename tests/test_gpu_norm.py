@@ -131,6 +131,20 @@ def test_bnact_maxpool(N, H, W, Cc, act):
     assert _rel(Y.permute(0, 3, 1, 2).cpu(), y.detach()) < 1e-6
     want_g = x.grad / sc.view(1, -1, 1, 1)          # kernel returns the gradient w.r.t. the BN output
     assert _rel(G.permute(0, 3, 1, 2).cpu(), want_g) < 1e-5
+    # the variant that also produces the stem BatchNorm's backward sums: same g bit for bit, sums as the separate reduce pass
+    mean = torch.randn(Cc, generator=g).to(dev)
+    tiles = L.rd_bnact_maxpool_bwd_tiles(N, H, W, Cc)
+    red = torch.zeros(tiles, 3, Cc, device=dev)
+    G2 = torch.empty(N, H, W, Cc, device=dev)
+    check(L.rd_bnact_maxpool_bwd_stats(ptr(DY), Cc, ptr(idx), ptr(X), ptr(SC), ptr(SH), act, N, H, W, Cc, ptr(G2), ptr(mean), ptr(red),
+                                       current_stream()), "poolb_stats")
+    torch.cuda.synchronize()
+    assert torch.equal(G2, G)
+    g64, x64 = G.double().reshape(-1, Cc), X.double().reshape(-1, Cc)
+    s0, s1 = g64.sum(0), (g64 * (x64 - mean.double())).sum(0)
+    got = red.double().sum(0)
+    scale_ = g64.abs().sum(0).max().item() + 1e-30
+    assert (got[0] - s0).abs().max().item() / scale_ < 1e-6 and (got[1] - s1).abs().max().item() / scale_ < 1e-5
 
 
 @pytest.mark.parametrize("N,H,W,Ho,Wo", [(2, 64, 96, 97, 161), (1, 240, 400, 450, 800), (2, 5, 7, 5, 7)])
