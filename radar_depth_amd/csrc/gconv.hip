@@ -558,7 +558,12 @@ static bool plan_gconv(const RdConvDesc& d, GconvPlan& best, bool allow_split = 
                 const double wgs1 = (double)d.N * cdiv(P.lh, TH) * cdiv(P.lw, TW) * n_cot * d.n_phases;
                 const double ncu = (double)num_cus();
                 static const char* nosplit = getenv("RD_GCONV_NOSPLIT");
-                const bool can_split = !nosplit && allow_split && d.n_phases == 1 && d.out_stride == 1 && d.ldo == d.Cout && d.Cout <= 1024;
+                // (multi-phase descriptors qualify when their phases tile the whole output, e.g. the four UpProj / stride-2
+                //  dgrad parity phases: every element of the partial buffers is then written before the combine reads it)
+                int64_t covered = 0;
+                for (int i = 0; i < d.n_phases; ++i) covered += (int64_t)d.phase[i].lh * d.phase[i].lw;
+                const bool hole_free = d.n_phases == 1 ? d.out_stride == 1 : covered == (int64_t)d.Ho * d.Wo;
+                const bool can_split = !nosplit && allow_split && hole_free && d.ldo == d.Cout && d.Cout <= 1024;
                 double base = score;
                 for (int ksp = 1; ksp <= (can_split ? 4 : 1); ksp *= 2) {
                     if (d.Cin % (ksp * ckp) != 0) continue;
