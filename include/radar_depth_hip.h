@@ -207,6 +207,18 @@ int rd_bn_bwd_apply_x(const float* dy, int32_t lddy, const float* x, int32_t ldx
                       const float* gamma, const float* mean, const float* invstd, const float* scale, const float* shift,
                       int32_t act, float* dgamma, float* dbeta, float* coef_ws, float* dx, int32_t lddx, int64_t M, int32_t C,
                       void* stream);
+/* out = act(bn1(x1) + bn2(x2)) (down-sampling blocks, UpProj joins): the same two passes for both operands at once -- the
+ * activation output is not read, the masked gradient is not written, dy is read once per pass.  red_partial as for
+ * rd_bn_bwd_reduce ([tiles][3][C]); coef_ws6: 6*C floats. */
+int rd_bn_bwd_reduce_x2(const float* dy, int32_t lddy, const float* x1, int32_t ldx1, const float* mean1, const float* scale1,
+                        const float* shift1, const float* x2, int32_t ldx2, const float* mean2, const float* scale2,
+                        const float* shift2, int64_t M, int32_t C, int32_t act, float* red_partial, void* stream);
+int rd_bn_bwd_apply_x2(const float* dy, int32_t lddy, const float* x1, int32_t ldx1, const float* x2, int32_t ldx2,
+                       const float* red_partial, int32_t n_tiles, const float* gamma1, const float* mean1, const float* invstd1,
+                       const float* scale1, const float* shift1, const float* gamma2, const float* mean2, const float* invstd2,
+                       const float* scale2, const float* shift2, int32_t act, float* dgamma1, float* dbeta1, float* dgamma2,
+                       float* dbeta2, float* coef_ws6, float* dx1, int32_t lddx1, float* dx2, int32_t lddx2, int64_t M,
+                       int32_t C, void* stream);
 
 /* MaxPool2d(3,2,1) fused with the stem's BN affine + activation (models.py:634-636,644-646):
  * y = maxpool(act(scale*x+shift)); idx = argmax position 0..8 in the window. */

@@ -132,7 +132,8 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restr
                                                             const float* __restrict__ m1, const float* __restrict__ x2, int ldx2,
                                                             const float* __restrict__ m2, float* __restrict__ g, int ldg,
                                                             int64_t M, int C, int act, int RPB, float* __restrict__ part,
-                                                            const float* __restrict__ s1, const float* __restrict__ t1) {
+                                                            const float* __restrict__ s1, const float* __restrict__ t1,
+                                                            const float* __restrict__ s2, const float* __restrict__ t2) {
     extern __shared__ float sm[];
     const int Q = C >> 2, RL = 256 / Q;
     const int q = threadIdx.x % Q, rl = threadIdx.x / Q;
@@ -146,14 +147,23 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restr
         const bool from_x = act != RD_ACT_NONE && !y;
         const float4 sa = from_x ? *reinterpret_cast<const float4*>(s1 + c) : make_float4(0, 0, 0, 0);
         const float4 sb = from_x ? *reinterpret_cast<const float4*>(t1 + c) : make_float4(0, 0, 0, 0);
+        const bool from_x2 = from_x && x2 && s2;        // act(bn1(x1) + bn2(x2)): both operands are read anyway
+        const float4 sa2 = from_x2 ? *reinterpret_cast<const float4*>(s2 + c) : make_float4(0, 0, 0, 0);
+        const float4 sb2 = from_x2 ? *reinterpret_cast<const float4*>(t2 + c) : make_float4(0, 0, 0, 0);
         for (int64_t r = r0 + rl; r < r1; r += RL) {
             float4 gv = *reinterpret_cast<const float4*>(dy + r * lddy + c);
-            float4 v = make_float4(0, 0, 0, 0);
+            float4 v = make_float4(0, 0, 0, 0), v2 = make_float4(0, 0, 0, 0);
             if (x1) v = *reinterpret_cast<const float4*>(x1 + r * ldx1 + c);
+            if (x2) v2 = *reinterpret_cast<const float4*>(x2 + r * ldx2 + c);
             if (act != RD_ACT_NONE) {
                 float4 yv;
-                if (from_x) yv = make_float4(fmaf(sa.x, v.x, sb.x), fmaf(sa.y, v.y, sb.y), fmaf(sa.z, v.z, sb.z), fmaf(sa.w, v.w, sb.w));
-                else yv = *reinterpret_cast<const float4*>(y + r * ldy + c);
+                if (from_x) {
+                    yv = make_float4(fmaf(sa.x, v.x, sb.x), fmaf(sa.y, v.y, sb.y), fmaf(sa.z, v.z, sb.z), fmaf(sa.w, v.w, sb.w));
+                    if (from_x2) {     // same order of operations as bn_act_kernel: z1 + fma(s2, x2, t2)
+                        yv.x += fmaf(sa2.x, v2.x, sb2.x); yv.y += fmaf(sa2.y, v2.y, sb2.y);
+                        yv.z += fmaf(sa2.z, v2.z, sb2.z); yv.w += fmaf(sa2.w, v2.w, sb2.w);
+                    }
+                } else yv = *reinterpret_cast<const float4*>(y + r * ldy + c);
                 gv.x *= act_grad_from_out(yv.x, act); gv.y *= act_grad_from_out(yv.y, act);
                 gv.z *= act_grad_from_out(yv.z, act); gv.w *= act_grad_from_out(yv.w, act);
             }
@@ -164,9 +174,8 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restr
                 acc[1].z += gv.z * (v.z - mu1.z); acc[1].w += gv.w * (v.w - mu1.w);
             }
             if (x2) {
-                const float4 v = *reinterpret_cast<const float4*>(x2 + r * ldx2 + c);
-                acc[2].x += gv.x * (v.x - mu2.x); acc[2].y += gv.y * (v.y - mu2.y);
-                acc[2].z += gv.z * (v.z - mu2.z); acc[2].w += gv.w * (v.w - mu2.w);
+                acc[2].x += gv.x * (v2.x - mu2.x); acc[2].y += gv.y * (v2.y - mu2.y);
+                acc[2].z += gv.z * (v2.z - mu2.z); acc[2].w += gv.w * (v2.w - mu2.w);
             }
         }
     }
@@ -231,6 +240,43 @@ __global__ __launch_bounds__(256) void bn_bwd_dx_kernel(const float* __restrict_
         o.z = fmaf(A.z, gv.z, fmaf(B.z, xv.z - mu.z, K.z));
         o.w = fmaf(A.w, gv.w, fmaf(B.w, xv.w - mu.w, K.w));
         *reinterpret_cast<float4*>(dx + r * lddx + c) = o;
+    }
+}
+
+// out = act(bn1(x1) + bn2(x2)): both input gradients in one pass from the raw output gradient (the masked gradient is never
+// materialised, dy is read once): dx_i = A_i*g + B_i*(x_i - mean_i) + K_i with g = dy * act'(s1*x1+t1 + s2*x2+t2)
+__global__ __launch_bounds__(256) void bn_bwd_dx2_kernel(const float* __restrict__ dy, int lddy, const float* __restrict__ x1, int ldx1,
+                                                         const float* __restrict__ x2, int ldx2, const float* __restrict__ m1,
+                                                         const float* __restrict__ m2, const float* __restrict__ coef1,
+                                                         const float* __restrict__ coef2, const float* __restrict__ s1,
+                                                         const float* __restrict__ t1, const float* __restrict__ s2,
+                                                         const float* __restrict__ t2, int act, float* __restrict__ dx1, int lddx1,
+                                                         float* __restrict__ dx2, int lddx2, int64_t M, int C) {
+    const int Q = C >> 2;
+    const int64_t total = M * Q;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t r = e / Q;
+        const int c = (int)(e - r * Q) * 4;
+        float4 gv = *reinterpret_cast<const float4*>(dy + r * lddy + c);
+        const float4 v1 = *reinterpret_cast<const float4*>(x1 + r * ldx1 + c), v2 = *reinterpret_cast<const float4*>(x2 + r * ldx2 + c);
+        const float4 a1 = *reinterpret_cast<const float4*>(s1 + c), b1 = *reinterpret_cast<const float4*>(t1 + c);
+        const float4 a2 = *reinterpret_cast<const float4*>(s2 + c), b2 = *reinterpret_cast<const float4*>(t2 + c);
+        gv.x *= act_grad_from_out(fmaf(a1.x, v1.x, b1.x) + fmaf(a2.x, v2.x, b2.x), act);
+        gv.y *= act_grad_from_out(fmaf(a1.y, v1.y, b1.y) + fmaf(a2.y, v2.y, b2.y), act);
+        gv.z *= act_grad_from_out(fmaf(a1.z, v1.z, b1.z) + fmaf(a2.z, v2.z, b2.z), act);
+        gv.w *= act_grad_from_out(fmaf(a1.w, v1.w, b1.w) + fmaf(a2.w, v2.w, b2.w), act);
+        const float4 mu1 = *reinterpret_cast<const float4*>(m1 + c), mu2 = *reinterpret_cast<const float4*>(m2 + c);
+        const float4 A1 = *reinterpret_cast<const float4*>(coef1 + c), B1 = *reinterpret_cast<const float4*>(coef1 + C + c),
+                     K1 = *reinterpret_cast<const float4*>(coef1 + 2 * C + c);
+        const float4 A2 = *reinterpret_cast<const float4*>(coef2 + c), B2 = *reinterpret_cast<const float4*>(coef2 + C + c),
+                     K2 = *reinterpret_cast<const float4*>(coef2 + 2 * C + c);
+        float4 o;
+        o.x = fmaf(A1.x, gv.x, fmaf(B1.x, v1.x - mu1.x, K1.x)); o.y = fmaf(A1.y, gv.y, fmaf(B1.y, v1.y - mu1.y, K1.y));
+        o.z = fmaf(A1.z, gv.z, fmaf(B1.z, v1.z - mu1.z, K1.z)); o.w = fmaf(A1.w, gv.w, fmaf(B1.w, v1.w - mu1.w, K1.w));
+        *reinterpret_cast<float4*>(dx1 + r * lddx1 + c) = o;
+        o.x = fmaf(A2.x, gv.x, fmaf(B2.x, v2.x - mu2.x, K2.x)); o.y = fmaf(A2.y, gv.y, fmaf(B2.y, v2.y - mu2.y, K2.y));
+        o.z = fmaf(A2.z, gv.z, fmaf(B2.z, v2.z - mu2.z, K2.z)); o.w = fmaf(A2.w, gv.w, fmaf(B2.w, v2.w - mu2.w, K2.w));
+        *reinterpret_cast<float4*>(dx2 + r * lddx2 + c) = o;
     }
 }
 
@@ -392,15 +438,16 @@ extern "C" int rd_bn_act(const float* x1, int32_t ldx1, const float* scale1, con
 static int bn_bwd_reduce_impl(const float* dy, int32_t lddy, const float* y, int32_t ldy, const float* x1, int32_t ldx1,
                               const float* mean1, const float* x2, int32_t ldx2, const float* mean2, float* g, int32_t ldg,
                               int64_t M, int32_t C, int32_t act, float* red_partial, const float* scale1, const float* shift1,
-                              void* stream) {
+                              void* stream, const float* scale2 = nullptr, const float* shift2 = nullptr) {
     RD_CHECK_ARG(dy && red_partial && M > 0 && C >= 4 && C % 4 == 0 && C <= 1024, "bn_bwd_reduce: bad arguments");
-    RD_CHECK_ARG(act == RD_ACT_NONE || y || (scale1 && shift1 && x1 && !x2), "bn_bwd_reduce: activation needs y (or scale/shift of a lone x1)");
+    RD_CHECK_ARG(act == RD_ACT_NONE || y || (scale1 && shift1 && x1 && (!x2 || (scale2 && shift2))),
+                 "bn_bwd_reduce: activation needs y (or the scale/shift of every operand)");
     RD_CHECK_ARG((!x1 || mean1) && (!x2 || mean2), "bn_bwd_reduce: x without mean");
     const int RPB = rows_per_block(M), grid = (int)cdiv64(M, RPB);
     const int Q = C / 4, RL = 256 / Q;
     hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(grid), dim3(256), (size_t)RL * 3 * C * sizeof(float),
                        static_cast<hipStream_t>(stream), dy, lddy, y, ldy, x1, ldx1, mean1, x2, ldx2, mean2, g, ldg, M, C, act, RPB,
-                       red_partial, scale1, shift1);
+                       red_partial, scale1, shift1, scale2, shift2);
     RD_CHECK_LAUNCH("bn_bwd_reduce_kernel");
     return RD_OK;
 }
@@ -428,6 +475,36 @@ extern "C" int rd_bn_bwd_apply(const float* g, int32_t ldg, const float* x, int3
     hipLaunchKernelGGL(bn_bwd_dx_kernel, dim3(ew_grid(M * (C / 4))), dim3(256), 0, s, g, ldg, x, ldx, mean, coef_ws, dx, lddx, M, C,
                        (const float*)nullptr, (const float*)nullptr, RD_ACT_NONE);
     RD_CHECK_LAUNCH("bn_bwd_dx_kernel");
+    return RD_OK;
+}
+
+// out = act(bn1(x1) + bn2(x2)) (downsample blocks, UpProj joins): sums and both input gradients straight from the raw output
+// gradient -- the activation output is not read, the masked gradient is not written, dy is read once per pass.
+extern "C" int rd_bn_bwd_reduce_x2(const float* dy, int32_t lddy, const float* x1, int32_t ldx1, const float* mean1, const float* scale1,
+                                   const float* shift1, const float* x2, int32_t ldx2, const float* mean2, const float* scale2,
+                                   const float* shift2, int64_t M, int32_t C, int32_t act, float* red_partial, void* stream) {
+    RD_CHECK_ARG(x1 && x2 && scale1 && shift1 && scale2 && shift2 && act != RD_ACT_NONE, "bn_bwd_reduce_x2: bad arguments");
+    return bn_bwd_reduce_impl(dy, lddy, nullptr, 0, x1, ldx1, mean1, x2, ldx2, mean2, nullptr, 0, M, C, act, red_partial, scale1, shift1, stream,
+                              scale2, shift2);
+}
+extern "C" int rd_bn_bwd_apply_x2(const float* dy, int32_t lddy, const float* x1, int32_t ldx1, const float* x2, int32_t ldx2,
+                                  const float* red_partial, int32_t n_tiles, const float* gamma1, const float* mean1, const float* invstd1,
+                                  const float* scale1, const float* shift1, const float* gamma2, const float* mean2, const float* invstd2,
+                                  const float* scale2, const float* shift2, int32_t act, float* dgamma1, float* dbeta1, float* dgamma2,
+                                  float* dbeta2, float* coef_ws6, float* dx1, int32_t lddx1, float* dx2, int32_t lddx2, int64_t M,
+                                  int32_t C, void* stream) {
+    RD_CHECK_ARG(dy && x1 && x2 && red_partial && gamma1 && gamma2 && mean1 && mean2 && invstd1 && invstd2 && scale1 && shift1 && scale2 &&
+                     shift2 && coef_ws6 && dx1 && dx2 && M > 0 && C % 4 == 0, "bn_bwd_apply_x2: bad arguments");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    hipLaunchKernelGGL(bn_bwd_coeffs_kernel, dim3(C), dim3(256), 0, s, red_partial, n_tiles, C, 1, (double)M, gamma1, invstd1, dgamma1, dbeta1,
+                       coef_ws6);
+    RD_CHECK_LAUNCH("bn_bwd_coeffs_kernel");
+    hipLaunchKernelGGL(bn_bwd_coeffs_kernel, dim3(C), dim3(256), 0, s, red_partial, n_tiles, C, 2, (double)M, gamma2, invstd2, dgamma2, dbeta2,
+                       coef_ws6 + 3 * C);
+    RD_CHECK_LAUNCH("bn_bwd_coeffs_kernel");
+    hipLaunchKernelGGL(bn_bwd_dx2_kernel, dim3(ew_grid(M * (C / 4))), dim3(256), 0, s, dy, lddy, x1, ldx1, x2, ldx2, mean1, mean2, coef_ws6,
+                       coef_ws6 + 3 * C, scale1, shift1, scale2, shift2, act, dx1, lddx1, dx2, lddx2, M, C);
+    RD_CHECK_LAUNCH("bn_bwd_dx2_kernel");
     return RD_OK;
 }
 

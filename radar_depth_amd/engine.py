@@ -323,6 +323,22 @@ class LateFusionPlan:
             dx1 = self.act(x1.N, x1.H, x1.W, Cc)
             self._bn_apply_x(name + ".bn1", dy, x1, red, tiles, co1, act, dx1)
             return dx1, None
+        if co2 is not None and act != ACT_NONE:
+            # act(bn1(x1) + bn2(x2)): same idea for both operands at once (y not read, g not materialised, dy read once per pass)
+            self.op(self.bwd, name + ".bwd_reduce", self.L.rd_bn_bwd_reduce_x2, dy.ptr, dy.ld, x1.ptr, x1.ld, _p(co1["mean"]),
+                    _p(co1["scale"]), _p(co1["shift"]), x2.ptr, x2.ld, _p(co2["mean"]), _p(co2["scale"]), _p(co2["shift"]),
+                    C.c_int64(M), Cc, act, _p(red), self.stream)
+            dx1 = self.act(x1.N, x1.H, x1.W, Cc)
+            if dx2 is None:
+                dx2 = self.act(x2.N, x2.H, x2.W, Cc)
+            b1, b2 = co1["bn"], co2["bn"]
+            coef = self.buf(6 * Cc)
+            self.op(self.bwd, name + ".bwd_apply", self.L.rd_bn_bwd_apply_x2, dy.ptr, dy.ld, x1.ptr, x1.ld, x2.ptr, x2.ld, _p(red), tiles,
+                    _p(b1.weight), _p(co1["mean"]), _p(co1["invstd"]), _p(co1["scale"]), _p(co1["shift"]),
+                    _p(b2.weight), _p(co2["mean"]), _p(co2["invstd"]), _p(co2["scale"]), _p(co2["shift"]), act,
+                    _p(self.grad_of(b1.weight)), _p(self.grad_of(b1.bias)), _p(self.grad_of(b2.weight)), _p(self.grad_of(b2.bias)),
+                    _p(coef), dx1.ptr, dx1.ld, dx2.ptr, dx2.ld, C.c_int64(M), Cc, self.stream)
+            return dx1, dx2
         # with no activation g == dy: skip the copy and let the apply pass read dy directly
         g = self.act(x1.N, x1.H, x1.W, Cc) if act != ACT_NONE else dy
         if True:

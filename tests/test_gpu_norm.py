@@ -102,6 +102,19 @@ def test_bn_forward_backward(M, Cc, act, res):
                                 ptr(DX), Cc, C.c_int64(M), Cc, current_stream()), "apply2")
         torch.cuda.synchronize()
         assert _rel(dG.cpu(), gam2.grad) < 5e-5 and _rel(DX.cpu(), x2.grad) < 5e-5
+        # the two-operand pair that reads neither y nor a materialised g: same sums bit for bit, same gradients
+        red2 = torch.zeros(tiles, 3, Cc, device=dev)
+        check(L.rd_bn_bwd_reduce_x2(ptr(DY), Cc, ptr(X1), Cc, ptr(mean1), ptr(sc1), ptr(sh1), ptr(X2), Cc, ptr(mean2), ptr(sc2), ptr(sh2),
+                                    C.c_int64(M), Cc, act, ptr(red2), current_stream()), "reduce_x2")
+        dg1, db1, dg2, db2 = (torch.empty(Cc, device=dev) for _ in range(4))
+        coef6, DX1, DX2 = torch.empty(6 * Cc, device=dev), torch.empty(M, Cc, device=dev), torch.empty(M, Cc, device=dev)
+        check(L.rd_bn_bwd_apply_x2(ptr(DY), Cc, ptr(X1), Cc, ptr(X2), Cc, ptr(red2), tiles, ptr(G1), ptr(mean1), ptr(inv1), ptr(sc1), ptr(sh1),
+                                   ptr(G2), ptr(mean2), ptr(inv2), ptr(sc2), ptr(sh2), act, ptr(dg1), ptr(db1), ptr(dg2), ptr(db2), ptr(coef6),
+                                   ptr(DX1), Cc, ptr(DX2), Cc, C.c_int64(M), Cc, current_stream()), "apply_x2")
+        torch.cuda.synchronize()
+        assert torch.equal(red2, red)
+        assert _rel(DX1.cpu(), x1.grad) < 5e-5 and _rel(DX2.cpu(), x2.grad) < 5e-5
+        assert _rel(dg1.cpu(), gam1.grad) < 5e-5 and _rel(dg2.cpu(), gam2.grad) < 5e-5 and _rel(db1.cpu(), bet1.grad) < 2e-5
     elif res == "id":
         assert _rel(Gt.cpu(), x2.grad) < 1e-6
 

@@ -50,7 +50,9 @@ def test_dry_run_plan_structure():
     n_reduce = sum(1 for n in names if n.endswith(".wreduce")) + 2 + 1      # + two stems + conv3 (own kernels)
     assert n_reduce == n_w
     n_bn = sum(1 for n, p in m.named_parameters() if n.endswith(".bias"))
-    assert sum(1 for n in names if n.endswith(".bwd_apply")) == n_bn
+    # one apply launch per BatchNorm, except the ten two-operand joins (4 UpProj + 3 + 3 down-sampling blocks), whose single
+    # launch produces both input gradients
+    assert sum(1 for n in names if n.endswith(".bwd_apply")) == n_bn - 10
 
 
 
