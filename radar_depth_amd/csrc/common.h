@@ -62,6 +62,12 @@ __device__ __forceinline__ void glds16(const float* gsrc, float* lds_wave_base) 
                                                (unsigned)(size_t)lds_wave_base), 16, 0, 0);
 }
 
+// Wait for this wave's outstanding global_load_lds copies.  hipcc usually emits the vmcnt(0) itself in front of the s_barrier
+// that follows a glds, but not when the copies were issued in an earlier loop iteration (seen in the pipelined gconv loop:
+// a barrier with lgkmcnt(0) only -> workgroups read weight slabs that had not landed); every barrier that publishes glds data
+// is therefore preceded by this explicit wait.
+__device__ __forceinline__ void glds_wait() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

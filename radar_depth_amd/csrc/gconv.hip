@@ -55,7 +55,7 @@ struct GconvArgs {
     int debug;         // ablation bits (RD_GCONV_DEBUG env): 1 skip patch staging, 2 skip weight staging, 4 skip MFMA loop
 };
 
-template <int MT, int NT, int WM, int WN, int CKW, bool SWZ>
+template <int MT, int NT, int WM, int WN, int CKW, bool SWZ, bool PIPE>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MT * NT <= 6 ? 2 : 1))) void gconv_kernel(const GconvArgs a) {
     constexpr int BM = WM * MT * 32;
     constexpr int BN = WN * NT * 32;
@@ -108,7 +108,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MT * NT <= 
     int* s_apix = s_opix + BM;                           // [BM] patch pixel index of tap (0,0)
     int* s_widx = s_apix + BM + 32;                      // [32] weight slab index of each tap ([32] ints before it are spare)
     float* s_w = reinterpret_cast<float*>(s_widx + 32);  // [taps][WSD/4][BN][4]  (quad layout, see layout.hip)
-    float* s_patch = s_w + a.taps_max * a.WSD * BN;      // [PP][CKP], quads swizzled
+    float* s_patch = s_w + (PIPE ? 2 : 1) * a.taps_max * a.WSD * BN;      // [PP + 2][PS] after the weight slab(s)
 
     for (int m = tid; m < BM; m += 256) {
         const int r = m / a.TW, c = m - r * a.TW;
@@ -145,9 +145,167 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MT * NT <= 
     const int patch_elems = PH * PW * q4;
     const float* in_n = a.in + (size_t)n * D.Hi * D.Wi * D.ldi;
 
+    // ---- one weight slab (WSD input channels of every tap) through the matrix cores; wsel: byte offset of the slab buffer
+    const int WSD = a.WSD, W4 = WSD >> 2;
+    auto run_slab = [&](int ks, int wsel) {
+    // ---- MFMA over (k-quantum, tap) steps.  One step = CKW input channels of one tap = KK*MT*NT MFMAs.  Software
+    // pipeline pinned with sched_barrier: the A/B fragments of step s+1 (and the patch offset of step s+2) are in
+    // flight from LDS while step s's MFMAs issue.
+    constexpr int KK = CKW / 2;
+    const int nq = WSD / CKW;
+    const int nsteps = (a.debug & 4) ? 0 : nq * ntaps;
+    typedef float fK __attribute__((ext_vector_type(KK)));   // KK consecutive channels per lane: one LDS read
+    // lane (row|col = l31, hh) feeds channel kq*CKW + hh*KK + kk to the kk-th MFMA of the step (any bijection of the
+    // CKW channels onto (kk, hh) is a valid reduction order as long as A and B agree).
+    //
+    // Cost model (tools/micro/mfma_mix.hip): fp32 MFMAs execute on the SIMD's fp32 lanes, so a VALU instruction
+    // in this loop is NOT free -- it costs ~8 clk of MFMA time -- and an LDS read costs ~10 clk when issued in a
+    // block but ~3.5 clk when issued between two MFMAs.  Hence: every address = lane-constant VGPR + wave-uniform
+    // SGPR term (one v_add per fragment, no multiplies), tap offsets come from the kernel arguments through the
+    // scalar unit, and the LDS reads of step s+1 are interleaved with the MFMAs of step s (sched_group_barrier).
+    fK ca[MT], cb_[NT], na[MT], nb[NT];
+    // (tap, k-quantum) of the step whose fragments are loaded next: wave-uniform, kept in SGPRs.  tap_nxt is fetched
+    // one step early so that its s_load is covered by the wait the MFMAs need anyway.
+    int t_n = 0, kqA = 0, kqB = 0;
+    int tap_cur = a.tapoff[ph][0], tap_nxt = a.tapoff[ph][ntaps > 1 ? 1 : 0];
+    const char* const wbase = reinterpret_cast<const char*>(s_w) + boffB + wsel;
+    const char* const pbase = reinterpret_cast<const char*>(s_patch);
+#define RD_GC_LOAD(AV, BV)                                                                     \
+    {                                                                                  \
+        if constexpr (SWZ) {                                                           \
+            const int cq = ks * WSD + (kqA >> 2) + hh * KK;                            \
+            _Pragma("unroll") for (int mt = 0; mt < MT; ++mt)                          \
+                AV[mt] = *reinterpret_cast<const fK*>(s_patch + paddr(abase[mt] + tap_cur, cq)); \
+        } else {                                                                       \
+            const int sA = tap_cur + ks * WSD * 4 + kqA;                               \
+            _Pragma("unroll") for (int mt = 0; mt < MT; ++mt)                          \
+                AV[mt] = *reinterpret_cast<const fK*>(pbase + (aoffB[mt] + sA));       \
+        }                                                                              \
+        const int sB = t_n * (W4 * BN * 16) + kqB;                                     \
+        _Pragma("unroll") for (int nt = 0; nt < NT; ++nt) BV[nt] = *reinterpret_cast<const fK*>(wbase + sB + nt * 512); \
+        ++t_n;                                                                         \
+        if (t_n == ntaps) { t_n = 0; kqA += CKW * 4; kqB += (CKW >> 2) * BN * 16; }    \
+        tap_cur = tap_nxt;                                                             \
+        tap_nxt = a.tapoff[ph][t_n + 1 == ntaps ? 0 : t_n + 1];                        \
+    }
+#define RD_GC_MFMA(AV, BV)                                                                     \
+    _Pragma("unroll") for (int kk = 0; kk < KK; ++kk)                                  \
+        _Pragma("unroll") for (int mt = 0; mt < MT; ++mt)                              \
+            _Pragma("unroll") for (int nt = 0; nt < NT; ++nt)                          \
+                acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(AV[mt][kk], BV[nt][kk], acc[mt][nt], 0, 0, 0);
+    // schedule of one half-iteration: the address VALU ops, then MFMAs with one LDS read slotted after every
+    // KK*NT of them (MT+NT reads in all), then the remaining MFMAs
+#define RD_GC_SCHED()                                                                          \
+    __builtin_amdgcn_sched_group_barrier(0x002, SWZ ? 8 * MT : MT + 1, 0);             \
+    _Pragma("unroll") for (int i = 0; i < MT + NT; ++i) {                              \
+        __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);                             \
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                             \
+    }                                                                                  \
+    __builtin_amdgcn_sched_group_barrier(0x008, KK * MT * NT - 2 * (MT + NT), 0);      \
+    __builtin_amdgcn_sched_barrier(0);
+    RD_GC_LOAD(ca, cb_)
+    __builtin_amdgcn_sched_barrier(0);
+    for (int st = 0; st < nsteps; st += 2) {
+        // (the step after the last one re-reads in-bounds LDS: kq_n may reach nq, still inside the patch/slab rows
+        //  because one extra quantum is reserved by the host-side LDS sizing)
+        RD_GC_LOAD(na, nb)
+        RD_GC_MFMA(ca, cb_)
+        RD_GC_SCHED()
+        if (st + 1 < nsteps) {
+            RD_GC_LOAD(ca, cb_)
+            RD_GC_MFMA(na, nb)
+            RD_GC_SCHED()
+        }
+    }
+#undef RD_GC_LOAD
+#undef RD_GC_MFMA
+#undef RD_GC_SCHED
+    };
+
     const int cin_per = D.Cin / a.ksplit;
     const int cb_lo = ksl * cin_per, cb_hi = cb_lo + cin_per;
     float* const outp = a.out + (size_t)ksl * a.split_stride;
+    if constexpr (PIPE) {
+        // ---- software-pipelined chunk loop (the whole patch chunk is one batch of <= UPP loads per thread and a weight slab
+        // <= UWP): the weight slabs alternate between two LDS buffers and are fetched with global_load_lds one slab ahead (no
+        // registers, no LDS-write pass); the next chunk's patch is loaded into registers while the last slab of the current
+        // chunk is in the matrix cores.  Per-element addresses are computed once per workgroup, so a chunk issues ~50 VALU
+        // instructions for its staging instead of ~900 (they would queue behind the co-resident workgroup's MFMAs).
+        constexpr int UPP = MT * NT >= 4 ? 8 : 4, UWP = 7;
+        const int welems = ntaps * W4 * BN;
+        const int slab_bytes = a.taps_max * WSD * BN * 4;
+        unsigned pgo[UPP];      // byte offset of the element inside the image at channel 0; ~0u: outside -> zero
+        int pdst[UPP];          // LDS float offset, -1: no such element
+#pragma unroll
+        for (int u = 0; u < UPP; ++u) {
+            const int e = tid + u * 256;
+            const int pix = e / q4, qq = e - pix * q4;
+            const int py = pix / PW, px = pix - py * PW;
+            const int ih = ih0 + py, iw = iw0 + px;
+            pdst[u] = e < patch_elems ? paddr(pix, qq * 4) : -1;
+            pgo[u] = (e < patch_elems && ih >= 0 && ih < D.Hi && iw >= 0 && iw < D.Wi) ? (unsigned)(((ih * D.Wi + iw) * D.ldi + qq * 4) * 4) : ~0u;
+        }
+        unsigned woff[UWP];     // byte offset of the element inside the packed weights at input-channel quad 0; ~0u: zero
+#pragma unroll
+        for (int u = 0; u < UWP; ++u) {
+            const int e = tid + u * 256;
+            const int j = e % BN, tk = e / BN;
+            const int k4 = tk % W4, t = min(tk / W4, ntaps - 1);
+            woff[u] = (e < welems && co0 + j < D.Cout) ? (unsigned)((((unsigned)s_widx[t] * (D.Cin >> 2) + k4) * a.ldw + co0 + j) * 16) : ~0u;
+        }
+        auto issue_slab = [&](int buf, int cq0) {          // cq0: first input-channel quad of the slab
+            const char* src = reinterpret_cast<const char*>(a.w) + (size_t)cq0 * a.ldw * 16;
+            float* dst = s_w + buf * (slab_bytes >> 2);
+#pragma unroll
+            for (int u = 0; u < UWP; ++u) {
+                const int e = tid + u * 256;
+                if (e < welems) {
+                    if (woff[u] != ~0u) glds16(reinterpret_cast<const float*>(src + woff[u]), dst + (e - lane) * 4);
+                    else *reinterpret_cast<float4*>(dst + e * 4) = make_float4(0.f, 0.f, 0.f, 0.f);
+                }
+            }
+        };
+        auto patch_fetch = [&](int cb, float4 (&v)[UPP]) {
+            const char* src = reinterpret_cast<const char*>(in_n + cb);
+#pragma unroll
+            for (int u = 0; u < UPP; ++u) {
+                v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (pgo[u] != ~0u) v[u] = *reinterpret_cast<const float4*>(src + pgo[u]);
+            }
+        };
+        auto patch_put = [&](float4 (&v)[UPP]) {
+#pragma unroll
+            for (int u = 0; u < UPP; ++u)
+                if (pdst[u] >= 0) *reinterpret_cast<float4*>(s_patch + pdst[u]) = v[u];
+        };
+        const int nsub = CKP / WSD;
+        int sidx = 0;
+        {
+            float4 vp[UPP];
+            issue_slab(0, cb_lo >> 2);
+            patch_fetch(cb_lo, vp);
+            patch_put(vp);
+        }
+        for (int cb = cb_lo; cb < cb_hi; cb += CKP) {
+            for (int ks = 0; ks < nsub; ++ks, ++sidx) {
+                glds_wait();
+                __syncthreads();          // slab sidx and the chunk's patch have landed; slab sidx-1 is fully consumed
+                RD_STAMP()
+                const bool last_ks = ks == nsub - 1;
+                const bool more = !(last_ks && cb + CKP >= cb_hi);
+                if (more) issue_slab((sidx + 1) & 1, (last_ks ? cb + CKP : cb + (ks + 1) * WSD) >> 2);
+                const bool swap = last_ks && cb + CKP < cb_hi;
+                float4 vp[UPP];
+                if (swap) patch_fetch(cb + CKP, vp);
+                run_slab(ks, (sidx & 1) * slab_bytes);
+                RD_STAMP()
+                if (swap) {
+                    __syncthreads();      // every wave is done reading this chunk's patch
+                    patch_put(vp);
+                }
+            }
+        }
+    } else
     for (int cb = cb_lo; cb < cb_hi; cb += CKP) {
         __syncthreads();
         // ---- stage the halo patch chunk [PH*PW][CKP] (zero outside the image / beyond Cin) and the first weight slab
@@ -157,7 +315,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MT * NT <= 
         // (batch sizes: the large register tiles run two waves per SIMD whatever the staging needs; the small ones keep
         //  their higher occupancy with shorter batches)
         constexpr int UP = MT * NT >= 4 ? 8 : 4, UW = MT * NT >= 4 ? 9 : 5;
-        const int WSD = a.WSD, W4 = WSD >> 2;
         const int nsub = min(CKP, cb_hi - cb) / WSD;
         const int welems = ntaps * W4 * BN;
         const int cinq = D.Cin >> 2;
@@ -232,78 +389,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MT * NT <= 
             }
             __syncthreads();
             RD_STAMP()
-            // ---- MFMA over (k-quantum, tap) steps.  One step = CKW input channels of one tap = KK*MT*NT MFMAs.  Software
-            // pipeline pinned with sched_barrier: the A/B fragments of step s+1 (and the patch offset of step s+2) are in
-            // flight from LDS while step s's MFMAs issue.
-            constexpr int KK = CKW / 2;
-            const int nq = WSD / CKW;
-            const int nsteps = (a.debug & 4) ? 0 : nq * ntaps;
-            typedef float fK __attribute__((ext_vector_type(KK)));   // KK consecutive channels per lane: one LDS read
-            // lane (row|col = l31, hh) feeds channel kq*CKW + hh*KK + kk to the kk-th MFMA of the step (any bijection of the
-            // CKW channels onto (kk, hh) is a valid reduction order as long as A and B agree).
-            //
-            // Cost model (tools/micro/mfma_mix.hip): fp32 MFMAs execute on the SIMD's fp32 lanes, so a VALU instruction
-            // in this loop is NOT free -- it costs ~8 clk of MFMA time -- and an LDS read costs ~10 clk when issued in a
-            // block but ~3.5 clk when issued between two MFMAs.  Hence: every address = lane-constant VGPR + wave-uniform
-            // SGPR term (one v_add per fragment, no multiplies), tap offsets come from the kernel arguments through the
-            // scalar unit, and the LDS reads of step s+1 are interleaved with the MFMAs of step s (sched_group_barrier).
-            fK ca[MT], cb_[NT], na[MT], nb[NT];
-            // (tap, k-quantum) of the step whose fragments are loaded next: wave-uniform, kept in SGPRs.  tap_nxt is fetched
-            // one step early so that its s_load is covered by the wait the MFMAs need anyway.
-            int t_n = 0, kqA = 0, kqB = 0;
-            int tap_cur = a.tapoff[ph][0], tap_nxt = a.tapoff[ph][ntaps > 1 ? 1 : 0];
-            const char* const wbase = reinterpret_cast<const char*>(s_w) + boffB;
-            const char* const pbase = reinterpret_cast<const char*>(s_patch);
-#define RD_GC_LOAD(AV, BV)                                                                     \
-            {                                                                                  \
-                if constexpr (SWZ) {                                                           \
-                    const int cq = ks * WSD + (kqA >> 2) + hh * KK;                            \
-                    _Pragma("unroll") for (int mt = 0; mt < MT; ++mt)                          \
-                        AV[mt] = *reinterpret_cast<const fK*>(s_patch + paddr(abase[mt] + tap_cur, cq)); \
-                } else {                                                                       \
-                    const int sA = tap_cur + ks * WSD * 4 + kqA;                               \
-                    _Pragma("unroll") for (int mt = 0; mt < MT; ++mt)                          \
-                        AV[mt] = *reinterpret_cast<const fK*>(pbase + (aoffB[mt] + sA));       \
-                }                                                                              \
-                const int sB = t_n * (W4 * BN * 16) + kqB;                                     \
-                _Pragma("unroll") for (int nt = 0; nt < NT; ++nt) BV[nt] = *reinterpret_cast<const fK*>(wbase + sB + nt * 512); \
-                ++t_n;                                                                         \
-                if (t_n == ntaps) { t_n = 0; kqA += CKW * 4; kqB += (CKW >> 2) * BN * 16; }    \
-                tap_cur = tap_nxt;                                                             \
-                tap_nxt = a.tapoff[ph][t_n + 1 == ntaps ? 0 : t_n + 1];                        \
-            }
-#define RD_GC_MFMA(AV, BV)                                                                     \
-            _Pragma("unroll") for (int kk = 0; kk < KK; ++kk)                                  \
-                _Pragma("unroll") for (int mt = 0; mt < MT; ++mt)                              \
-                    _Pragma("unroll") for (int nt = 0; nt < NT; ++nt)                          \
-                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(AV[mt][kk], BV[nt][kk], acc[mt][nt], 0, 0, 0);
-            // schedule of one half-iteration: the address VALU ops, then MFMAs with one LDS read slotted after every
-            // KK*NT of them (MT+NT reads in all), then the remaining MFMAs
-#define RD_GC_SCHED()                                                                          \
-            __builtin_amdgcn_sched_group_barrier(0x002, SWZ ? 8 * MT : MT + 1, 0);             \
-            _Pragma("unroll") for (int i = 0; i < MT + NT; ++i) {                              \
-                __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);                             \
-                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                             \
-            }                                                                                  \
-            __builtin_amdgcn_sched_group_barrier(0x008, KK * MT * NT - 2 * (MT + NT), 0);      \
-            __builtin_amdgcn_sched_barrier(0);
-            RD_GC_LOAD(ca, cb_)
-            __builtin_amdgcn_sched_barrier(0);
-            for (int st = 0; st < nsteps; st += 2) {
-                // (the step after the last one re-reads in-bounds LDS: kq_n may reach nq, still inside the patch/slab rows
-                //  because one extra quantum is reserved by the host-side LDS sizing)
-                RD_GC_LOAD(na, nb)
-                RD_GC_MFMA(ca, cb_)
-                RD_GC_SCHED()
-                if (st + 1 < nsteps) {
-                    RD_GC_LOAD(ca, cb_)
-                    RD_GC_MFMA(na, nb)
-                    RD_GC_SCHED()
-                }
-            }
-#undef RD_GC_LOAD
-#undef RD_GC_MFMA
-#undef RD_GC_SCHED
+            run_slab(ks, 0);
             RD_STAMP()
         }
     }
@@ -480,6 +566,7 @@ static inline int combine_rows_per_block(long long M) {
 struct GconvPlan {
     int MT, NT, WM, WN, CKW, CKP, TH, TW, PP, tiles_total, n_cotiles, taps_max, WSD, ksplit;
     size_t lds_bytes;
+    int pipe;      // software-pipelined chunk loop (double-buffered weight slabs via global_load_lds)
 };
 
 static int patch_pixels(const RdConvDesc& d, const RdPhase& p, int TH, int TW) {
@@ -490,16 +577,16 @@ static int patch_pixels(const RdConvDesc& d, const RdPhase& p, int TH, int TW) {
 }
 
 // weight-slab depth: as many input channels as fit ~40 KB (fewer barriers), at least one CKW quantum
-static int pick_wsd(int taps_max, int BN, int CKW, int CKP) {
-    static const char* cap = getenv("RD_GCONV_WSD_KB");   // diagnostics: slab budget in KB (default 40)
-    const size_t budget = (size_t)(cap ? atoi(cap) : 40) * 1024;
+static int pick_wsd(int taps_max, int BN, int CKW, int CKP, bool pipe = false) {
+    static const char* cap = getenv("RD_GCONV_WSD_KB");   // diagnostics: slab budget in KB (default 40; two slabs when pipelined)
+    const size_t budget = (size_t)(cap ? atoi(cap) : 40) * 1024 / (pipe ? 2 : 1);
     int w = CKP;
     while (w > CKW && (size_t)taps_max * w * BN * 4 > budget) w >>= 1;
     return w < CKW ? CKW : w;
 }
-static size_t lds_need(int BM, int BN, int CKW, int CKP, int PP, int taps_max, bool swz) {
+static size_t lds_need(int BM, int BN, int CKW, int CKP, int PP, int taps_max, bool swz, bool pipe = false) {
     // + one CKW quantum of slab rows and one patch pixel row of slack: the pipelined loop prefetches one step past the end
-    return (size_t)(2 * BM + 64) * 4 + ((size_t)taps_max * pick_wsd(taps_max, BN, CKW, CKP) + CKW) * BN * 4 +
+    return (size_t)(2 * BM + 64) * 4 + ((size_t)taps_max * pick_wsd(taps_max, BN, CKW, CKP, pipe) * (pipe ? 2 : 1) + CKW) * BN * 4 +
             (size_t)(PP + 2) * (swz ? CKP : CKP + 4) * 4 + 64;
 }
 
@@ -544,7 +631,12 @@ static bool plan_gconv(const RdConvDesc& d, GconvPlan& best, bool allow_split = 
                     const int pp = patch_pixels(d, d.phase[i], TH, TW);
                     PP = PP > pp ? PP : pp;
                 }
-                const size_t lds = lds_need(BM, BN, CKW, ckp, PP, taps_max, d.in_stride == 2);
+                // pipelined chunk loop: the patch chunk must be one batch of loads per thread, a weight slab at most seven
+                static const char* nopipe = getenv("RD_GCONV_NOPIPE");
+                const int upp = c.MT * c.NT >= 4 ? 8 : 4;
+                const int wsd_p = pick_wsd(taps_max, BN, CKW, ckp, true);
+                const bool pipe = !nopipe && PP * (ckp / 4) <= upp * 256 && taps_max * (wsd_p / 4) * BN <= 7 * 256;
+                const size_t lds = lds_need(BM, BN, CKW, ckp, PP, taps_max, d.in_stride == 2, pipe);
                 if (lds > 160 * 1024 - 512) continue;
                 const double m_util = (double)P.lh * P.lw / ((double)cdiv(P.lh, TH) * cdiv(P.lw, TW) * BM);
                 const double halo = (double)PP / (TH * TW * d.in_stride * d.in_stride);
@@ -573,7 +665,7 @@ static bool plan_gconv(const RdConvDesc& d, GconvPlan& best, bool allow_split = 
                             (wgs < 2 * ncu && lds <= 80 * 1024 ? 0.9 : 1.0);   // (a > 80 KB tile already paid for single residency)
                     if (score > best_score) {
                         best_score = score;
-                        best = GconvPlan{c.MT, c.NT, c.WM, c.WN, CKW, ckp, TH, TW, PP, 0, n_cot, taps_max, pick_wsd(taps_max, BN, CKW, ckp), ksp, lds};
+                        best = GconvPlan{c.MT, c.NT, c.WM, c.WN, CKW, ckp, TH, TW, PP, 0, n_cot, taps_max, pick_wsd(taps_max, BN, CKW, ckp, pipe), ksp, lds, pipe ? 1 : 0};
                     }
                 }
             }
@@ -582,10 +674,10 @@ static bool plan_gconv(const RdConvDesc& d, GconvPlan& best, bool allow_split = 
     return best_score > 0;
 }
 
-template <int MT, int NT, int WM, int WN, int CKW, bool SWZ>
+template <int MT, int NT, int WM, int WN, int CKW, bool SWZ, bool PIPE>
 static int launch_cfg(const GconvArgs& a, int grid, size_t lds, hipStream_t s) {
     static bool attr_set = false;
-    auto k = gconv_kernel<MT, NT, WM, WN, CKW, SWZ>;
+    auto k = gconv_kernel<MT, NT, WM, WN, CKW, SWZ, PIPE>;
     if (!attr_set) {
         RD_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr_set = true;
@@ -639,10 +731,10 @@ extern "C" int rd_gconv_plan_info(const RdConvDesc* d, int32_t* out) {
     return RD_OK;
 }
 
-template <int MT, int NT, int WM, int WN, int CKW, bool SWZ>
+template <int MT, int NT, int WM, int WN, int CKW, bool SWZ, bool PIPE>
 static int occ_cfg(size_t lds) {
     int n = -1;
-    auto k = gconv_kernel<MT, NT, WM, WN, CKW, SWZ>;
+    auto k = gconv_kernel<MT, NT, WM, WN, CKW, SWZ, PIPE>;
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k, 256, lds) != hipSuccess) n = -1;
     return n;
@@ -653,13 +745,16 @@ extern "C" int rd_gconv_occupancy(const RdConvDesc* d) {
     GconvPlan pl;
     RdConvDesc dd = *d;
     if (!plan_gconv(dd, pl)) return RD_EINVAL;
+#define RD_OCC2(MT_, NT_, WM_, WN_, P_)                                                                                        \
+    (swz ? (pl.CKW == 8 ? occ_cfg<MT_, NT_, WM_, WN_, 8, true, P_>(pl.lds_bytes) : occ_cfg<MT_, NT_, WM_, WN_, 4, true, P_>(pl.lds_bytes)) \
+         : (pl.CKW == 8 ? occ_cfg<MT_, NT_, WM_, WN_, 8, false, P_>(pl.lds_bytes) : occ_cfg<MT_, NT_, WM_, WN_, 4, false, P_>(pl.lds_bytes)))
 #define RD_OCC(MT_, NT_, WM_, WN_) \
     if (pl.MT == MT_ && pl.NT == NT_ && pl.WM == WM_ && pl.WN == WN_) \
-        return swz ? (pl.CKW == 8 ? occ_cfg<MT_, NT_, WM_, WN_, 8, true>(pl.lds_bytes) : occ_cfg<MT_, NT_, WM_, WN_, 4, true>(pl.lds_bytes)) \
-                   : (pl.CKW == 8 ? occ_cfg<MT_, NT_, WM_, WN_, 8, false>(pl.lds_bytes) : occ_cfg<MT_, NT_, WM_, WN_, 4, false>(pl.lds_bytes));
+        return pl.pipe ? RD_OCC2(MT_, NT_, WM_, WN_, true) : RD_OCC2(MT_, NT_, WM_, WN_, false);
     const bool swz = d->in_stride == 2;
     RD_OCC(2, 2, 4, 1) RD_OCC(2, 1, 4, 1) RD_OCC(3, 2, 4, 1) RD_OCC(1, 2, 4, 1) RD_OCC(1, 1, 4, 1)
 #undef RD_OCC
+#undef RD_OCC2
     return -1;
 }
 
@@ -764,13 +859,15 @@ static int gconv_impl(const RdConvDesc* d, const float* in, const float* w_packe
     hipStream_t s = static_cast<hipStream_t>(stream);
     rc = RD_EINVAL;
     bool launched = false;
+#define RD_LAUNCH2(MT_, NT_, WM_, WN_, P_)                                                           \
+    (swz ? (pl.CKW == 8 ? launch_cfg<MT_, NT_, WM_, WN_, 8, true, P_>(a, grid, lds_launch, s)             \
+                        : launch_cfg<MT_, NT_, WM_, WN_, 4, true, P_>(a, grid, lds_launch, s))            \
+         : (pl.CKW == 8 ? launch_cfg<MT_, NT_, WM_, WN_, 8, false, P_>(a, grid, lds_launch, s)            \
+                        : launch_cfg<MT_, NT_, WM_, WN_, 4, false, P_>(a, grid, lds_launch, s)))
 #define RD_TRY(MT_, NT_, WM_, WN_)                                                                  \
     if (!launched && pl.MT == MT_ && pl.NT == NT_ && pl.WM == WM_ && pl.WN == WN_) {                \
         launched = true;                                                                            \
-        rc = swz ? (pl.CKW == 8 ? launch_cfg<MT_, NT_, WM_, WN_, 8, true>(a, grid, lds_launch, s)                \
-                                : launch_cfg<MT_, NT_, WM_, WN_, 4, true>(a, grid, lds_launch, s))               \
-                 : (pl.CKW == 8 ? launch_cfg<MT_, NT_, WM_, WN_, 8, false>(a, grid, lds_launch, s)               \
-                                : launch_cfg<MT_, NT_, WM_, WN_, 4, false>(a, grid, lds_launch, s));             \
+        rc = pl.pipe ? RD_LAUNCH2(MT_, NT_, WM_, WN_, true) : RD_LAUNCH2(MT_, NT_, WM_, WN_, false);              \
     }
     const bool swz = d->in_stride == 2;
     const size_t lds_launch = (size_t)a.lds_floats * 4 + (a.trace ? 512 : 0);
@@ -780,6 +877,7 @@ static int gconv_impl(const RdConvDesc* d, const float* in, const float* w_packe
     RD_TRY(1, 2, 4, 1)
     RD_TRY(1, 1, 4, 1)
 #undef RD_TRY
+#undef RD_LAUNCH2
     if (!launched) { set_error("gconv: unsupported plan"); return RD_EINVAL; }
     if (rc != RD_OK || !split) return rc;
     const long long M = (long long)d->N * d->Ho * d->Wo;

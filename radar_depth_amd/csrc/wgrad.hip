@@ -171,6 +171,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void w
             }
         }
         }
+        glds_wait();
         __syncthreads();
         // Software pipeline pinned with sched_barrier (hipcc otherwise sinks every ds_read next to its MFMA and waits
         // lgkmcnt(0) per instruction).  Two register sets ping-pong (no copy moves): while one set's TG MFMAs issue, the
@@ -377,6 +378,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void w
         stage_dout_row(0);
         stage_dout_row(1);
         for (int it = 0; it < niter; ++it) {
+            glds_wait();
             __syncthreads();                               // rows of iteration `it` have landed; iteration it-1 is fully consumed
             if (it + 1 < niter && !(a.debug & 1)) {
                 stage_patch_row(2 * it + RH + 1);
