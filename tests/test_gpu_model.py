@@ -249,6 +249,25 @@ def test_multistage_fused_step_matches_oracle():
     assert np.abs(po - pg).max() / po.max() < 5e-3          # 3 chaotic steps (tests/test_conditioning.py)
 
 
+def test_step_is_bitwise_reproducible_under_concurrency():
+    """Two identically initialised models stepped on the same batches must stay bit-identical: the step runs ~650 kernels on
+    three streams, so any race in a kernel's own synchronisation (e.g. reading an LDS buffer an asynchronous copy has not
+    finished filling) or a missing cross-stream edge shows up as a last-bit difference here."""
+    from radar_depth_amd.main import HipTrainStep
+    from radar_depth_amd.synthetic import make_batch
+    b, h, w = 4, 129, 193
+    m1, m2 = build(h, w), build(h, w)
+    t1, t2 = HipTrainStep(m1, b, h, w), HipTrainStep(m2, b, h, w)
+    for it in range(6):
+        x, t = make_batch(b, h, w, 900 + it, ref_pixels=h * w)
+        l1, _ = t1.step(x.cuda(), t.cuda())
+        l2, _ = t2.step(x.cuda(), t.cuda())
+        torch.cuda.synchronize()
+        assert l1.item() == l2.item(), it
+    for p, q in zip(m1.parameters(), m2.parameters()):
+        assert torch.equal(p, q)
+
+
 def test_data_parallel_path_single_rank(monkeypatch):
     """The DP code path (one hipGraph per backward segment, async RCCL all-reduce per gradient bucket, wait, SGD scaled by
     1/world) on a 1-rank nccl group must reproduce the single-graph step exactly."""
