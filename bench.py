@@ -43,8 +43,9 @@ def kernel_identity(L, kind, d):
     """Kernel name as rocprofv3 prints it (spaces removed), from the library's own plan for the descriptor."""
     if kind == "gconv":
         info = (C.c_int32 * 10)()
-        L.rd_gconv_plan_info(C.byref(d), info)                 # info[4] = ksplit*100 + CKW
-        return "gconv_kernel<%d,%d,%d,%d,%d,%s>" % (info[0], info[1], info[2], info[3], info[4] % 100, "true" if d.in_stride == 2 else "false")
+        L.rd_gconv_plan_info(C.byref(d), info)                 # info[4] = pipelined*10000 + ksplit*100 + CKW
+        return "gconv_kernel<%d,%d,%d,%d,%d,%s,%s>" % (info[0], info[1], info[2], info[3], info[4] % 100,
+                                                       "true" if d.in_stride == 2 else "false", "true" if info[4] >= 10000 else "false")
     w = (C.c_int32 * 9)()
     L.rd_wgrad_plan_info(C.byref(d), w)
     tb = lambda v: "true" if v else "false"

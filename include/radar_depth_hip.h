@@ -96,7 +96,8 @@ int rd_gconv_ws(const RdConvDesc* d, const float* in, const float* w_packed, flo
  * with the eval-mode BatchNorm folded in: scale into the packed weights, shift = bias.  bias / addend / ws may be NULL. */
 int rd_gconv_fused(const RdConvDesc* d, const float* in, const float* w_packed, float* out, const float* bias,
                    int32_t act, int32_t act_cols, const float* addend, int32_t ld_add, float* ws, void* stream);
-/* diagnostics: out[0..9] = MT, NT, WM, WN, ksplit*100+CKW, CKP, TH, TW, lds_bytes, workgroups chosen for d (workspace plan) */
+/* diagnostics: out[0..9] = MT, NT, WM, WN, pipelined*10000+ksplit*100+CKW, CKP, TH, TW, lds_bytes, workgroups chosen for d
+ * (workspace plan) */
 int rd_gconv_plan_info(const RdConvDesc* d, int32_t* out);
 /* diagnostics: workgroups per CU the HIP occupancy API reports for that plan (-1 without a GPU) */
 int rd_gconv_occupancy(const RdConvDesc* d);

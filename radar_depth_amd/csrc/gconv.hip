@@ -724,8 +724,8 @@ extern "C" int rd_gconv_plan_info(const RdConvDesc* d, int32_t* out) {
     RdConvDesc dd = *d;
     if (!plan_gconv(dd, pl, true)) { set_error("gconv: no feasible tiling"); return RD_EINVAL; }
     fill_tiles(dd, pl);
-    // (reports the plan used WITH a workspace; CKW slot carries ksplit*100 + CKW)
-    const int v[10] = {pl.MT, pl.NT, pl.WM, pl.WN, pl.ksplit * 100 + pl.CKW, pl.CKP, pl.TH, pl.TW, (int)pl.lds_bytes,
+    // (reports the plan used WITH a workspace; CKW slot carries pipe*10000 + ksplit*100 + CKW)
+    const int v[10] = {pl.MT, pl.NT, pl.WM, pl.WN, pl.pipe * 10000 + pl.ksplit * 100 + pl.CKW, pl.CKP, pl.TH, pl.TW, (int)pl.lds_bytes,
                        d->N * pl.tiles_total * pl.n_cotiles * pl.ksplit};
     for (int i = 0; i < 10; ++i) out[i] = v[i];
     return RD_OK;

@@ -55,7 +55,7 @@ t0 = st[:, 0].min()
 st = st - t0
 CLK = 100e6   # s_memtime ticks at the constant 100 MHz reference on gfx9xx
 us = st / CLK * 1e6
-print("%s: %d workgroups, %d stamps each, plan MT,NT=%d,%d tile %dx%d CKP %d ksplit*100+CKW %d" % (name, nwg, n, info[0], info[1], info[6], info[7], info[5], info[4]))
+print("%s: %d workgroups, %d stamps each, plan MT,NT=%d,%d tile %dx%d CKP %d pipe*10000+ksplit*100+CKW %d" % (name, nwg, n, info[0], info[1], info[6], info[7], info[5], info[4]))
 print("kernel span %.1f us; workgroup start: min %.1f p50 %.1f max %.1f; end: min %.1f p50 %.1f max %.1f" % (
     us.max(), us[:, 0].min(), np.median(us[:, 0]), us[:, 0].max(), us[:, -1].min(), np.median(us[:, -1]), us[:, -1].max()))
 dur = np.diff(us, axis=1)
