@@ -299,7 +299,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void w
     constexpr int TG = RH * RW, CIB = 64, COB = 64;
     constexpr int TWS = 25, PW = WG_PITCH, DW = 26;        // strip width, patch row pixels, dout row slots (slot 25 stays zero)
     constexpr int RP = 6, RD = 4;                          // ring depths in rows
-    constexpr int PROW = PW * CIB, DROW = DW * COB;        // floats per ring row
+    // The 13th step of a row multiplies the zero pad pixel of the dout row (slot 25) by patch pixel 25 + dw, i.e. pixel 27 for
+    // dw = 2: one pixel past the 27 staged ones.  It must be FINITE (0 * NaN = NaN), so every ring row carries a 28th pixel that
+    // is zeroed once per workgroup and never written again (uninitialised LDS can hold NaN bit patterns from other kernels:
+    // under concurrency this showed up as whole taps of the gradient turning NaN).
+    constexpr int PWR = PW + 1;
+    constexpr int PROW = PWR * CIB, DROW = DW * COB;       // floats per ring row
     constexpr int STEPS = (TWS + 1) / 2;                   // 13 two-pixel steps per output row
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* s_in = smem;                                    // [RP][PW][CIB]
@@ -321,6 +326,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void w
 #pragma unroll
         for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
 
+    for (int i = tid; i < RP * CIB; i += 256) s_in[(i / CIB) * PROW + PW * CIB + (i % CIB)] = 0.f;     // the pad pixel of every ring row
     const int laneA = lk * CIB + wci * 32 + lm, laneB = lk * COB + wco * 32 + lm;
     const int gst = a.compact ? a.OS : 1;                  // global dout pixel step per logical pixel
     const int u_begin = split * sa.units_per_split, u_end = min(u_begin + sa.units_per_split, sa.n_units);
@@ -584,7 +590,7 @@ static int plan_wgrad(const RdConvDesc& d_in, WgradPlan& pl, WgradArgs* out, int
         pl.strip = 1;
         pl.pitch = WG_PITCH;
         pl.TH = 2; pl.TW = 25; pl.tiles_h = pl.tiles_w = pl.total_tiles = pl.tiles_per_split = 0;
-        pl.lds = (size_t)(6 * WG_PITCH * 64 + 4 * 26 * 64) * 4;
+        pl.lds = (size_t)(6 * (WG_PITCH + 1) * 64 + 4 * 26 * 64) * 4;
         if (out) {
             WgradArgs& a = *out;
             a.N = d.N; a.Hi = d.Hi; a.Wi = d.Wi; a.Cin = d.Cin; a.ldi = d.ldi;
