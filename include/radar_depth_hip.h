@@ -314,6 +314,10 @@ int rd_event_destroy(void* event);
 int rd_event_record(void* event, void* stream);
 int rd_stream_wait_event(void* stream, void* event);
 
+/* diagnostics: fill every CU's LDS with NaN bit patterns (LDS is not cleared between kernels): a kernel that consumes an LDS
+ * word it never wrote then yields NaN instead of depending on its predecessor's leftovers (tools/fuzz_conv.py --poison) */
+int rd_debug_poison_lds(void* stream);
+
 /* hipGraph capture helpers so a whole step replays without host launch cost */
 int rd_graph_begin(void* stream);
 int rd_graph_end(void* stream, void** graph_exec);

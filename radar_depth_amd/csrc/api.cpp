@@ -65,6 +65,27 @@ extern "C" int rd_graph_destroy(void* graph_exec) {
     return RD_OK;
 }
 
+// Diagnostics: fill the LDS of every CU with NaN bit patterns.  LDS is not cleared between kernels, so a kernel that reads an LDS
+// word it never wrote (and, say, multiplies it by a zero operand) then produces NaN instead of silently depending on whatever
+// the previous kernel left there (tools/fuzz_conv.py --poison; this is how the 0*NaN hazard of the strip wgrad kernel is kept out).
+__global__ __launch_bounds__(256) void poison_lds_kernel(unsigned* sink, int words) {
+    extern __shared__ unsigned lds_words[];
+    for (int i = threadIdx.x; i < words; i += 256) lds_words[i] = 0xFFFFFFFFu;
+    __syncthreads();
+    if (sink && lds_words[(threadIdx.x * 97) % words] == 0u) sink[0] = 1;      // keep the stores alive
+}
+extern "C" int rd_debug_poison_lds(void* stream) {
+    static bool attr_set = false;
+    const int bytes = 160 * 1024 - 1024;
+    if (!attr_set) {
+        RD_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(poison_lds_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(poison_lds_kernel, dim3(rd::num_cus() * 4), dim3(256), bytes, static_cast<hipStream_t>(stream), (unsigned*)nullptr, bytes / 4);
+    RD_CHECK_LAUNCH("poison_lds_kernel");
+    return RD_OK;
+}
+
 // Events for fork/join between the plan's streams (captured as graph edges under hipStreamBeginCapture)
 extern "C" int rd_event_create(void** ev) {
     RD_CHECK_ARG(ev != nullptr, "rd_event_create: null out pointer");

@@ -679,7 +679,12 @@ class LateFusionPlan:
     def _run(self, ops):
         if self.dry_run:
             raise RuntimeError("dry-run plans cannot execute: the HIP path has no CPU fallback")
+        # diagnostics: RD_POISON_LDS=1 (with RD_SINGLE_STREAM=1) NaN-fills every CU's LDS before each op, so that a kernel
+        # consuming LDS it never wrote shows up as NaN in the parity tests instead of depending on its predecessor's leftovers
+        poison = os.environ.get("RD_POISON_LDS") == "1" and not self.multi_stream
         for name, fn, args in ops:
+            if poison:
+                self.L.rd_debug_poison_lds(self.streams[0])
             rc = fn(*args)
             if rc != 0:
                 check(rc, name)

@@ -1,6 +1,7 @@
 """Thin torch-tensor wrappers over the C ABI (one function per entry point of include/radar_depth_hip.h).
 Tensors must live on the GPU; all calls are asynchronous on torch's current HIP stream."""
 import ctypes as C
+import os as _os
 
 import torch
 
@@ -41,8 +42,15 @@ def gconv_stat_tiles(desc):
 _WS = {}
 
 
+def _poison():
+    """RD_POISON_LDS=1: NaN-fill every CU's LDS before the launch (a kernel that consumes unwritten LDS then yields NaN)."""
+    if _os.environ.get("RD_POISON_LDS") == "1":
+        check(lib().rd_debug_poison_lds(current_stream()), "rd_debug_poison_lds")
+
+
 def gconv(desc, x, w_packed, out, addend=None, ld_add=0, stat=None):
     """Runs through rd_gconv_ws (split-K allowed); the workspace is cached per size on the tensor's device."""
+    _poison()
     n = int(lib().rd_gconv_workspace_floats(C.byref(desc)))
     if n < 0:
         check(n, "rd_gconv_workspace_floats")
@@ -83,6 +91,7 @@ def wgrad_workspace_floats(desc):
 
 
 def wgrad(desc, x, dout, slabs):
+    _poison()
     check(lib().rd_wgrad(C.byref(desc), ptr(x), ptr(dout), ptr(slabs), current_stream()), "rd_wgrad")
     return slabs
 

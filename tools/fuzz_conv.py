@@ -7,7 +7,17 @@ import torch.nn.functional as F
 sys.path.insert(0, ".")
 from radar_depth_amd import convdesc as cd, ops
 
+POISON = "--poison" in sys.argv          # NaN-fill every CU's LDS before each launch: catches reads of unwritten LDS
+sys.argv = [a for a in sys.argv if a != "--poison"]
 n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 80
+from radar_depth_amd._lib import current_stream, lib
+
+
+def poison():
+    if POISON:
+        assert lib().rd_debug_poison_lds(current_stream()) == 0
+
+
 rng = np.random.RandomState(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
 
 
@@ -37,9 +47,12 @@ for case in range(n_cases):
         d = cd.conv_fwd(n, h, w, ci, co, k, s, p)
         xs, gys = ops.nchw_to_nhwc(x.detach().cuda()), ops.nchw_to_nhwc(gy.cuda())
         out = torch.empty(n, d.Ho, d.Wo, co, device="cuda")
-        ops.gconv(d, xs, ops.pack_weights(wt.detach().cuda()), out)
+        wp_ = ops.pack_weights(wt.detach().cuda())
+        poison()
+        ops.gconv(d, xs, wp_, out)
         e_f = rel(ops.nhwc_to_nchw(out).cpu(), y.detach())
         slabs = torch.empty(ops.wgrad_workspace_floats(d), device="cuda")
+        poison()
         ops.wgrad(d, xs, gys, slabs)
         gw = torch.full((co, ci, k, k), float("nan"), device="cuda")
         ops.wgrad_reduce(d, slabs, gw)
@@ -48,7 +61,9 @@ for case in range(n_cases):
         if co % 16 == 0:        # dgrad: the reduction dimension (forward Cout) must be a multiple of 16
             dd, zero_fill = cd.conv_dgrad(n, h, w, ci, co, k, s, p)
             dx = torch.zeros(n, h, w, ci, device="cuda") if zero_fill else torch.empty(n, h, w, ci, device="cuda")
-            ops.gconv(dd, gys, ops.pack_weights(wt.detach().cuda(), transpose=True), dx)
+            wd_ = ops.pack_weights(wt.detach().cuda(), transpose=True)
+            poison()
+            ops.gconv(dd, gys, wd_, dx)
             e_d = rel(ops.nhwc_to_nchw(dx).cpu(), x.grad)
         torch.cuda.synchronize()
         ok = e_f < 5e-5 and e_w < 1e-4 and e_d < 5e-5
