@@ -96,6 +96,17 @@ int rd_gconv_ws(const RdConvDesc* d, const float* in, const float* w_packed, flo
  * with the eval-mode BatchNorm folded in: scale into the packed weights, shift = bias.  bias / addend / ws may be NULL. */
 int rd_gconv_fused(const RdConvDesc* d, const float* in, const float* w_packed, float* out, const float* bias,
                    int32_t act, int32_t act_cols, const float* addend, int32_t ld_add, float* ws, void* stream);
+/* bf16-operand form of rd_gconv / rd_gconv_fused (BASELINE.json configs 3/5; opt-in, the fp32 entry points above stay the
+ * parity path): in / out / bias / addend are fp32 tensors exactly as above, the activations are rounded to bf16 (nearest even)
+ * while they are staged, w_packed_bf16 is the bf16 operand written by rd_pack_weights_batched with quad == 2 -- element
+ * (slab, ci, co) at ((slab*Cin/8 + ci/8)*ld + co)*8 + ci%8 -- and the reduction accumulates in fp32 on
+ * v_mfma_f32_32x32x16_bf16.  stat_partial as in rd_gconv (rd_gconv_bf16_stat_tiles rows), may be NULL.  Replaces the
+ * same F.conv2d call sites under torch.autocast(bfloat16) semantics (operands bf16, accumulate fp32). */
+int rd_gconv_bf16(const RdConvDesc* d, const float* in, const void* w_packed_bf16, float* out, const float* bias,
+                  int32_t act, int32_t act_cols, const float* addend, int32_t ld_add, float* stat_partial, void* stream);
+int rd_gconv_bf16_stat_tiles(const RdConvDesc* d);
+/* diagnostics: out[0..7] = MT, NT, CKP, TH, TW, patch pixels, lds_bytes, workgroups */
+int rd_gconv_bf16_plan_info(const RdConvDesc* d, int32_t* out);
 /* diagnostics: out[0..9] = MT, NT, WM, WN, pipelined*10000+ksplit*100+CKW, CKP, TH, TW, lds_bytes, workgroups chosen for d
  * (workspace plan) */
 int rd_gconv_plan_info(const RdConvDesc* d, int32_t* out);
@@ -129,11 +140,16 @@ int rd_wgrad_plan_info(const RdConvDesc* d, int32_t* out);
 int rd_pack_weights(const float* w_oihw, float* packed, int32_t O, int32_t I, int32_t KH, int32_t KW,
                     int32_t ldc, int32_t co_off, int32_t rows_total, int32_t transpose, void* stream);
 
+/* bf16 operand of rd_gconv_bf16: same arguments, element (slab, row, col) at ((slab*R/8 + row/8)*ldc + col)*8 + row%8,
+ * rounded to nearest even; the reduction dimension must be a multiple of 8. */
+int rd_pack_weights_bf16(const float* w_oihw, void* packed_bf16, int32_t O, int32_t I, int32_t KH, int32_t KW,
+                         int32_t ldc, int32_t co_off, int32_t rows_total, int32_t transpose, void* stream);
+
 /* All weight tensors of a network in ONE launch.  jobs_dev: device array of
  *   struct { const float* src; float* dst; const float* scale; int32_t O, I, T(=KH*KW), ldc, off, rows_total,
  *            transpose, first_block, quad, pad; }
- *   scale (nullable): per-output-channel factor = folded BatchNorm scale (eval mode); quad != 0: row-interleaved gconv
- *   operand layout, 0: plain [slab][row][col] (the 7x7 stem kernels)
+ *   scale (nullable): per-output-channel factor = folded BatchNorm scale (eval mode); quad 1: row-interleaved gconv
+ *   operand layout, 2: bf16 operand of rd_gconv_bf16, 0: plain [slab][row][col] (the 7x7 stem kernels)
  * (same meaning as rd_pack_weights' arguments); block_job_dev[b] = job index of block b, where job j owns blocks
  * [first_block, first_block + ceil(O*I*T / rd_pack_chunk())).  Both arrays are built once by the host plan. */
 int rd_pack_chunk(void);

@@ -9,6 +9,11 @@ namespace rd {
 __device__ __forceinline__ int64_t packed_index(int quad, int64_t t, int64_t rows, int64_t row, int64_t ldc, int64_t col) {
     return quad ? ((t * (rows >> 2) + (row >> 2)) * ldc + col) * 4 + (row & 3) : (t * rows + row) * ldc + col;
 }
+// bf16 operand of gconv_bf16.hip (quad == 2): eight reduction rows per 16-byte unit, element (slab, row, col) at
+// ((slab * R/8 + row/8) * ldc + col) * 8 + row%8 (bf16 units)
+__device__ __forceinline__ int64_t packed_index_bf16(int64_t t, int64_t rows, int64_t row, int64_t ldc, int64_t col) {
+    return ((t * (rows >> 3) + (row >> 3)) * ldc + col) * 8 + (row & 7);
+}
 __global__ void pack_weights_kernel(const float* __restrict__ w, float* __restrict__ packed, int O, int I, int T,
                                     int ldc, int off, int rows_total, int transpose) {
     const int64_t total = (int64_t)O * I * T;
@@ -31,6 +36,19 @@ __global__ void pack_weights_kernel(const float* __restrict__ w, float* __restri
     }
 }
 
+__global__ void pack_weights_bf16_kernel(const float* __restrict__ w, __bf16* __restrict__ packed, int O, int I, int T,
+                                         int ldc, int off, int rows_total, int transpose) {
+    const int64_t total = (int64_t)O * I * T;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+        const int o = (int)(e % O);
+        const int64_t r = e / O;
+        const int i = (int)(r % I), t = (int)(r / I);
+        const float v = w[((int64_t)o * I + i) * T + t];
+        if (!transpose) packed[packed_index_bf16(t, I, i, ldc, off + o)] = (__bf16)v;
+        else packed[packed_index_bf16(t, rows_total, off + o, ldc, i)] = (__bf16)v;
+    }
+}
+
 // One launch for every weight tensor of the network: block b works on chunk (b - job.first_block) of job block_job[b].
 // Same index mapping as pack_weights_kernel.
 struct PackJob {
@@ -38,7 +56,7 @@ struct PackJob {
     float* dst;
     const float* scale;   // optional per-output-channel factor (eval mode: folded BatchNorm scale), may be null
     int O, I, T, ldc, off, rows_total, transpose, first_block;
-    int quad, pad_;       // quad != 0: gconv operand layout (rows interleaved by four); 0: plain [slab][row][col] (stem kernels)
+    int quad, pad_;       // 1: gconv operand layout (rows interleaved by four); 2: bf16 operand (by eight); 0: plain [slab][row][col] (stem kernels)
 };
 constexpr int PACK_CHUNK = 2048;
 __global__ __launch_bounds__(256) void pack_weights_batched_kernel(const PackJob* __restrict__ jobs, const int* __restrict__ block_job) {
@@ -55,14 +73,16 @@ __global__ __launch_bounds__(256) void pack_weights_batched_kernel(const PackJob
             const int i = (int)(r % j.I), t = (int)(r / j.I);
             float v = j.src[((int64_t)o * j.I + i) * j.T + t];
             if (j.scale) v *= j.scale[o];
-            j.dst[packed_index(j.quad, t, j.I, i, j.ldc, j.off + o)] = v;
+            if (j.quad == 2) reinterpret_cast<__bf16*>(j.dst)[packed_index_bf16(t, j.I, i, j.ldc, j.off + o)] = (__bf16)v;
+            else j.dst[packed_index(j.quad, t, j.I, i, j.ldc, j.off + o)] = v;
         } else {
             const int i = (int)(e % j.I);
             const int64_t r = e / j.I;
             const int o = (int)(r % j.O), t = (int)(r / j.O);
             float v = j.src[((int64_t)o * j.I + i) * j.T + t];
             if (j.scale) v *= j.scale[o];
-            j.dst[packed_index(j.quad, t, j.rows_total, j.off + o, j.ldc, i)] = v;
+            if (j.quad == 2) reinterpret_cast<__bf16*>(j.dst)[packed_index_bf16(t, j.rows_total, j.off + o, j.ldc, i)] = (__bf16)v;
+            else j.dst[packed_index(j.quad, t, j.rows_total, j.off + o, j.ldc, i)] = v;
         }
     }
 }
@@ -106,6 +126,17 @@ extern "C" int rd_pack_weights(const float* w_oihw, float* packed, int32_t O, in
     hipLaunchKernelGGL(pack_weights_kernel, dim3(grid_for(total, 256)), dim3(256), 0, static_cast<hipStream_t>(stream),
                        w_oihw, packed, O, I, KH * KW, ldc, co_off, rows_total, transpose);
     RD_CHECK_LAUNCH("pack_weights_kernel");
+    return RD_OK;
+}
+
+extern "C" int rd_pack_weights_bf16(const float* w_oihw, void* packed_bf16, int32_t O, int32_t I, int32_t KH, int32_t KW,
+                                    int32_t ldc, int32_t co_off, int32_t rows_total, int32_t transpose, void* stream) {
+    RD_CHECK_ARG(w_oihw && packed_bf16 && O > 0 && I > 0 && KH > 0 && KW > 0, "pack_weights_bf16: bad arguments");
+    RD_CHECK_ARG((transpose ? rows_total : I) % 8 == 0, "pack_weights_bf16: the reduction dimension must be a multiple of 8");
+    const int64_t total = (int64_t)O * I * KH * KW;
+    hipLaunchKernelGGL(pack_weights_bf16_kernel, dim3(grid_for(total, 256)), dim3(256), 0, static_cast<hipStream_t>(stream),
+                       w_oihw, static_cast<__bf16*>(packed_bf16), O, I, KH * KW, ldc, co_off, rows_total, transpose);
+    RD_CHECK_LAUNCH("pack_weights_bf16_kernel");
     return RD_OK;
 }
 

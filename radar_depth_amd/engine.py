@@ -74,14 +74,17 @@ def _p(t):
 
 class LateFusionPlan:
     def __init__(self, module, batch, height, width, train=True, depth_planes=None, x_source=None, dense_grad_dst=None,
-                 dry_run=False):
-        """module: a radar_depth_amd ResNet_latefusion(2); depth_planes: None (depth stem reads channel(s) 3.. of the
+                 dry_run=False, bf16=False):
+        """module: a radar_depth_amd ResNet_latefusion(2); bf16: run the gconv-lowered convolutions with bf16 operands on
+        v_mfma_f32_32x32x16_bf16 (fp32 tensors, fp32 accumulation; eval plans only -- BASELINE.json configs 3/5, opt-in); depth_planes: None (depth stem reads channel(s) 3.. of the
         network input) or, for stage 2 of the multistage net, a list of stand-alone [N,H,W] maps; x_source: share another
         plan's static input buffer (stage 2 reads the RGB planes of stage 1's); dense_grad_dst: [N,H,W]-sized buffer that
         receives the gradient w.r.t. the second depth plane (stage-1 prediction, multistage_model.py:75)."""
         self.m = module
         self.N, self.H, self.W = batch, height, width
         self.train = train
+        self.bf16 = bool(bf16)
+        assert not (self.bf16 and train), "bf16 operands are implemented for eval plans"
         self.dev = module.conv1.weight.device
         # dry_run: record the op lists against host buffers without ever launching (CPU tests of the host logic)
         assert dry_run or self.dev.type == "cuda", "the HIP path needs the module on a GPU"
@@ -265,7 +268,7 @@ class LateFusionPlan:
         if out is None:
             out = self.act(N, d.Ho, d.Wo, cout)
         d.ldo = out.ld
-        wp = self.buf(k * k, cin, cout)
+        wp = self.buf(k * k, cin, cout, dtype=torch.bfloat16 if self.bf16 else torch.float32)
         bias = self.buf(cout)
         scale = self.buf(cout)
         for w, off, bn in parts:
@@ -274,9 +277,15 @@ class LateFusionPlan:
             sh = C.c_void_p(bias.data_ptr() + 4 * off)
             self.op(self.prep, name + ".evalcoef", self.L.rd_bn_eval_coeffs, o, _p(bn.weight), _p(bn.bias), _p(bn.running_mean),
                     _p(bn.running_var), C.c_float(BN_EPS), sc, sh, self.streams[0])
-            self.pack_jobs.append((w, wp, o, i, kh * kw, cout, off, i, 0, scale[off:off + o], 1))
-        ws = self._gconv_ws(d, name)
+            self.pack_jobs.append((w, wp, o, i, kh * kw, cout, off, i, 0, scale[off:off + o], 2 if self.bf16 else 1))
         self.keep += [d, scale]
+        if self.bf16:
+            self.op(self.fwd, name, self.L.rd_gconv_bf16, C.byref(d), x.ptr, _p(wp), out.ptr, _p(bias), act,
+                    cout if act_cols is None else act_cols, addend.ptr if addend is not None else C.c_void_p(0),
+                    addend.ld if addend is not None else 0, C.c_void_p(0), self.stream)
+            self.meta[name] = ("gconv_bf16", d)
+            return out
+        ws = self._gconv_ws(d, name)
         self.op(self.fwd, name, self.L.rd_gconv_fused, C.byref(d), x.ptr, _p(wp), out.ptr, _p(bias), act,
                 cout if act_cols is None else act_cols, addend.ptr if addend is not None else C.c_void_p(0),
                 addend.ld if addend is not None else 0, _p(ws), self.stream)

@@ -276,17 +276,21 @@ class HipInference:
     """Eval-mode forward of the validate() body (main.py:564-595: model.eval(), no_grad, batch 1) as one hipGraph:
     BatchNorm folded into the convolutions (scale in the packed weights, shift/ReLU/residual in the conv epilogue)."""
 
-    def __init__(self, model, batch, height, width, use_graph=True):
+    def __init__(self, model, batch, height, width, use_graph=True, operands="fp32"):
+        """operands: "fp32" (default; the parity path, within 1e-3 of the reference) or "bf16" (conv operands rounded to bf16,
+        fp32 accumulation and tensors: csrc/gconv_bf16.hip; tolerance stated in tests/test_gpu_bf16.py)."""
         from .model.multistage_model import ResNet_multistage
+        assert operands in ("fp32", "bf16")
+        bf16 = operands == "bf16"
         self.L = lib()
         model.eval()
         self.multistage = isinstance(model, ResNet_multistage)
         if self.multistage:
-            self.mp = model._plans(batch, height, width, False)
+            self.mp = model._plans(batch, height, width, False, bf16=bf16)
             self.plans = [self.mp.p1, self.mp.p2]
         else:
             self.mp = None
-            self.plans = [model._plan(batch, height, width, False)]
+            self.plans = [model._plan(batch, height, width, False, bf16=bf16)]
         self.use_graph = use_graph
         self.graph = None
         self.calls = 0

@@ -251,15 +251,15 @@ class ResNet_latefusion(ArenaOwner, nn.Module):
         return 1
 
     # ------------------------------------------------------------------ HIP execution
-    def _plan(self, batch, height, width, train, depth_planes=None):
+    def _plan(self, batch, height, width, train, depth_planes=None, bf16=False):
         from ..engine import LateFusionPlan
         st = self._ensure_arenas()
-        key = (batch, height, width, bool(train), st["version"], None if depth_planes is None else tuple(t.data_ptr() for t in depth_planes))
+        key = (batch, height, width, bool(train), st["version"], None if depth_planes is None else tuple(t.data_ptr() for t in depth_planes), bool(bf16))
         plans = self.__dict__.setdefault("_plans", {})
         if key not in plans:
             for k in [k for k in plans if k[4] != st["version"]]:
                 del plans[k]
-            plans[key] = LateFusionPlan(self, batch, height, width, train=train, depth_planes=depth_planes)
+            plans[key] = LateFusionPlan(self, batch, height, width, train=train, depth_planes=depth_planes, bf16=bf16)
         return plans[key]
 
     def forward(self, x):

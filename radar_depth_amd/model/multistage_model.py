@@ -79,22 +79,22 @@ class ResNet_multistage(ArenaOwner, nn.Module):
         return {k: v for k, v in pretrain_dict.items() if target_dict[k].shape == v.shape}
 
     # ------------------------------------------------------------------ HIP execution
-    def _plans(self, batch, height, width, train):
+    def _plans(self, batch, height, width, train, bf16=False):
         from ..engine import LateFusionPlan
         assert list(self.output_size) == [height, width], "the multistage net feeds its stage-1 output back as an input map: " \
             "output_size must equal the input size"
         st = self._ensure_arenas()
-        key = (batch, height, width, bool(train), st["version"])
+        key = (batch, height, width, bool(train), st["version"], bool(bf16))
         cache = self.__dict__.setdefault("_ms_plans", {})
         if key not in cache:
             for k in [k for k in cache if k[4] != st["version"]]:
                 del cache[k]
-            p1 = LateFusionPlan(self.stage1, batch, height, width, train=train)
+            p1 = LateFusionPlan(self.stage1, batch, height, width, train=train, bf16=bf16)
             dev = p1.dev
             kept = torch.empty(batch, 1, height, width, device=dev)
             mask = torch.empty(batch, 1, height, width, device=dev)
             p2 = LateFusionPlan(self.stage2, batch, height, width, train=train, depth_planes=[kept, p1.pred], x_source=p1.x_in,
-                                dense_grad_dst=p1.dpred if train else None)
+                                dense_grad_dst=p1.dpred if train else None, bf16=bf16)
             cache[key] = MultistagePlan(p1, p2, kept, mask)
         return cache[key]
 

@@ -32,6 +32,28 @@ def pack_weights(w_oihw, transpose=False, out=None, ldc=None, off=0, rows_total=
     return out
 
 
+def pack_weights_bf16(w_oihw, transpose=False, ldc=None, off=0, rows_total=None):
+    """bf16 operand of gconv_bf16 (same logical shapes as pack_weights)."""
+    o, i, kh, kw = w_oihw.shape
+    if not transpose:
+        ldc, rows_total = ldc or o, i
+    else:
+        ldc, rows_total = ldc or i, rows_total or o
+    out = torch.zeros((kh * kw, rows_total, ldc), dtype=torch.bfloat16, device=w_oihw.device)
+    check(lib().rd_pack_weights_bf16(ptr(_f32(w_oihw)), ptr(out), o, i, kh, kw, ldc, off, rows_total, int(transpose),
+                                     current_stream()), "rd_pack_weights_bf16")
+    return out
+
+
+def gconv_bf16(desc, x, w_packed_bf16, out, bias=None, act=0, act_cols=0, addend=None, ld_add=0, stat=None):
+    """bf16-operand convolution (fp32 tensors, fp32 accumulation): rd_gconv_bf16."""
+    _poison()
+    assert w_packed_bf16.dtype == torch.bfloat16
+    check(lib().rd_gconv_bf16(C.byref(desc), ptr(_f32(x)), ptr(w_packed_bf16), ptr(_f32(out)), ptr(bias), act, act_cols,
+                              ptr(addend), ld_add, ptr(stat), current_stream()), "rd_gconv_bf16")
+    return out
+
+
 def gconv_stat_tiles(desc):
     n = lib().rd_gconv_stat_tiles_ws(C.byref(desc))
     if n < 0:

@@ -7,8 +7,10 @@ from radar_depth_amd.model.models import ResNet_latefusion
 from radar_depth_amd.synthetic import make_batch
 torch.manual_seed(0)
 m = ResNet_latefusion(18, "upproj", [450, 800], 4, False).cuda()
+ops = sys.argv[1] if len(sys.argv) > 1 else "fp32"     # fp32 | bf16 (conv operands; csrc/gconv_bf16.hip)
+print("conv operands:", ops)
 for b, g in ((1, True), (1, False), (16, True), (16, False)):
-    inf = HipInference(m, b, 450, 800, use_graph=g)
+    inf = HipInference(m, b, 450, 800, use_graph=g, operands=ops)
     x, _ = make_batch(b, 450, 800, 1)
     x = x.cuda()
     for _ in range(5): inf(x)
