@@ -138,6 +138,10 @@ def main():
                     help="headline = resnet18_latefusion (BASELINE configs[1]); the multistage arch is configs[3] (use --batch 8)")
     ap.add_argument("--graph", action="store_true", help="replay the step as hipGraphs (slower than plain stream launches here)")
     ap.add_argument("--no-graph", action="store_true", help="(default; kept for older command lines)")
+    ap.add_argument("--operands", default="fp32", choices=["fp32", "bf16"],
+                    help="conv operand precision.  fp32 (default) is the BASELINE.json configs[1] measurement; bf16 (configs 2/4) runs the "
+                         "forward / input-gradient convolutions on bf16 MFMA with fp32 tensors + accumulation and is reported with "
+                         "dtype \"bf16\" and its own metric name -- never as the fp32 headline")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     args = ap.parse_args()
@@ -167,7 +171,7 @@ def main():
     model, loss_weights = made if isinstance(made, tuple) else (made, None)
     model = model.cuda()
     ts = HipTrainStep(model, args.batch, args.height, args.width, lr=0.01, momentum=0.9, weight_decay=1e-4,
-                      loss_weights=loss_weights, use_graph=args.graph)
+                      loss_weights=loss_weights, use_graph=args.graph, operands=args.operands)
     x, t = make_batch(args.batch, args.height, args.width, 1234 + 1000 * rank)
     x, t = x.cuda(), t.cuda()
 
@@ -200,7 +204,12 @@ def main():
                    "hipgraph": args.graph, "final_loss": round(final_loss, 5)},
     }
     multistage = args.arch != "resnet18_latefusion"
-    if rank == 0 and not args.no_roofline and not multistage:
+    bf16 = args.operands == "bf16"
+    if bf16:
+        out["dtype"] = "bf16"
+        out["metric"] = METRIC + " [bf16 conv operands: fwd + dgrad on v_mfma_f32_32x32x16_bf16, wgrad fp32; fp32 tensors/accumulation]"
+        out["config"]["workload"] = out["config"]["workload"].replace(" fp32,", " bf16-operand convs,")
+    if rank == 0 and not args.no_roofline and not multistage and not bf16:
         agg, fam = instrumented_pass(ts)
         name, (ms, n, flops) = max(agg.items(), key=lambda kv: kv[1][0])
         achieved = flops / (ms * 1e-3) / 1e12
@@ -233,7 +242,7 @@ def main():
             out["metric"] = "training samples/sec, %s b=%d %dx%d rgbd" % (args.arch, args.batch, args.height, args.width)
             out["roofline_note"] = "algorithmic work 209.57 GFLOP/sample at 450x800 (SURVEY 8d): %.1f%% of the fp32 peak" % (
                 100 * 209.57e9 * (args.height * args.width / 360000.0) * out["value"] / 157.3e12)
-        if world == 1 and not args.no_cpu_baseline and not multistage:
+        if world == 1 and not args.no_cpu_baseline and not multistage and not bf16:
             out["cpu_baseline"] = cpu_baseline(args.height, args.width)
         print(json.dumps(out), flush=True)
     if torch.distributed.is_available() and torch.distributed.is_initialized():

@@ -76,7 +76,8 @@ class LateFusionPlan:
     def __init__(self, module, batch, height, width, train=True, depth_planes=None, x_source=None, dense_grad_dst=None,
                  dry_run=False, bf16=False):
         """module: a radar_depth_amd ResNet_latefusion(2); bf16: run the gconv-lowered convolutions with bf16 operands on
-        v_mfma_f32_32x32x16_bf16 (fp32 tensors, fp32 accumulation; eval plans only -- BASELINE.json configs 3/5, opt-in); depth_planes: None (depth stem reads channel(s) 3.. of the
+        v_mfma_f32_32x32x16_bf16 (fp32 tensors, fp32 accumulation -- BASELINE.json configs 3/5, opt-in; in train plans the
+        forward and input-gradient convolutions, the weight gradients stay on the fp32 kernels); depth_planes: None (depth stem reads channel(s) 3.. of the
         network input) or, for stage 2 of the multistage net, a list of stand-alone [N,H,W] maps; x_source: share another
         plan's static input buffer (stage 2 reads the RGB planes of stage 1's); dense_grad_dst: [N,H,W]-sized buffer that
         receives the gradient w.r.t. the second depth plane (stage-1 prediction, multistage_model.py:75)."""
@@ -84,7 +85,6 @@ class LateFusionPlan:
         self.N, self.H, self.W = batch, height, width
         self.train = train
         self.bf16 = bool(bf16)
-        assert not (self.bf16 and train), "bf16 operands are implemented for eval plans"
         self.dev = module.conv1.weight.device
         # dry_run: record the op lists against host buffers without ever launching (CPU tests of the host logic)
         assert dry_run or self.dev.type == "cuda", "the HIP path needs the module on a GPU"
@@ -183,21 +183,27 @@ class LateFusionPlan:
             out = self.act(N, d.Ho, d.Wo, cout)
         d.ldo = out.ld
         S = k * k
-        wp = self.buf(S, cin, cout)
-        wd = self.buf(S, cout, cin)
+        wdt = torch.bfloat16 if self.bf16 else torch.float32
+        quad = 2 if self.bf16 else 1
+        wp = self.buf(S, cin, cout, dtype=wdt)
+        wd = self.buf(S, cout, cin, dtype=wdt)
         for w, off in weights:
             o, i, kh, kw = w.shape
-            self.pack_jobs.append((w, wp, o, i, kh * kw, cout, off, i, 0, None, 1))
-            self.pack_jobs.append((w, wd, o, i, kh * kw, cin, off, cout, 1, None, 1))
-        tiles = self.L.rd_gconv_stat_tiles_ws(C.byref(d))
+            self.pack_jobs.append((w, wp, o, i, kh * kw, cout, off, i, 0, None, quad))
+            self.pack_jobs.append((w, wd, o, i, kh * kw, cin, off, cout, 1, None, quad))
+        tiles = (self.L.rd_gconv_bf16_stat_tiles if self.bf16 else self.L.rd_gconv_stat_tiles_ws)(C.byref(d))
         if tiles < 0:
-            check(tiles, "rd_gconv_stat_tiles_ws(%s)" % name)
+            check(tiles, "rd_gconv_stat_tiles(%s)" % name)
         stat = self.buf(tiles, 2, cout) if self.train else None
-        ws = self._gconv_ws(d, name)
         self.keep.append(d)
-        self.op(lst, name, self.L.rd_gconv_ws, C.byref(d), x.ptr, _p(wp), out.ptr, C.c_void_p(0), 0, _p(stat), _p(ws), self.stream)
+        if self.bf16:
+            self.op(lst, name, self.L.rd_gconv_bf16, C.byref(d), x.ptr, _p(wp), out.ptr, C.c_void_p(0), 0, 0, C.c_void_p(0), 0,
+                    _p(stat), self.stream)
+        else:
+            ws = self._gconv_ws(d, name)
+            self.op(lst, name, self.L.rd_gconv_ws, C.byref(d), x.ptr, _p(wp), out.ptr, C.c_void_p(0), 0, _p(stat), _p(ws), self.stream)
         self.taps[name] = out
-        self.meta[name] = ("gconv", d)
+        self.meta[name] = ("gconv_bf16" if self.bf16 else "gconv", d)
         ctx = dict(name=name, d=d, x=x, out=out, weights=weights, wd=wd, k=k, stride=stride, pad=pad, upproj=upproj,
                    stat=stat, tiles=tiles, cin=cin, cout=cout)
         return out, ctx
@@ -250,10 +256,15 @@ class LateFusionPlan:
             self.op(self.bwd, name + ".zero", self.L.rd_fill, dx.ptr, C.c_int64(dx.t.numel()), C.c_float(0.0), self.stream)
             if addend is not None:
                 raise NotImplementedError("addend with a zero-filled stride-2 dgrad")
-        self.meta[name + ".dgrad"] = ("gconv", dd)
-        self.op(self.bwd, name + ".dgrad", self.L.rd_gconv_ws, C.byref(dd), dout.ptr, _p(ctx["wd"]), dx.ptr,
-                addend.ptr if addend is not None else C.c_void_p(0), addend.ld if addend is not None else 0,
-                C.c_void_p(0), _p(self._gconv_ws(dd, name + ".dgrad")), self.stream)
+        self.meta[name + ".dgrad"] = ("gconv_bf16" if self.bf16 else "gconv", dd)
+        if self.bf16:
+            self.op(self.bwd, name + ".dgrad", self.L.rd_gconv_bf16, C.byref(dd), dout.ptr, _p(ctx["wd"]), dx.ptr, C.c_void_p(0), 0, 0,
+                    addend.ptr if addend is not None else C.c_void_p(0), addend.ld if addend is not None else 0,
+                    C.c_void_p(0), self.stream)
+        else:
+            self.op(self.bwd, name + ".dgrad", self.L.rd_gconv_ws, C.byref(dd), dout.ptr, _p(ctx["wd"]), dx.ptr,
+                    addend.ptr if addend is not None else C.c_void_p(0), addend.ld if addend is not None else 0,
+                    C.c_void_p(0), _p(self._gconv_ws(dd, name + ".dgrad")), self.stream)
         if late:
             launch_wgrad()
         return dx

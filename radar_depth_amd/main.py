@@ -99,21 +99,26 @@ class HipTrainStep:
     use_graph: replay the step as hipGraphs from the second call on.  Off by default: the step keeps ~650 kernels on three
     streams in flight from a few ms of host time, and on this stack the graph executor's handling of the cross-stream edges is
     slower than the plain stream launches (661 vs 679 samples/s for latefusion b=16, 272 vs 288 for multistage b=8, and the
-    data-parallel path loses 2.5 % as five graphs but nothing as plain launches)."""
+    data-parallel path loses 2.5 % as five graphs but nothing as plain launches).
 
-    def __init__(self, model, batch, height, width, lr=0.01, momentum=0.9, weight_decay=1e-4, loss_weights=None, use_graph=False):
+    operands: "fp32" (default, the parity path) or "bf16": forward and input-gradient convolutions with bf16 operands on the bf16
+    matrix cores (csrc/gconv_bf16.hip; fp32 tensors, fp32 accumulation, fp32 weight gradients / BatchNorm / SGD) -- the
+    torch.autocast(bfloat16) analogue for BASELINE.json configs 2/4; tolerances in tests/test_gpu_bf16.py."""
+
+    def __init__(self, model, batch, height, width, lr=0.01, momentum=0.9, weight_decay=1e-4, loss_weights=None, use_graph=False,
+                 operands="fp32"):
         from .model.multistage_model import ResNet_multistage
         self.model = model
         self.L = lib()
         model.train()
         self.multistage = isinstance(model, ResNet_multistage)
         if self.multistage:
-            self.mp = model._plans(batch, height, width, True)
+            self.mp = model._plans(batch, height, width, True, bf16=operands == "bf16")
             self.plans = [self.mp.p1, self.mp.p2]
         else:
             assert isinstance(model, ResNet_latefusion)
             self.mp = None
-            self.plans = [model._plan(batch, height, width, True)]
+            self.plans = [model._plan(batch, height, width, True, bf16=operands == "bf16")]
         self.plan = self.plans[0]
         self.st = model._ensure_arenas()
         dev = self.plan.dev

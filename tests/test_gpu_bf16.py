@@ -119,6 +119,48 @@ def test_gconv_bf16_stats_and_dgrad_operand():
     assert _rel(dx.permute(0, 3, 1, 2).cpu(), ref) < 2e-5
 
 
+@pytest.mark.parametrize("cfg", [(2, 64, 128, 3, 2, 1, 57, 100), (2, 16, 32, 3, 2, 1, 57, 101), (1, 96, 48, 3, 2, 1, 33, 45),
+                                 (2, 64, 128, 1, 2, 0, 57, 100), (2, 48, 80, 3, 1, 1, 31, 17)])
+def test_gconv_bf16_dgrad(cfg):
+    """Input gradients (stride-2 parity phases, 1x1 stride-2 with its zero-filled holes) with a residual addend."""
+    from radar_depth_amd import convdesc as cd, ops
+    n, ci, co, k, s, p, h, w = cfg
+    g = torch.Generator().manual_seed(4)
+    wt = torch.randn(co, ci, k, k, generator=g) * 0.05
+    ho, wo = cd.conv_out_size(h, k, s, p), cd.conv_out_size(w, k, s, p)
+    dy = torch.randn(n, co, ho, wo, generator=g)
+    add = torch.randn(n, ci, h, w, generator=g)
+    dd, zero_fill = cd.conv_dgrad(n, h, w, ci, co, k, s, p)
+    ref = F.conv_transpose2d(_bf(dy).double(), _bf(wt).double(), stride=s, padding=p,
+                             output_padding=(h - ((ho - 1) * s - 2 * p + k), w - ((wo - 1) * s - 2 * p + k))).float()
+    dx = torch.zeros(n, h, w, ci, device="cuda") if zero_fill else torch.full((n, h, w, ci), float("nan"), device="cuda")
+    use_add = not zero_fill
+    ops.gconv_bf16(dd, ops.nchw_to_nhwc(dy.cuda()), ops.pack_weights_bf16(wt.cuda(), transpose=True), dx,
+                   addend=ops.nchw_to_nhwc(add.cuda()) if use_add else None, ld_add=ci if use_add else 0)
+    if use_add:
+        ref = ref + add
+    got = dx.permute(0, 3, 1, 2).cpu()
+    assert not torch.isnan(got).any()
+    assert _rel(got, ref) < 2e-5, (_rel(got, ref), cfg)
+
+
+@pytest.mark.parametrize("cfg", [(2, 64, 32, 29, 50), (1, 32, 32, 40, 33)])
+def test_gconv_bf16_upproj_dgrad(cfg):
+    from radar_depth_amd import convdesc as cd, ops
+    n, ci, co, h, w = cfg
+    g = torch.Generator().manual_seed(5)
+    wt = torch.randn(co, ci, 5, 5, generator=g) * 0.05
+    dy = torch.randn(n, co, 2 * h, 2 * w, generator=g)
+    full = F.conv_transpose2d(_bf(dy).double(), _bf(wt).double(), padding=2)     # gradient w.r.t. the unpooled map
+    ref = full[:, :, ::2, ::2].float()                                           # unpool backward keeps the even positions
+    dd = cd.upproj_dgrad(n, h, w, ci, co)
+    dx = torch.full((n, h, w, ci), float("nan"), device="cuda")
+    ops.gconv_bf16(dd, ops.nchw_to_nhwc(dy.cuda()), ops.pack_weights_bf16(wt.cuda(), transpose=True), dx)
+    got = dx.permute(0, 3, 1, 2).cpu()
+    assert not torch.isnan(got).any()
+    assert _rel(got, ref) < 2e-5, _rel(got, ref)
+
+
 @pytest.mark.parametrize("arch", ["resnet18_latefusion", "resnet18_multistage_uncertainty_fixs"])
 def test_bf16_inference_matches_fp32(arch):
     from radar_depth_amd.main import HipInference
@@ -146,3 +188,120 @@ def test_bf16_inference_matches_fp32(arch):
         err = ((g_ - r).abs().max() / r.abs().max()).item()
         assert err <= 2e-2, err
         assert err > 0.0   # the bf16 path really ran
+
+
+class _BfConv(torch.autograd.Function):
+    """What rd_gconv_bf16 computes, restated with torch CPU ops: forward and input gradient with both operands rounded to bf16
+    (nearest even) and fp32 accumulation; the weight gradient from the unrounded fp32 tensors (rd_wgrad)."""
+
+    @staticmethod
+    def forward(ctx, x, w, stride, pad):
+        ctx.save_for_backward(x, w)
+        ctx.sp = (stride, pad)
+        return F.conv2d(_bf(x), _bf(w), None, stride, pad)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w = ctx.saved_tensors
+        stride, pad = ctx.sp
+        dx = torch.nn.grad.conv2d_input(x.shape, _bf(w), _bf(dy), stride, pad) if ctx.needs_input_grad[0] else None
+        dw = torch.nn.grad.conv2d_weight(x, w.shape, dy, stride, pad)
+        return dx, dw, None, None
+
+
+def _emulate_bf16_operands(model):
+    """Route every convolution the engine lowers to gconv (all but the 7x7 stems and the 1-channel head) through _BfConv."""
+    import types
+    n = 0
+    for m in model.modules():
+        if isinstance(m, torch.nn.Conv2d) and m.in_channels % 16 == 0 and m.out_channels > 1:
+            assert m.bias is None
+            m.forward = types.MethodType(lambda self, x: _BfConv.apply(x, self.weight, self.stride, self.padding), m)
+            n += 1
+    return n
+
+
+def test_bf16_train_step_matches_emulated_oracle():
+    """The parity test of the bf16 training path.  The fp32 step is NOT a usable yardstick for single-step gradients: a bf16
+    perturbation (2^-9 relative) flips ~0.3 % of the ReLU masks per layer, each flip switching that element's gradient on or
+    off, so the deep layers' gradients differ by tens of percent from fp32 for ANY bf16 implementation (tools/diag_bf16_grads.py).
+    The yardstick is the CPU oracle with the same rounding points (_BfConv).  Stated tolerances against it: loss 2e-4, gradient
+    norm of EVERY parameter tensor 2e-2 (tail 1e-2), tail gradients element-wise 0.1, output map 0.1 max-norm."""
+    import numpy as np
+    from oracle.criteria import MaskedL1Loss as OL1
+    from oracle.models import ResNet_latefusion as ORef
+    from radar_depth_amd.main import HipTrainStep
+    from radar_depth_amd.model.models import ResNet_latefusion
+    from radar_depth_amd.synthetic import make_batch, procedural_fill_
+    b, h, w = 2, 97, 161
+    torch.manual_seed(0)
+    o = ORef(18, "upproj", [h, w], 4, False)
+    procedural_fill_(o)
+    o.train()
+    assert _emulate_bf16_operands(o) == 52
+    m = ResNet_latefusion(18, "upproj", [h, w], 4, False)
+    procedural_fill_(m)
+    init = [p.detach().clone() for p in m.parameters()]
+    m = m.cuda()
+    x, t = make_batch(b, h, w, 300, ref_pixels=h * w)
+    yo = o(x)
+    lo = OL1()(yo, t)
+    lo.backward()
+    ts = HipTrainStep(m, b, h, w, lr=1.0, momentum=0.0, weight_decay=0.0, operands="bf16")   # update == gradient
+    loss, pred = ts.step(x.cuda(), t.cuda())
+    torch.cuda.synchronize()
+    e_out = _rel(pred.detach().cpu(), yo.detach())
+    e_rms = ((pred.detach().cpu() - yo.detach()).norm() / yo.detach().norm()).item()
+    e_loss = abs(loss.item() - lo.item()) / lo.item()
+    names = [n for n, _ in o.named_parameters()]
+    go = [p.grad for p in o.parameters()]
+    gg = [i0 - p.detach().cpu() for i0, p in zip(init, m.parameters())]
+    no = np.array([g.double().norm().item() for g in go])
+    ng = np.array([g.double().norm().item() for g in gg])
+    tail = [i for i, n in enumerate(names) if n.startswith(("decoder.layer4", "conv3"))]
+    e_tail_norm = np.abs(no[tail] - ng[tail]).max() / no[tail].max()
+    e_all_norm = np.abs(no - ng).max() / no.max()
+    e_tail_elem = max((go[i] - gg[i]).norm().item() / max(go[i].norm().item(), 1e-20) for i in tail)
+    print("bf16 HIP step vs emulated oracle: out max %.3e rms %.3e loss %.3e tail-norm %.3e all-norm %.3e tail-elem %.3e"
+          % (e_out, e_rms, e_loss, e_tail_norm, e_all_norm, e_tail_elem))
+    # measured on MI355X: out max 4.9e-2 (isolated pixels: a 1e-6 fp32 summation-order difference moves ~2.5e-4 of the activations
+    # across a bf16 rounding boundary, and the random-init network amplifies those one-ulp flips), loss 1.4e-5, gradient norms
+    # 3.5e-3 (tail) / 6.2e-3 (all 112 tensors), tail gradients element-wise 4.4e-2
+    assert e_out < 1e-1 and e_loss < 2e-4 and e_tail_norm < 1e-2 and e_all_norm < 2e-2 and e_tail_elem < 0.1
+
+
+def test_bf16_train_step_tracks_fp32():
+    """Full SGD steps with bf16 conv operands (forward + input gradients; weight gradients fp32) against the fp32 HIP step from
+    the same initial state: the losses of three consecutive steps within 1e-2 relative, the tail of the network (conv3, decoder
+    layer 4) within 0.1 of the update it received in fp32, no NaN anywhere.  (Deep-layer single-step gradients are NOT comparable
+    to fp32 -- see test_bf16_train_step_matches_emulated_oracle, which is the parity test.)"""
+    import copy
+    from radar_depth_amd.main import HipTrainStep
+    from radar_depth_amd.model.models import ResNet_latefusion
+    from radar_depth_amd.synthetic import make_batch, procedural_fill_
+    b, h, w = 2, 97, 161
+    torch.manual_seed(0)
+    m0 = ResNet_latefusion(18, "upproj", [h, w], 4, False)
+    procedural_fill_(m0)
+    init = [p.detach().clone() for p in m0.parameters()]
+    res = {}
+    for ops_ in ("fp32", "bf16"):
+        m = copy.deepcopy(m0).cuda()
+        ts = HipTrainStep(m, b, h, w, lr=0.01, momentum=0.9, weight_decay=1e-4, operands=ops_)
+        losses = []
+        for it in range(3):
+            x, t = make_batch(b, h, w, 300 + it, ref_pixels=h * w)
+            loss, _ = ts.step(x.cuda(), t.cuda())
+            losses.append(float(loss.item()))
+        torch.cuda.synchronize()
+        res[ops_] = (losses, [p.detach().cpu().clone() for p in m.parameters()])
+    (l32, p32), (l16, p16) = res["fp32"], res["bf16"]
+    assert all(x == x for x in l16)
+    for a, c in zip(l32, l16):
+        assert abs(a - c) / abs(a) < 1e-2, (l32, l16)
+    assert l32 != l16
+    names = [n for n, _ in m0.named_parameters()]
+    for n, i0, a, c in zip(names, init, p32, p16):
+        assert torch.isfinite(c).all(), n
+        if n.startswith(("conv3", "decoder.layer4.upper_branch.batchnorm2", "decoder.layer4.bottom_branch.batchnorm")):
+            assert (a - c).norm().item() / (a - i0).norm().item() < 0.1, n
