@@ -105,8 +105,11 @@ int rd_gconv_fused(const RdConvDesc* d, const float* in, const float* w_packed, 
 int rd_gconv_bf16(const RdConvDesc* d, const float* in, const void* w_packed_bf16, float* out, const float* bias,
                   int32_t act, int32_t act_cols, const float* addend, int32_t ld_add, float* stat_partial, void* stream);
 int rd_gconv_bf16_stat_tiles(const RdConvDesc* d);
-/* diagnostics: out[0..7] = MT, NT, CKP, TH, TW, patch pixels, lds_bytes, workgroups */
+/* diagnostics: out[0..7] = MT, NT, pipelined*1000 + CKP, TH, TW, patch pixels, lds_bytes, workgroups */
 int rd_gconv_bf16_plan_info(const RdConvDesc* d, int32_t* out);
+/* diagnostics: with RD_GCONV_BF16_TRACE=1 every workgroup records cycle-counter stamps at its phase boundaries (32 slots per
+ * workgroup: count, stamps); copies the last traced launch to the host (tools/trace_gconv_bf16.py) */
+int rd_gconv_bf16_trace_read(unsigned long long* host, int n_wg);
 /* diagnostics: out[0..9] = MT, NT, WM, WN, pipelined*10000+ksplit*100+CKW, CKP, TH, TW, lds_bytes, workgroups chosen for d
  * (workspace plan) */
 int rd_gconv_plan_info(const RdConvDesc* d, int32_t* out);
@@ -139,6 +142,19 @@ int rd_wgrad_plan_info(const RdConvDesc* d, int32_t* out);
  * reference (layout glue). */
 int rd_pack_weights(const float* w_oihw, float* packed, int32_t O, int32_t I, int32_t KH, int32_t KW,
                     int32_t ldc, int32_t co_off, int32_t rows_total, int32_t transpose, void* stream);
+
+/* bf16-operand form of rd_wgrad / rd_wgrad_reduce for the stride-1 3x3 "same" convolutions (single phase, nine taps in
+ * [-1,1]^2, channel counts multiples of 16; rd_wgrad_bf16_supported says whether a descriptor qualifies -- everything else stays
+ * on rd_wgrad): in / dout are the fp32 tensors of rd_wgrad, rounded to bf16 (nearest even) while they are staged, accumulated
+ * in fp32 on v_mfma_f32_32x32x16_bf16.  slabs: rd_wgrad_bf16_workspace_floats(d) floats; rd_wgrad_bf16_reduce sums them in a
+ * fixed order into OIHW gradients exactly like rd_wgrad_reduce. */
+int rd_wgrad_bf16_supported(const RdConvDesc* d);
+int64_t rd_wgrad_bf16_workspace_floats(const RdConvDesc* d);
+int rd_wgrad_bf16(const RdConvDesc* d, const float* in, const float* dout, float* slabs, void* stream);
+int rd_wgrad_bf16_reduce(const RdConvDesc* d, const float* slabs, float* grad_oihw, int32_t O, int32_t I, int32_t KH,
+                         int32_t KW, int32_t co_off, int32_t accumulate, void* stream);
+/* diagnostics: out[0..5] = ci tiles per block, co tiles per block, channel blocks, pixel splits, slabs, lds bytes */
+int rd_wgrad_bf16_plan_info(const RdConvDesc* d, int32_t* out);
 
 /* bf16 operand of rd_gconv_bf16: same arguments, element (slab, row, col) at ((slab*R/8 + row/8)*ldc + col)*8 + row%8,
  * rounded to nearest even; the reduction dimension must be a multiple of 8. */

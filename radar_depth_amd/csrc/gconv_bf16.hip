@@ -22,6 +22,17 @@ namespace rd {
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+// 32 bytes (8 fp32 channels) through a raw buffer descriptor: offsets at or beyond num_records return zeros, so padding / halo
+// units need no branch (a branch per unit makes the compiler wait for each load before it issues the next)
+constexpr unsigned RD_OOB = 0x80000000u;
+__device__ __forceinline__ void buf_load8(__amdgpu_buffer_rsrc_t r, unsigned off, float4& v0, float4& v1) {
+    const u32x4 a = __builtin_amdgcn_raw_buffer_load_b128(r, (int)off, 0, 0);
+    const u32x4 b = __builtin_amdgcn_raw_buffer_load_b128(r, (int)off + 16, 0, 0);
+    v0 = __builtin_bit_cast(float4, a);
+    v1 = __builtin_bit_cast(float4, b);
+}
 
 struct GconvBfArgs {
     RdConvDesc d;
@@ -34,6 +45,7 @@ struct GconvBfArgs {
     int act, act_cols, ld_add, ldw;
     int TH, TW, PP, CKP, tiles_total, n_cotiles, taps_max;
     int tapoff[RD_MAX_PHASES][RD_MAX_TAPS];   // byte offset of tap t inside the patch
+    unsigned long long* trace;                // diagnostics (RD_GCONV_BF16_TRACE=1): 32 cycle-counter stamps per workgroup
 };
 
 __device__ __forceinline__ bf16x4 cvt4(const float4 v) {
@@ -42,7 +54,7 @@ __device__ __forceinline__ bf16x4 cvt4(const float4 v) {
     return r;
 }
 
-template <int MT, int NT>
+template <int MT, int NT, bool PIPE>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void gconv_bf16_kernel(const GconvBfArgs a) {
     constexpr int WM = 4;
     constexpr int BM = WM * MT * 32;
@@ -52,14 +64,23 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void g
     const int l31 = lane & 31, hh = lane >> 5;
     const RdConvDesc& D = a.d;
 
+    int n_stamp = 0;
+#define RD_STAMP() \
+    if (a.trace && tid == 0 && n_stamp < 30) a.trace[(size_t)blockIdx.x * 32 + 1 + n_stamp++] = __builtin_readcyclecounter();
+    RD_STAMP()
+    const unsigned long long rt0 = a.trace ? __builtin_amdgcn_s_memrealtime() : 0;   // 100 MHz constant clock
     const int vid = xcd_remap(blockIdx.x, gridDim.x);
     const int cot = vid % a.n_cotiles;
     const int pt = vid / a.n_cotiles;
     const int n = pt / a.tiles_total;
     const int tt = pt - n * a.tiles_total;
-    int ph = 0;
+    int ph_ = 0;
     for (int i = 1; i < D.n_phases; ++i)
-        if (tt >= D.phase[i].tile_begin) ph = i;
+        if (tt >= D.phase[i].tile_begin) ph_ = i;
+    // (wave-uniform by construction; said explicitly so that everything indexed by it -- tap offsets, tap counts, loop bounds --
+    //  goes through the scalar unit: a vector load of a tap offset would put a vmcnt(0) wait, i.e. a wait for the prefetched
+    //  next chunk, in front of every MFMA walk)
+    const int ph = __builtin_amdgcn_readfirstlane(ph_);
     const RdPhase& P = D.phase[ph];
     const int tloc = tt - P.tile_begin;
     const int tiles_w = (P.lw + a.TW - 1) / a.TW;
@@ -71,15 +92,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void g
     const int ih0 = r0 * IS + P.dh_min, iw0 = c0 * IS + P.dw_min;
     const int CKP = a.CKP;
     const int PSB = (CKP + 8) * 2;           // patch pixel pitch in bytes
-    const int ntaps = P.n_taps;
+    const int ntaps = __builtin_amdgcn_readfirstlane(P.n_taps);
     const int co0 = cot * BN;
 
     // LDS carve-up
     int* s_opix = reinterpret_cast<int*>(smem);          // [BM] output pixel index or -1
     int* s_apix = s_opix + BM;                           // [BM] patch pixel index of tap (0,0)
     int* s_widx = s_apix + BM;                           // [32] weight slab index of each tap
-    char* s_w = reinterpret_cast<char*>(s_widx + 32);    // [taps][CKP/8][BN] x 16 B
-    char* s_patch = s_w + (size_t)a.taps_max * (CKP >> 3) * BN * 16;   // [PP][PSB]
+    char* s_w = reinterpret_cast<char*>(s_widx + 32);    // [taps][CKP/8][BN] x 16 B (two of them when pipelined)
+    const int slab_bytes = a.taps_max * (CKP >> 3) * BN * 16;
+    char* s_patch = s_w + (PIPE ? 2 : 1) * slab_bytes;   // [PP][PSB]
 
     for (int m = tid; m < BM; m += 256) {
         const int r = m / a.TW, c = m - r * a.TW;
@@ -89,6 +111,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void g
     }
     if (tid < ntaps) s_widx[tid] = P.widx[tid];
     __syncthreads();
+    RD_STAMP()
 
     int aoffB[MT];
 #pragma unroll
@@ -103,89 +126,176 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void g
 #pragma unroll
             for (int i = 0; i < 16; ++i) acc[mt][nt][i] = 0.f;
 
-    const int q8 = CKP >> 3;                  // 8-channel units per patch pixel
-    const int patch_elems = PH * PW * q8;
-    const int welems = ntaps * q8 * BN;       // 16-byte units of the weight slab
+    const int q8 = CKP >> 3;                  // 8-channel (32-byte fp32 / 16-byte bf16) units per patch pixel: 2, 4 or 8
+    const int lq8 = 31 - __clz(q8);
+    const int welems = ntaps << (lq8 + (NT == 2 ? 6 : 5));   // 16-byte units of the weight slab [tap][q8][BN]
     const int cin8 = D.Cin >> 3;
     const float* in_n = a.in + (size_t)n * D.Hi * D.Wi * D.ldi;
-    const int ksteps = CKP >> 4;
-    const int nsteps = ntaps * ksteps;
+    const int lks = lq8 - 1;                  // log2 of the 16-channel MFMA steps per tap
+    const int nsteps = ntaps << lks;
 
-    for (int cb = 0; cb < D.Cin; cb += CKP) {
-        __syncthreads();
-        // ---- stage the halo patch chunk [PH*PW][CKP] as bf16 (zero outside the image) and the chunk's weight slab.  Batches of
-        // loads are issued before their LDS writes so that a batch pays one memory round trip.
-        constexpr int UP = 4, UW = 4;
-        for (int base = tid; base < patch_elems; base += UP * 256) {
-            float4 v0[UP], v1[UP];
-#pragma unroll
-            for (int u = 0; u < UP; ++u) {
-                const int e = base + u * 256;
-                const int pix = e / q8, qq = e - pix * q8;
-                const int py = pix / PW, px = pix - py * PW;
-                const int ih = ih0 + py, iw = iw0 + px;
-                v0[u] = v1[u] = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (e < patch_elems && ih >= 0 && ih < D.Hi && iw >= 0 && iw < D.Wi) {
-                    const float* p = in_n + ((size_t)ih * D.Wi + iw) * D.ldi + cb + qq * 8;
-                    v0[u] = *reinterpret_cast<const float4*>(p);
-                    v1[u] = *reinterpret_cast<const float4*>(p + 4);
-                }
-            }
-#pragma unroll
-            for (int u = 0; u < UP; ++u) {
-                const int e = base + u * 256;
-                if (e < patch_elems) {
-                    const int pix = e / q8, qq = e - pix * q8;
-                    bf16x8 r;
-                    const bf16x4 lo = cvt4(v0[u]), hi = cvt4(v1[u]);
-                    r[0] = lo[0]; r[1] = lo[1]; r[2] = lo[2]; r[3] = lo[3];
-                    r[4] = hi[0]; r[5] = hi[1]; r[6] = hi[2]; r[7] = hi[3];
-                    *reinterpret_cast<bf16x8*>(s_patch + pix * PSB + qq * 16) = r;
-                }
-            }
-        }
-        for (int base = tid; base < welems; base += UW * 256) {
-            uint4 v[UW];
-#pragma unroll
-            for (int u = 0; u < UW; ++u) {
-                const int e = base + u * 256;
-                const int j = e % BN, tk = e / BN;
-                const int k8 = tk % q8, t = tk / q8;
-                v[u] = make_uint4(0u, 0u, 0u, 0u);
-                if (e < welems && co0 + j < D.Cout)
-                    v[u] = *reinterpret_cast<const uint4*>(a.w + (((size_t)s_widx[t] * cin8 + (cb >> 3) + k8) * a.ldw + co0 + j) * 8);
-            }
-#pragma unroll
-            for (int u = 0; u < UW; ++u) {
-                const int e = base + u * 256;
-                if (e < welems) *reinterpret_cast<uint4*>(s_w + (size_t)e * 16) = v[u];
-            }
-        }
-        __syncthreads();
-
-        // ---- (tap, 16-channel step) walk; fragments of step s+1 are read while step s's MFMAs issue
-        bf16x8 ca[MT], cbv[NT], na[MT], nb[NT];
+    // ---- (tap, 16-channel step) walk over one staged chunk.  Two fragment sets alternate: the reads of step s+1 are issued
+    // before the MFMAs of step s.  The tap offsets live in the lanes of one VGPR and are fetched with v_readlane (an s_load
+    // in this loop would force lgkmcnt(0) waits, i.e. serialize the LDS reads behind it).
+    const int tapv = a.tapoff[ph][min(lane, RD_MAX_TAPS - 1)];
+    auto run_chunk = [&](const char* wbuf) {
+        bf16x8 a0[MT], b0[NT], a1[MT], b1[NT];
         auto load = [&](int s, bf16x8 (&A)[MT], bf16x8 (&B)[NT]) {
-            const int t = s / ksteps, k = s - t * ksteps;
-            const int ao = a.tapoff[ph][t] + k * 32;
-            const int bo = ((t * q8 + k * 2) * BN) * 16;
+            const int t = s >> lks, k = s & ((1 << lks) - 1);
+            const int ao = __builtin_amdgcn_readlane(tapv, t) + k * 32;
+            const int bo = (((t << lq8) + k * 2) * BN) * 16;
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) A[mt] = *reinterpret_cast<const bf16x8*>(s_patch + aoffB[mt] + ao);
 #pragma unroll
-            for (int nt = 0; nt < NT; ++nt) B[nt] = *reinterpret_cast<const bf16x8*>(s_w + boffB + bo + nt * 512);
+            for (int nt = 0; nt < NT; ++nt) B[nt] = *reinterpret_cast<const bf16x8*>(wbuf + boffB + bo + nt * 512);
         };
-        load(0, ca, cbv);
-        for (int s = 0; s < nsteps; ++s) {
-            if (s + 1 < nsteps) load(s + 1, na, nb);
+        auto mma = [&](const bf16x8 (&A)[MT], const bf16x8 (&B)[NT]) {
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt)
-                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ca[mt], cbv[nt], acc[mt][nt], 0, 0, 0);
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[mt], B[nt], acc[mt][nt], 0, 0, 0);
+        };
+        load(0, a0, b0);
+        for (int s = 0; s < nsteps; s += 2) {
+            if (s + 1 < nsteps) load(s + 1, a1, b1);
+            mma(a0, b0);
+            if (s + 1 < nsteps) {
+                if (s + 2 < nsteps) load(s + 2, a0, b0);
+                mma(a1, b1);
+            }
+        }
+    };
+
+    // ---- staging.  These layers are bound by memory and by the integer work of the staging itself (the bf16 MFMAs of a chunk
+    // take a few hundred clocks), so the element -> address maps avoid every division by a runtime value:
+    //   patch  : a wave copies whole patch ROW SEGMENTS (64 consecutive units of one row); segment = wave + 4*k is wave-uniform
+    //            (scalar unit), a lane's pixel / channel-unit inside it are shifts of the lane id;
+    //   weights: unit e of the slab [tap][q8][BN] decomposes by shifts (BN and q8 are powers of two) and lands in LDS by
+    //            global_load_lds -- the packed operand in HBM already has the LDS layout.
+    const int wave_u = __builtin_amdgcn_readfirstlane(wm);
+    const int rowu = PW << lq8;               // units per patch row
+    const int nseg = (rowu + 63) >> 6;        // 64-unit segments per row
+    const int nsegs = PH * nseg;
+    auto unit_of = [&](int k, unsigned& goff, int& ldst) {
+        const int seg = wave_u + 4 * k;
+        const int row = nseg == 1 ? seg : seg / nseg;
+        const int cu = ((seg - row * nseg) << 6) + lane;
+        const int px = cu >> lq8, qq = cu & (q8 - 1);
+        const int ih = ih0 + row, iw = iw0 + px;
+        const bool ok = seg < nsegs && cu < rowu;
+        ldst = ok ? (row * PW + px) * PSB + qq * 16 : -1;
+        goff = (ok && ih >= 0 && ih < D.Hi && iw >= 0 && iw < D.Wi) ? (unsigned)(((ih * D.Wi + iw) * D.ldi + qq * 8) * 4) : RD_OOB;
+    };
+    const unsigned img_bytes = (unsigned)(D.Hi * D.Wi * D.ldi) * 4u;
+    auto chunk_rsrc = [&](int cb) {           // image n from channel cb on
+        return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(in_n + cb), 0, img_bytes - cb * 4, 0x00020000);
+    };
+    auto weight_off = [&](int e) -> unsigned {      // byte offset of slab unit e inside the packed weights at input-channel group 0
+        const int j = e & (BN - 1), tk = e >> (NT == 2 ? 6 : 5);
+        const int k8 = tk & (q8 - 1), t = tk >> lq8;
+        return (e < welems && co0 + j < D.Cout) ? (unsigned)((((unsigned)s_widx[min(t, ntaps - 1)] * cin8 + k8) * a.ldw + co0 + j) * 16) : ~0u;
+    };
+    auto put_unit = [&](int ldst, const float4 v0, const float4 v1) {
+        if (ldst >= 0) {
+            bf16x8 r;
+            const bf16x4 lo = cvt4(v0), hi = cvt4(v1);
+            r[0] = lo[0]; r[1] = lo[1]; r[2] = lo[2]; r[3] = lo[3];
+            r[4] = hi[0]; r[5] = hi[1]; r[6] = hi[2]; r[7] = hi[3];
+            *reinterpret_cast<bf16x8*>(s_patch + ldst) = r;
+        }
+    };
+
+    if constexpr (PIPE) {
+        // ---- software-pipelined chunk loop (host guarantees: the patch is at most 4*UPP row segments, a weight slab at most UWP
+        // units per thread).  The weight slabs alternate between two LDS buffers and arrive one chunk ahead; the next chunk's
+        // activations are fetched into registers before the current chunk's MFMAs and converted / written to LDS after them.
+        // Per-unit addresses are computed once per workgroup.
+        constexpr int UPP = MT * NT >= 6 ? 4 : 8, UWP = 9;   // (the 3x2 register tile has no room for eight staged units)
+        unsigned pgo[UPP];      // byte offset of the unit inside the image at channel 0; RD_OOB: outside -> zero
+        int pdst[UPP];          // LDS byte offset inside the patch, -1: no such unit
 #pragma unroll
-            for (int mt = 0; mt < MT; ++mt) ca[mt] = na[mt];
+        for (int u = 0; u < UPP; ++u) unit_of(u, pgo[u], pdst[u]);
+        unsigned woff[UWP];
 #pragma unroll
-            for (int nt = 0; nt < NT; ++nt) cbv[nt] = nb[nt];
+        for (int u = 0; u < UWP; ++u) woff[u] = weight_off(tid + u * 256);
+        auto issue_slab = [&](int buf, int cb) {
+            const char* src = reinterpret_cast<const char*>(a.w) + (size_t)(cb >> 3) * a.ldw * 16;
+            char* dst = s_w + buf * slab_bytes;
+#pragma unroll
+            for (int u = 0; u < UWP; ++u) {
+                const int e = tid + u * 256;
+                if (e < welems) {
+                    if (woff[u] != ~0u) glds16(reinterpret_cast<const float*>(src + woff[u]), reinterpret_cast<float*>(dst + (e - lane) * 16));
+                    else *reinterpret_cast<uint4*>(dst + e * 16) = make_uint4(0u, 0u, 0u, 0u);
+                }
+            }
+        };
+        auto patch_fetch = [&](int cb, float4 (&v0)[UPP], float4 (&v1)[UPP]) {
+            const __amdgpu_buffer_rsrc_t r = chunk_rsrc(cb);
+#pragma unroll
+            for (int u = 0; u < UPP; ++u) buf_load8(r, pgo[u], v0[u], v1[u]);
+        };
+        {
+            float4 v0[UPP], v1[UPP];
+            issue_slab(0, 0);
+            patch_fetch(0, v0, v1);
+#pragma unroll
+            for (int u = 0; u < UPP; ++u) put_unit(pdst[u], v0[u], v1[u]);
+        }
+        int idx = 0;
+        for (int cb = 0; cb < D.Cin; cb += CKP, ++idx) {
+            glds_wait();
+            __syncthreads();          // slab idx and the chunk's patch have landed; slab idx-1 is fully consumed
+            RD_STAMP()
+            const bool more = cb + CKP < D.Cin;
+            float4 v0[UPP], v1[UPP];
+            if (more) {
+                issue_slab((idx + 1) & 1, cb + CKP);
+                patch_fetch(cb + CKP, v0, v1);
+            }
+            run_chunk(s_w + (idx & 1) * slab_bytes);
+            RD_STAMP()
+            if (more) {
+                __syncthreads();      // every wave is done reading this chunk's patch
+#pragma unroll
+                for (int u = 0; u < UPP; ++u) put_unit(pdst[u], v0[u], v1[u]);
+            }
+        }
+    } else {
+        // ---- plain chunk loop: weights by global_load_lds, then the patch in batches of UP row segments per wave (all loads of
+        // a batch are issued before its first conversion), one barrier pair per chunk.  Workgroups of the same CU overlap each
+        // other's phases.
+        constexpr int UP = 8;
+        const int nk = (nsegs + 3) >> 2;            // row segments per wave
+        for (int cb = 0; cb < D.Cin; cb += CKP) {
+            __syncthreads();
+            {
+                const char* src = reinterpret_cast<const char*>(a.w) + (size_t)(cb >> 3) * a.ldw * 16;
+                for (int e = tid; e < welems; e += 256) {
+                    const unsigned wo = weight_off(e);
+                    if (wo != ~0u) glds16(reinterpret_cast<const float*>(src + wo), reinterpret_cast<float*>(s_w + (e - lane) * 16));
+                    else *reinterpret_cast<uint4*>(s_w + e * 16) = make_uint4(0u, 0u, 0u, 0u);
+                }
+            }
+            const __amdgpu_buffer_rsrc_t r = chunk_rsrc(cb);
+            for (int k0 = 0; k0 < nk; k0 += UP) {
+                float4 v0[UP], v1[UP];
+                int ld[UP];
+#pragma unroll
+                for (int u = 0; u < UP; ++u) {
+                    unsigned go;
+                    unit_of(k0 + u, go, ld[u]);
+                    buf_load8(r, go, v0[u], v1[u]);
+                }
+#pragma unroll
+                for (int u = 0; u < UP; ++u) put_unit(ld[u], v0[u], v1[u]);
+            }
+            glds_wait();
+            __syncthreads();
+            RD_STAMP()
+            run_chunk(s_w);
+            RD_STAMP()
         }
     }
 
@@ -199,24 +309,61 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void g
     float biasv[NT];
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) biasv[nt] = (has_bias && cob + nt * 32 < D.Cout) ? a.bias[cob + nt * 32] : 0.f;
+    const bool want_stat = a.stat != nullptr;
+    const bool cols_full = co0 + NT * 32 <= D.Cout;       // wave-uniform
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
         int ro[16];
+        bool rows_ok = true;
 #pragma unroll
-        for (int i = 0; i < 16; ++i) ro[i] = s_opix[(wm * MT + mt) * 32 + (i & 3) + 8 * (i >> 2) + 4 * hh];   // -1: no such pixel
+        for (int i = 0; i < 16; ++i) {
+            ro[i] = s_opix[(wm * MT + mt) * 32 + (i & 3) + 8 * (i >> 2) + 4 * hh];   // -1: no such pixel
+            rows_ok = rows_ok && ro[i] >= 0;
+        }
+        if (cols_full && __all(rows_ok)) {
+            // full M-tile (almost all of them): no exec masking; the addends of eight rows are gathered before their first use
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt) {
-            const int co = cob + nt * 32;
-            const bool cok = co < D.Cout;
+            for (int h8 = 0; h8 < 16; h8 += 8) {
+                float addv[NT][8];
+                if (has_add) {
 #pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                if (cok && ro[i] >= 0) {
-                    float v = acc[mt][nt][i] + biasv[nt];
-                    if (has_add) v += a.addend[(size_t)ro[i] * a.ld_add + co];
-                    if (co < a.act_cols) v = act_fwd(v, a.act);
-                    a.out[(size_t)ro[i] * D.ldo + co] = v;
-                    ssum[nt] += v;
-                    ssq[nt] += v * v;
+                    for (int i = 0; i < 8; ++i) {
+                        const float* ap = a.addend + (size_t)ro[h8 + i] * a.ld_add + cob;
+#pragma unroll
+                        for (int nt = 0; nt < NT; ++nt) addv[nt][i] = ap[nt * 32];
+                    }
+                }
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    float* rp = a.out + (size_t)ro[h8 + i] * D.ldo + cob;
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt) {
+                        float v = acc[mt][nt][h8 + i] + biasv[nt];
+                        if (has_add) v += addv[nt][i];
+                        if (cob + nt * 32 < a.act_cols) v = act_fwd(v, a.act);
+                        rp[nt * 32] = v;
+                        if (want_stat) {
+                            ssum[nt] += v;
+                            ssq[nt] += v * v;
+                        }
+                    }
+                }
+            }
+        } else {
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                const int co = cob + nt * 32;
+                const bool cok = co < D.Cout;
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    if (cok && ro[i] >= 0) {
+                        float v = acc[mt][nt][i] + biasv[nt];
+                        if (has_add) v += a.addend[(size_t)ro[i] * a.ld_add + co];
+                        if (co < a.act_cols) v = act_fwd(v, a.act);
+                        a.out[(size_t)ro[i] * D.ldo + co] = v;
+                        ssum[nt] += v;
+                        ssq[nt] += v * v;
+                    }
                 }
             }
         }
@@ -243,12 +390,19 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void g
             if (co < D.Cout) a.stat[((size_t)pt * 2 + which) * D.Cout + co] = s;
         }
     }
+    RD_STAMP()
+    if (a.trace && tid == 0) {
+        a.trace[(size_t)blockIdx.x * 32] = n_stamp;
+        a.trace[(size_t)blockIdx.x * 32 + 31] = __builtin_amdgcn_s_memrealtime() - rt0;
+    }
+#undef RD_STAMP
 }
 
 // ------------------------------------------------------------------------------------------ host
 struct GconvBfPlan {
     int MT, NT, CKP, TH, TW, PP, tiles_total, n_cotiles, taps_max;
     size_t lds_bytes;
+    int pipe;
 };
 
 static int bf_patch_pixels(const RdConvDesc& d, const RdPhase& p, int TH, int TW) {
@@ -280,8 +434,8 @@ static bool plan_gconv_bf16(const RdConvDesc& d, GconvBfPlan& best) {
         for (int ckp = 64; ckp >= 16; ckp >>= 1) {
             if (d.Cin % ckp != 0) continue;
             if (force_ckp && atoi(force_ckp) != ckp && d.Cin % atoi(force_ckp) == 0) continue;
-            const size_t wbytes = (size_t)taps_max * ckp * BN * 2;
-            if (wbytes > 72 * 1024) continue;
+            const size_t wbytes1 = (size_t)taps_max * ckp * BN * 2;
+            if (wbytes1 > 72 * 1024) continue;
             for (int twt = 1; twt <= cdiv(P.lw, 4); ++twt) {
                 const int TW = cdiv(P.lw, twt);
                 if (TW > BM) continue;
@@ -293,20 +447,33 @@ static bool plan_gconv_bf16(const RdConvDesc& d, GconvBfPlan& best) {
                     const int pp = bf_patch_pixels(d, d.phase[i], TH, TW);
                     PP = PP > pp ? PP : pp;
                 }
+                // pipelined chunk loop: the patch chunk must be one batch of <= 8 loads per thread, a weight slab at most nine
+                static const char* nopipe = getenv("RD_GCONV_BF16_NOPIPE");
+                int segs = 0;       // 64-unit row segments of the largest patch (what one wave quarter copies)
+                for (int i = 0; i < d.n_phases; ++i) {
+                    const RdPhase& q = d.phase[i];
+                    const int th = TH < q.lh ? TH : q.lh;
+                    const int ph_ = (th - 1) * d.in_stride + (q.dh_max - q.dh_min) + 1, pw_ = (TW - 1) * d.in_stride + (q.dw_max - q.dw_min) + 1;
+                    const int sg = ph_ * cdiv(pw_ * (ckp / 8), 64);
+                    segs = segs > sg ? segs : sg;
+                }
+                const bool pipe = !nopipe && segs <= 4 * (c.MT * c.NT >= 6 ? 4 : 8) && taps_max * (ckp / 8) * BN <= 9 * 256;
+                const size_t wbytes = wbytes1 * (pipe ? 2 : 1);
                 const size_t lds = (size_t)(2 * BM + 32) * 4 + wbytes + (size_t)(PP + 1) * (ckp + 8) * 2 + 64;
                 if (lds > 160 * 1024 - 512) continue;
                 const double m_util = (double)P.lh * P.lw / ((double)cdiv(P.lh, TH) * cdiv(P.lw, TW) * BM);
                 const double halo = (double)PP / (TH * TW * d.in_stride * d.in_stride);
                 double score = c.prior * m_util * n_util / (1.0 + 0.15 * (halo - 1.0));   // HBM-side cost weighs more than in fp32
                 if (lds > 80 * 1024) score *= 0.8;
-                if (ckp == 16 && d.Cin >= 32) score *= 0.9;
-                if (ckp == 32 && d.Cin >= 64) score *= 0.97;
+                if (!pipe) score *= 0.6;                       // serialized load -> convert -> MFMA per chunk
+                if (ckp == 16 && d.Cin >= 32) score *= 0.92;   // half-line loads, twice the barriers
                 const double wgs = (double)d.N * cdiv(P.lh, TH) * cdiv(P.lw, TW) * n_cot * d.n_phases;
                 const double ncu = (double)num_cus();
                 score *= wgs / (ncu * ceil(wgs / ncu));
+                if (wgs < 2 * ncu) score *= 0.85;              // a lone workgroup per CU has nothing to hide its latencies behind
                 if (score > best_score) {
                     best_score = score;
-                    best = GconvBfPlan{c.MT, c.NT, ckp, TH, TW, PP, 0, n_cot, taps_max, lds};
+                    best = GconvBfPlan{c.MT, c.NT, ckp, TH, TW, PP, 0, n_cot, taps_max, lds, pipe ? 1 : 0};
                 }
             }
         }
@@ -314,10 +481,10 @@ static bool plan_gconv_bf16(const RdConvDesc& d, GconvBfPlan& best) {
     return best_score > 0;
 }
 
-template <int MT, int NT>
+template <int MT, int NT, bool PIPE>
 static int launch_bf(const GconvBfArgs& a, int grid, size_t lds, hipStream_t s) {
     static bool attr_set = false;
-    auto k = gconv_bf16_kernel<MT, NT>;
+    auto k = gconv_bf16_kernel<MT, NT, PIPE>;
     if (!attr_set) {
         RD_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr_set = true;
@@ -366,11 +533,19 @@ static int bf_plan_query(const RdConvDesc* d, GconvBfPlan& pl, RdConvDesc& dd) {
 
 using namespace rd;
 
+static unsigned long long* g_bf_trace = nullptr;
+// diagnostics: copy the stamps of the last traced launch (32 slots per workgroup: count, then cycle-counter values)
+extern "C" int rd_gconv_bf16_trace_read(unsigned long long* host, int n_wg) {
+    if (!g_bf_trace) return RD_EINVAL;
+    RD_CHECK_HIP(hipMemcpy(host, g_bf_trace, (size_t)n_wg * 32 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    return RD_OK;
+}
+
 extern "C" int rd_gconv_bf16_plan_info(const RdConvDesc* d, int32_t* out) {
     GconvBfPlan pl; RdConvDesc dd;
     int rc = bf_plan_query(d, pl, dd);
     if (rc != RD_OK) return rc;
-    const int v[8] = {pl.MT, pl.NT, pl.CKP, pl.TH, pl.TW, pl.PP, (int)pl.lds_bytes, d->N * pl.tiles_total * pl.n_cotiles};
+    const int v[8] = {pl.MT, pl.NT, pl.pipe * 1000 + pl.CKP, pl.TH, pl.TW, pl.PP, (int)pl.lds_bytes, d->N * pl.tiles_total * pl.n_cotiles};
     for (int i = 0; i < 8; ++i) out[i] = v[i];
     return RD_OK;
 }
@@ -402,7 +577,17 @@ extern "C" int rd_gconv_bf16(const RdConvDesc* d, const float* in, const void* w
     }
     const int grid = d->N * pl.tiles_total * pl.n_cotiles;
     hipStream_t s = static_cast<hipStream_t>(stream);
-#define RD_BF(MT_, NT_) if (pl.MT == MT_ && pl.NT == NT_) return launch_bf<MT_, NT_>(a, grid, pl.lds_bytes, s);
+    a.trace = nullptr;
+    {
+        static const char* tr = getenv("RD_GCONV_BF16_TRACE");
+        if (tr && atoi(tr)) {
+            if (!g_bf_trace) RD_CHECK_HIP(hipMalloc(&g_bf_trace, (size_t)65536 * 32 * sizeof(unsigned long long)));
+            a.trace = g_bf_trace;
+        }
+    }
+#define RD_BF(MT_, NT_)                 \
+    if (pl.MT == MT_ && pl.NT == NT_)   \
+        return pl.pipe ? launch_bf<MT_, NT_, true>(a, grid, pl.lds_bytes, s) : launch_bf<MT_, NT_, false>(a, grid, pl.lds_bytes, s);
     RD_BF(2, 2) RD_BF(2, 1) RD_BF(3, 2) RD_BF(1, 2) RD_BF(1, 1)
 #undef RD_BF
     set_error("gconv_bf16: no kernel for tile %dx%d", pl.MT, pl.NT);

@@ -1,0 +1,310 @@
+// bf16-operand weight gradient of the stride-1 3x3 convolutions (the layers that hold two thirds of the weight-gradient time):
+//     dW[kh][kw][ci][co] = sum_p x[p + (kh-1, kw-1)][ci] * dy[p][co]
+// on v_mfma_f32_32x32x16_bf16 (fp32 tensors in HBM, operands rounded to bf16 while they are staged, fp32 accumulation).
+// BASELINE.json configs 2/4 (bf16) -- opt-in like gconv_bf16.hip; rd_wgrad (fp32) stays the default and the parity reference.
+//
+// The reduction dimension of this GEMM is the PIXEL index, and the bf16 MFMA wants eight consecutive k per lane, so both
+// operands are transposed on their way into LDS: XT[ci][row][col] and YT[co][row][col] (bf16, columns contiguous).  A lane then
+// reads eight consecutive pixels of one channel with a single 16-byte LDS read.  The three horizontal taps of one patch row are
+// the same 16 bytes shifted by one pixel: they are built from the aligned read plus the neighbouring dwords with
+// v_alignbyte, the vertical taps are row offsets.
+//
+//   workgroup : one (<=64 input channels) x (<=64 output channels) block of dW, all nine taps, a range of pixel tiles (split)
+//   pixel tile: R rows x 32 columns of one image; X patch (R+2) x 36 columns (halo), staged with pixel PAIRS packed per dword
+//   wave      : one 32x32 (ci, co) tile pair of the block and all nine taps (nine 32x32 accumulators); when the block has fewer
+//               than four tile pairs the spare waves take alternate k-steps and write their own partial slab
+//   output    : per-split slabs [split][tap][Cin][Cout] like rd_wgrad, reduced in a fixed order by the same slab reduction
+#include <math.h>
+#include <stdlib.h>
+
+#include <mutex>
+#include <string>
+#include <unordered_map>
+
+#include "common.h"
+
+namespace rd {
+
+int launch_slab_reduce(const float* slabs, int n_splits, int64_t E, float* tmp, float* grad_oihw, int S, int Cin, int Cout,
+                       int O, int I, int co_off, int accumulate, hipStream_t s);   // wgrad.hip
+
+typedef __bf16 wbf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned int wu32x4 __attribute__((ext_vector_type(4)));
+
+struct WgradBfArgs {
+    const float* x;
+    const float* dy;
+    float* slabs;
+    int N, H, W, Cin, Cout, ldi, ldo;
+    int tiles_h, tiles_w, total_tiles, tiles_per_split, n_splits;
+    int n_cib, n_cob, cpi, cpo;      // channel blocks; 32-channel tiles per block (1 or 2) on the input / output side
+    int slab_of_tap[9];              // weight slab index of tap (dh+1)*3 + (dw+1)
+};
+
+constexpr int WB_R = 4;                      // rows per pixel tile
+constexpr int WB_TW = 32;                    // columns per pixel tile
+constexpr int WB_XROW = 24;                  // dwords per staged X row: 48 bf16 columns, column c0 of the tile at index 8
+constexpr int WB_XPLANE = (WB_R + 2) * WB_XROW;   // dwords per channel plane (multiple of 4: planes stay 16-byte aligned)
+constexpr int WB_YROW = 16;                  // dwords per staged dY row (32 bf16 columns)
+constexpr int WB_YPLANE = WB_R * WB_YROW;
+constexpr int WB_XP0 = 3, WB_XPN = 18;       // staged column pairs of X: 3..20 = plane columns 6..41 (image columns c0-2 .. c0+33)
+
+// 32 bytes through a raw buffer descriptor: offsets at or beyond num_records return zeros (halo / padding without branches)
+constexpr unsigned WB_OOB = 0x80000000u;
+__device__ __forceinline__ void wb_load8(__amdgpu_buffer_rsrc_t r, unsigned off, float4& v0, float4& v1) {
+    v0 = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)off, 0, 0));
+    v1 = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)off + 16, 0, 0));
+}
+
+__device__ __forceinline__ unsigned pack2(float lo, float hi) {
+    const __bf16 a = (__bf16)lo, b = (__bf16)hi;
+    return (unsigned)__builtin_bit_cast(unsigned short, a) | ((unsigned)__builtin_bit_cast(unsigned short, b) << 16);
+}
+
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void wgrad_bf16_kernel(const WgradBfArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned wsm[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, hh = lane >> 5;
+    const int nblk = a.n_cib * a.n_cob;
+    const int blk = blockIdx.x % nblk, split = blockIdx.x / nblk;
+    const int cib = blk / a.n_cob, cob = blk - cib * a.n_cob;
+    const int ci0 = cib * 32 * a.cpi, co0 = cob * 32 * a.cpo;
+    const int n_pairs = a.cpi * a.cpo, n_kparts = 4 / n_pairs;
+    const int pair = wave % n_pairs, kpart = wave / n_pairs;
+    const int wci = pair / a.cpo, wco = pair - wci * a.cpo;
+    const int ncgi = a.cpi * 4, ncgo = a.cpo * 4;      // 8-channel groups of the block
+
+    unsigned* XT = wsm;                                // [32*cpi][WB_XPLANE]
+    unsigned* YT = wsm + 32 * a.cpi * WB_XPLANE;       // [32*cpo][WB_YPLANE]
+
+    f32x16 acc[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
+
+    const int t_lo = split * a.tiles_per_split, t_hi = min(t_lo + a.tiles_per_split, a.total_tiles);
+    const int tiles_img = a.tiles_h * a.tiles_w;
+    for (int tile = t_lo; tile < t_hi; ++tile) {
+        const int n = tile / tiles_img, tr = tile - n * tiles_img;
+        const int th = tr / a.tiles_w, tw = tr - th * a.tiles_w;
+        const int r0 = th * WB_R, c0 = tw * WB_TW;
+        const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.x + (size_t)n * a.H * a.W * a.ldi), 0,
+                                                                            a.H * a.W * a.ldi * 4, 0x00020000);
+        const __amdgpu_buffer_rsrc_t yr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.dy + (size_t)n * a.H * a.W * a.ldo), 0,
+                                                                            a.H * a.W * a.ldo * 4, 0x00020000);
+        __syncthreads();      // the previous tile's MFMAs are done with XT / YT
+        // ---- stage X: unit = (8-channel group, patch row, column pair); a lane converts 2 pixels x 8 channels and writes eight
+        // dwords, one per channel plane (consecutive lanes = consecutive column pairs: conflict-free)
+        {
+            constexpr int PER_CG = (WB_R + 2) * WB_XPN;
+            const int nunits = ncgi * PER_CG;
+            for (int u0 = tid; u0 < nunits; u0 += 2 * 256) {
+                float4 v[2][4];
+                int dst[2];
+#pragma unroll
+                for (int q = 0; q < 2; ++q) {
+                    const int u = u0 + q * 256;
+                    const int cg = u / PER_CG, rem = u - cg * PER_CG;
+                    const int rr = rem / WB_XPN, pp = rem - rr * WB_XPN + WB_XP0;
+                    const int ih = r0 - 1 + rr, iw = c0 + 2 * pp - 8, c = ci0 + cg * 8;
+                    dst[q] = u < nunits ? (cg * 8) * WB_XPLANE + rr * WB_XROW + pp : -1;
+                    const bool rowok = u < nunits && ih >= 0 && ih < a.H && c < a.Cin;
+#pragma unroll
+                    for (int px = 0; px < 2; ++px) {
+                        const bool ok = rowok && iw + px >= 0 && iw + px < a.W;
+                        wb_load8(xr, ok ? (unsigned)(((ih * a.W + iw + px) * a.ldi + c) * 4) : WB_OOB, v[q][2 * px], v[q][2 * px + 1]);
+                    }
+                }
+#pragma unroll
+                for (int q = 0; q < 2; ++q)
+                    if (dst[q] >= 0) {
+                        unsigned* d = XT + dst[q];
+                        d[0 * WB_XPLANE] = pack2(v[q][0].x, v[q][2].x);
+                        d[1 * WB_XPLANE] = pack2(v[q][0].y, v[q][2].y);
+                        d[2 * WB_XPLANE] = pack2(v[q][0].z, v[q][2].z);
+                        d[3 * WB_XPLANE] = pack2(v[q][0].w, v[q][2].w);
+                        d[4 * WB_XPLANE] = pack2(v[q][1].x, v[q][3].x);
+                        d[5 * WB_XPLANE] = pack2(v[q][1].y, v[q][3].y);
+                        d[6 * WB_XPLANE] = pack2(v[q][1].z, v[q][3].z);
+                        d[7 * WB_XPLANE] = pack2(v[q][1].w, v[q][3].w);
+                    }
+            }
+        }
+        // ---- stage dY the same way (no halo; zeros beyond the image: those pixels then contribute nothing)
+        {
+            constexpr int PER_CG = WB_R * WB_YROW;
+            const int nunits = ncgo * PER_CG;
+            for (int u0 = tid; u0 < nunits; u0 += 2 * 256) {
+                float4 v[2][4];
+                int dst[2];
+#pragma unroll
+                for (int q = 0; q < 2; ++q) {
+                    const int u = u0 + q * 256;
+                    const int cg = u / PER_CG, rem = u - cg * PER_CG;
+                    const int rr = rem / WB_YROW, pp = rem - rr * WB_YROW;
+                    const int ih = r0 + rr, iw = c0 + 2 * pp, c = co0 + cg * 8;
+                    dst[q] = u < nunits ? (cg * 8) * WB_YPLANE + rr * WB_YROW + pp : -1;
+                    const bool rowok = u < nunits && ih < a.H && c < a.Cout;
+#pragma unroll
+                    for (int px = 0; px < 2; ++px) {
+                        const bool ok = rowok && iw + px < a.W;
+                        wb_load8(yr, ok ? (unsigned)(((ih * a.W + iw + px) * a.ldo + c) * 4) : WB_OOB, v[q][2 * px], v[q][2 * px + 1]);
+                    }
+                }
+#pragma unroll
+                for (int q = 0; q < 2; ++q)
+                    if (dst[q] >= 0) {
+                        unsigned* d = YT + dst[q];
+                        d[0 * WB_YPLANE] = pack2(v[q][0].x, v[q][2].x);
+                        d[1 * WB_YPLANE] = pack2(v[q][0].y, v[q][2].y);
+                        d[2 * WB_YPLANE] = pack2(v[q][0].z, v[q][2].z);
+                        d[3 * WB_YPLANE] = pack2(v[q][0].w, v[q][2].w);
+                        d[4 * WB_YPLANE] = pack2(v[q][1].x, v[q][3].x);
+                        d[5 * WB_YPLANE] = pack2(v[q][1].y, v[q][3].y);
+                        d[6 * WB_YPLANE] = pack2(v[q][1].z, v[q][3].z);
+                        d[7 * WB_YPLANE] = pack2(v[q][1].w, v[q][3].w);
+                    }
+            }
+        }
+        __syncthreads();
+        // ---- k-steps of this wave: 16 consecutive pixels of one tile row; lane (l31, hh) holds channel l31 of its 32-channel
+        // tile and pixels hh*8 .. hh*8+7 of the step
+        const unsigned* xa = XT + (wci * 32 + l31) * WB_XPLANE + 4 + hh * 4;     // dword of plane column 8 + hh*8 in row 0
+        const unsigned* yb = YT + (wco * 32 + l31) * WB_YPLANE + hh * 4;
+        for (int ks = kpart; ks < 2 * WB_R; ks += n_kparts) {
+            const int r = ks >> 1, h = ks & 1;
+            const wu32x4 bw = *reinterpret_cast<const wu32x4*>(yb + r * WB_YROW + h * 8);
+            const wbf16x8 B = __builtin_bit_cast(wbf16x8, bw);
+#pragma unroll
+            for (int dh = 0; dh < 3; ++dh) {
+                const unsigned* p = xa + (r + dh) * WB_XROW + h * 8;
+                const wu32x4 cur = *reinterpret_cast<const wu32x4*>(p);
+                const unsigned prev = p[-1], next = p[4];
+                wu32x4 lft, rgt;       // windows starting one pixel earlier / later
+                lft[0] = __builtin_amdgcn_alignbyte(cur[0], prev, 2);
+                lft[1] = __builtin_amdgcn_alignbyte(cur[1], cur[0], 2);
+                lft[2] = __builtin_amdgcn_alignbyte(cur[2], cur[1], 2);
+                lft[3] = __builtin_amdgcn_alignbyte(cur[3], cur[2], 2);
+                rgt[0] = __builtin_amdgcn_alignbyte(cur[1], cur[0], 2);
+                rgt[1] = __builtin_amdgcn_alignbyte(cur[2], cur[1], 2);
+                rgt[2] = __builtin_amdgcn_alignbyte(cur[3], cur[2], 2);
+                rgt[3] = __builtin_amdgcn_alignbyte(next, cur[3], 2);
+                acc[dh * 3 + 0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(wbf16x8, lft), B, acc[dh * 3 + 0], 0, 0, 0);
+                acc[dh * 3 + 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(wbf16x8, cur), B, acc[dh * 3 + 1], 0, 0, 0);
+                acc[dh * 3 + 2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(wbf16x8, rgt), B, acc[dh * 3 + 2], 0, 0, 0);
+            }
+        }
+    }
+
+    // ---- this wave's partial slab: [tap][Cin][Cout], accumulator row = input channel, lane = output channel
+    float* slab = a.slabs + (size_t)(split * n_kparts + kpart) * 9 * a.Cin * a.Cout;
+    const int co = co0 + wco * 32 + l31;
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+        float* dst = slab + (size_t)a.slab_of_tap[t] * a.Cin * a.Cout;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int ci = ci0 + wci * 32 + (i & 3) + 8 * (i >> 2) + 4 * hh;
+            if (ci < a.Cin && co < a.Cout) dst[(size_t)ci * a.Cout + co] = acc[t][i];
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------ host
+struct WgradBfPlan {
+    int cpi, cpo, n_cib, n_cob, tiles_h, tiles_w, total_tiles, tiles_per_split, n_splits, slab_splits;
+    size_t lds_bytes;
+    int slab_of_tap[9];
+};
+
+// stride-1 3x3 "same" convolution, channel counts multiples of 16
+static bool wgrad_bf16_plan(const RdConvDesc* d, WgradBfPlan& pl) {
+    if (!d || d->n_phases != 1 || d->in_stride != 1 || d->out_stride != 1) return false;
+    const RdPhase& p = d->phase[0];
+    if (p.n_taps != 9 || p.lh != d->Hi || p.lw != d->Wi || d->Ho != d->Hi || d->Wo != d->Wi) return false;
+    if (p.out_off_h != 0 || p.out_off_w != 0) return false;
+    if (d->Cin % 16 != 0 || d->Cout % 16 != 0 || d->ldi % 4 != 0 || d->ldo % 4 != 0) return false;
+    for (int t = 0; t < 9; ++t) pl.slab_of_tap[t] = -1;
+    for (int t = 0; t < 9; ++t) {
+        if (p.dh[t] < -1 || p.dh[t] > 1 || p.dw[t] < -1 || p.dw[t] > 1) return false;
+        pl.slab_of_tap[(p.dh[t] + 1) * 3 + (p.dw[t] + 1)] = p.widx[t];
+    }
+    for (int t = 0; t < 9; ++t)
+        if (pl.slab_of_tap[t] < 0 || pl.slab_of_tap[t] > 8) return false;
+    pl.cpi = d->Cin >= 64 ? 2 : 1;
+    pl.cpo = d->Cout >= 64 ? 2 : 1;
+    pl.n_cib = cdiv(d->Cin, 32 * pl.cpi);
+    pl.n_cob = cdiv(d->Cout, 32 * pl.cpo);
+    pl.tiles_h = cdiv(d->Hi, WB_R);
+    pl.tiles_w = cdiv(d->Wi, WB_TW);
+    pl.total_tiles = d->N * pl.tiles_h * pl.tiles_w;
+    const int nblk = pl.n_cib * pl.n_cob;
+    static const char* wgs_env = getenv("RD_WGRAD_BF16_WGS");      // diagnostics: target workgroup count (default 512)
+    const int target = wgs_env ? atoi(wgs_env) : 512;
+    int splits = cdiv(target, nblk);
+    if (splits > pl.total_tiles) splits = pl.total_tiles;
+    if (splits < 1) splits = 1;
+    pl.tiles_per_split = cdiv(pl.total_tiles, splits);
+    pl.n_splits = cdiv(pl.total_tiles, pl.tiles_per_split);
+    pl.slab_splits = pl.n_splits * (4 / (pl.cpi * pl.cpo));
+    pl.lds_bytes = (size_t)(32 * pl.cpi * WB_XPLANE + 32 * pl.cpo * WB_YPLANE) * 4;
+    return true;
+}
+
+}  // namespace rd
+
+using namespace rd;
+
+extern "C" int rd_wgrad_bf16_supported(const RdConvDesc* d) {
+    WgradBfPlan pl;
+    return wgrad_bf16_plan(d, pl) ? 1 : 0;
+}
+
+extern "C" int64_t rd_wgrad_bf16_workspace_floats(const RdConvDesc* d) {
+    WgradBfPlan pl;
+    if (!wgrad_bf16_plan(d, pl)) { set_error("wgrad_bf16: unsupported descriptor (stride-1 3x3, channels %% 16 == 0 only)"); return RD_EINVAL; }
+    return (int64_t)(pl.slab_splits + 16) * 9 * d->Cin * d->Cout;
+}
+
+// diagnostics: out[0..5] = ci tiles per block, co tiles per block, channel blocks, pixel splits, slabs, lds bytes
+extern "C" int rd_wgrad_bf16_plan_info(const RdConvDesc* d, int32_t* out) {
+    WgradBfPlan pl;
+    if (!wgrad_bf16_plan(d, pl)) return RD_EINVAL;
+    out[0] = pl.cpi; out[1] = pl.cpo; out[2] = pl.n_cib * pl.n_cob; out[3] = pl.n_splits; out[4] = pl.slab_splits; out[5] = (int)pl.lds_bytes;
+    return RD_OK;
+}
+
+extern "C" int rd_wgrad_bf16(const RdConvDesc* d, const float* in, const float* dout, float* slabs, void* stream) {
+    RD_CHECK_ARG(d && in && dout && slabs, "wgrad_bf16: null argument");
+    WgradBfPlan pl;
+    if (!wgrad_bf16_plan(d, pl)) { set_error("wgrad_bf16: unsupported descriptor (stride-1 3x3, channels %% 16 == 0 only)"); return RD_EINVAL; }
+    WgradBfArgs a;
+    a.x = in; a.dy = dout; a.slabs = slabs;
+    a.N = d->N; a.H = d->Hi; a.W = d->Wi; a.Cin = d->Cin; a.Cout = d->Cout; a.ldi = d->ldi; a.ldo = d->ldo;
+    a.tiles_h = pl.tiles_h; a.tiles_w = pl.tiles_w; a.total_tiles = pl.total_tiles; a.tiles_per_split = pl.tiles_per_split;
+    a.n_splits = pl.n_splits; a.n_cib = pl.n_cib; a.n_cob = pl.n_cob; a.cpi = pl.cpi; a.cpo = pl.cpo;
+    for (int t = 0; t < 9; ++t) a.slab_of_tap[t] = pl.slab_of_tap[t];
+    static bool attr_set = false;
+    if (!attr_set) {
+        RD_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_bf16_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(wgrad_bf16_kernel, dim3(pl.n_cib * pl.n_cob * pl.n_splits), dim3(256), pl.lds_bytes,
+                       static_cast<hipStream_t>(stream), a);
+    RD_CHECK_LAUNCH("wgrad_bf16_kernel");
+    return RD_OK;
+}
+
+extern "C" int rd_wgrad_bf16_reduce(const RdConvDesc* d, const float* slabs, float* grad_oihw, int32_t O, int32_t I, int32_t KH,
+                                    int32_t KW, int32_t co_off, int32_t accumulate, void* stream) {
+    RD_CHECK_ARG(d && slabs && grad_oihw, "wgrad_bf16_reduce: null argument");
+    WgradBfPlan pl;
+    if (!wgrad_bf16_plan(d, pl)) { set_error("wgrad_bf16_reduce: unsupported descriptor"); return RD_EINVAL; }
+    RD_CHECK_ARG(KH * KW == 9 && I == d->Cin && co_off + O <= d->Cout, "wgrad_bf16_reduce: shape mismatch");
+    const int64_t E = (int64_t)9 * d->Cin * d->Cout;
+    float* tmp = const_cast<float*>(slabs) + (int64_t)pl.slab_splits * E;
+    return launch_slab_reduce(slabs, pl.slab_splits, E, tmp, grad_oihw, 9, d->Cin, d->Cout, O, I, co_off, accumulate,
+                              static_cast<hipStream_t>(stream));
+}

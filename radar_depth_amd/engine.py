@@ -77,7 +77,8 @@ class LateFusionPlan:
                  dry_run=False, bf16=False):
         """module: a radar_depth_amd ResNet_latefusion(2); bf16: run the gconv-lowered convolutions with bf16 operands on
         v_mfma_f32_32x32x16_bf16 (fp32 tensors, fp32 accumulation -- BASELINE.json configs 3/5, opt-in; in train plans the
-        forward and input-gradient convolutions, the weight gradients stay on the fp32 kernels); depth_planes: None (depth stem reads channel(s) 3.. of the
+        forward and input-gradient convolutions and the weight gradients of the stride-1 3x3 layers -- wgrad_bf16.hip; the other
+        weight gradients stay on the fp32 kernels); depth_planes: None (depth stem reads channel(s) 3.. of the
         network input) or, for stage 2 of the multistage net, a list of stand-alone [N,H,W] maps; x_source: share another
         plan's static input buffer (stage 2 reads the RGB planes of stage 1's); dense_grad_dst: [N,H,W]-sized buffer that
         receives the gradient w.r.t. the second depth plane (stage-1 prediction, multistage_model.py:75)."""
@@ -217,7 +218,14 @@ class LateFusionPlan:
         C.memmove(C.byref(dwd), C.byref(d), C.sizeof(d))
         dwd.ldo = dout.ld
         self.keep.append(dwd)
-        nws = self.L.rd_wgrad_workspace_floats(C.byref(dwd))
+        # bf16 plans: the stride-1 3x3 layers (two thirds of the weight-gradient time) run on the bf16 matrix cores as well; every
+        # other shape keeps the fp32 kernel
+        # (32-wide MFMA tiles: the 16-channel layers are faster on the fp32 kernel -- 42 vs 55 us for the depth encoder's layer1)
+        wg_bf16 = (self.bf16 and os.environ.get("RD_WGRAD_BF16", "1") == "1" and min(cin, cout) >= 32
+                   and self.L.rd_wgrad_bf16_supported(C.byref(dwd)) == 1)
+        f_ws, f_wgrad, f_reduce, fam = ((self.L.rd_wgrad_bf16_workspace_floats, self.L.rd_wgrad_bf16, self.L.rd_wgrad_bf16_reduce, "wgrad_bf16")
+                                        if wg_bf16 else (self.L.rd_wgrad_workspace_floats, self.L.rd_wgrad, self.L.rd_wgrad_reduce, "wgrad"))
+        nws = f_ws(C.byref(dwd))
         if nws < 0:
             check(int(nws), "rd_wgrad_workspace_floats(%s)" % name)
         ws = self.buf(int(nws))
@@ -229,11 +237,11 @@ class LateFusionPlan:
         def launch_wgrad():
             self.edge(self.bwd, name + ".fork_wgrad", cur, wst)
             with self.on(wst):
-                self.op(self.bwd, name + ".wgrad", self.L.rd_wgrad, C.byref(dwd), x.ptr, dout.ptr, _p(ws), self.stream)
-                self.meta[name + ".wgrad"] = ("wgrad", dwd)
+                self.op(self.bwd, name + ".wgrad", f_wgrad, C.byref(dwd), x.ptr, dout.ptr, _p(ws), self.stream)
+                self.meta[name + ".wgrad"] = (fam, dwd)
                 for w, off in sorted(ctx["weights"], key=lambda t: t[1]):
                     o, i, kh, kw = w.shape
-                    self.op(self.bwd, name + ".wreduce", self.L.rd_wgrad_reduce, C.byref(dwd), _p(ws), _p(self.grad_of(w)), o, i, kh, kw,
+                    self.op(self.bwd, name + ".wreduce", f_reduce, C.byref(dwd), _p(ws), _p(self.grad_of(w)), o, i, kh, kw,
                             off, 0, self.stream)
 
         # the weight-gradient chain is forked BEHIND the dgrad launch rather than beside it: both are MFMA-bound and gain nothing

@@ -101,8 +101,9 @@ class HipTrainStep:
     slower than the plain stream launches (661 vs 679 samples/s for latefusion b=16, 272 vs 288 for multistage b=8, and the
     data-parallel path loses 2.5 % as five graphs but nothing as plain launches).
 
-    operands: "fp32" (default, the parity path) or "bf16": forward and input-gradient convolutions with bf16 operands on the bf16
-    matrix cores (csrc/gconv_bf16.hip; fp32 tensors, fp32 accumulation, fp32 weight gradients / BatchNorm / SGD) -- the
+    operands: "fp32" (default, the parity path) or "bf16": forward, input-gradient and stride-1 3x3 weight-gradient convolutions
+    with bf16 operands on the bf16 matrix cores (csrc/gconv_bf16.hip, csrc/wgrad_bf16.hip; fp32 tensors, fp32 accumulation, fp32
+    BatchNorm / loss / SGD and the remaining weight gradients) -- the
     torch.autocast(bfloat16) analogue for BASELINE.json configs 2/4; tolerances in tests/test_gpu_bf16.py."""
 
     def __init__(self, model, batch, height, width, lr=0.01, momentum=0.9, weight_decay=1e-4, loss_weights=None, use_graph=False,

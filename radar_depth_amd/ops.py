@@ -135,3 +135,17 @@ def bn_stats(x2d, C_):
     check(lib().rd_bn_stats(ptr(x2d), C.c_int64(M), C_, x2d.stride(0), ptr(part), C.byref(nt), current_stream()), "rd_bn_stats")
     assert nt.value == tiles
     return part, tiles
+
+
+def wgrad_bf16(desc, x, dout, grad_oihw):
+    """bf16-operand weight gradient of a stride-1 3x3 convolution (rd_wgrad_bf16 + rd_wgrad_bf16_reduce) into grad_oihw."""
+    _poison()
+    n = int(lib().rd_wgrad_bf16_workspace_floats(C.byref(desc)))
+    if n < 0:
+        check(n, "rd_wgrad_bf16_workspace_floats")
+    slabs = torch.empty(n, dtype=torch.float32, device=x.device)
+    check(lib().rd_wgrad_bf16(C.byref(desc), ptr(_f32(x)), ptr(_f32(dout)), ptr(slabs), current_stream()), "rd_wgrad_bf16")
+    o, i, kh, kw = grad_oihw.shape
+    check(lib().rd_wgrad_bf16_reduce(C.byref(desc), ptr(slabs), ptr(_f32(grad_oihw)), o, i, kh, kw, 0, 0, current_stream()),
+          "rd_wgrad_bf16_reduce")
+    return grad_oihw

@@ -161,6 +161,53 @@ def test_gconv_bf16_upproj_dgrad(cfg):
     assert _rel(got, ref) < 2e-5, _rel(got, ref)
 
 
+@pytest.mark.parametrize("cfg", [
+    (2, 64, 64, 113, 200),    # layer1
+    (2, 128, 128, 57, 100),
+    (2, 256, 256, 29, 50),
+    (2, 512, 512, 15, 25),    # layer4: 8x8 channel blocks
+    (2, 16, 16, 113, 200),    # depth layer1: one half-empty tile pair, four k-parts
+    (2, 32, 32, 57, 100),
+    (1, 16, 16, 240, 400),    # decoder.layer4 conv2
+    (3, 32, 48, 9, 7),        # tiny / ragged: 48 output channels, one partial tile
+    (2, 48, 80, 31, 17),
+    (2, 64, 32, 33, 65),      # 2x1 tile pairs, a tile boundary at column 32/64
+    (1, 32, 64, 5, 33),
+    (3, 64, 64, 1, 1),
+    (2, 16, 16, 40, 1),
+])
+def test_wgrad_bf16(cfg):
+    """Weight gradient on the bf16 matrix cores against a float64 torch weight gradient of the SAME bf16-rounded operands:
+    2e-5 of the largest gradient element (fp32 accumulation, summation order only)."""
+    from radar_depth_amd import convdesc as cd, ops
+    from radar_depth_amd._lib import lib
+    import ctypes as C
+    n, ci, co, h, w = cfg
+    g = torch.Generator().manual_seed(6)
+    x = torch.randn(n, ci, h, w, generator=g)
+    dy = torch.randn(n, co, h, w, generator=g)
+    d = cd.conv_fwd(n, h, w, ci, co, 3, 1, 1)
+    assert lib().rd_wgrad_bf16_supported(C.byref(d)) == 1
+    ref = torch.nn.grad.conv2d_weight(_bf(x).double(), (co, ci, 3, 3), _bf(dy).double(), padding=1).float()
+    grad = torch.full((co, ci, 3, 3), float("nan"), device="cuda")
+    ops.wgrad_bf16(d, ops.nchw_to_nhwc(x.cuda()), ops.nchw_to_nhwc(dy.cuda()), grad)
+    torch.cuda.synchronize()
+    got = grad.cpu()
+    assert not torch.isnan(got).any()
+    assert _rel(got, ref) < 2e-5, (_rel(got, ref), cfg)
+    ref32 = torch.nn.grad.conv2d_weight(x, (co, ci, 3, 3), dy, padding=1)
+    assert _rel(got, ref32) < 2e-2
+
+
+def test_wgrad_bf16_rejects_other_shapes():
+    from radar_depth_amd import convdesc as cd
+    from radar_depth_amd._lib import lib
+    import ctypes as C
+    for d in (cd.conv_fwd(2, 32, 32, 64, 128, 3, 2, 1), cd.conv_fwd(2, 32, 32, 64, 128, 1, 1, 0), cd.upproj_fwd(2, 16, 16, 64, 64)):
+        assert lib().rd_wgrad_bf16_supported(C.byref(d)) == 0
+        assert lib().rd_wgrad_bf16_workspace_floats(C.byref(d)) < 0
+
+
 @pytest.mark.parametrize("arch", ["resnet18_latefusion", "resnet18_multistage_uncertainty_fixs"])
 def test_bf16_inference_matches_fp32(arch):
     from radar_depth_amd.main import HipInference
@@ -192,7 +239,8 @@ def test_bf16_inference_matches_fp32(arch):
 
 class _BfConv(torch.autograd.Function):
     """What rd_gconv_bf16 computes, restated with torch CPU ops: forward and input gradient with both operands rounded to bf16
-    (nearest even) and fp32 accumulation; the weight gradient from the unrounded fp32 tensors (rd_wgrad)."""
+    (nearest even) and fp32 accumulation; the weight gradient likewise for the stride-1 3x3 layers (rd_wgrad_bf16), from the
+    unrounded fp32 tensors for the others (rd_wgrad)."""
 
     @staticmethod
     def forward(ctx, x, w, stride, pad):
@@ -205,7 +253,11 @@ class _BfConv(torch.autograd.Function):
         x, w = ctx.saved_tensors
         stride, pad = ctx.sp
         dx = torch.nn.grad.conv2d_input(x.shape, _bf(w), _bf(dy), stride, pad) if ctx.needs_input_grad[0] else None
-        dw = torch.nn.grad.conv2d_weight(x, w.shape, dy, stride, pad)
+        # rd_wgrad_bf16 serves the stride-1 3x3 layers (rounded operands); every other shape keeps the fp32 rd_wgrad
+        if tuple(w.shape[2:]) == (3, 3) and tuple(stride) == (1, 1):
+            dw = torch.nn.grad.conv2d_weight(_bf(x), w.shape, _bf(dy), stride, pad)
+        else:
+            dw = torch.nn.grad.conv2d_weight(x, w.shape, dy, stride, pad)
         return dx, dw, None, None
 
 

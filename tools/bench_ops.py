@@ -12,7 +12,7 @@ sys.path.insert(0, ".")
 from radar_depth_amd import convdesc as cd, ops  # noqa: E402
 
 PEAK = 157.3
-B = int(sys.argv[1]) if len(sys.argv) > 1 else 16
+B = int(sys.argv[1]) if len(sys.argv) > 1 and sys.argv[1].isdigit() else 16
 # (name, count, Cin, Cout, k, s, p, Hin, Win)
 CONVS = [
     ("layer1 3x3 64", 4, 64, 64, 3, 1, 1, 113, 200),
