@@ -457,20 +457,32 @@ static bool plan_gconv_bf16(const RdConvDesc& d, GconvBfPlan& best) {
                     const int sg = ph_ * cdiv(pw_ * (ckp / 8), 64);
                     segs = segs > sg ? segs : sg;
                 }
-                const bool pipe = !nopipe && segs <= 4 * (c.MT * c.NT >= 6 ? 4 : 8) && taps_max * (ckp / 8) * BN <= 9 * 256;
+                // the pipelined loop pays a longer prologue and more registers: worth it for long reductions (tools/sweep_gconv_bf16.py)
+                const bool pipe = !nopipe && d.Cin >= 320 && segs <= 4 * (c.MT * c.NT >= 6 ? 4 : 8) && taps_max * (ckp / 8) * BN <= 9 * 256;
                 const size_t wbytes = wbytes1 * (pipe ? 2 : 1);
                 const size_t lds = (size_t)(2 * BM + 32) * 4 + wbytes + (size_t)(PP + 1) * (ckp + 8) * 2 + 64;
                 if (lds > 160 * 1024 - 512) continue;
-                const double m_util = (double)P.lh * P.lw / ((double)cdiv(P.lh, TH) * cdiv(P.lw, TW) * BM);
-                const double halo = (double)PP / (TH * TW * d.in_stride * d.in_stride);
-                double score = c.prior * m_util * n_util / (1.0 + 0.15 * (halo - 1.0));   // HBM-side cost weighs more than in fp32
-                if (lds > 80 * 1024) score *= 0.8;
-                if (!pipe) score *= 0.6;                       // serialized load -> convert -> MFMA per chunk
-                if (ckp == 16 && d.Cin >= 32) score *= 0.92;   // half-line loads, twice the barriers
+                // Cost model (fits the sweeps to ~15 %): with bf16 MFMAs every layer of this network is bound by the bytes its
+                // workgroups pull through L2 -- each one reads its halo patch over all input channels plus the weight slab of
+                // its output-channel tile -- at ~6 TB/s aggregate, plus a fixed per-workgroup cost (prologue, first-load latency,
+                // epilogue drain ~ 48 KB worth of transfer time).  Fewer than two workgroups per CU leave latencies uncovered.
+                double taps_avg = 0;
+                for (int i = 0; i < d.n_phases; ++i) taps_avg += d.phase[i].n_taps;
+                taps_avg /= d.n_phases;
                 const double wgs = (double)d.N * cdiv(P.lh, TH) * cdiv(P.lw, TW) * n_cot * d.n_phases;
                 const double ncu = (double)num_cus();
-                score *= wgs / (ncu * ceil(wgs / ncu));
-                if (wgs < 2 * ncu) score *= 0.85;              // a lone workgroup per CU has nothing to hide its latencies behind
+                const double per_wg = (double)PP * d.Cin * 4.0 * (ckp == 16 && d.Cin >= 32 ? 1.08 : 1.0) + taps_avg * d.Cin * BN * 2.0 + 48.0 * 1024;
+                double cost = wgs * per_wg + (double)d.N * d.Ho * d.Wo * d.Cout * 4.0;
+                const int occ_regs = pipe ? 2 : (c.MT * c.NT >= 4 ? 2 : (c.MT * c.NT == 2 ? 3 : 4));
+                int occ = (int)((160 * 1024) / lds);
+                occ = occ < 1 ? 1 : (occ > occ_regs ? occ_regs : occ);
+                const double slots = ncu * occ;
+                cost *= ceil(wgs / slots) * slots / wgs;             // tail imbalance
+                if (wgs < 2 * ncu) cost *= 2 * ncu / wgs;            // latency-bound: too few workgroups in flight
+                cost *= 1.0 + 0.5 / occ;                             // more resident workgroups hide more of each other's phases
+                cost /= sqrt(n_util);                                // output-channel tiles wider than Cout: wasted LDS reads / epilogue
+                if (!pipe && d.Cin >= 320) cost *= 1.3;              // serialized chunk loop over a long reduction
+                const double score = 1e12 / cost;
                 if (score > best_score) {
                     best_score = score;
                     best = GconvBfPlan{c.MT, c.NT, ckp, TH, TW, PP, 0, n_cot, taps_max, lds, pipe ? 1 : 0};

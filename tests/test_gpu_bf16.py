@@ -253,8 +253,8 @@ class _BfConv(torch.autograd.Function):
         x, w = ctx.saved_tensors
         stride, pad = ctx.sp
         dx = torch.nn.grad.conv2d_input(x.shape, _bf(w), _bf(dy), stride, pad) if ctx.needs_input_grad[0] else None
-        # rd_wgrad_bf16 serves the stride-1 3x3 layers (rounded operands); every other shape keeps the fp32 rd_wgrad
-        if tuple(w.shape[2:]) == (3, 3) and tuple(stride) == (1, 1):
+        # rd_wgrad_bf16 serves the stride-1 3x3 layers with >= 32 channels (rounded operands); every other shape keeps rd_wgrad
+        if tuple(w.shape[2:]) == (3, 3) and tuple(stride) == (1, 1) and min(w.shape[0], w.shape[1]) >= 32:
             dw = torch.nn.grad.conv2d_weight(_bf(x), w.shape, _bf(dy), stride, pad)
         else:
             dw = torch.nn.grad.conv2d_weight(x, w.shape, dy, stride, pad)
