@@ -140,7 +140,7 @@ def main():
     ap.add_argument("--no-graph", action="store_true", help="(default; kept for older command lines)")
     ap.add_argument("--operands", default="fp32", choices=["fp32", "bf16"],
                     help="conv operand precision.  fp32 (default) is the BASELINE.json configs[1] measurement; bf16 (configs 2/4) runs the "
-                         "forward / input-gradient / 3x3 weight-gradient convolutions on bf16 MFMA with fp32 tensors + accumulation and is reported with "
+                         "forward / input-gradient / weight-gradient convolutions on bf16 MFMA with fp32 tensors + accumulation and is reported with "
                          "dtype \"bf16\" and its own metric name -- never as the fp32 headline")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
@@ -207,7 +207,7 @@ def main():
     bf16 = args.operands == "bf16"
     if bf16:
         out["dtype"] = "bf16"
-        out["metric"] = METRIC + " [bf16 conv operands on v_mfma_f32_32x32x16_bf16: forward, input gradients, stride-1 3x3 weight gradients; other weight gradients fp32; fp32 tensors/accumulation]"
+        out["metric"] = METRIC + " [bf16 conv operands on v_mfma_f32_32x32x16_bf16: forward, input gradients, weight gradients of the >=32-channel layers; stems/head/16-channel weight gradients fp32; fp32 tensors/accumulation]"
         out["config"]["workload"] = out["config"]["workload"].replace(" fp32,", " bf16-operand convs,")
     if rank == 0 and not args.no_roofline and not multistage and not bf16:
         agg, fam = instrumented_pass(ts)

@@ -143,9 +143,9 @@ int rd_wgrad_plan_info(const RdConvDesc* d, int32_t* out);
 int rd_pack_weights(const float* w_oihw, float* packed, int32_t O, int32_t I, int32_t KH, int32_t KW,
                     int32_t ldc, int32_t co_off, int32_t rows_total, int32_t transpose, void* stream);
 
-/* bf16-operand form of rd_wgrad / rd_wgrad_reduce for the stride-1 3x3 "same" convolutions (single phase, nine taps in
- * [-1,1]^2, channel counts multiples of 16; rd_wgrad_bf16_supported says whether a descriptor qualifies -- everything else stays
- * on rd_wgrad): in / dout are the fp32 tensors of rd_wgrad, rounded to bf16 (nearest even) while they are staged, accumulated
+/* bf16-operand form of rd_wgrad / rd_wgrad_reduce for descriptors that decompose into at most four stride-1 3x3-shaped
+ * passes over decimated tensors (3x3 / 1x1 at stride 1 or 2, the UpProj phases; channel counts multiples of 16;
+ * rd_wgrad_bf16_supported says whether a descriptor qualifies -- everything else stays on rd_wgrad): in / dout are the fp32 tensors of rd_wgrad, rounded to bf16 (nearest even) while they are staged, accumulated
  * in fp32 on v_mfma_f32_32x32x16_bf16.  slabs: rd_wgrad_bf16_workspace_floats(d) floats; rd_wgrad_bf16_reduce sums them in a
  * fixed order into OIHW gradients exactly like rd_wgrad_reduce. */
 int rd_wgrad_bf16_supported(const RdConvDesc* d);
@@ -153,7 +153,7 @@ int64_t rd_wgrad_bf16_workspace_floats(const RdConvDesc* d);
 int rd_wgrad_bf16(const RdConvDesc* d, const float* in, const float* dout, float* slabs, void* stream);
 int rd_wgrad_bf16_reduce(const RdConvDesc* d, const float* slabs, float* grad_oihw, int32_t O, int32_t I, int32_t KH,
                          int32_t KW, int32_t co_off, int32_t accumulate, void* stream);
-/* diagnostics: out[0..5] = ci tiles per block, co tiles per block, channel blocks, pixel splits, slabs, lds bytes */
+/* diagnostics: out[0..6] = ci tiles per block, co tiles per block, channel blocks, pixel splits, slabs, lds bytes, passes */
 int rd_wgrad_bf16_plan_info(const RdConvDesc* d, int32_t* out);
 
 /* bf16 operand of rd_gconv_bf16: same arguments, element (slab, row, col) at ((slab*R/8 + row/8)*ldc + col)*8 + row%8,

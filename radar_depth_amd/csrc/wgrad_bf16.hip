@@ -1,6 +1,6 @@
-// bf16-operand weight gradient of the stride-1 3x3 convolutions (the layers that hold two thirds of the weight-gradient time):
-//     dW[kh][kw][ci][co] = sum_p x[p + (kh-1, kw-1)][ci] * dy[p][co]
-// on v_mfma_f32_32x32x16_bf16 (fp32 tensors in HBM, operands rounded to bf16 while they are staged, fp32 accumulation).
+// bf16-operand weight gradient of the gconv-lowered convolutions:
+//     dW[slab][ci][co] = sum over the phase's logical grid (r,c) of  x[IS*(r,c) + (dh,dw)][ci] * dy[OS*(r,c) + off][co]
+// (3x3 / 1x1 at stride 1 and 2, the four UpProj parity phases of the zero-skipped 5x5) on v_mfma_f32_32x32x16_bf16 (fp32 tensors in HBM, operands rounded to bf16 while they are staged, fp32 accumulation).
 // BASELINE.json configs 2/4 (bf16) -- opt-in like gconv_bf16.hip; rd_wgrad (fp32) stays the default and the parity reference.
 //
 // The reduction dimension of this GEMM is the PIXEL index, and the bf16 MFMA wants eight consecutive k per lane, so both
@@ -9,7 +9,12 @@
 // the same 16 bytes shifted by one pixel: they are built from the aligned read plus the neighbouring dwords with
 // v_alignbyte, the vertical taps are row offsets.
 //
-//   workgroup : one (<=64 input channels) x (<=64 output channels) block of dW, all nine taps, a range of pixel tiles (split)
+// A descriptor is decomposed into at most four PASSES, each a stride-1 3x3-shaped problem over decimated tensors: a pass owns
+// the taps of one descriptor phase whose offsets share the same residue modulo the input stride -- x sampled at IS*q + (xa,xb),
+// dy at OS*q + (ya,yb), tap shifts in [-1,1]^2 (stride-2 conv: 4 input-parity passes of 4/2/2/1 taps; UpProj: its 4 phases of
+// 9/6/6/4 taps; 1x1: one tap).  Passes write disjoint weight slabs.
+//
+//   workgroup : one (<=64 input channels) x (<=64 output channels) block of dW, the pass's taps, a range of pixel tiles (split)
 //   pixel tile: R rows x 32 columns of one image; X patch (R+2) x 36 columns (halo), staged with pixel PAIRS packed per dword
 //   wave      : one 32x32 (ci, co) tile pair of the block and all nine taps (nine 32x32 accumulators); when the block has fewer
 //               than four tile pairs the spare waves take alternate k-steps and write their own partial slab
@@ -35,10 +40,12 @@ struct WgradBfArgs {
     const float* x;
     const float* dy;
     float* slabs;
-    int N, H, W, Cin, Cout, ldi, ldo;
+    int N, Hx, Wx, Hy, Wy, lh, lw, Cin, Cout, ldi, ldo, IS, OS, S;
     int tiles_h, tiles_w, total_tiles, tiles_per_split, n_splits;
     int n_cib, n_cob, cpi, cpo;      // channel blocks; 32-channel tiles per block (1 or 2) on the input / output side
-    int slab_of_tap[9];              // weight slab index of tap (dh+1)*3 + (dw+1)
+    int n_pass;
+    int xa[4], xb[4], ya[4], yb[4];  // per pass: sampling offsets of x (input stride IS) and dy (output stride OS)
+    int slab_of_tap[4][9];           // per pass: weight slab index of tap shift (sh+1)*3 + (sw+1), -1: tap absent
 };
 
 constexpr int WB_R = 4;                      // rows per pixel tile
@@ -67,7 +74,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void w
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l31 = lane & 31, hh = lane >> 5;
     const int nblk = a.n_cib * a.n_cob;
-    const int blk = blockIdx.x % nblk, split = blockIdx.x / nblk;
+    const int blk = blockIdx.x % nblk;
+    const int sp_ = blockIdx.x / nblk;
+    const int pass = __builtin_amdgcn_readfirstlane(sp_ / a.n_splits), split = sp_ - pass * a.n_splits;
+    const int xa = a.xa[pass], xb = a.xb[pass], ya = a.ya[pass], yb = a.yb[pass];
+    unsigned tapmask = 0;
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+        if (a.slab_of_tap[pass][t] >= 0) tapmask |= 1u << t;
     const int cib = blk / a.n_cob, cob = blk - cib * a.n_cob;
     const int ci0 = cib * 32 * a.cpi, co0 = cob * 32 * a.cpo;
     const int n_pairs = a.cpi * a.cpo, n_kparts = 4 / n_pairs;
@@ -90,10 +104,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void w
         const int n = tile / tiles_img, tr = tile - n * tiles_img;
         const int th = tr / a.tiles_w, tw = tr - th * a.tiles_w;
         const int r0 = th * WB_R, c0 = tw * WB_TW;
-        const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.x + (size_t)n * a.H * a.W * a.ldi), 0,
-                                                                            a.H * a.W * a.ldi * 4, 0x00020000);
-        const __amdgpu_buffer_rsrc_t yr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.dy + (size_t)n * a.H * a.W * a.ldo), 0,
-                                                                            a.H * a.W * a.ldo * 4, 0x00020000);
+        const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.x + (size_t)n * a.Hx * a.Wx * a.ldi), 0,
+                                                                            a.Hx * a.Wx * a.ldi * 4, 0x00020000);
+        const __amdgpu_buffer_rsrc_t yr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.dy + (size_t)n * a.Hy * a.Wy * a.ldo), 0,
+                                                                            a.Hy * a.Wy * a.ldo * 4, 0x00020000);
         __syncthreads();      // the previous tile's MFMAs are done with XT / YT
         // ---- stage X: unit = (8-channel group, patch row, column pair); a lane converts 2 pixels x 8 channels and writes eight
         // dwords, one per channel plane (consecutive lanes = consecutive column pairs: conflict-free)
@@ -108,13 +122,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void w
                     const int u = u0 + q * 256;
                     const int cg = u / PER_CG, rem = u - cg * PER_CG;
                     const int rr = rem / WB_XPN, pp = rem - rr * WB_XPN + WB_XP0;
-                    const int ih = r0 - 1 + rr, iw = c0 + 2 * pp - 8, c = ci0 + cg * 8;
+                    const int ih = a.IS * (r0 - 1 + rr) + xa, c = ci0 + cg * 8;
                     dst[q] = u < nunits ? (cg * 8) * WB_XPLANE + rr * WB_XROW + pp : -1;
-                    const bool rowok = u < nunits && ih >= 0 && ih < a.H && c < a.Cin;
+                    const bool rowok = u < nunits && ih >= 0 && ih < a.Hx && c < a.Cin;
 #pragma unroll
                     for (int px = 0; px < 2; ++px) {
-                        const bool ok = rowok && iw + px >= 0 && iw + px < a.W;
-                        wb_load8(xr, ok ? (unsigned)(((ih * a.W + iw + px) * a.ldi + c) * 4) : WB_OOB, v[q][2 * px], v[q][2 * px + 1]);
+                        const int iw = a.IS * (c0 + 2 * pp - 8 + px) + xb;
+                        const bool ok = rowok && iw >= 0 && iw < a.Wx;
+                        wb_load8(xr, ok ? (unsigned)(((ih * a.Wx + iw) * a.ldi + c) * 4) : WB_OOB, v[q][2 * px], v[q][2 * px + 1]);
                     }
                 }
 #pragma unroll
@@ -144,13 +159,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void w
                     const int u = u0 + q * 256;
                     const int cg = u / PER_CG, rem = u - cg * PER_CG;
                     const int rr = rem / WB_YROW, pp = rem - rr * WB_YROW;
-                    const int ih = r0 + rr, iw = c0 + 2 * pp, c = co0 + cg * 8;
+                    const int qr = r0 + rr, ih = a.OS * qr + ya, c = co0 + cg * 8;
                     dst[q] = u < nunits ? (cg * 8) * WB_YPLANE + rr * WB_YROW + pp : -1;
-                    const bool rowok = u < nunits && ih < a.H && c < a.Cout;
+                    const bool rowok = u < nunits && qr < a.lh && ih < a.Hy && c < a.Cout;
 #pragma unroll
                     for (int px = 0; px < 2; ++px) {
-                        const bool ok = rowok && iw + px < a.W;
-                        wb_load8(yr, ok ? (unsigned)(((ih * a.W + iw + px) * a.ldo + c) * 4) : WB_OOB, v[q][2 * px], v[q][2 * px + 1]);
+                        const int qc = c0 + 2 * pp + px, iw = a.OS * qc + yb;
+                        const bool ok = rowok && qc < a.lw && iw < a.Wy;
+                        wb_load8(yr, ok ? (unsigned)(((ih * a.Wy + iw) * a.ldo + c) * 4) : WB_OOB, v[q][2 * px], v[q][2 * px + 1]);
                     }
                 }
 #pragma unroll
@@ -171,7 +187,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void w
         __syncthreads();
         // ---- k-steps of this wave: 16 consecutive pixels of one tile row; lane (l31, hh) holds channel l31 of its 32-channel
         // tile and pixels hh*8 .. hh*8+7 of the step
-        const unsigned* xa = XT + (wci * 32 + l31) * WB_XPLANE + 4 + hh * 4;     // dword of plane column 8 + hh*8 in row 0
+        const unsigned* xq = XT + (wci * 32 + l31) * WB_XPLANE + 4 + hh * 4;     // dword of plane column 8 + hh*8 in row 0
         const unsigned* yb = YT + (wco * 32 + l31) * WB_YPLANE + hh * 4;
         for (int ks = kpart; ks < 2 * WB_R; ks += n_kparts) {
             const int r = ks >> 1, h = ks & 1;
@@ -179,7 +195,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void w
             const wbf16x8 B = __builtin_bit_cast(wbf16x8, bw);
 #pragma unroll
             for (int dh = 0; dh < 3; ++dh) {
-                const unsigned* p = xa + (r + dh) * WB_XROW + h * 8;
+                if (!((tapmask >> (dh * 3)) & 7u)) continue;      // no tap of this pass in the patch row (wave-uniform)
+                const unsigned* p = xq + (r + dh) * WB_XROW + h * 8;
                 const wu32x4 cur = *reinterpret_cast<const wu32x4*>(p);
                 const unsigned prev = p[-1], next = p[4];
                 wu32x4 lft, rgt;       // windows starting one pixel earlier / later
@@ -191,19 +208,23 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void w
                 rgt[1] = __builtin_amdgcn_alignbyte(cur[2], cur[1], 2);
                 rgt[2] = __builtin_amdgcn_alignbyte(cur[3], cur[2], 2);
                 rgt[3] = __builtin_amdgcn_alignbyte(next, cur[3], 2);
-                acc[dh * 3 + 0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(wbf16x8, lft), B, acc[dh * 3 + 0], 0, 0, 0);
-                acc[dh * 3 + 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(wbf16x8, cur), B, acc[dh * 3 + 1], 0, 0, 0);
-                acc[dh * 3 + 2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(wbf16x8, rgt), B, acc[dh * 3 + 2], 0, 0, 0);
+                if (tapmask & (1u << (dh * 3 + 0)))
+                    acc[dh * 3 + 0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(wbf16x8, lft), B, acc[dh * 3 + 0], 0, 0, 0);
+                if (tapmask & (1u << (dh * 3 + 1)))
+                    acc[dh * 3 + 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(wbf16x8, cur), B, acc[dh * 3 + 1], 0, 0, 0);
+                if (tapmask & (1u << (dh * 3 + 2)))
+                    acc[dh * 3 + 2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(wbf16x8, rgt), B, acc[dh * 3 + 2], 0, 0, 0);
             }
         }
     }
 
     // ---- this wave's partial slab: [tap][Cin][Cout], accumulator row = input channel, lane = output channel
-    float* slab = a.slabs + (size_t)(split * n_kparts + kpart) * 9 * a.Cin * a.Cout;
+    float* slab = a.slabs + (size_t)(split * n_kparts + kpart) * a.S * a.Cin * a.Cout;
     const int co = co0 + wco * 32 + l31;
 #pragma unroll
     for (int t = 0; t < 9; ++t) {
-        float* dst = slab + (size_t)a.slab_of_tap[t] * a.Cin * a.Cout;
+        if (!(tapmask & (1u << t))) continue;
+        float* dst = slab + (size_t)a.slab_of_tap[pass][t] * a.Cin * a.Cout;
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
             const int ci = ci0 + wci * 32 + (i & 3) + 8 * (i >> 2) + 4 * hh;
@@ -216,31 +237,61 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void w
 struct WgradBfPlan {
     int cpi, cpo, n_cib, n_cob, tiles_h, tiles_w, total_tiles, tiles_per_split, n_splits, slab_splits;
     size_t lds_bytes;
-    int slab_of_tap[9];
+    int S, lh, lw, n_pass;
+    int xa[4], xb[4], ya[4], yb[4];
+    int slab_of_tap[4][9];
 };
 
-// stride-1 3x3 "same" convolution, channel counts multiples of 16
+static inline int floor_div(int a, int b) { return (a >= 0) ? a / b : -((-a + b - 1) / b); }
+
+// Decompose the (forward) descriptor into passes; false when it does not fit (then the caller keeps rd_wgrad).
 static bool wgrad_bf16_plan(const RdConvDesc* d, WgradBfPlan& pl) {
-    if (!d || d->n_phases != 1 || d->in_stride != 1 || d->out_stride != 1) return false;
-    const RdPhase& p = d->phase[0];
-    if (p.n_taps != 9 || p.lh != d->Hi || p.lw != d->Wi || d->Ho != d->Hi || d->Wo != d->Wi) return false;
-    if (p.out_off_h != 0 || p.out_off_w != 0) return false;
+    if (!d || d->n_phases < 1 || d->n_phases > RD_MAX_PHASES) return false;
+    if (d->in_stride < 1 || d->in_stride > 2 || d->out_stride < 1 || d->out_stride > 2) return false;
     if (d->Cin % 16 != 0 || d->Cout % 16 != 0 || d->ldi % 4 != 0 || d->ldo % 4 != 0) return false;
-    for (int t = 0; t < 9; ++t) pl.slab_of_tap[t] = -1;
-    for (int t = 0; t < 9; ++t) {
-        if (p.dh[t] < -1 || p.dh[t] > 1 || p.dw[t] < -1 || p.dw[t] > 1) return false;
-        pl.slab_of_tap[(p.dh[t] + 1) * 3 + (p.dw[t] + 1)] = p.widx[t];
+    if ((int64_t)d->Hi * d->Wi * d->ldi * 4 >= (int64_t)WB_OOB || (int64_t)d->Ho * d->Wo * d->ldo * 4 >= (int64_t)WB_OOB) return false;
+    const int IS = d->in_stride;
+    pl.lh = d->phase[0].lh; pl.lw = d->phase[0].lw;
+    pl.n_pass = 0;
+    int S = 0;
+    for (int i = 0; i < d->n_phases; ++i) {
+        const RdPhase& p = d->phase[i];
+        if (p.lh != pl.lh || p.lw != pl.lw || p.n_taps < 1 || p.n_taps > RD_MAX_TAPS) return false;
+        int pass_of[2][2] = {{-1, -1}, {-1, -1}};
+        for (int t = 0; t < p.n_taps; ++t) {
+            const int sh = floor_div(p.dh[t], IS), sw = floor_div(p.dw[t], IS);
+            const int ra = p.dh[t] - sh * IS, rb = p.dw[t] - sw * IS;          // residues 0..IS-1
+            if (sh < -1 || sh > 1 || sw < -1 || sw > 1 || p.widx[t] < 0) return false;
+            int& ps = pass_of[ra][rb];
+            if (ps < 0) {
+                if (pl.n_pass == 4) return false;
+                ps = pl.n_pass++;
+                pl.xa[ps] = ra; pl.xb[ps] = rb; pl.ya[ps] = p.out_off_h; pl.yb[ps] = p.out_off_w;
+                for (int k = 0; k < 9; ++k) pl.slab_of_tap[ps][k] = -1;
+            }
+            int& slot = pl.slab_of_tap[ps][(sh + 1) * 3 + (sw + 1)];
+            if (slot >= 0) return false;                                         // two taps on the same shift
+            slot = p.widx[t];
+            S = S > p.widx[t] + 1 ? S : p.widx[t] + 1;
+        }
     }
-    for (int t = 0; t < 9; ++t)
-        if (pl.slab_of_tap[t] < 0 || pl.slab_of_tap[t] > 8) return false;
+    // every slab must be produced exactly once (the reduction reads all S of every split)
+    if (S < 1 || S > 25) return false;
+    int seen[25] = {0};
+    for (int ps = 0; ps < pl.n_pass; ++ps)
+        for (int k = 0; k < 9; ++k)
+            if (pl.slab_of_tap[ps][k] >= 0 && seen[pl.slab_of_tap[ps][k]]++) return false;
+    for (int k = 0; k < S; ++k)
+        if (!seen[k]) return false;
+    pl.S = S;
     pl.cpi = d->Cin >= 64 ? 2 : 1;
     pl.cpo = d->Cout >= 64 ? 2 : 1;
     pl.n_cib = cdiv(d->Cin, 32 * pl.cpi);
     pl.n_cob = cdiv(d->Cout, 32 * pl.cpo);
-    pl.tiles_h = cdiv(d->Hi, WB_R);
-    pl.tiles_w = cdiv(d->Wi, WB_TW);
+    pl.tiles_h = cdiv(pl.lh, WB_R);
+    pl.tiles_w = cdiv(pl.lw, WB_TW);
     pl.total_tiles = d->N * pl.tiles_h * pl.tiles_w;
-    const int nblk = pl.n_cib * pl.n_cob;
+    const int nblk = pl.n_cib * pl.n_cob * pl.n_pass;
     static const char* wgs_env = getenv("RD_WGRAD_BF16_WGS");      // diagnostics: target workgroup count
     const int target = wgs_env ? atoi(wgs_env) : 256;   // one workgroup per CU: fewer slabs to reduce (13.01 vs 13.18 ms/step at 512)
     int splits = cdiv(target, nblk);
@@ -264,34 +315,39 @@ extern "C" int rd_wgrad_bf16_supported(const RdConvDesc* d) {
 
 extern "C" int64_t rd_wgrad_bf16_workspace_floats(const RdConvDesc* d) {
     WgradBfPlan pl;
-    if (!wgrad_bf16_plan(d, pl)) { set_error("wgrad_bf16: unsupported descriptor (stride-1 3x3, channels %% 16 == 0 only)"); return RD_EINVAL; }
-    return (int64_t)(pl.slab_splits + 16) * 9 * d->Cin * d->Cout;
+    if (!wgrad_bf16_plan(d, pl)) { set_error("wgrad_bf16: unsupported descriptor"); return RD_EINVAL; }
+    return (int64_t)(pl.slab_splits + 16) * pl.S * d->Cin * d->Cout;
 }
 
-// diagnostics: out[0..5] = ci tiles per block, co tiles per block, channel blocks, pixel splits, slabs, lds bytes
+// diagnostics: out[0..6] = ci tiles per block, co tiles per block, channel blocks, pixel splits, slabs, lds bytes, passes
 extern "C" int rd_wgrad_bf16_plan_info(const RdConvDesc* d, int32_t* out) {
     WgradBfPlan pl;
     if (!wgrad_bf16_plan(d, pl)) return RD_EINVAL;
     out[0] = pl.cpi; out[1] = pl.cpo; out[2] = pl.n_cib * pl.n_cob; out[3] = pl.n_splits; out[4] = pl.slab_splits; out[5] = (int)pl.lds_bytes;
+    out[6] = pl.n_pass;
     return RD_OK;
 }
 
 extern "C" int rd_wgrad_bf16(const RdConvDesc* d, const float* in, const float* dout, float* slabs, void* stream) {
     RD_CHECK_ARG(d && in && dout && slabs, "wgrad_bf16: null argument");
     WgradBfPlan pl;
-    if (!wgrad_bf16_plan(d, pl)) { set_error("wgrad_bf16: unsupported descriptor (stride-1 3x3, channels %% 16 == 0 only)"); return RD_EINVAL; }
+    if (!wgrad_bf16_plan(d, pl)) { set_error("wgrad_bf16: unsupported descriptor"); return RD_EINVAL; }
     WgradBfArgs a;
     a.x = in; a.dy = dout; a.slabs = slabs;
-    a.N = d->N; a.H = d->Hi; a.W = d->Wi; a.Cin = d->Cin; a.Cout = d->Cout; a.ldi = d->ldi; a.ldo = d->ldo;
+    a.N = d->N; a.Hx = d->Hi; a.Wx = d->Wi; a.Hy = d->Ho; a.Wy = d->Wo; a.lh = pl.lh; a.lw = pl.lw;
+    a.Cin = d->Cin; a.Cout = d->Cout; a.ldi = d->ldi; a.ldo = d->ldo; a.IS = d->in_stride; a.OS = d->out_stride; a.S = pl.S;
     a.tiles_h = pl.tiles_h; a.tiles_w = pl.tiles_w; a.total_tiles = pl.total_tiles; a.tiles_per_split = pl.tiles_per_split;
-    a.n_splits = pl.n_splits; a.n_cib = pl.n_cib; a.n_cob = pl.n_cob; a.cpi = pl.cpi; a.cpo = pl.cpo;
-    for (int t = 0; t < 9; ++t) a.slab_of_tap[t] = pl.slab_of_tap[t];
+    a.n_splits = pl.n_splits; a.n_cib = pl.n_cib; a.n_cob = pl.n_cob; a.cpi = pl.cpi; a.cpo = pl.cpo; a.n_pass = pl.n_pass;
+    for (int ps = 0; ps < 4; ++ps) {
+        a.xa[ps] = pl.xa[ps]; a.xb[ps] = pl.xb[ps]; a.ya[ps] = pl.ya[ps]; a.yb[ps] = pl.yb[ps];
+        for (int t = 0; t < 9; ++t) a.slab_of_tap[ps][t] = ps < pl.n_pass ? pl.slab_of_tap[ps][t] : -1;
+    }
     static bool attr_set = false;
     if (!attr_set) {
         RD_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_bf16_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr_set = true;
     }
-    hipLaunchKernelGGL(wgrad_bf16_kernel, dim3(pl.n_cib * pl.n_cob * pl.n_splits), dim3(256), pl.lds_bytes,
+    hipLaunchKernelGGL(wgrad_bf16_kernel, dim3(pl.n_cib * pl.n_cob * pl.n_splits * pl.n_pass), dim3(256), pl.lds_bytes,
                        static_cast<hipStream_t>(stream), a);
     RD_CHECK_LAUNCH("wgrad_bf16_kernel");
     return RD_OK;
@@ -302,9 +358,9 @@ extern "C" int rd_wgrad_bf16_reduce(const RdConvDesc* d, const float* slabs, flo
     RD_CHECK_ARG(d && slabs && grad_oihw, "wgrad_bf16_reduce: null argument");
     WgradBfPlan pl;
     if (!wgrad_bf16_plan(d, pl)) { set_error("wgrad_bf16_reduce: unsupported descriptor"); return RD_EINVAL; }
-    RD_CHECK_ARG(KH * KW == 9 && I == d->Cin && co_off + O <= d->Cout, "wgrad_bf16_reduce: shape mismatch");
-    const int64_t E = (int64_t)9 * d->Cin * d->Cout;
+    RD_CHECK_ARG(KH * KW == pl.S && I == d->Cin && co_off + O <= d->Cout, "wgrad_bf16_reduce: shape mismatch");
+    const int64_t E = (int64_t)pl.S * d->Cin * d->Cout;
     float* tmp = const_cast<float*>(slabs) + (int64_t)pl.slab_splits * E;
-    return launch_slab_reduce(slabs, pl.slab_splits, E, tmp, grad_oihw, 9, d->Cin, d->Cout, O, I, co_off, accumulate,
+    return launch_slab_reduce(slabs, pl.slab_splits, E, tmp, grad_oihw, pl.S, d->Cin, d->Cout, O, I, co_off, accumulate,
                               static_cast<hipStream_t>(stream));
 }

@@ -77,8 +77,8 @@ class LateFusionPlan:
                  dry_run=False, bf16=False):
         """module: a radar_depth_amd ResNet_latefusion(2); bf16: run the gconv-lowered convolutions with bf16 operands on
         v_mfma_f32_32x32x16_bf16 (fp32 tensors, fp32 accumulation -- BASELINE.json configs 3/5, opt-in; in train plans the
-        forward and input-gradient convolutions and the weight gradients of the stride-1 3x3 layers -- wgrad_bf16.hip; the other
-        weight gradients stay on the fp32 kernels); depth_planes: None (depth stem reads channel(s) 3.. of the
+        forward and input-gradient convolutions and the weight gradients of the >= 32-channel layers -- wgrad_bf16.hip; the
+        16-channel layers, stems and head keep their fp32 weight-gradient kernels); depth_planes: None (depth stem reads channel(s) 3.. of the
         network input) or, for stage 2 of the multistage net, a list of stand-alone [N,H,W] maps; x_source: share another
         plan's static input buffer (stage 2 reads the RGB planes of stage 1's); dense_grad_dst: [N,H,W]-sized buffer that
         receives the gradient w.r.t. the second depth plane (stage-1 prediction, multistage_model.py:75)."""
@@ -218,8 +218,8 @@ class LateFusionPlan:
         C.memmove(C.byref(dwd), C.byref(d), C.sizeof(d))
         dwd.ldo = dout.ld
         self.keep.append(dwd)
-        # bf16 plans: the stride-1 3x3 layers (two thirds of the weight-gradient time) run on the bf16 matrix cores as well; every
-        # other shape keeps the fp32 kernel
+        # bf16 plans: the weight gradients run on the bf16 matrix cores as well (3x3 / 1x1 at both strides, UpProj 5x5); what the
+        # bf16 kernel cannot decompose keeps the fp32 kernel
         # (32-wide MFMA tiles: the 16-channel layers are faster on the fp32 kernel -- 42 vs 55 us for the depth encoder's layer1)
         wg_bf16 = (self.bf16 and os.environ.get("RD_WGRAD_BF16", "1") == "1" and min(cin, cout) >= 32
                    and self.L.rd_wgrad_bf16_supported(C.byref(dwd)) == 1)

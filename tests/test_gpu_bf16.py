@@ -199,11 +199,59 @@ def test_wgrad_bf16(cfg):
     assert _rel(got, ref32) < 2e-2
 
 
-def test_wgrad_bf16_rejects_other_shapes():
+@pytest.mark.parametrize("cfg", [
+    (2, 64, 128, 3, 2, 1, 57, 100),   # layer2.0.conv1: four input-parity passes (4/2/2/1 taps)
+    (2, 32, 64, 3, 2, 1, 33, 45),     # odd sizes: the last output row/column reads the zero padding
+    (1, 96, 48, 3, 2, 1, 8, 9),
+    (2, 64, 128, 1, 2, 0, 57, 100),   # downsample 1x1 stride 2
+    (2, 640, 512, 1, 1, 0, 15, 25),   # conv_fusion
+    (3, 32, 32, 1, 1, 0, 7, 70),
+])
+def test_wgrad_bf16_strided_and_pointwise(cfg):
+    from radar_depth_amd import convdesc as cd, ops
+    from radar_depth_amd._lib import lib
+    import ctypes as C
+    n, ci, co, k, s_, p, h, w = cfg
+    g = torch.Generator().manual_seed(8)
+    x = torch.randn(n, ci, h, w, generator=g)
+    d = cd.conv_fwd(n, h, w, ci, co, k, s_, p)
+    dy = torch.randn(n, co, d.Ho, d.Wo, generator=g)
+    assert lib().rd_wgrad_bf16_supported(C.byref(d)) == 1
+    ref = torch.nn.grad.conv2d_weight(_bf(x).double(), (co, ci, k, k), _bf(dy).double(), stride=s_, padding=p).float()
+    grad = torch.full((co, ci, k, k), float("nan"), device="cuda")
+    ops.wgrad_bf16(d, ops.nchw_to_nhwc(x.cuda()), ops.nchw_to_nhwc(dy.cuda()), grad)
+    got = grad.cpu()
+    assert not torch.isnan(got).any()
+    assert _rel(got, ref) < 2e-5, (_rel(got, ref), cfg)
+
+
+@pytest.mark.parametrize("cfg", [(2, 64, 64, 29, 50), (1, 32, 32, 40, 33), (2, 128, 64, 15, 25), (1, 32, 48, 3, 5)])
+def test_wgrad_bf16_upproj(cfg):
+    """The four parity phases of the zero-skipped 5x5 (9/6/6/4 taps): dy decimated by two per phase, 25 weight slabs."""
+    from radar_depth_amd import convdesc as cd, ops
+    from radar_depth_amd._lib import lib
+    import ctypes as C
+    n, ci, co, h, w = cfg
+    g = torch.Generator().manual_seed(9)
+    x = torch.randn(n, ci, h, w, generator=g)
+    dy = torch.randn(n, co, 2 * h, 2 * w, generator=g)
+    xu = torch.zeros(n, ci, 2 * h, 2 * w, dtype=torch.float64)
+    xu[:, :, ::2, ::2] = _bf(x).double()
+    ref = torch.nn.grad.conv2d_weight(xu, (co, ci, 5, 5), _bf(dy).double(), padding=2).float()
+    d = cd.upproj_fwd(n, h, w, ci, co)
+    assert lib().rd_wgrad_bf16_supported(C.byref(d)) == 1
+    grad = torch.full((co, ci, 5, 5), float("nan"), device="cuda")
+    ops.wgrad_bf16(d, ops.nchw_to_nhwc(x.cuda()), ops.nchw_to_nhwc(dy.cuda()), grad)
+    got = grad.cpu()
+    assert not torch.isnan(got).any()
+    assert _rel(got, ref) < 2e-5, (_rel(got, ref), cfg)
+
+
+def test_wgrad_bf16_rejects_what_it_cannot_decompose():
     from radar_depth_amd import convdesc as cd
     from radar_depth_amd._lib import lib
     import ctypes as C
-    for d in (cd.conv_fwd(2, 32, 32, 64, 128, 3, 2, 1), cd.conv_fwd(2, 32, 32, 64, 128, 1, 1, 0), cd.upproj_fwd(2, 16, 16, 64, 64)):
+    for d in (cd.conv_fwd(2, 32, 32, 24, 32, 3, 1, 1), cd.conv_fwd(2, 32, 32, 32, 64, 5, 1, 2)):   # Cin % 16, tap shifts of +-2
         assert lib().rd_wgrad_bf16_supported(C.byref(d)) == 0
         assert lib().rd_wgrad_bf16_workspace_floats(C.byref(d)) < 0
 
@@ -239,8 +287,8 @@ def test_bf16_inference_matches_fp32(arch):
 
 class _BfConv(torch.autograd.Function):
     """What rd_gconv_bf16 computes, restated with torch CPU ops: forward and input gradient with both operands rounded to bf16
-    (nearest even) and fp32 accumulation; the weight gradient likewise for the stride-1 3x3 layers (rd_wgrad_bf16), from the
-    unrounded fp32 tensors for the others (rd_wgrad)."""
+    (nearest even) and fp32 accumulation; the weight gradient likewise for the layers rd_wgrad_bf16 serves, from the unrounded
+    fp32 tensors for the others (rd_wgrad)."""
 
     @staticmethod
     def forward(ctx, x, w, stride, pad):
@@ -253,8 +301,11 @@ class _BfConv(torch.autograd.Function):
         x, w = ctx.saved_tensors
         stride, pad = ctx.sp
         dx = torch.nn.grad.conv2d_input(x.shape, _bf(w), _bf(dy), stride, pad) if ctx.needs_input_grad[0] else None
-        # rd_wgrad_bf16 serves the stride-1 3x3 layers with >= 32 channels (rounded operands); every other shape keeps rd_wgrad
-        if tuple(w.shape[2:]) == (3, 3) and tuple(stride) == (1, 1) and min(w.shape[0], w.shape[1]) >= 32:
+        # rd_wgrad_bf16 (rounded operands) serves every layer with >= 32 channels on both sides -- counted on the launch, and the
+        # two 5x5 convolutions of an UpProj module are one launch with their output channels concatenated; the 16-channel
+        # layers keep the fp32 rd_wgrad
+        cout_launch = 2 * w.shape[0] if tuple(w.shape[2:]) == (5, 5) else w.shape[0]
+        if min(cout_launch, w.shape[1]) >= 32:
             dw = torch.nn.grad.conv2d_weight(_bf(x), w.shape, _bf(dy), stride, pad)
         else:
             dw = torch.nn.grad.conv2d_weight(x, w.shape, dy, stride, pad)
