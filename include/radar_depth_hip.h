@@ -155,6 +155,9 @@ int rd_wgrad_bf16_reduce(const RdConvDesc* d, const float* slabs, float* grad_oi
                          int32_t KW, int32_t co_off, int32_t accumulate, void* stream);
 /* diagnostics: out[0..6] = ci tiles per block, co tiles per block, channel blocks, pixel splits, slabs, lds bytes, passes */
 int rd_wgrad_bf16_plan_info(const RdConvDesc* d, int32_t* out);
+/* diagnostics: RD_WGRAD_BF16_TRACE=1 records cycle-counter stamps per workgroup (32 slots: count, stamps at: start, then per
+ * tile: buffer ready, next tile's loads issued, MFMAs done, next tile written to LDS; end) -- tools/trace_wgrad_bf16.py */
+int rd_wgrad_bf16_trace_read(unsigned long long* host, int n_wg);
 
 /* bf16 operand of rd_gconv_bf16: same arguments, element (slab, row, col) at ((slab*R/8 + row/8)*ldc + col)*8 + row%8,
  * rounded to nearest even; the reduction dimension must be a multiple of 8. */

@@ -18,6 +18,9 @@
 //   pixel tile: R rows x 32 columns of one image; X patch (R+2) x 36 columns (halo), staged with pixel PAIRS packed per dword
 //   wave      : one 32x32 (ci, co) tile pair of the block and all nine taps (nine 32x32 accumulators); when the block has fewer
 //               than four tile pairs the spare waves take alternate k-steps and write their own partial slab
+//   pipeline  : one 8-wave workgroup per CU, two LDS tile buffers: waves 0-3 run the MFMAs of tile i while waves 4-7 load,
+//               convert and write tile i+1 (role split instead of software pipelining: loads, conversions and matrix
+//               instructions of different tiles are then issued by different waves of the same SIMD)
 //   output    : per-split slabs [split][tap][Cin][Cout] like rd_wgrad, reduced in a fixed order by the same slab reduction
 #include <math.h>
 #include <stdlib.h>
@@ -46,14 +49,18 @@ struct WgradBfArgs {
     int n_pass;
     int xa[4], xb[4], ya[4], yb[4];  // per pass: sampling offsets of x (input stride IS) and dy (output stride OS)
     int slab_of_tap[4][9];           // per pass: weight slab index of tap shift (sh+1)*3 + (sw+1), -1: tap absent
+    unsigned long long* trace;       // diagnostics (RD_WGRAD_BF16_TRACE=1 compute wave, =2 loader wave): 32 stamps per workgroup
+    int trace_loader;
 };
 
 constexpr int WB_R = 4;                      // rows per pixel tile
 constexpr int WB_TW = 32;                    // columns per pixel tile
 constexpr int WB_XROW = 24;                  // dwords per staged X row: 48 bf16 columns, column c0 of the tile at index 8
-constexpr int WB_XPLANE = (WB_R + 2) * WB_XROW;   // dwords per channel plane (multiple of 4: planes stay 16-byte aligned)
+// dwords per channel plane = 4 * odd: planes stay 16-byte aligned AND the 16 lanes of a b128 read pass (consecutive channels,
+// same pixel) fall into 16 different bank groups (a pitch of 144 / 64 dwords made these reads 8- / 32-way conflicted)
+constexpr int WB_XPLANE = (WB_R + 2) * WB_XROW + 4;
 constexpr int WB_YROW = 16;                  // dwords per staged dY row (32 bf16 columns)
-constexpr int WB_YPLANE = WB_R * WB_YROW;
+constexpr int WB_YPLANE = WB_R * WB_YROW + 4;
 constexpr int WB_XP0 = 3, WB_XPN = 18;       // staged column pairs of X: 3..20 = plane columns 6..41 (image columns c0-2 .. c0+33)
 
 // 32 bytes through a raw buffer descriptor: offsets at or beyond num_records return zeros (halo / padding without branches)
@@ -68,11 +75,22 @@ __device__ __forceinline__ unsigned pack2(float lo, float hi) {
     return (unsigned)__builtin_bit_cast(unsigned short, a) | ((unsigned)__builtin_bit_cast(unsigned short, b) << 16);
 }
 
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void wgrad_bf16_kernel(const WgradBfArgs a) {
+// FULL: all nine taps present (stride-1 3x3, UpProj phase 0) -> no tap tests in the MFMA phase; NK: k-parts = 4 / tile pairs
+template <bool FULL, int NK>
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void wgrad_bf16_kernel(const WgradBfArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned wsm[];
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    // eight waves, two roles: waves 0-3 own the accumulators and issue the MFMAs, waves 4-7 stage the NEXT tile meanwhile
+    // (global loads -> registers -> bf16 -> LDS); one barrier per tile hands the buffers over
+    const int lane = threadIdx.x & 63;
+    const int wave8 = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const bool loader = wave8 >= 4;
+    const int wave = wave8 & 3;
+    const int tid = threadIdx.x & 255;        // index inside the role
     const int l31 = lane & 31, hh = lane >> 5;
+    int n_stamp = 0;
+#define WB_STAMP() \
+    if (a.trace && threadIdx.x == (unsigned)(a.trace_loader ? 256 : 0) && n_stamp < 31) a.trace[(size_t)blockIdx.x * 32 + 1 + n_stamp++] = __builtin_readcyclecounter();
+    WB_STAMP()
     const int nblk = a.n_cib * a.n_cob;
     const int blk = blockIdx.x % nblk;
     const int sp_ = blockIdx.x / nblk;
@@ -84,7 +102,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void w
         if (a.slab_of_tap[pass][t] >= 0) tapmask |= 1u << t;
     const int cib = blk / a.n_cob, cob = blk - cib * a.n_cob;
     const int ci0 = cib * 32 * a.cpi, co0 = cob * 32 * a.cpo;
-    const int n_pairs = a.cpi * a.cpo, n_kparts = 4 / n_pairs;
+    const int n_pairs = a.cpi * a.cpo;
+    constexpr int n_kparts = NK;
     const int pair = wave % n_pairs, kpart = wave / n_pairs;
     const int wci = pair / a.cpo, wco = pair - wci * a.cpo;
     const int ncgi = a.cpi * 4, ncgo = a.cpo * 4;      // 8-channel groups of the block
@@ -92,15 +111,36 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void w
     unsigned* XT = wsm;                                // [32*cpi][WB_XPLANE]
     unsigned* YT = wsm + 32 * a.cpi * WB_XPLANE;       // [32*cpo][WB_YPLANE]
 
-    f32x16 acc[9];
-#pragma unroll
-    for (int t = 0; t < 9; ++t)
-#pragma unroll
-        for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
-
     const int t_lo = split * a.tiles_per_split, t_hi = min(t_lo + a.tiles_per_split, a.total_tiles);
     const int tiles_img = a.tiles_h * a.tiles_w;
-    for (int tile = t_lo; tile < t_hi; ++tile) {
+    const int buf_dwords = 32 * a.cpi * WB_XPLANE + 32 * a.cpo * WB_YPLANE;       // one (XT, YT) buffer pair
+
+    // ---- staging, split in two so that a tile's global loads fly under the previous tile's MFMAs (one workgroup per CU, 512
+    // registers per lane: the accumulators and a whole tile of staged activations are live together):
+    //   fetch: every thread's share of the X patch (UX units) and of the dY tile (UY units) into registers; unit = (8-channel
+    //          group, row, column PAIR) = 2 pixels x 8 channels = 64 bytes; halo / padding through out-of-range buffer offsets;
+    //   put  : convert to bf16, pack the pixel pair per dword and write one dword per channel plane (consecutive lanes =
+    //          consecutive column pairs: conflict-free).
+    constexpr int UX = 4, UY = 2;             // 4*256 >= 8 groups * 6 rows * 18 pairs, 2*256 >= 8 groups * 4 rows * 16 pairs
+    constexpr int XPER = (WB_R + 2) * WB_XPN, YPER = WB_R * WB_YROW;
+    const int nux = ncgi * XPER, nuy = ncgo * YPER;
+    // unit u -> (8-channel group, row, column pair): four channel groups vary fastest, so that four neighbouring lanes read the
+    // four 32-byte pieces of one pixel's 128-byte line (16 lines per load instruction instead of 64), then the pairs of a row
+    auto xunit = [&](int u, int& cg, int& rr, int& pp) {
+        const int pos = u >> 2, cgh = pos / XPER, rem = pos - cgh * XPER;
+        cg = cgh * 4 + (u & 3);
+        rr = rem / WB_XPN;
+        pp = rem - rr * WB_XPN + WB_XP0;
+        return u < nux;
+    };
+    auto yunit = [&](int u, int& cg, int& rr, int& pp) {
+        const int pos = u >> 2, cgh = pos / YPER, rem = pos - cgh * YPER;
+        cg = cgh * 4 + (u & 3);
+        rr = rem / WB_YROW;
+        pp = rem - rr * WB_YROW;
+        return u < nuy;
+    };
+    auto fetch = [&](int tile, float4 (&vx)[UX][4], float4 (&vy)[UY][4]) {
         const int n = tile / tiles_img, tr = tile - n * tiles_img;
         const int th = tr / a.tiles_w, tw = tr - th * a.tiles_w;
         const int r0 = th * WB_R, c0 = tw * WB_TW;
@@ -108,95 +148,109 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void w
                                                                             a.Hx * a.Wx * a.ldi * 4, 0x00020000);
         const __amdgpu_buffer_rsrc_t yr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.dy + (size_t)n * a.Hy * a.Wy * a.ldo), 0,
                                                                             a.Hy * a.Wy * a.ldo * 4, 0x00020000);
-        __syncthreads();      // the previous tile's MFMAs are done with XT / YT
-        // ---- stage X: unit = (8-channel group, patch row, column pair); a lane converts 2 pixels x 8 channels and writes eight
-        // dwords, one per channel plane (consecutive lanes = consecutive column pairs: conflict-free)
-        {
-            constexpr int PER_CG = (WB_R + 2) * WB_XPN;
-            const int nunits = ncgi * PER_CG;
-            for (int u0 = tid; u0 < nunits; u0 += 2 * 256) {
-                float4 v[2][4];
-                int dst[2];
 #pragma unroll
-                for (int q = 0; q < 2; ++q) {
-                    const int u = u0 + q * 256;
-                    const int cg = u / PER_CG, rem = u - cg * PER_CG;
-                    const int rr = rem / WB_XPN, pp = rem - rr * WB_XPN + WB_XP0;
-                    const int ih = a.IS * (r0 - 1 + rr) + xa, c = ci0 + cg * 8;
-                    dst[q] = u < nunits ? (cg * 8) * WB_XPLANE + rr * WB_XROW + pp : -1;
-                    const bool rowok = u < nunits && ih >= 0 && ih < a.Hx && c < a.Cin;
+        for (int q = 0; q < UX; ++q) {
+            int cg, rr, pp;
+            const bool live = xunit(tid + q * 256, cg, rr, pp);
+            const int ih = a.IS * (r0 - 1 + rr) + xa, c = ci0 + cg * 8;
+            const bool rowok = live && ih >= 0 && ih < a.Hx && c < a.Cin;
 #pragma unroll
-                    for (int px = 0; px < 2; ++px) {
-                        const int iw = a.IS * (c0 + 2 * pp - 8 + px) + xb;
-                        const bool ok = rowok && iw >= 0 && iw < a.Wx;
-                        wb_load8(xr, ok ? (unsigned)(((ih * a.Wx + iw) * a.ldi + c) * 4) : WB_OOB, v[q][2 * px], v[q][2 * px + 1]);
-                    }
-                }
-#pragma unroll
-                for (int q = 0; q < 2; ++q)
-                    if (dst[q] >= 0) {
-                        unsigned* d = XT + dst[q];
-                        d[0 * WB_XPLANE] = pack2(v[q][0].x, v[q][2].x);
-                        d[1 * WB_XPLANE] = pack2(v[q][0].y, v[q][2].y);
-                        d[2 * WB_XPLANE] = pack2(v[q][0].z, v[q][2].z);
-                        d[3 * WB_XPLANE] = pack2(v[q][0].w, v[q][2].w);
-                        d[4 * WB_XPLANE] = pack2(v[q][1].x, v[q][3].x);
-                        d[5 * WB_XPLANE] = pack2(v[q][1].y, v[q][3].y);
-                        d[6 * WB_XPLANE] = pack2(v[q][1].z, v[q][3].z);
-                        d[7 * WB_XPLANE] = pack2(v[q][1].w, v[q][3].w);
-                    }
+            for (int px = 0; px < 2; ++px) {
+                const int iw = a.IS * (c0 + 2 * pp - 8 + px) + xb;
+                const bool ok = rowok && iw >= 0 && iw < a.Wx;
+                wb_load8(xr, ok ? (unsigned)(((ih * a.Wx + iw) * a.ldi + c) * 4) : WB_OOB, vx[q][2 * px], vx[q][2 * px + 1]);
             }
         }
-        // ---- stage dY the same way (no halo; zeros beyond the image: those pixels then contribute nothing)
-        {
-            constexpr int PER_CG = WB_R * WB_YROW;
-            const int nunits = ncgo * PER_CG;
-            for (int u0 = tid; u0 < nunits; u0 += 2 * 256) {
-                float4 v[2][4];
-                int dst[2];
 #pragma unroll
-                for (int q = 0; q < 2; ++q) {
-                    const int u = u0 + q * 256;
-                    const int cg = u / PER_CG, rem = u - cg * PER_CG;
-                    const int rr = rem / WB_YROW, pp = rem - rr * WB_YROW;
-                    const int qr = r0 + rr, ih = a.OS * qr + ya, c = co0 + cg * 8;
-                    dst[q] = u < nunits ? (cg * 8) * WB_YPLANE + rr * WB_YROW + pp : -1;
-                    const bool rowok = u < nunits && qr < a.lh && ih < a.Hy && c < a.Cout;
+        for (int q = 0; q < UY; ++q) {
+            int cg, rr, pp;
+            const bool live = yunit(tid + q * 256, cg, rr, pp);
+            const int qr = r0 + rr, ih = a.OS * qr + ya, c = co0 + cg * 8;
+            const bool rowok = live && qr < a.lh && ih < a.Hy && c < a.Cout;
 #pragma unroll
-                    for (int px = 0; px < 2; ++px) {
-                        const int qc = c0 + 2 * pp + px, iw = a.OS * qc + yb;
-                        const bool ok = rowok && qc < a.lw && iw < a.Wy;
-                        wb_load8(yr, ok ? (unsigned)(((ih * a.Wy + iw) * a.ldo + c) * 4) : WB_OOB, v[q][2 * px], v[q][2 * px + 1]);
-                    }
-                }
-#pragma unroll
-                for (int q = 0; q < 2; ++q)
-                    if (dst[q] >= 0) {
-                        unsigned* d = YT + dst[q];
-                        d[0 * WB_YPLANE] = pack2(v[q][0].x, v[q][2].x);
-                        d[1 * WB_YPLANE] = pack2(v[q][0].y, v[q][2].y);
-                        d[2 * WB_YPLANE] = pack2(v[q][0].z, v[q][2].z);
-                        d[3 * WB_YPLANE] = pack2(v[q][0].w, v[q][2].w);
-                        d[4 * WB_YPLANE] = pack2(v[q][1].x, v[q][3].x);
-                        d[5 * WB_YPLANE] = pack2(v[q][1].y, v[q][3].y);
-                        d[6 * WB_YPLANE] = pack2(v[q][1].z, v[q][3].z);
-                        d[7 * WB_YPLANE] = pack2(v[q][1].w, v[q][3].w);
-                    }
+            for (int px = 0; px < 2; ++px) {
+                const int qc = c0 + 2 * pp + px, iw = a.OS * qc + yb;
+                const bool ok = rowok && qc < a.lw && iw < a.Wy;
+                wb_load8(yr, ok ? (unsigned)(((ih * a.Wy + iw) * a.ldo + c) * 4) : WB_OOB, vy[q][2 * px], vy[q][2 * px + 1]);
             }
         }
-        __syncthreads();
+    };
+    auto put8 = [&](unsigned* d, int plane, const float4 (&v)[4]) {
+        d[0 * plane] = pack2(v[0].x, v[2].x);
+        d[1 * plane] = pack2(v[0].y, v[2].y);
+        d[2 * plane] = pack2(v[0].z, v[2].z);
+        d[3 * plane] = pack2(v[0].w, v[2].w);
+        d[4 * plane] = pack2(v[1].x, v[3].x);
+        d[5 * plane] = pack2(v[1].y, v[3].y);
+        d[6 * plane] = pack2(v[1].z, v[3].z);
+        d[7 * plane] = pack2(v[1].w, v[3].w);
+    };
+    auto put = [&](int buf, const float4 (&vx)[UX][4], const float4 (&vy)[UY][4]) {
+        unsigned* xt = XT + buf * buf_dwords;
+        unsigned* yt = YT + buf * buf_dwords;
+#pragma unroll
+        for (int q = 0; q < UX; ++q) {
+            int cg, rr, pp;
+            if (xunit(tid + q * 256, cg, rr, pp)) put8(xt + (cg * 8) * WB_XPLANE + rr * WB_XROW + pp, WB_XPLANE, vx[q]);
+        }
+#pragma unroll
+        for (int q = 0; q < UY; ++q) {
+            int cg, rr, pp;
+            if (yunit(tid + q * 256, cg, rr, pp)) put8(yt + (cg * 8) * WB_YPLANE + rr * WB_YROW + pp, WB_YPLANE, vy[q]);
+        }
+    };
+
+    if (loader) {
+        // ---- staging role: tile i+1 while the other four waves run the MFMAs of tile i (same barrier sequence as below)
+        if (t_lo < t_hi) {
+            float4 vx[UX][4], vy[UY][4];
+            fetch(t_lo, vx, vy);
+            put(0, vx, vy);
+        }
+        int bs = 0;
+        for (int tile = t_lo; tile < t_hi; ++tile, bs ^= 1) {
+            __syncthreads();
+            WB_STAMP()
+            if (tile + 1 < t_hi) {
+                float4 vx[UX][4], vy[UY][4];
+                fetch(tile + 1, vx, vy);
+                WB_STAMP()
+                put(bs ^ 1, vx, vy);
+                WB_STAMP()
+            }
+        }
+        if (a.trace && threadIdx.x == 256 && a.trace_loader) a.trace[(size_t)blockIdx.x * 32] = n_stamp;
+        return;
+    }
+
+    // ---- MFMA role
+    f32x16 acc[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
+
+    int bsel = 0;
+    for (int tile = t_lo; tile < t_hi; ++tile, bsel ^= 1) {
+        __syncthreads();      // buffer `bsel` is complete; the MFMAs of the previous tile are done with the other one
+        WB_STAMP()
+        const unsigned* XTc = XT + bsel * buf_dwords;
+        const unsigned* YTc = YT + bsel * buf_dwords;
         // ---- k-steps of this wave: 16 consecutive pixels of one tile row; lane (l31, hh) holds channel l31 of its 32-channel
         // tile and pixels hh*8 .. hh*8+7 of the step
-        const unsigned* xq = XT + (wci * 32 + l31) * WB_XPLANE + 4 + hh * 4;     // dword of plane column 8 + hh*8 in row 0
-        const unsigned* yb = YT + (wco * 32 + l31) * WB_YPLANE + hh * 4;
-        for (int ks = kpart; ks < 2 * WB_R; ks += n_kparts) {
-            const int r = ks >> 1, h = ks & 1;
-            const wu32x4 bw = *reinterpret_cast<const wu32x4*>(yb + r * WB_YROW + h * 8);
-            const wbf16x8 B = __builtin_bit_cast(wbf16x8, bw);
+        const unsigned* xq = XTc + (wci * 32 + l31) * WB_XPLANE + 4 + hh * 4;     // dword of plane column 8 + hh*8 in row 0
+        const unsigned* yq = YTc + (wco * 32 + l31) * WB_YPLANE + hh * 4;
+        // Every patch row fragment is read (and its two shifted windows built) ONCE and feeds up to three tile rows: patch row
+        // rr is tap row dh of tile row r = rr - dh.  The dY fragments of the wave's k-steps are read up front.
+        wu32x4 Bf[2 * WB_R];
 #pragma unroll
-            for (int dh = 0; dh < 3; ++dh) {
-                if (!((tapmask >> (dh * 3)) & 7u)) continue;      // no tap of this pass in the patch row (wave-uniform)
-                const unsigned* p = xq + (r + dh) * WB_XROW + h * 8;
+        for (int ks = 0; ks < 2 * WB_R; ++ks)
+            if (NK == 1 || (ks % NK) == kpart) Bf[ks] = *reinterpret_cast<const wu32x4*>(yq + (ks >> 1) * WB_YROW + (ks & 1) * 8);
+#pragma unroll
+        for (int rr = 0; rr < WB_R + 2; ++rr) {
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const unsigned* p = xq + rr * WB_XROW + h * 8;
                 const wu32x4 cur = *reinterpret_cast<const wu32x4*>(p);
                 const unsigned prev = p[-1], next = p[4];
                 wu32x4 lft, rgt;       // windows starting one pixel earlier / later
@@ -208,14 +262,23 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void w
                 rgt[1] = __builtin_amdgcn_alignbyte(cur[2], cur[1], 2);
                 rgt[2] = __builtin_amdgcn_alignbyte(cur[3], cur[2], 2);
                 rgt[3] = __builtin_amdgcn_alignbyte(next, cur[3], 2);
-                if (tapmask & (1u << (dh * 3 + 0)))
-                    acc[dh * 3 + 0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(wbf16x8, lft), B, acc[dh * 3 + 0], 0, 0, 0);
-                if (tapmask & (1u << (dh * 3 + 1)))
-                    acc[dh * 3 + 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(wbf16x8, cur), B, acc[dh * 3 + 1], 0, 0, 0);
-                if (tapmask & (1u << (dh * 3 + 2)))
-                    acc[dh * 3 + 2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(wbf16x8, rgt), B, acc[dh * 3 + 2], 0, 0, 0);
+#pragma unroll
+                for (int dh = 0; dh < 3; ++dh) {
+                    const int r = rr - dh;
+                    if (r < 0 || r >= WB_R) continue;                                   // compile time
+                    const int ks = 2 * r + h;
+                    if (NK != 1 && (ks % NK) != kpart) continue;                        // another wave's k-step (wave-uniform)
+                    const wbf16x8 B = __builtin_bit_cast(wbf16x8, Bf[ks]);
+                    if (FULL || (tapmask & (1u << (dh * 3 + 0))))
+                        acc[dh * 3 + 0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(wbf16x8, lft), B, acc[dh * 3 + 0], 0, 0, 0);
+                    if (FULL || (tapmask & (1u << (dh * 3 + 1))))
+                        acc[dh * 3 + 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(wbf16x8, cur), B, acc[dh * 3 + 1], 0, 0, 0);
+                    if (FULL || (tapmask & (1u << (dh * 3 + 2))))
+                        acc[dh * 3 + 2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(wbf16x8, rgt), B, acc[dh * 3 + 2], 0, 0, 0);
+                }
             }
         }
+        WB_STAMP()
     }
 
     // ---- this wave's partial slab: [tap][Cin][Cout], accumulator row = input channel, lane = output channel
@@ -231,6 +294,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void w
             if (ci < a.Cin && co < a.Cout) dst[(size_t)ci * a.Cout + co] = acc[t][i];
         }
     }
+    WB_STAMP()
+    if (a.trace && threadIdx.x == 0 && !a.trace_loader) a.trace[(size_t)blockIdx.x * 32] = n_stamp;
+#undef WB_STAMP
 }
 
 // ------------------------------------------------------------------------------------------ host
@@ -300,13 +366,21 @@ static bool wgrad_bf16_plan(const RdConvDesc* d, WgradBfPlan& pl) {
     pl.tiles_per_split = cdiv(pl.total_tiles, splits);
     pl.n_splits = cdiv(pl.total_tiles, pl.tiles_per_split);
     pl.slab_splits = pl.n_splits * (4 / (pl.cpi * pl.cpo));
-    pl.lds_bytes = (size_t)(32 * pl.cpi * WB_XPLANE + 32 * pl.cpo * WB_YPLANE) * 4;
+    pl.lds_bytes = (size_t)(32 * pl.cpi * WB_XPLANE + 32 * pl.cpo * WB_YPLANE) * 4 * 2;      // two tile buffers
     return true;
 }
 
 }  // namespace rd
 
 using namespace rd;
+
+static unsigned long long* g_wb_trace = nullptr;
+// diagnostics: stamps of the last traced launch (32 slots per workgroup: count, cycle-counter values)
+extern "C" int rd_wgrad_bf16_trace_read(unsigned long long* host, int n_wg) {
+    if (!g_wb_trace) return RD_EINVAL;
+    RD_CHECK_HIP(hipMemcpy(host, g_wb_trace, (size_t)n_wg * 32 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    return RD_OK;
+}
 
 extern "C" int rd_wgrad_bf16_supported(const RdConvDesc* d) {
     WgradBfPlan pl;
@@ -342,15 +416,38 @@ extern "C" int rd_wgrad_bf16(const RdConvDesc* d, const float* in, const float* 
         a.xa[ps] = pl.xa[ps]; a.xb[ps] = pl.xb[ps]; a.ya[ps] = pl.ya[ps]; a.yb[ps] = pl.yb[ps];
         for (int t = 0; t < 9; ++t) a.slab_of_tap[ps][t] = ps < pl.n_pass ? pl.slab_of_tap[ps][t] : -1;
     }
-    static bool attr_set = false;
-    if (!attr_set) {
-        RD_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_bf16_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        attr_set = true;
+    a.trace = nullptr;
+    a.trace_loader = 0;
+    {
+        static const char* tr = getenv("RD_WGRAD_BF16_TRACE");
+        if (tr && atoi(tr)) {
+            a.trace_loader = atoi(tr) == 2;
+            if (!g_wb_trace) RD_CHECK_HIP(hipMalloc(&g_wb_trace, (size_t)65536 * 32 * sizeof(unsigned long long)));
+            a.trace = g_wb_trace;
+        }
     }
-    hipLaunchKernelGGL(wgrad_bf16_kernel, dim3(pl.n_cib * pl.n_cob * pl.n_splits * pl.n_pass), dim3(256), pl.lds_bytes,
-                       static_cast<hipStream_t>(stream), a);
-    RD_CHECK_LAUNCH("wgrad_bf16_kernel");
-    return RD_OK;
+    bool full = true;
+    for (int ps = 0; ps < pl.n_pass; ++ps)
+        for (int t = 0; t < 9; ++t) full = full && pl.slab_of_tap[ps][t] >= 0;
+    const int nk = 4 / (pl.cpi * pl.cpo);
+    const dim3 grid(pl.n_cib * pl.n_cob * pl.n_splits * pl.n_pass);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+#define RD_WB(FULL_, NK_)                                                                                                       \
+    if (full == FULL_ && nk == NK_) {                                                                                           \
+        static bool attr_set = false;                                                                                           \
+        auto k = wgrad_bf16_kernel<FULL_, NK_>;                                                                                 \
+        if (!attr_set) {                                                                                                        \
+            RD_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); \
+            attr_set = true;                                                                                                    \
+        }                                                                                                                       \
+        hipLaunchKernelGGL(k, grid, dim3(512), pl.lds_bytes, st, a);                                                            \
+        RD_CHECK_LAUNCH("wgrad_bf16_kernel");                                                                                   \
+        return RD_OK;                                                                                                           \
+    }
+    RD_WB(true, 1) RD_WB(true, 2) RD_WB(true, 4) RD_WB(false, 1) RD_WB(false, 2) RD_WB(false, 4)
+#undef RD_WB
+    set_error("wgrad_bf16: no kernel for %d k-parts", nk);
+    return RD_EINVAL;
 }
 
 extern "C" int rd_wgrad_bf16_reduce(const RdConvDesc* d, const float* slabs, float* grad_oihw, int32_t O, int32_t I, int32_t KH,
