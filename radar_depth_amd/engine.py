@@ -221,7 +221,7 @@ class LateFusionPlan:
         # bf16 plans: the weight gradients run on the bf16 matrix cores as well (3x3 / 1x1 at both strides, UpProj 5x5); what the
         # bf16 kernel cannot decompose keeps the fp32 kernel
         # (32-wide MFMA tiles: the 16-channel layers are faster on the fp32 kernel -- 42 vs 55 us for the depth encoder's layer1)
-        wg_bf16 = (self.bf16 and os.environ.get("RD_WGRAD_BF16", "1") == "1" and min(cin, cout) >= 32
+        wg_bf16 = (self.bf16 and os.environ.get("RD_WGRAD_BF16", "1") == "1" and min(cin, cout) >= int(os.environ.get("RD_WGRAD_BF16_MINC", "32"))
                    and self.L.rd_wgrad_bf16_supported(C.byref(dwd)) == 1)
         f_ws, f_wgrad, f_reduce, fam = ((self.L.rd_wgrad_bf16_workspace_floats, self.L.rd_wgrad_bf16, self.L.rd_wgrad_bf16_reduce, "wgrad_bf16")
                                         if wg_bf16 else (self.L.rd_wgrad_workspace_floats, self.L.rd_wgrad, self.L.rd_wgrad_reduce, "wgrad"))
