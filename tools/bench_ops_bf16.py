@@ -46,12 +46,13 @@ def main():
         if lib().rd_wgrad_bf16_supported(C.byref(d)) == 1:
             n = int(lib().rd_wgrad_bf16_workspace_floats(C.byref(d)))
             slabs = torch.empty(n, device=dev)
-            grad = torch.empty(d.Cout, d.Cin, 3, 3, device=dev)
+            kk = int(round(wp.shape[0] ** 0.5))          # 3, 1 or 5 (UpProj)
+            grad = torch.empty(d.Cout, d.Cin, kk, kk, device=dev)
             cs = ops.current_stream
 
             def wgf():
-                lib().rd_wgrad_bf16(C.byref(d), ops.ptr(x), ops.ptr(y), ops.ptr(slabs), cs())
-                lib().rd_wgrad_bf16_reduce(C.byref(d), ops.ptr(slabs), ops.ptr(grad), d.Cout, d.Cin, 3, 3, 0, 0, cs())
+                assert lib().rd_wgrad_bf16(C.byref(d), ops.ptr(x), ops.ptr(y), ops.ptr(slabs), cs()) == 0
+                assert lib().rd_wgrad_bf16_reduce(C.byref(d), ops.ptr(slabs), ops.ptr(grad), d.Cout, d.Cin, kk, kk, 0, 0, cs()) == 0
             tw = timeit(wgf)
             info = (C.c_int32 * 6)()
             lib().rd_wgrad_bf16_plan_info(C.byref(d), info)
@@ -60,7 +61,7 @@ def main():
         print("%-18s x%d %7.2f GF %7.1f MB | %7.1f us %6.1f TF %6.0f GB/s | %s%s" % (name, cnt, flops / 1e9, byts / 1e6, t * 1e6,
                                                                                   flops / t / 1e12, byts / t / 1e9, plan(d), wg))
         tot += cnt * t
-    print("TOTAL %.2f ms per forward (B=%d); bf16 weight gradients of the stride-1 3x3 layers %.2f ms" % (tot * 1e3, B, totw * 1e3))
+    print("TOTAL %.2f ms per forward (B=%d); bf16 weight gradients (incl. slab reduction) %.2f ms" % (tot * 1e3, B, totw * 1e3))
 
 
 if __name__ == "__main__":
