@@ -187,6 +187,12 @@ int rd_stem_fwd(const float* const* planes, const int64_t* strides, int32_t Cin,
                 int32_t W, const float* w_packed, int32_t Cout, float* out, float* stat_partial,
                 void* stream);
 int rd_stem_stat_tiles(int32_t N, int32_t H, int32_t W);
+/* bf16-operand form of rd_stem_fwd (opt-in with rd_gconv_bf16): identical arguments, tile geometry and stat_partial layout;
+ * input planes and the packed fp32 weights are rounded to bf16 while they are staged, fp32 accumulation on
+ * v_mfma_f32_32x32x16_bf16 (K ordered (plane, kernel row, kernel column padded to 8): no im2col buffer). */
+int rd_stem_fwd_bf16(const float* const* planes, const int64_t* strides, int32_t Cin, int32_t N, int32_t H,
+                     int32_t W, const float* w_packed, int32_t Cout, float* out, float* stat_partial,
+                     void* stream);
 /* weight gradient (OIHW, overwritten) of the stem; ws needs rd_stem_wgrad_workspace_floats */
 int64_t rd_stem_wgrad_workspace_floats(int32_t N, int32_t H, int32_t W, int32_t Cin, int32_t Cout);
 int rd_stem_wgrad(const float* const* planes, const int64_t* strides, int32_t Cin, int32_t N, int32_t H,

@@ -256,6 +256,38 @@ def test_wgrad_bf16_rejects_what_it_cannot_decompose():
         assert lib().rd_wgrad_bf16_workspace_floats(C.byref(d)) < 0
 
 
+@pytest.mark.parametrize("cfg", [(2, 3, 64, 97, 161), (1, 1, 16, 97, 161), (2, 2, 16, 64, 70), (1, 3, 64, 450, 800), (3, 1, 32, 9, 8)])
+def test_stem_fwd_bf16(cfg):
+    """7x7/2 stem on the bf16 matrix cores against a float64 convolution of the same rounded operands (2e-5) + BN partial sums."""
+    import ctypes as C
+    from radar_depth_amd import ops
+    from radar_depth_amd._lib import check, current_stream, lib, ptr
+    n, ci, co, h, w = cfg
+    g = torch.Generator().manual_seed(12)
+    x = torch.rand(n, 4, h, w, generator=g).cuda()          # the stems read channel planes of the 4-channel network input
+    wt = torch.randn(co, ci, 7, 7, generator=g) * 0.1
+    c_lo = 0 if ci == 3 else 3 - (ci - 1)                    # rgb: planes 0..2; depth: the last plane(s)
+    ref = F.conv2d(_bf(x[:, c_lo:c_lo + ci].cpu()).double(), _bf(wt).double(), stride=2, padding=3).float()
+    L = lib()
+    wp = torch.zeros(49, ci, co, device="cuda")
+    wp.copy_(wt.permute(2, 3, 1, 0).reshape(49, ci, co).cuda())        # plain [tap][ci][co] layout of the stem kernels
+    ho, wo = (h - 1) // 2 + 1, (w - 1) // 2 + 1
+    out = torch.full((n, ho, wo, co), float("nan"), device="cuda")
+    tiles = L.rd_stem_stat_tiles(n, h, w)
+    stat = torch.zeros(tiles, 2, co, device="cuda")
+    planes = (C.c_void_p * 3)(*([x[0, c_lo + i].data_ptr() for i in range(ci)] + [None] * (3 - ci)))
+    strides = (C.c_int64 * 3)(*([4 * h * w] * ci + [0] * (3 - ci)))
+    ops._poison()
+    check(L.rd_stem_fwd_bf16(planes, strides, ci, n, h, w, ptr(wp), co, ptr(out), ptr(stat), current_stream()), "rd_stem_fwd_bf16")
+    torch.cuda.synchronize()
+    got = out.permute(0, 3, 1, 2).cpu()
+    assert not torch.isnan(got).any()
+    assert _rel(got, ref) < 2e-5, (_rel(got, ref), cfg)
+    s_ = stat.sum(0).cpu().double()
+    assert ((s_[0] - ref.double().sum((0, 2, 3))).abs().max() / (ref.double() ** 2).sum((0, 2, 3)).sqrt().max()).item() < 1e-4
+    assert _rel(s_[1], (ref.double() ** 2).sum((0, 2, 3))) < 1e-4
+
+
 @pytest.mark.parametrize("arch", ["resnet18_latefusion", "resnet18_multistage_uncertainty_fixs"])
 def test_bf16_inference_matches_fp32(arch):
     from radar_depth_amd.main import HipInference
@@ -312,6 +344,23 @@ class _BfConv(torch.autograd.Function):
         return dx, dw, None, None
 
 
+class _BfStem(torch.autograd.Function):
+    """rd_stem_fwd_bf16: forward with both operands rounded to bf16; the stem's weight and input gradients are the fp32 kernels."""
+
+    @staticmethod
+    def forward(ctx, x, w, stride, pad):
+        ctx.save_for_backward(x, w)
+        ctx.sp = (stride, pad)
+        return F.conv2d(_bf(x), _bf(w), None, stride, pad)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w = ctx.saved_tensors
+        stride, pad = ctx.sp
+        dx = torch.nn.grad.conv2d_input(x.shape, w, dy, stride, pad) if ctx.needs_input_grad[0] else None
+        return dx, torch.nn.grad.conv2d_weight(x, w.shape, dy, stride, pad), None, None
+
+
 def _emulate_bf16_operands(model):
     """Route every convolution the engine lowers to gconv (all but the 7x7 stems and the 1-channel head) through _BfConv."""
     import types
@@ -321,6 +370,8 @@ def _emulate_bf16_operands(model):
             assert m.bias is None
             m.forward = types.MethodType(lambda self, x: _BfConv.apply(x, self.weight, self.stride, self.padding), m)
             n += 1
+        elif isinstance(m, torch.nn.Conv2d) and m.kernel_size == (7, 7) and m.out_channels >= 64:     # the RGB stem only
+            m.forward = types.MethodType(lambda self, x: _BfStem.apply(x, self.weight, self.stride, self.padding), m)
     return n
 
 
