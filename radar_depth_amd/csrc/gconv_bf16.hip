@@ -413,8 +413,8 @@ static int bf_patch_pixels(const RdConvDesc& d, const RdPhase& p, int TH, int TW
 }
 
 static bool plan_gconv_bf16(const RdConvDesc& d, GconvBfPlan& best) {
-    struct Cfg { int MT, NT; double prior; };
-    static const Cfg cfgs[] = {{2, 2, 0.95}, {2, 1, 0.8}, {3, 2, 1.0}, {1, 2, 0.75}, {1, 1, 0.7}};
+    struct Cfg { int MT, NT; };
+    static const Cfg cfgs[] = {{2, 2}, {2, 1}, {3, 2}, {1, 2}, {1, 1}};
     int taps_max = 0;
     for (int i = 0; i < d.n_phases; ++i) taps_max = taps_max > d.phase[i].n_taps ? taps_max : d.phase[i].n_taps;
     int pr = 0;
