@@ -520,6 +520,7 @@ static int bf_plan_query(const RdConvDesc* d, GconvBfPlan& pl, RdConvDesc& dd) {
     RD_CHECK_ARG(d->n_phases >= 1 && d->n_phases <= RD_MAX_PHASES, "gconv_bf16: n_phases=%d", d->n_phases);
     RD_CHECK_ARG(d->Cin % 16 == 0 && d->ldi % 4 == 0, "gconv_bf16: Cin=%d must be a multiple of 16, ldi=%d of 4", d->Cin, d->ldi);
     RD_CHECK_ARG(d->in_stride >= 1 && d->in_stride <= 2 && d->out_stride >= 1 && d->out_stride <= 2, "gconv_bf16: strides");
+    RD_CHECK_ARG((int64_t)d->Hi * d->Wi * d->ldi * 4 < (int64_t)RD_OOB, "gconv_bf16: one input image must stay below 2 GiB (32-bit buffer offsets)");
     for (int i = 0; i < d->n_phases; ++i) {
         const RdPhase& p = d->phase[i];
         RD_CHECK_ARG(p.n_taps >= 1 && p.n_taps <= RD_MAX_TAPS, "gconv_bf16: phase %d has %d taps", i, p.n_taps);
