@@ -319,30 +319,39 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MT * NT <= 
         const int welems = ntaps * W4 * BN;
         const int cinq = D.Cin >> 2;
         const int pe = ((a.debug & 1) && cb > cb_lo) ? 0 : patch_elems;
-        auto patch_load = [&](int base, auto& v) {
+        // The patch is copied as ROW SEGMENTS: segment = wave + 4*k is wave-uniform (scalar unit) and covers 64 consecutive
+        // float4 units of one patch row, so a lane's (pixel, channel quad) are shifts of the lane id -- no division by a runtime
+        // value per element (fp32 MFMAs share the SIMD's fp32 lanes: every VALU instruction of the staging costs matrix time).
+        // Halo / padding units go through a raw buffer descriptor whose out-of-range offsets return zeros: no branch per unit
+        // (a branch makes the compiler wait for each load before issuing the next).
+        const int lq4 = 31 - __clz(q4);
+        const int rowu = PW << lq4, nseg = (rowu + 63) >> 6, nsegs = pe ? PH * nseg : 0;
+        const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+        const __amdgpu_buffer_rsrc_t prsrc = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<float*>(in_n + cb), 0, (unsigned)(D.Hi * D.Wi * D.ldi - cb) * 4u, 0x00020000);
+        auto patch_load = [&](int k0, auto& v, auto& ld) {
             constexpr int N = sizeof(v) / sizeof(v[0]);
 #pragma unroll
             for (int u = 0; u < N; ++u) {
-                const int e = base + u * 256;
-                const int pix = e / q4, qq = e - pix * q4;
-                const int py = pix / PW, px = pix - py * PW;
-                const int ih = ih0 + py, iw = iw0 + px, c = cb + qq * 4;
-                v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (e < pe && ih >= 0 && ih < D.Hi && iw >= 0 && iw < D.Wi && c < D.Cin)
-                    v[u] = *reinterpret_cast<const float4*>(in_n + ((size_t)ih * D.Wi + iw) * D.ldi + c);
+                const int seg = wave_u + 4 * (k0 + u);
+                const int row = nseg == 1 ? seg : seg / nseg;
+                const int cu = ((seg - row * nseg) << 6) + lane;
+                const int px = cu >> lq4, qq = cu & (q4 - 1);
+                const int ih = ih0 + row, iw = iw0 + px;
+                const bool ok = seg < nsegs && cu < rowu;
+                ld[u] = ok ? paddr(row * PW + px, qq * 4) : -1;
+                const unsigned go = (ok && ih >= 0 && ih < D.Hi && iw >= 0 && iw < D.Wi && cb + qq * 4 < D.Cin)
+                                        ? (unsigned)(((ih * D.Wi + iw) * D.ldi + qq * 4) * 4) : 0x80000000u;
+                v[u] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(prsrc, (int)go, 0, 0));
             }
         };
-        auto patch_store = [&](int base, auto& v) {
+        auto patch_store = [&](auto& v, auto& ld) {
             constexpr int N = sizeof(v) / sizeof(v[0]);
 #pragma unroll
-            for (int u = 0; u < N; ++u) {
-                const int e = base + u * 256;
-                if (e < pe) {
-                    const int pix = e / q4, qq = e - pix * q4;
-                    *reinterpret_cast<float4*>(s_patch + paddr(pix, qq * 4)) = v[u];
-                }
-            }
+            for (int u = 0; u < N; ++u)
+                if (ld[u] >= 0) *reinterpret_cast<float4*>(s_patch + ld[u]) = v[u];
         };
+        const int lW4 = 31 - __clz(W4);
         auto w_load = [&](int base, int ks, auto& v) {
             constexpr int N = sizeof(v) / sizeof(v[0]);
             const int we = ((a.debug & 2) && (cb > cb_lo || ks > 0)) ? 0 : welems;
@@ -352,7 +361,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MT * NT <= 
                 const int e = base + u * 256;
                 const int j = e % BN;
                 const int tk = e / BN;
-                const int k4 = tk % W4, t = min(tk / W4, ntaps - 1);
+                const int k4 = tk & (W4 - 1), t = min(tk >> lW4, ntaps - 1);      // W4 is a power of two
                 const int co = co0 + j;
                 v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
                 if (e < we && co < D.Cout)
@@ -368,17 +377,20 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MT * NT <= 
                 if (e < we) *reinterpret_cast<float4*>(s_w + (size_t)e * 4) = v[u];   // [t][k4][BN] is linear in e
             }
         };
+        const int nk = (nsegs + 3) >> 2;            // row segments per wave
         {
             float4 vp[UP], vw[UW];
-            patch_load(tid, vp);
+            int ld[UP];
+            patch_load(0, vp, ld);
             w_load(tid, 0, vw);
-            patch_store(tid, vp);
+            patch_store(vp, ld);
             w_store(tid, 0, vw);
         }
-        for (int base = tid + 256 * UP; base < pe; base += 256 * UP) {
+        for (int k0 = UP; k0 < nk; k0 += UP) {
             float4 vp[UP];
-            patch_load(base, vp);
-            patch_store(base, vp);
+            int ld[UP];
+            patch_load(k0, vp, ld);
+            patch_store(vp, ld);
         }
         for (int ks = 0; ks < nsub; ++ks) {
             if (ks > 0) __syncthreads();
@@ -692,6 +704,7 @@ static int validate_desc(const RdConvDesc* d) {
     RD_CHECK_ARG(d->n_phases >= 1 && d->n_phases <= RD_MAX_PHASES, "gconv: n_phases=%d", d->n_phases);
     RD_CHECK_ARG(d->Cin % 16 == 0 && d->ldi % 4 == 0, "gconv: Cin=%d must be a multiple of 16, ldi=%d of 4", d->Cin, d->ldi);
     RD_CHECK_ARG(d->Cout % 4 == 0, "gconv: Cout=%d must be a multiple of 4", d->Cout);
+    RD_CHECK_ARG((int64_t)d->Hi * d->Wi * d->ldi * 4 < (int64_t)0x80000000u, "gconv: one input image must stay below 2 GiB (32-bit buffer offsets)");
     RD_CHECK_ARG(d->in_stride >= 1 && d->in_stride <= 2 && d->out_stride >= 1 && d->out_stride <= 2, "gconv: strides");
     for (int i = 0; i < d->n_phases; ++i) {
         const RdPhase& p = d->phase[i];
