@@ -216,6 +216,9 @@ int rd_bn_finalize(const float* stat_partial, int32_t n_tiles, int32_t ld, int32
 /* eval mode: scale/shift from running stats */
 int rd_bn_eval_coeffs(int32_t C, const float* gamma, const float* beta, const float* running_mean,
                       const float* running_var, float eps, float* scale, float* shift, void* stream);
+/* the same for many BatchNorm layers in one launch.  jobs_dev: device array of
+ *   struct { const float *gamma, *beta, *running_mean, *running_var; float *scale, *shift; int32_t C, pad; } */
+int rd_bn_eval_coeffs_batched(const void* jobs_dev, int32_t n_jobs, float eps, void* stream);
 /* partial stats of an existing tensor (used where the producer has no fused epilogue) */
 int rd_bn_stats(const float* x, int64_t M, int32_t C, int32_t ldx, float* stat_partial, int32_t* n_tiles,
                 void* stream);

@@ -55,6 +55,21 @@ __global__ void bn_eval_coeffs_kernel(int C, const float* gamma, const float* be
     }
 }
 
+// every folded BatchNorm of an inference plan in ONE launch (54 launches of ~4 us each were 18 % of the batch-1 eval forward)
+struct EvalCoefJob {
+    const float *gamma, *beta, *rm, *rv;
+    float *scale, *shift;
+    int C, pad_;
+};
+__global__ __launch_bounds__(256) void bn_eval_coeffs_batched_kernel(const EvalCoefJob* __restrict__ jobs, float eps) {
+    const EvalCoefJob j = jobs[blockIdx.x];
+    for (int c = threadIdx.x; c < j.C; c += blockDim.x) {
+        const float r = 1.0f / sqrtf(j.rv[c] + eps);       // same expression as bn_eval_coeffs_kernel: bit-identical results
+        j.scale[c] = j.gamma[c] * r;
+        j.shift[c] = j.beta[c] - j.rm[c] * j.gamma[c] * r;
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // row-block reductions: thread (q = channel quad, rl = row lane); block covers rows [b*RPB, (b+1)*RPB)
 static inline int rows_per_block(int64_t M) {
@@ -406,6 +421,14 @@ extern "C" int rd_bn_eval_coeffs(int32_t C, const float* gamma, const float* bet
     hipLaunchKernelGGL(bn_eval_coeffs_kernel, dim3(cdiv(C, 256)), dim3(256), 0, static_cast<hipStream_t>(stream), C, gamma, beta,
                        running_mean, running_var, eps, scale, shift);
     RD_CHECK_LAUNCH("bn_eval_coeffs_kernel");
+    return RD_OK;
+}
+
+extern "C" int rd_bn_eval_coeffs_batched(const void* jobs_dev, int32_t n_jobs, float eps, void* stream) {
+    RD_CHECK_ARG(jobs_dev && n_jobs > 0, "bn_eval_coeffs_batched: bad arguments");
+    hipLaunchKernelGGL(bn_eval_coeffs_batched_kernel, dim3(n_jobs), dim3(256), 0, static_cast<hipStream_t>(stream),
+                       static_cast<const EvalCoefJob*>(jobs_dev), eps);
+    RD_CHECK_LAUNCH("bn_eval_coeffs_batched_kernel");
     return RD_OK;
 }
 

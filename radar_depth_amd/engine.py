@@ -102,6 +102,7 @@ class LateFusionPlan:
         self.stream_mask = int(os.environ.get("RD_STREAM_MASK", "3"))
         self.fwd, self.bwd = [], []
         self.prep = []
+        self.evalcoef_jobs = []   # (C, bn, scale ptr, shift ptr) of the folded BatchNorms of an inference plan
         self.pack_jobs = []    # (src, dst, O, I, T, ldc, off, rows_total, transpose, scale, quad): packed in ONE launch per forward
         self.taps = {}         # name -> Act of intermediate tensors (tests / debugging)
         self.meta = {}         # op name -> (kernel family, descriptor) for the conv launches (bench roofline accounting)
@@ -294,8 +295,7 @@ class LateFusionPlan:
             o, i, kh, kw = w.shape
             sc = C.c_void_p(scale.data_ptr() + 4 * off)
             sh = C.c_void_p(bias.data_ptr() + 4 * off)
-            self.op(self.prep, name + ".evalcoef", self.L.rd_bn_eval_coeffs, o, _p(bn.weight), _p(bn.bias), _p(bn.running_mean),
-                    _p(bn.running_var), C.c_float(BN_EPS), sc, sh, self.streams[0])
+            self.evalcoef_jobs.append((o, bn, sc, sh))       # all folded BatchNorms: ONE launch (see _finish_pack_jobs)
             self.pack_jobs.append((w, wp, o, i, kh * kw, cout, off, i, 0, scale[off:off + o], 2 if self.bf16 else 1))
         self.keep += [d, scale]
         if self.bf16:
@@ -632,6 +632,18 @@ class LateFusionPlan:
             _fields_ = [("src", C.c_void_p), ("dst", C.c_void_p), ("scale", C.c_void_p), ("O", C.c_int32), ("I", C.c_int32), ("T", C.c_int32),
                         ("ldc", C.c_int32), ("off", C.c_int32), ("rows_total", C.c_int32), ("transpose", C.c_int32),
                         ("first_block", C.c_int32), ("quad", C.c_int32), ("pad_", C.c_int32)]
+        if self.evalcoef_jobs:
+            class EJob(C.Structure):
+                _fields_ = [("gamma", C.c_void_p), ("beta", C.c_void_p), ("rm", C.c_void_p), ("rv", C.c_void_p), ("scale", C.c_void_p),
+                            ("shift", C.c_void_p), ("C", C.c_int32), ("pad_", C.c_int32)]
+            ej = (EJob * len(self.evalcoef_jobs))()
+            for k, (o, bn, sc, sh) in enumerate(self.evalcoef_jobs):
+                ej[k] = EJob(bn.weight.data_ptr(), bn.bias.data_ptr(), bn.running_mean.data_ptr(), bn.running_var.data_ptr(), sc.value,
+                             sh.value, o, 0)
+            self.evalcoef_table = torch.from_numpy(np.frombuffer(bytes(ej), dtype=np.uint8).copy()).to(self.dev)
+            self.keep.append(self.evalcoef_table)
+            self.op(self.prep, "evalcoef_all", self.L.rd_bn_eval_coeffs_batched, _p(self.evalcoef_table), len(self.evalcoef_jobs),
+                    C.c_float(BN_EPS), self.streams[0])
         chunk = self.L.rd_pack_chunk()
         jobs = (Job * len(self.pack_jobs))()
         block_job, nb = [], 0
