@@ -14,7 +14,20 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restric
                                                           int64_t* nbt, float* mean, float* invstd, float* scale, float* shift) {
     const int c = blockIdx.x;
     double s = 0.0, q = 0.0;
-    for (int t = threadIdx.x; t < n_tiles; t += blockDim.x) {
+    // four tiles per trip with all eight loads issued before the first add: the kernel is a chain of L2 round trips (it sits on
+    // the critical path between a convolution and its BatchNorm 54 times per step), so the trips are what there is to save
+    int t = threadIdx.x;
+    for (; t + 3 * 256 < n_tiles; t += 4 * 256) {
+        float a[4], b[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            a[k] = part[((size_t)(t + k * 256) * 2 + 0) * ld + c0 + c];
+            b[k] = part[((size_t)(t + k * 256) * 2 + 1) * ld + c0 + c];
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { s += (double)a[k]; q += (double)b[k]; }
+    }
+    for (; t < n_tiles; t += 256) {
         s += (double)part[((size_t)t * 2 + 0) * ld + c0 + c];
         q += (double)part[((size_t)t * 2 + 1) * ld + c0 + c];
     }
@@ -204,7 +217,18 @@ __global__ __launch_bounds__(256) void bn_bwd_coeffs_kernel(const float* __restr
                                                             float* coef) {
     const int c = blockIdx.x;
     double s0 = 0.0, s1 = 0.0;
-    for (int t = threadIdx.x; t < n_tiles; t += blockDim.x) {
+    int t = threadIdx.x;
+    for (; t + 3 * 256 < n_tiles; t += 4 * 256) {       // (see bn_finalize_kernel: one round trip for four tiles)
+        float a[4], b[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            a[k] = part[((size_t)(t + k * 256) * 3 + 0) * C + c];
+            b[k] = part[((size_t)(t + k * 256) * 3 + which) * C + c];
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { s0 += (double)a[k]; s1 += (double)b[k]; }
+    }
+    for (; t < n_tiles; t += 256) {
         s0 += (double)part[((size_t)t * 3 + 0) * C + c];
         s1 += (double)part[((size_t)t * 3 + which) * C + c];
     }
