@@ -1,5 +1,5 @@
 """Race hunt: two identically initialised training steps (latefusion at several geometries, then multistage) must stay
-bit-identical while ~650 kernels run on three streams.   python tools/stress_repro.py"""
+bit-identical while ~650 kernels run on three streams.   python tools/stress_repro.py [fp32|bf16]"""
 import sys, types
 import torch
 sys.path.insert(0, ".")
@@ -16,13 +16,15 @@ def build(arch, h, w):
     return m.cuda(), lw
 
 
+OPERANDS = sys.argv[1] if len(sys.argv) > 1 else "fp32"
+print("conv operands:", OPERANDS)
 bad = 0
 for arch, b, h, w, steps in [("resnet18_latefusion", 16, 450, 800, 6), ("resnet18_latefusion", 3, 225, 401, 6), ("resnet18_latefusion", 1, 450, 800, 6),
                             ("resnet18_latefusion", 5, 97, 161, 8), ("resnet18_multistage_uncertainty_fixs", 4, 225, 400, 5),
                             ("resnet18_multistage_uncertainty_fixs", 8, 450, 800, 3)]:
     (m1, lw1), (m2, lw2) = build(arch, h, w), build(arch, h, w)
-    t1 = HipTrainStep(m1, b, h, w, loss_weights=lw1)
-    t2 = HipTrainStep(m2, b, h, w, loss_weights=lw2)
+    t1 = HipTrainStep(m1, b, h, w, loss_weights=lw1, operands=OPERANDS)
+    t2 = HipTrainStep(m2, b, h, w, loss_weights=lw2, operands=OPERANDS)
     ok = True
     for it in range(steps):
         x, t = make_batch(b, h, w, 4000 + it, ref_pixels=h * w)
@@ -30,7 +32,7 @@ for arch, b, h, w, steps in [("resnet18_latefusion", 16, 450, 800, 6), ("resnet1
         l2, _ = t2.step(x.cuda(), t.cuda())
         torch.cuda.synchronize()
         ok = ok and l1.item() == l2.item()
-    ok = ok and all(torch.equal(p, q) for p, q in zip(m1.parameters(), m2.parameters()))
+    ok = ok and all(torch.equal(p, q) and bool(torch.isfinite(p).all()) for p, q in zip(m1.parameters(), m2.parameters()))
     print("%-40s b=%d %dx%d: %s (final loss %.6f)" % (arch, b, h, w, "bit-identical" if ok else "MISMATCH", l1.item()))
     bad += not ok
     del t1, t2, m1, m2
