@@ -51,6 +51,7 @@ struct WgradBfArgs {
     int slab_of_tap[4][9];           // per pass: weight slab index of tap shift (sh+1)*3 + (sw+1), -1: tap absent
     unsigned long long* trace;       // diagnostics (RD_WGRAD_BF16_TRACE=1 compute wave, =2 loader wave): 32 stamps per workgroup
     int trace_loader;
+    int xcd;                         // XCD-aware workgroup order (diagnostics: RD_WGRAD_BF16_NOXCD=1 disables)
 };
 
 constexpr int WB_R = 4;                      // rows per pixel tile
@@ -92,8 +93,11 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     if (a.trace && threadIdx.x == (unsigned)(a.trace_loader ? 256 : 0) && n_stamp < 31) a.trace[(size_t)blockIdx.x * 32 + 1 + n_stamp++] = __builtin_readcyclecounter();
     WB_STAMP()
     const int nblk = a.n_cib * a.n_cob;
-    const int blk = blockIdx.x % nblk;
-    const int sp_ = blockIdx.x / nblk;
+    // consecutive logical ids = the channel blocks of ONE pixel split: they read the same x / dy tiles, so they are mapped to the
+    // same XCD (hardware deals workgroup ids round-robin over the eight XCDs, each with its own L2)
+    const int vid = a.xcd ? xcd_remap(blockIdx.x, gridDim.x) : (int)blockIdx.x;
+    const int blk = vid % nblk;
+    const int sp_ = vid / nblk;
     const int pass = __builtin_amdgcn_readfirstlane(sp_ / a.n_splits), split = sp_ - pass * a.n_splits;
     const int xa = a.xa[pass], xb = a.xb[pass], ya = a.ya[pass], yb = a.yb[pass];
     unsigned tapmask = 0;
@@ -418,6 +422,7 @@ extern "C" int rd_wgrad_bf16(const RdConvDesc* d, const float* in, const float* 
     }
     a.trace = nullptr;
     a.trace_loader = 0;
+    { static const char* nox = getenv("RD_WGRAD_BF16_NOXCD"); a.xcd = nox ? 0 : 1; }
     {
         static const char* tr = getenv("RD_WGRAD_BF16_TRACE");
         if (tr && atoi(tr)) {
