@@ -308,6 +308,11 @@ int rd_loss_tiles(int64_t n);
 /* dpred (+)= coef_dev[0] * (-sign(t-p)) / count on valid pixels; coef read on device */
 int rd_masked_l1_bwd(const float* pred, const float* target, int64_t n, const double* sums,
                      const float* coef, float* dpred, int32_t accumulate, void* stream);
+/* MaskedMSELoss (:31-41, `-c l2`, main.py:294-305): sums[0] = sum (t-p)^2 over t>0, sums[1] = count; same workspace.
+ * dpred (+)= coef_dev[0] * 2 (p-t) / count on valid pixels. */
+int rd_masked_l2_sums(const float* pred, const float* target, int64_t n, float* ws, double* sums, void* stream);
+int rd_masked_l2_bwd(const float* pred, const float* target, int64_t n, const double* sums,
+                     const float* coef, float* dpred, int32_t accumulate, void* stream);
 /* Result.evaluate (evaluation/metrics.py:34-58) as ONE masked reduction instead of ~12 blocking float() syncs:
  * sums[10] = count, sum d^2, sum |d|, sum |log10 o - log10 t|, sum |d|/t, #(r<1.25), #(r<1.25^2), #(r<1.25^3),
  * sum (1/o-1/t)^2, sum |1/o-1/t| over pixels with target > 0.  ws: 10*rd_loss_tiles(n) doubles. */

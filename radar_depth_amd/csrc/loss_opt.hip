@@ -20,6 +20,8 @@ __device__ __forceinline__ double block_sum_d(double v, double* sh) {
 }
 
 // ---------------------------------------------------------------- masked L1
+// SQ = false: MaskedL1Loss (sum |t-p|); SQ = true: MaskedMSELoss (criteria_new.py:31-41, sum (t-p)^2)
+template <bool SQ>
 __global__ __launch_bounds__(256) void l1_partial_kernel(const float* __restrict__ pred, const float* __restrict__ target,
                                                          int64_t n, double* __restrict__ part) {
     __shared__ double sh[4];
@@ -27,7 +29,8 @@ __global__ __launch_bounds__(256) void l1_partial_kernel(const float* __restrict
     for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (int64_t)gridDim.x * blockDim.x) {
         const float t = target[e];
         if (t > 0.f) {
-            s += (double)fabsf(t - pred[e]);
+            const float diff = t - pred[e];
+            s += SQ ? (double)(diff * diff) : (double)fabsf(diff);
             c += 1.0;
         }
     }
@@ -50,6 +53,7 @@ __global__ __launch_bounds__(256) void pair_final_kernel(const double* __restric
     }
 }
 
+template <bool SQ>
 __global__ __launch_bounds__(256) void l1_bwd_kernel(const float* __restrict__ pred, const float* __restrict__ target, int64_t n,
                                                      const double* __restrict__ sums, const float* __restrict__ coef,
                                                      float* __restrict__ dpred, int accumulate) {
@@ -59,7 +63,7 @@ __global__ __launch_bounds__(256) void l1_bwd_kernel(const float* __restrict__ p
         float g = 0.f;
         if (t > 0.f) {
             const float diff = t - pred[e];
-            g = diff > 0.f ? -k : (diff < 0.f ? k : 0.f);
+            g = SQ ? -2.f * diff * k : (diff > 0.f ? -k : (diff < 0.f ? k : 0.f));
         }
         dpred[e] = accumulate ? dpred[e] + g : g;
     }
@@ -288,8 +292,20 @@ extern "C" int rd_masked_l1_sums(const float* pred, const float* target, int64_t
     hipStream_t s = static_cast<hipStream_t>(stream);
     const int g = red_grid(n);
     double* part = reinterpret_cast<double*>(ws);
-    hipLaunchKernelGGL(l1_partial_kernel, dim3(g), dim3(256), 0, s, pred, target, n, part);
+    hipLaunchKernelGGL(l1_partial_kernel<false>, dim3(g), dim3(256), 0, s, pred, target, n, part);
     RD_CHECK_LAUNCH("l1_partial_kernel");
+    hipLaunchKernelGGL(pair_final_kernel, dim3(1), dim3(256), 0, s, part, g, 2, sums);
+    RD_CHECK_LAUNCH("pair_final_kernel");
+    return RD_OK;
+}
+// MaskedMSELoss (criteria_new.py:31-41): sums[0] = sum (t-p)^2 over t>0, sums[1] = count
+extern "C" int rd_masked_l2_sums(const float* pred, const float* target, int64_t n, float* ws, double* sums, void* stream) {
+    RD_CHECK_ARG(pred && target && ws && sums && n > 0 && ((uintptr_t)ws & 7) == 0, "masked_l2_sums: bad arguments");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const int g = red_grid(n);
+    double* part = reinterpret_cast<double*>(ws);
+    hipLaunchKernelGGL(l1_partial_kernel<true>, dim3(g), dim3(256), 0, s, pred, target, n, part);
+    RD_CHECK_LAUNCH("l2_partial_kernel");
     hipLaunchKernelGGL(pair_final_kernel, dim3(1), dim3(256), 0, s, part, g, 2, sums);
     RD_CHECK_LAUNCH("pair_final_kernel");
     return RD_OK;
@@ -311,9 +327,18 @@ extern "C" int rd_depth_metrics(const float* output, const float* target, int64_
 extern "C" int rd_masked_l1_bwd(const float* pred, const float* target, int64_t n, const double* sums, const float* coef,
                                 float* dpred, int32_t accumulate, void* stream) {
     RD_CHECK_ARG(pred && target && sums && coef && dpred && n > 0, "masked_l1_bwd: bad arguments");
-    hipLaunchKernelGGL(l1_bwd_kernel, dim3(ew_grid2(n)), dim3(256), 0, static_cast<hipStream_t>(stream), pred, target, n, sums, coef,
+    hipLaunchKernelGGL(l1_bwd_kernel<false>, dim3(ew_grid2(n)), dim3(256), 0, static_cast<hipStream_t>(stream), pred, target, n, sums, coef,
                        dpred, accumulate);
     RD_CHECK_LAUNCH("l1_bwd_kernel");
+    return RD_OK;
+}
+// dpred = coef * 2 (pred - target) / count on valid pixels, 0 elsewhere
+extern "C" int rd_masked_l2_bwd(const float* pred, const float* target, int64_t n, const double* sums, const float* coef,
+                                float* dpred, int32_t accumulate, void* stream) {
+    RD_CHECK_ARG(pred && target && sums && coef && dpred && n > 0, "masked_l2_bwd: bad arguments");
+    hipLaunchKernelGGL(l1_bwd_kernel<true>, dim3(ew_grid2(n)), dim3(256), 0, static_cast<hipStream_t>(stream), pred, target, n, sums, coef,
+                       dpred, accumulate);
+    RD_CHECK_LAUNCH("l2_bwd_kernel");
     return RD_OK;
 }
 

@@ -86,7 +86,7 @@ class LateFusionPlan:
         self.N, self.H, self.W = batch, height, width
         self.train = train
         self.bf16 = bool(bf16)
-        self.dev = module.conv1.weight.device
+        self.dev = next(module.parameters()).device
         # dry_run: record the op lists against host buffers without ever launching (CPU tests of the host logic)
         assert dry_run or self.dev.type == "cuda", "the HIP path needs the module on a GPU"
         self.dry_run = dry_run
@@ -110,8 +110,23 @@ class LateFusionPlan:
         self.depth_planes = depth_planes
         self.x_source = x_source
         self.dense_grad_dst = dense_grad_dst
-        self.Ho, self.Wo = module.output_size
+        self.Ho, self.Wo = getattr(module, "output_size", (height, width))
+        self.generation = 0    # bumped by every forward: autograd nodes of an earlier forward must not read this plan's buffers
         self._build()
+
+    def close(self):
+        """Destroy the plan's hipEvents (its buffers are torch tensors and go with the object)."""
+        evs, self.events = getattr(self, "events", []), []
+        if not getattr(self, "dry_run", True):
+            for ev in evs:
+                if ev.value:
+                    self.L.rd_event_destroy(ev)
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
     # ------------------------------------------------------------------ small helpers
     def buf(self, *shape, dtype=torch.float32):
@@ -748,7 +763,10 @@ class LateFusionPlan:
     def run_forward(self, x=None):
         """x: [N,>=4,H,W] fp32 CUDA tensor (copied into the plan's static input buffer) or None if already there."""
         self.set_stream()
+        self.generation += 1
         if x is not None and self.x_source is None:
+            if tuple(x.shape[:1]) + tuple(x.shape[2:]) != (self.N, self.H, self.W):
+                raise ValueError("plan built for [%d,*,%d,%d], got %s" % (self.N, self.H, self.W, tuple(x.shape)))
             self.x_in.copy_(x[:, :self.x_in.shape[1]])
         self._run(self.prep)
         self._run(self.fwd)
@@ -759,3 +777,36 @@ class LateFusionPlan:
         if dpred is not None:
             self.dpred.copy_(dpred)
         self._run(self.bwd)
+
+
+class ModulePlan(LateFusionPlan):
+    """ONE BasicBlock (models.py:75-112) or UpProjModule (models.py:181-209) run through the very op builders the network
+    plan uses (_block / _upproj and their backward), on a stand-alone NHWC input: layer-level forward + backward parity
+    against the reference-generated fixtures (tests/golden/upproj_module.npz, basic_block.npz) at kernel-level tolerance,
+    between "one kernel" and "the whole network".  owner: an ArenaOwner nn.Module holding `mod` (gradient arena)."""
+
+    def __init__(self, owner, mod, kind, batch, height, width, cin, bf16=False):
+        assert kind in ("block", "upproj")
+        self._mod, self._kind, self._cin = mod, kind, cin
+        super().__init__(owner, batch, height, width, train=True, bf16=bf16)
+
+    def _build(self):
+        self.x = self.act(self.N, self.H, self.W, self._cin)
+        build, back = (self._upproj, self._upproj_bwd) if self._kind == "upproj" else (self._block, self._block_bwd)
+        self.y, ctx = build("m", self._mod, self.x)
+        self._finish_pack_jobs()
+        self.dy = self.act(self.y.N, self.y.H, self.y.W, self.y.C)
+        self.dx = back(ctx, self.dy)
+        self.edge(self.bwd, "join1", 1, 0)
+        self.edge(self.bwd, "join2", 2, 0)
+
+    def run(self, x_nchw, dy_nchw):
+        """x [N,C,H,W], dy [N,C',H',W'] CUDA fp32 -> (y, dx) as NCHW tensors; parameter gradients land in the owner's arena."""
+        self.set_stream()
+        self.x.t.copy_(x_nchw.permute(0, 2, 3, 1))
+        self._run(self.prep)
+        self._run(self.fwd)
+        self.dy.t.copy_(dy_nchw.permute(0, 2, 3, 1))
+        self._run(self.bwd)
+        torch.cuda.synchronize()
+        return self.y.view().permute(0, 3, 1, 2).contiguous(), self.dx.view().permute(0, 3, 1, 2).contiguous()

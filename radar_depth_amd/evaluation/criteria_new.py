@@ -1,5 +1,5 @@
 """MI355X-native counterpart of the reference's evaluation/criteria_new.py (hot-path subset):
-MaskedL1Loss (:44-54) and SmoothnessLoss (:8-28) as HIP reductions behind torch.autograd.  Same call
+MaskedL1Loss (:44-54), MaskedMSELoss (:31-41) and SmoothnessLoss (:8-28) as HIP reductions behind torch.autograd.  Same call
 signatures; losses are 0-dim CUDA tensors; an all-invalid target gives NaN exactly like the reference."""
 import ctypes as C
 
@@ -14,8 +14,10 @@ def _f64(n, dev):
 
 
 class _MaskedL1Fn(torch.autograd.Function):
-    @staticmethod
-    def forward(ctx, pred, target):
+    SUMS, BWD = "rd_masked_l1_sums", "rd_masked_l1_bwd"
+
+    @classmethod
+    def forward(cls, ctx, pred, target):
         L = lib()
         pred = pred.contiguous()
         target = target.contiguous()
@@ -23,18 +25,33 @@ class _MaskedL1Fn(torch.autograd.Function):
         tiles = L.rd_loss_tiles(C.c_int64(n))
         ws = _f64(2 * tiles, pred.device)
         sums = _f64(2, pred.device)
-        check(L.rd_masked_l1_sums(ptr(pred), ptr(target), C.c_int64(n), ptr(ws), ptr(sums), current_stream()), "rd_masked_l1_sums")
+        check(getattr(L, cls.SUMS)(ptr(pred), ptr(target), C.c_int64(n), ptr(ws), ptr(sums), current_stream()), cls.SUMS)
         ctx.save_for_backward(pred, target, sums)
         return (sums[0] / sums[1]).float()
 
-    @staticmethod
-    def backward(ctx, gout):
+    @classmethod
+    def backward(cls, ctx, gout):
         pred, target, sums = ctx.saved_tensors
         dpred = torch.empty_like(pred)
         coef = gout.reshape(1).float().contiguous()
-        check(lib().rd_masked_l1_bwd(ptr(pred), ptr(target), C.c_int64(pred.numel()), ptr(sums), ptr(coef), ptr(dpred), 0,
-                                     current_stream()), "rd_masked_l1_bwd")
+        check(getattr(lib(), cls.BWD)(ptr(pred), ptr(target), C.c_int64(pred.numel()), ptr(sums), ptr(coef), ptr(dpred), 0,
+                                      current_stream()), cls.BWD)
         return dpred, None
+
+
+class _MaskedL2Fn(_MaskedL1Fn):
+    SUMS, BWD = "rd_masked_l2_sums", "rd_masked_l2_bwd"
+
+
+class MaskedMSELoss(nn.Module):
+    """`-c l2` (main.py:294-305): mean of (target - pred)^2 over target > 0, NaN on an all-invalid target."""
+
+    def forward(self, pred, target):
+        assert pred.dim() == target.dim(), "inconsistent dimensions"
+        if not pred.is_cuda:
+            raise RuntimeError("radar_depth_amd losses run on MI355X only (HIP kernels)")
+        self.loss = _MaskedL2Fn.apply(pred.float(), target.float())
+        return self.loss
 
 
 class MaskedL1Loss(nn.Module):

@@ -10,27 +10,29 @@ import torch
 from .._lib import check, current_stream, lib, ptr
 
 
+_ERRORS = ("irmse", "imae", "mse", "rmse", "mae", "absrel", "lg10")     # lower is better -> worst = +inf
+_SCORES = ("delta1", "delta2", "delta3")                                # higher is better -> worst = 0
+_TIMES = ("gpu_time", "data_time")
+_METRICS = _ERRORS + _SCORES
+
+
 class Result(object):
+    """Record of one evaluation (same attribute names and `update` argument order as evaluation/metrics.py:10-31; picklable
+    under the same module path so reference checkpoints' `best_result` round-trips)."""
+
     def __init__(self):
-        self.irmse, self.imae = 0, 0
-        self.mse, self.rmse, self.mae = 0, 0, 0
-        self.absrel, self.lg10 = 0, 0
-        self.delta1, self.delta2, self.delta3 = 0, 0, 0
-        self.data_time, self.gpu_time = 0, 0
+        self._assign(dict.fromkeys(_METRICS + _TIMES, 0))
+
+    def _assign(self, values):
+        for key, val in values.items():
+            setattr(self, key, val)
 
     def set_to_worst(self):
-        self.irmse, self.imae = np.inf, np.inf
-        self.mse, self.rmse, self.mae = np.inf, np.inf, np.inf
-        self.absrel, self.lg10 = np.inf, np.inf
-        self.delta1, self.delta2, self.delta3 = 0, 0, 0
-        self.data_time, self.gpu_time = 0, 0
+        self._assign({**dict.fromkeys(_ERRORS, np.inf), **dict.fromkeys(_SCORES + _TIMES, 0)})
 
     def update(self, irmse, imae, mse, rmse, mae, absrel, lg10, delta1, delta2, delta3, gpu_time, data_time):
-        self.irmse, self.imae = irmse, imae
-        self.mse, self.rmse, self.mae = mse, rmse, mae
-        self.absrel, self.lg10 = absrel, lg10
-        self.delta1, self.delta2, self.delta3 = delta1, delta2, delta3
-        self.data_time, self.gpu_time = data_time, gpu_time
+        self._assign(dict(zip(_METRICS + _TIMES, (irmse, imae, mse, rmse, mae, absrel, lg10, delta1, delta2, delta3,
+                                                  gpu_time, data_time))))
 
     def evaluate(self, output, target):
         if not output.is_cuda:
@@ -59,7 +61,7 @@ class Result(object):
 
 
 class AverageMeter(object):
-    _FIELDS = ("irmse", "imae", "mse", "rmse", "mae", "absrel", "lg10", "delta1", "delta2", "delta3")
+    _FIELDS = _METRICS
 
     def __init__(self):
         self.reset()

@@ -107,10 +107,14 @@ class HipTrainStep:
     torch.autocast(bfloat16) analogue for BASELINE.json configs 2/4; tolerances in tests/test_gpu_bf16.py."""
 
     def __init__(self, model, batch, height, width, lr=0.01, momentum=0.9, weight_decay=1e-4, loss_weights=None, use_graph=False,
-                 operands="fp32"):
+                 operands="fp32", criterion="l1"):
+        """criterion: "l1" (MaskedL1Loss, the default of utils.parse_command) or "l2" (MaskedMSELoss, `-c l2`, main.py:294-305)."""
         from .model.multistage_model import ResNet_multistage
+        assert criterion in ("l1", "l2"), criterion
         self.model = model
         self.L = lib()
+        self._f_sums, self._f_bwd = ((self.L.rd_masked_l1_sums, self.L.rd_masked_l1_bwd) if criterion == "l1" else
+                                     (self.L.rd_masked_l2_sums, self.L.rd_masked_l2_bwd))
         model.train()
         self.multistage = isinstance(model, ResNet_multistage)
         if self.multistage:
@@ -122,9 +126,13 @@ class HipTrainStep:
             self.plans = [model._plan(batch, height, width, True, bf16=operands == "bf16")]
         self.plan = self.plans[0]
         self.st = model._ensure_arenas()
+        self._arena_version = self.st["version"]
         dev = self.plan.dev
+        self.batch, self.height, self.width = batch, height, width
         self.lr, self.momentum, self.wd = lr, momentum, weight_decay
         self.world = torch.distributed.get_world_size() if torch.distributed.is_available() and torch.distributed.is_initialized() else 1
+        if self.world > 1:
+            self.sync_state_from_rank0()
         # RD_FORCE_DP=1 runs the data-parallel code path (segmented graphs + bucketed all-reduce) even with one rank (tests)
         self.dp = self.world > 1 or (os.environ.get("RD_FORCE_DP") == "1" and torch.distributed.is_initialized())
         p = self.plan
@@ -166,6 +174,51 @@ class HipTrainStep:
             self._segments = bucket_segments(self.plan, offs)
             self._buckets = [sl for _, _, sl in self._segments]
 
+    def sync_state_from_rank0(self):
+        """Data-parallel replicas must start from one state (DDP broadcasts at construction): parameters, momentum and the
+        BatchNorm buffers of rank 0 replace every other rank's, so a checkpoint loaded on rank 0 only -- or different seeds --
+        cannot silently train divergent replicas whose gradients are still averaged."""
+        dist = torch.distributed
+        dist.broadcast(self.st["arena"], 0)
+        dist.broadcast(self.st["mom"], 0)
+        for b in self.model.buffers():
+            dist.broadcast(b, 0)
+
+    # ---- optimizer state in torch.optim.SGD's layout (the reference checkpoints `optimizer.state_dict()`, main.py:358-374)
+    def state_dict(self):
+        params = self.st["params"]
+        offs, off = [], 0
+        for p in params:
+            offs.append(off)
+            off += (p.numel() + 3) // 4 * 4
+        state = {}
+        if self.steps > 0:
+            state = {i: {"momentum_buffer": self.st["mom"][o:o + p.numel()].view(p.shape).clone()}
+                     for i, (p, o) in enumerate(zip(params, offs))}
+        group = {"lr": self.lr, "momentum": self.momentum, "dampening": 0, "weight_decay": self.wd, "nesterov": False,
+                 "params": list(range(len(params)))}
+        return {"state": state, "param_groups": [group]}
+
+    def load_state_dict(self, sd):
+        g = sd["param_groups"][0]
+        self.set_lr(g["lr"])
+        if g["momentum"] != self.momentum or g["weight_decay"] != self.wd:
+            self.momentum, self.wd = g["momentum"], g["weight_decay"]
+            self._drop_graphs()
+        params = self.st["params"]
+        off = 0
+        loaded = 0
+        for i, p in enumerate(params):
+            ent = sd["state"].get(i)
+            if ent is not None and ent.get("momentum_buffer") is not None:
+                self.st["mom"][off:off + p.numel()].view(p.shape).copy_(ent["momentum_buffer"])
+                loaded += 1
+            off += (p.numel() + 3) // 4 * 4
+        # torch.optim.SGD starts a missing buffer as buf = grad; rd_sgd_step's first step does the same on a zero buffer
+        # (0.9 * 0 + g), so only a restored state switches the "first step" behaviour off
+        if loaded:
+            self.steps = max(self.steps, 1)
+
     def set_lr(self, lr):
         if lr != self.lr:
             self.lr = lr
@@ -180,11 +233,11 @@ class HipTrainStep:
     # ---- pieces of one step: each is a sequence of C-ABI launches on the step's stream, separately graph-capturable;
     # ---- after piece i (i < len(buckets)) the gradient bucket i is final
     def _l1(self, pred, sums):
-        check(self.L.rd_masked_l1_sums(ptr(pred), ptr(self.target), C.c_int64(self.n_out), ptr(self.l1_ws), ptr(sums), self.plan.stream), "l1_sums")
+        check(self._f_sums(ptr(pred), ptr(self.target), C.c_int64(self.n_out), ptr(self.l1_ws), ptr(sums), self.plan.stream), "masked_sums")
 
     def _l1_bwd(self, pred, sums, coef, dpred, accumulate):
-        check(self.L.rd_masked_l1_bwd(ptr(pred), ptr(self.target), C.c_int64(self.n_out), ptr(sums), coef, ptr(dpred), accumulate,
-                                      self.plan.stream), "l1_bwd")
+        check(self._f_bwd(ptr(pred), ptr(self.target), C.c_int64(self.n_out), ptr(sums), coef, ptr(dpred), accumulate,
+                          self.plan.stream), "masked_bwd")
 
     def _latefusion_pieces(self):
         p = self.plan
@@ -250,6 +303,18 @@ class HipTrainStep:
 
     def _step_on_side(self, inputs, target):
         p = self.plan
+        # the step is bound to one batch geometry (static buffers): never rely on copy_ broadcasting a ragged last batch
+        want_in, want_t = (self.batch, p.x_in.shape[1], self.height, self.width), tuple(self.target.shape)
+        if tuple(inputs.shape[:1]) + tuple(inputs.shape[2:]) != (want_in[0],) + want_in[2:] or inputs.shape[1] < want_in[1]:
+            raise ValueError("HipTrainStep was built for inputs [%d,>=%d,%d,%d], got %s (build another HipTrainStep for a ragged "
+                             "last batch or use drop_last=True)" % (want_in + (tuple(inputs.shape),)))
+        if tuple(target.shape) != want_t:
+            raise ValueError("HipTrainStep was built for target %s, got %s" % (want_t, tuple(target.shape)))
+        st = self.st                    # cheap per-step check (no module traversal): first / last parameter still view the arena
+        if (self.model._arena_root().__dict__.get("_arena_state") is not st or st["params"][0].data_ptr() != st["ptrs"][0]
+                or st["params"][-1].data_ptr() != st["ptrs"][-1]):
+            raise RuntimeError("the model's parameter arena was rebuilt after this HipTrainStep was created (model.to() / "
+                               "reassigned parameter .data): build a new HipTrainStep")
         for pl in self.plans:
             pl.set_stream()
         p.x_in.copy_(inputs[:, :p.x_in.shape[1]])

@@ -144,6 +144,20 @@ def choose_decoder(decoder, in_channels):
     assert False, "invalid option for decoder: {}".format(decoder)
 
 
+PLAN_CACHE_SIZE = int(os.environ.get("RD_PLAN_CACHE", "3"))
+
+
+def _evict_plans(cache, version, room_for=1):
+    """A plan owns every activation / gradient / workspace buffer of one (batch, size, mode) key -- about 11 GB at b=16
+    450x800 training.  The cache is a small LRU (the steady batch, a ragged last batch, validate()'s batch 1): plans of a
+    rebuilt parameter arena go first, then the least recently used; a dropped plan frees its HBM and its hipEvents."""
+    stale = [k for k in cache if k[4] != version]
+    for k in stale + [k for k in cache if k not in stale][:max(0, len(cache) - len(stale) + room_for - PLAN_CACHE_SIZE)]:
+        plan = cache.pop(k)
+        for pl in (getattr(plan, "p1", None), getattr(plan, "p2", None)) if hasattr(plan, "p1") else (plan,):
+            pl.close()
+
+
 # ------------------------------------------------------------------------------------------------
 class ArenaOwner:
     """Mixin: keeps every parameter of the (top-level) network in one flat fp32 arena, with matching flat
@@ -242,7 +256,7 @@ class ResNet_latefusion(ArenaOwner, nn.Module):
         if not os.path.exists(path):
             raise RuntimeError("pretrained=True needs ImageNet ResNet-18 weights: set RADAR_DEPTH_RESNET18_WEIGHTS to a "
                                "torchvision resnet18 state_dict file, or construct with pretrained=False (--no-pretrain)")
-        sd = torch.load(path, map_location="cpu")
+        sd = torch.load(path, map_location="cpu", weights_only=True)      # a plain torchvision state_dict: tensors only
         own = self.state_dict()
         picked = {k: v for k, v in sd.items() if k.split(".")[0] in ("layer1", "layer2", "layer3", "layer4") and k in own}
         self.load_state_dict(picked, strict=False)
@@ -257,9 +271,10 @@ class ResNet_latefusion(ArenaOwner, nn.Module):
         key = (batch, height, width, bool(train), st["version"], None if depth_planes is None else tuple(t.data_ptr() for t in depth_planes), bool(bf16))
         plans = self.__dict__.setdefault("_plans", {})
         if key not in plans:
-            for k in [k for k in plans if k[4] != st["version"]]:
-                del plans[k]
+            _evict_plans(plans, st["version"])
             plans[key] = LateFusionPlan(self, batch, height, width, train=train, depth_planes=depth_planes, bf16=bf16)
+        else:
+            plans[key] = plans.pop(key)          # most recently used last
         return plans[key]
 
     def forward(self, x):
@@ -281,11 +296,17 @@ class _PlanFunction(torch.autograd.Function):
         ctx.plan = plan
         ctx.n_params = len(params)
         ctx.params = params
-        return plan.run_forward(x).clone()
+        out = plan.run_forward(x).clone()
+        ctx.generation = plan.generation
+        return out
 
     @staticmethod
     def backward(ctx, gout):
         plan = ctx.plan
+        if plan.generation != ctx.generation:
+            raise RuntimeError("this plan ran another forward since the one being differentiated: its saved activations are "
+                               "static buffers, so call backward() before the next training-mode forward of the same "
+                               "(batch, size) -- e.g. accumulate gradients one batch at a time")
         plan.run_backward(gout.contiguous())
         own = {id(p) for p in plan.m.parameters()}
         grads = [plan.m._grad_view(p) if id(p) in own else None for p in ctx.params]

@@ -69,7 +69,8 @@ class ResNet_multistage(ArenaOwner, nn.Module):
             if not os.path.exists(path):
                 raise ValueError("[Error] Can't find pretrained latefusion model. "
                                  "Please follow the instructions in README.md to download the weights!")
-            weights = torch.load(path, map_location="cpu")["model_state_dict"]
+            from ..utils import load_checkpoint      # reference .pth.tar: pickled Namespace + Result next to the state_dict
+            weights = load_checkpoint(path)["model_state_dict"]
             self.stage1.load_state_dict(weights)
             self.stage2.load_state_dict(self.filter_state_dict(weights, self.stage2.state_dict()), strict=False)
         self.__dict__["_ms_plans"] = {}
@@ -86,9 +87,11 @@ class ResNet_multistage(ArenaOwner, nn.Module):
         st = self._ensure_arenas()
         key = (batch, height, width, bool(train), st["version"], bool(bf16))
         cache = self.__dict__.setdefault("_ms_plans", {})
-        if key not in cache:
-            for k in [k for k in cache if k[4] != st["version"]]:
-                del cache[k]
+        if key in cache:
+            cache[key] = cache.pop(key)
+        else:
+            from .models import _evict_plans
+            _evict_plans(cache, st["version"])
             p1 = LateFusionPlan(self.stage1, batch, height, width, train=train, bf16=bf16)
             dev = p1.dev
             kept = torch.empty(batch, 1, height, width, device=dev)
@@ -152,11 +155,15 @@ class _MultistageFunction(torch.autograd.Function):
     def forward(ctx, mp, x, *params):
         ctx.mp, ctx.params = mp, params
         mp.run_forward(x)
+        ctx.generation = (mp.p1.generation, mp.p2.generation)
         return mp.p1.pred.clone(), mp.p2.pred.clone()
 
     @staticmethod
     def backward(ctx, g1, g2):
         mp = ctx.mp
+        if (mp.p1.generation, mp.p2.generation) != ctx.generation:
+            raise RuntimeError("these plans ran another forward since the one being differentiated (static activation buffers): "
+                               "call backward() before the next training-mode forward of the same (batch, size)")
         mp.run_backward(None if g1 is None else g1.contiguous(), None if g2 is None else g2.contiguous())
         root = mp.p1.m._arena_root()
         staged = {id(p) for p in mp.p1.m.parameters()} | {id(p) for p in mp.p2.m.parameters()}

@@ -59,6 +59,24 @@ def save_checkpoint(state, is_best, epoch, output_directory):
     return checkpoint_filename
 
 
+def load_checkpoint(path, map_location="cpu"):
+    """Read a reference-format .pth.tar (main.py:194-266).  The reference pickles an argparse.Namespace under `args` and an
+    evaluation.metrics.Result under `best_result`, so the file needs the full unpickler (torch >= 2.6 defaults to
+    weights_only=True, which rejects both) and the reference's module path `evaluation.metrics` must resolve: it is aliased
+    to radar_depth_amd.evaluation.metrics (same class name, same attributes) for the duration of the load."""
+    import sys
+    from . import evaluation as _ev
+    from .evaluation import metrics as _metrics
+    added = [k for k in ("evaluation", "evaluation.metrics") if k not in sys.modules]
+    sys.modules.setdefault("evaluation", _ev)
+    sys.modules.setdefault("evaluation.metrics", _metrics)
+    try:
+        return torch.load(path, map_location=map_location, weights_only=False)
+    finally:
+        for k in added:
+            sys.modules.pop(k, None)
+
+
 def adjust_learning_rate(optimizer, epoch, lr_init):
     """lr = lr_init * 0.1^(epoch // 5); works on torch optimizers and on radar_depth_amd.main.HipTrainStep."""
     lr = lr_init * (0.1 ** (epoch // 5))

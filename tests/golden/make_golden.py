@@ -180,7 +180,7 @@ def latefusion_case(ResNet_latefusion, MaskedL1Loss, batch, h, w, seed, sub, den
     return out
 
 
-def multistage_case(ResNet_multistage, MaskedL1Loss, SmoothnessLoss, batch, h, w, seed, sub):
+def multistage_case(ResNet_multistage, MaskedL1Loss, SmoothnessLoss, batch, h, w, seed, sub, dense_small=True):
     out = {}
     torch.manual_seed(0)
     model = ResNet_multistage(18, "upproj", [h, w], False)
@@ -189,7 +189,7 @@ def multistage_case(ResNet_multistage, MaskedL1Loss, SmoothnessLoss, batch, h, w
     model.register_parameter("w_stage1", w1)   # main.py:166-172
     model.register_parameter("w_stage2", w2)
     procedural_fill_(model)
-    x, t = make_batch(batch, h, w, seed, ref_pixels=h * w)
+    x, t = make_batch(batch, h, w, seed, ref_pixels=h * w if dense_small else 450 * 800)
     # place a few radar returns far from any plausible prediction so the filter rejects some
     x[:, 3, ::7, ::11] = torch.where(x[:, 3, ::7, ::11] > 0, x[:, 3, ::7, ::11], torch.full_like(x[:, 3, ::7, ::11], 60.0))
     out["inputs_patch_note"] = np.array(["x[:,3,::7,::11] zeros replaced by 60.0"])
@@ -218,6 +218,23 @@ def multistage_case(ResNet_multistage, MaskedL1Loss, SmoothnessLoss, batch, h, w
     opt.step()
     out["param_norms1"] = np.array([p.double().norm().item() for _, p in model.named_parameters()])
     return out
+
+
+def init_stats(model):
+    """Per-tensor moments of a FRESHLY CONSTRUCTED reference model (no procedural fill): pins the initialisers
+    (model/models.py:30-72 applied at :541-542,:561-562,:591-594,:622-623, incl. the RGB-stem double init and the PyTorch
+    default init of conv1_depth / conv_fusion).  Columns: n, mean, std, abs-max, kurtosis m4/m2^2 (3.0 normal, 1.8 uniform)."""
+    names, rows = [], []
+    for k, v in model.state_dict().items():
+        if v.dim() == 0 and not v.is_floating_point():
+            continue
+        d = v.detach().double().flatten()
+        c = d - d.mean()
+        m2 = (c ** 2).mean().item()
+        kurt = ((c ** 4).mean().item() / (m2 * m2)) if m2 > 0 else 0.0
+        names.append(k)
+        rows.append([d.numel(), d.mean().item(), d.std(unbiased=False).item() if d.numel() > 1 else 0.0, d.abs().max().item(), kurt])
+    return {"names": np.array(names), "rows": np.array(rows, dtype=np.float64)}
 
 
 def unit_cases(mm, crit_mod):
@@ -266,6 +283,28 @@ def upproj_case(models):
     return out
 
 
+def block_case(models):
+    """The reference's own BasicBlock (models.py:75-112) forward/backward in train mode: an identity-residual block (32 -> 32)
+    and a stride-2 block with the 1x1 downsample branch (32 -> 64), on odd-sized maps."""
+    out = {}
+    g = torch.Generator().manual_seed(23)
+    for tag, cin, cout, stride in (("id", 32, 32, 1), ("ds", 32, 64, 2)):
+        down = None
+        if stride != 1 or cin != cout:
+            down = nn.Sequential(nn.Conv2d(cin, cout, 1, stride, bias=False), nn.BatchNorm2d(cout))
+        m = models.BasicBlock(cin, cout, stride, down)
+        procedural_fill_(m)
+        m.train()
+        x = torch.randn(2, cin, 11, 13, generator=g).requires_grad_(True)
+        y = m(x)
+        gy = torch.randn(y.shape, generator=g)
+        y.backward(gy)
+        out.update({tag + "/x": _np(x), tag + "/y": _np(y), tag + "/gy": _np(gy), tag + "/gx": _np(x.grad)})
+        for n, p in m.named_parameters():
+            out[tag + "/grad/" + n] = _np(p.grad)
+    return out
+
+
 def main():
     _install_shims()
     from model import models, multistage_model as mm
@@ -280,8 +319,19 @@ def main():
     np.savez_compressed(os.path.join(HERE, "latefusion_full.npz"), **full)
     multi = multistage_case(mm.ResNet_multistage, crit_mod.MaskedL1Loss, crit_mod.SmoothnessLoss, 2, 97, 161, 777, 1)
     np.savez_compressed(os.path.join(HERE, "multistage_small.npz"), **multi)
+    # config 4's own geometry (the reference's 450x800 multistage smoke, multistage_model.py:279-287), maps strided by 8
+    mfull = multistage_case(mm.ResNet_multistage, crit_mod.MaskedL1Loss, crit_mod.SmoothnessLoss, 2, 450, 800, 4242, 8, dense_small=False)
+    np.savez_compressed(os.path.join(HERE, "multistage_full.npz"), **mfull)
+    # initialiser pins: freshly constructed reference models under a fixed seed (torch RNG; the stand-in torchvision
+    # resnet18 consumes the stream differently from the real one, so the pin is statistical: moments per tensor)
+    torch.manual_seed(20240917)
+    lf = init_stats(models.ResNet_latefusion(18, "upproj", [450, 800], 4, False))
+    torch.manual_seed(20240917)
+    ms = init_stats(mm.ResNet_multistage(18, "upproj", [450, 800], False))
+    np.savez_compressed(os.path.join(HERE, "init_stats.npz"), lf_names=lf["names"], lf_rows=lf["rows"], ms_names=ms["names"], ms_rows=ms["rows"])
     np.savez_compressed(os.path.join(HERE, "units.npz"), **unit_cases(mm, crit_mod))
     np.savez_compressed(os.path.join(HERE, "upproj_module.npz"), **upproj_case(models))
+    np.savez_compressed(os.path.join(HERE, "basic_block.npz"), **block_case(models))
     for f in sorted(os.listdir(HERE)):
         if f.endswith(".npz"):
             print(f, os.path.getsize(os.path.join(HERE, f)))

@@ -99,3 +99,65 @@ def test_checkpoint_wire_format(tmp_path):
     # and back: a HIP-module checkpoint loads into the reference-shaped module
     om = OMulti(18, "upproj", [97, 161], False)
     om.load_state_dict(ms.state_dict())
+
+
+def test_authors_checkpoint_payload_loads(tmp_path):
+    """The authors' .pth.tar files pickle an argparse.Namespace under `args` and an `evaluation.metrics.Result` under
+    `best_result` (main.py:358-374).  torch >= 2.6 refuses both under its weights_only default and the Result class lives at
+    the REFERENCE's module path: utils.load_checkpoint must read such a file, and ResNet_multistage(pretrained=True) must
+    initialise both stages from it (multistage_model.py:34-61)."""
+    import argparse
+    import sys
+    import types
+
+    from oracle.models import ResNet_latefusion as ORef
+    from radar_depth_amd import utils
+    from radar_depth_amd.evaluation.metrics import Result
+    from radar_depth_amd.model.multistage_model import ResNet_multistage
+    from radar_depth_amd.synthetic import procedural_fill_
+    # write the file the way the reference does: Result pickled as evaluation.metrics.Result
+    pkg, mod = types.ModuleType("evaluation"), types.ModuleType("evaluation.metrics")
+
+    class RefResult(object):
+        def __init__(self):
+            self.rmse, self.mae, self.delta1 = 5.25, 2.5, 0.875
+    RefResult.__module__, RefResult.__qualname__, RefResult.__name__ = "evaluation.metrics", "Result", "Result"
+    mod.Result, pkg.metrics = RefResult, mod
+    src = ORef(18, "upproj", [97, 161], 4, False)
+    procedural_fill_(src)
+    root = tmp_path / "proj"
+    (root / "pretrained").mkdir(parents=True)
+    path = str(root / "pretrained" / "resnet18_latefusion.pth.tar")
+    sys.modules["evaluation"], sys.modules["evaluation.metrics"] = pkg, mod
+    try:
+        torch.save({"args": argparse.Namespace(arch="resnet18_latefusion", lr=0.01), "epoch": 19, "arch": "resnet18_latefusion",
+                    "model_state_dict": src.state_dict(), "best_result": RefResult(), "optimizer_state_dict": None}, path)
+    finally:
+        del sys.modules["evaluation"], sys.modules["evaluation.metrics"]
+    with pytest.raises(Exception):
+        torch.load(path, map_location="cpu")              # what the round-1 code did: rejected by the weights_only default
+    ck = utils.load_checkpoint(path)
+    assert isinstance(ck["best_result"], Result) and ck["best_result"].rmse == 5.25 and ck["args"].arch == "resnet18_latefusion"
+    assert "evaluation.metrics" not in sys.modules        # the alias does not leak
+    ms = ResNet_multistage(18, "upproj", [97, 161], pretrained=True, project_root=str(root))
+    assert torch.equal(ms.stage1.conv1_depth.weight, src.conv1_depth.weight)
+    assert torch.equal(ms.stage2.layer4[1].conv2.weight, src.layer4[1].conv2.weight)
+    assert ms.stage2.conv1_depth.weight.shape == (16, 2, 7, 7)        # shape-filtered: keeps its own init
+
+
+def test_result_container_semantics():
+    """Result keeps the reference's attribute names / update() argument order (evaluation/metrics.py:10-31)."""
+    import numpy as np
+    from radar_depth_amd.evaluation.metrics import AverageMeter, Result
+    r = Result()
+    assert (r.irmse, r.imae, r.mse, r.rmse, r.mae, r.absrel, r.lg10, r.delta1, r.delta2, r.delta3, r.data_time, r.gpu_time) == (0,) * 12
+    r.set_to_worst()
+    assert r.rmse == np.inf and r.irmse == np.inf and r.lg10 == np.inf and r.delta1 == 0 and r.gpu_time == 0
+    r.update(1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12)
+    assert (r.irmse, r.imae, r.mse, r.rmse, r.mae, r.absrel, r.lg10, r.delta1, r.delta2, r.delta3) == tuple(range(1, 11))
+    assert r.gpu_time == 11 and r.data_time == 12
+    am = AverageMeter()
+    am.update(r, 0.5, 0.25, n=2)
+    am.update(r, 1.5, 0.75, n=2)
+    avg = am.average()
+    assert avg.rmse == 4 and avg.delta3 == 10 and avg.gpu_time == 1.0 and avg.data_time == 0.5

@@ -1,0 +1,397 @@
+"""Parity on BASELINE.json's own configurations (the sizes the metric is quoted on), plus layer-level forward/backward pins.
+
+  config 2  resnet18_latefusion b=16 450x800 fp32          forward + loss vs the live CPU oracle          (<= 1e-3 / 1e-4)
+  config 4  multistage_uncertainty_fixs 450x800            b=2 vs the reference-generated golden fixture   (multistage_full.npz)
+                                                           b=8 forward + losses vs the live CPU oracle
+  config 5  multistage bf16, 900x1600                      bf16 multistage training step vs the oracle with the same rounding
+                                                           points (97x161); fp32 multistage 900x1600 b=1 vs the oracle;
+                                                           bf16 multistage 900x1600 b=1 step vs the emulated oracle's losses
+  layers    one UpProjModule / BasicBlock fwd+bwd through the plan's builders vs upproj_module.npz / basic_block.npz (1e-4)
+  misc      plain resnet18_multistage (loss = d1 + d2, main.py:431-438); MaskedMSELoss (`-c l2`)
+"""
+import os
+import types
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def rel(a, b):
+    a, b = np.asarray(a, dtype=np.float64), np.asarray(b, dtype=np.float64)
+    return float(np.abs(a - b).max() / max(np.abs(b).max(), 1e-30))
+
+
+def _t(x):
+    return x.detach().cpu().numpy()
+
+
+def _latefusion_pair(h, w):
+    from oracle.models import ResNet_latefusion as ORef
+    from radar_depth_amd.model.models import ResNet_latefusion
+    from radar_depth_amd.synthetic import procedural_fill_
+    torch.manual_seed(0)
+    m = ResNet_latefusion(18, "upproj", [h, w], 4, False)
+    procedural_fill_(m)
+    o = ORef(18, "upproj", [h, w], 4, False)
+    procedural_fill_(o)
+    return m.cuda().train(), o.train()
+
+
+def _multistage_pair(h, w, arch="resnet18_multistage_uncertainty_fixs"):
+    from oracle import train as otrain
+    from radar_depth_amd import main as hmain
+    from radar_depth_amd.synthetic import procedural_fill_
+    args = types.SimpleNamespace(arch=arch, decoder="upproj", modality="rgbd", pretrained=False)
+    torch.manual_seed(0)
+    made_h, made_o = hmain.create_model(args, [h, w]), otrain.create_model(args, [h, w])
+    hm, hw_ = made_h if isinstance(made_h, tuple) else (made_h, None)
+    om, ow = made_o if isinstance(made_o, tuple) else (made_o, None)
+    procedural_fill_(hm)
+    procedural_fill_(om)
+    return args, hm.cuda().train(), hw_, om.train(), ow
+
+
+# ------------------------------------------------------------------------------------------------ config 2
+def test_config2_latefusion_b16_450x800_vs_oracle():
+    """BASELINE configs[1] exactly: b=16, 450x800, fp32, train mode (batch statistics over 16 samples).  Forward map within
+    1e-3 of the CPU oracle's (north_star), loss within 1e-4, then one fused step must leave the same loss in the step's
+    own loss slot and a finite, changed parameter set."""
+    from oracle.criteria import MaskedL1Loss as OL1
+    from radar_depth_amd.evaluation.criteria_new import MaskedL1Loss
+    from radar_depth_amd.main import HipTrainStep
+    from radar_depth_amd.synthetic import make_batch
+    b, h, w = 16, 450, 800
+    m, o = _latefusion_pair(h, w)
+    x, t = make_batch(b, h, w, 1234)
+    with torch.no_grad():
+        yo = o(x)
+        lo = OL1()(yo, t)
+        y = m(x.cuda())
+        lg = MaskedL1Loss()(y, t.cuda())
+    e = rel(_t(y), _t(yo))
+    assert e < 1e-3, e
+    assert abs(lg.item() - lo.item()) / lo.item() < 1e-4
+    # running statistics of the first and the last BatchNorm after that one training-mode forward
+    for k in ("bn1.running_mean", "bn1.running_var", "decoder.layer4.upper_branch.batchnorm2.running_var", "bn_fusion.running_mean"):
+        assert rel(_t(m.state_dict()[k]), _t(o.state_dict()[k])) < 1e-3, k
+    before = m.conv3.weight.detach().clone()
+    ts = HipTrainStep(m, b, h, w)
+    loss, pred = ts.step(x.cuda(), t.cuda())
+    torch.cuda.synchronize()
+    # the fused step's forward saw BN running stats one update later, which do not enter train-mode outputs: same loss
+    assert abs(loss.item() - lo.item()) / lo.item() < 1e-4
+    assert rel(_t(pred), _t(yo)) < 1e-3
+    assert not torch.equal(before, m.conv3.weight) and all(torch.isfinite(p).all() for p in m.parameters())
+
+
+# ------------------------------------------------------------------------------------------------ config 4
+def test_config4_multistage_450x800_vs_golden():
+    """multistage_uncertainty_fixs at 450x800 (b=2) against vectors generated from the real reference
+    (model/multistage_model.py:63-83, main.py:416-429): the four output maps (strided by 8), the filter mask, the three loss
+    terms + total, d(total)/d(w_stage1,2), every parameter's gradient norm, two full gradients, parameter norms after SGD."""
+    from radar_depth_amd.evaluation.criteria_new import MaskedL1Loss, SmoothnessLoss
+    from radar_depth_amd.model.multistage_model import ResNet_multistage
+    from radar_depth_amd.synthetic import make_batch, procedural_fill_
+    want = np.load(os.path.join(GOLD, "multistage_full.npz"))
+    b, h, w, sub = 2, 450, 800, 8
+    torch.manual_seed(0)
+    m = ResNet_multistage(18, "upproj", [h, w], False)
+    w1, w2 = torch.nn.Parameter(torch.tensor(1.0)), torch.nn.Parameter(torch.tensor(1.0))
+    m.register_parameter("w_stage1", w1)
+    m.register_parameter("w_stage2", w2)
+    procedural_fill_(m)
+    m = m.cuda().train()
+    x, t = make_batch(b, h, w, 4242)
+    x[:, 3, ::7, ::11] = torch.where(x[:, 3, ::7, ::11] > 0, x[:, 3, ::7, ::11], torch.full_like(x[:, 3, ::7, ::11], 60.0))
+    x, t = x.cuda(), t.cuda()
+    assert [n for n, _ in m.named_parameters()] == list(want["param_names"])
+    opt = torch.optim.SGD(m.parameters(), 0.01, momentum=0.9, weight_decay=1e-4)
+    crit, smooth = MaskedL1Loss(), SmoothnessLoss()
+    o = m(x)
+    for k in ("stage1", "stage2", "radar_filtered"):
+        assert rel(_t(o[k])[:, :, ::sub, ::sub], want["out/" + k]) < 1e-3, k
+    assert (_t(o["mask"])[:, :, ::sub, ::sub] != want["out/mask"]).mean() < 1e-4
+    assert abs(o["mask"].mean().item() - want["mask_density"][0]) < 1e-5
+    d1, d2, sm = crit(o["stage1"], t), crit(o["stage2"], t), smooth(o["stage1"], x)
+    W1, W2 = m.w_stage1, m.w_stage2
+    loss = torch.exp(-W1) * (d1 + 0.1 * sm) + torch.exp(-W2) * d2 + (W1 + W2)
+    got = np.array([d1.item(), d2.item(), sm.item(), loss.item()])
+    assert np.abs(got - want["losses"]).max() / np.abs(want["losses"]).max() < 1e-4, (got, want["losses"])
+    opt.zero_grad()
+    loss.backward()
+    assert np.abs(np.array([W1.grad.item(), W2.grad.item()]) - want["w_grads"]).max() < 1e-4 * np.abs(want["w_grads"]).max()
+    gn = np.array([p.grad.double().norm().item() for p in m.parameters()])
+    floor = 1e-6 * want["grad_norms"].max()
+    bad = [(n, a, c) for n, a, c in zip(want["param_names"], gn, want["grad_norms"]) if abs(a - c) > 2e-2 * c + floor]
+    assert not bad, bad[:8]
+    for k in ("stage1.conv3.weight", "stage2.conv1_depth.weight"):
+        g = _t(dict(m.named_parameters())[k].grad)
+        assert np.abs(g - want["grad/" + k]).max() <= 3e-2 * np.abs(want["grad/" + k]).max(), k
+    opt.step()
+    pn = np.array([p.double().norm().item() for p in m.parameters()])
+    assert np.abs(pn - want["param_norms1"]).max() / want["param_norms1"].max() < 1e-4
+
+
+def test_config4_multistage_b8_450x800_fused_step_vs_oracle():
+    """BASELINE configs[3] exactly (b=8, 450x800): the fused multistage step's forward maps and its four loss terms against the
+    live CPU oracle's training-mode forward."""
+    from oracle import train as otrain
+    from radar_depth_amd.main import HipTrainStep
+    from radar_depth_amd.synthetic import make_batch
+    b, h, w = 8, 450, 800
+    args, hm, hw_, om, ow = _multistage_pair(h, w)
+    x, t = make_batch(b, h, w, 1234)
+    crit = otrain.make_criterion(args.arch)
+    with torch.no_grad():
+        lo, po, ex = otrain.compute_loss(args.arch, om, crit, x, t, ow)
+    ts = HipTrainStep(hm, b, h, w, loss_weights=hw_)
+    loss, pred = ts.step(x.cuda(), t.cuda())
+    torch.cuda.synchronize()
+    assert rel(_t(pred), _t(po)) < 1e-3
+    assert rel(_t(ts.mp.p1.pred), _t(ex["pred1"])) < 1e-3
+    want4 = np.array([ex["d1"].item(), ex["d2"].item(), ex["smooth"].item(), lo.item()])
+    got4 = _t(ts.loss4)
+    assert np.abs(got4 - want4).max() / np.abs(want4).max() < 1e-4, (got4, want4)
+
+
+# ------------------------------------------------------------------------------------------------ config 5
+def test_config5_multistage_900x1600_fp32_vs_oracle():
+    """configs[4]'s geometry in fp32, b=1: both stages' maps, the loss terms and gradient norms vs the live CPU oracle."""
+    from oracle import train as otrain
+    from radar_depth_amd.main import HipTrainStep
+    from radar_depth_amd.synthetic import make_batch
+    b, h, w = 1, 900, 1600
+    args, hm, hw_, om, ow = _multistage_pair(h, w)
+    x, t = make_batch(b, h, w, 55)
+    crit = otrain.make_criterion(args.arch)
+    lo, po, ex = otrain.compute_loss(args.arch, om, crit, x, t, ow)
+    lo.backward()
+    init = [p.detach().clone() for p in hm.parameters()]
+    ts = HipTrainStep(hm, b, h, w, lr=1.0, momentum=0.0, weight_decay=0.0, loss_weights=hw_)   # update == gradient
+    loss, pred = ts.step(x.cuda(), t.cuda())
+    torch.cuda.synchronize()
+    assert rel(_t(pred), _t(po)) < 1e-3
+    assert rel(_t(ts.mp.p1.pred), _t(ex["pred1"])) < 1e-3
+    assert abs(loss.item() - lo.item()) / abs(lo.item()) < 1e-4
+    go = np.array([p.grad.double().norm().item() for p in om.parameters()])
+    gg = np.array([(i0 - p.detach()).double().norm().item() for i0, p in zip(init, hm.parameters())])
+    assert np.abs(go - gg).max() / go.max() < 2e-2
+
+
+def _bf16_emulated(om):
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("_bf16_tests", os.path.join(os.path.dirname(os.path.abspath(__file__)), "test_gpu_bf16.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod._emulate_bf16_operands(om)
+
+
+@pytest.mark.parametrize("geom", [(2, 97, 161), (1, 900, 1600)])
+def test_config5_multistage_bf16_step_vs_emulated_oracle(geom):
+    """config 5's arithmetic: the multistage_uncertainty_fixs TRAINING STEP with bf16 conv operands against the CPU oracle with
+    the same rounding points (tests/test_gpu_bf16.py::_BfConv/_BfStem: forward / input-gradient / >=32-channel weight-gradient
+    operands rounded to bf16, fp32 accumulation, everything else fp32).  Stated tolerances: the four loss terms 5e-4; at the small
+    geometry additionally the gradient norm of every parameter tensor 3e-2 of the largest and w_stage1/2 gradients 1e-3;
+    at 900x1600 (config 5's geometry, b=1) both maps 0.1 max-norm (isolated pixels flip a bf16 rounding boundary, see
+    test_gpu_bf16.py) and 2e-2 rms."""
+    from oracle import train as otrain
+    from radar_depth_amd.main import HipTrainStep
+    from radar_depth_amd.synthetic import make_batch
+    b, h, w = geom
+    args, hm, hw_, om, ow = _multistage_pair(h, w)
+    assert _bf16_emulated(om) == 104
+    x, t = make_batch(b, h, w, 600, ref_pixels=h * w if h < 400 else 450 * 800)
+    crit = otrain.make_criterion(args.arch)
+    lo, po, ex = otrain.compute_loss(args.arch, om, crit, x, t, ow)
+    small = h < 400
+    if small:
+        lo.backward()
+    init = [p.detach().clone() for p in hm.parameters()]
+    ts = HipTrainStep(hm, b, h, w, lr=1.0, momentum=0.0, weight_decay=0.0, loss_weights=hw_, operands="bf16")
+    loss, pred = ts.step(x.cuda(), t.cuda())
+    torch.cuda.synchronize()
+    want4 = np.array([ex["d1"].item(), ex["d2"].item(), ex["smooth"].item(), lo.item()])
+    got4 = _t(ts.loss4)
+    e_loss = np.abs(got4 - want4).max() / np.abs(want4).max()
+    e1, e2 = rel(_t(ts.mp.p1.pred), _t(ex["pred1"])), rel(_t(pred), _t(po))
+    r2 = ((pred.detach().cpu() - po.detach()).norm() / po.detach().norm()).item()
+    print("multistage bf16 %s: losses %.3e  stage1 max %.3e  stage2 max %.3e rms %.3e" % (geom, e_loss, e1, e2, r2))
+    assert e_loss < 5e-4 and e1 < 0.1 and e2 < 0.1 and r2 < 2e-2
+    if small:
+        names = [n for n, _ in om.named_parameters()]
+        go = np.array([p.grad.double().norm().item() for p in om.parameters()])
+        gg = np.array([(i0 - p.detach().cpu()).double().norm().item() for i0, p in zip(init, hm.parameters())])
+        e_norm = np.abs(go - gg).max() / go.max()
+        print("  gradient norms: worst %.3e (%s)" % (e_norm, names[int(np.abs(go - gg).argmax())]))
+        assert e_norm < 3e-2
+        assert abs(gg[0] - go[0]) < 1e-3 * max(go[0], 1e-6) + 1e-6 and abs(gg[1] - go[1]) < 1e-3 * max(go[1], 1e-6) + 1e-6
+
+
+# ------------------------------------------------------------------------------------------------ plain multistage
+def test_plain_multistage_step_vs_oracle():
+    """--arch resnet18_multistage (main.py:431-438): loss = d1 + d2, no uncertainty weights, no smoothness term."""
+    from oracle import train as otrain
+    from radar_depth_amd.main import HipTrainStep
+    from radar_depth_amd.synthetic import make_batch
+    b, h, w = 2, 97, 161
+    args, hm, hw_, om, ow = _multistage_pair(h, w, arch="resnet18_multistage")
+    assert hw_ is None and ow is None and "w_stage1" not in dict(hm.named_parameters())
+    opt = torch.optim.SGD(om.parameters(), 0.01, momentum=0.9, weight_decay=1e-4)
+    crit = otrain.make_criterion(args.arch)
+    ts = HipTrainStep(hm, b, h, w, lr=0.01, momentum=0.9, weight_decay=1e-4, loss_weights=None)
+    for it in range(3):
+        x, t = make_batch(b, h, w, 700 + it, ref_pixels=h * w)
+        lo, po, ex = otrain.train_step(args.arch, om, crit, opt, x, t, None)
+        lg, pred = ts.step(x.cuda(), t.cuda())
+        torch.cuda.synchronize()
+        assert abs(lg.item() - lo.item()) / abs(lo.item()) < 2e-3, (it, lg.item(), lo.item())
+        if it == 0:
+            assert rel(_t(pred), _t(po)) < 1e-3
+            assert abs(lg.item() - (ex["d1"].item() + ex["d2"].item())) < 1e-4 * abs(lg.item())
+    po_ = np.array([p.double().norm().item() for p in om.parameters()])
+    pg_ = np.array([p.double().norm().item() for p in hm.parameters()])
+    assert np.abs(po_ - pg_).max() / po_.max() < 5e-3
+
+
+# ------------------------------------------------------------------------------------------------ -c l2
+def test_masked_mse_loss_vs_golden_and_oracle():
+    """MaskedMSELoss (evaluation/criteria_new.py:31-41): the reference-generated value in units.npz, the gradient against torch
+    autograd of the oracle's restatement, the NaN of an all-invalid target, and the fused step with criterion='l2'."""
+    from oracle.criteria import MaskedMSELoss as OL2
+    from radar_depth_amd.evaluation.criteria_new import MaskedMSELoss
+    from radar_depth_amd.main import HipTrainStep
+    from radar_depth_amd.synthetic import make_batch
+    want = np.load(os.path.join(GOLD, "units.npz"))
+    pred = torch.tensor(want["l1/pred"]).cuda().requires_grad_(True)
+    target = torch.tensor(want["l1/target"]).cuda()
+    loss = MaskedMSELoss()(pred, target)
+    assert abs(loss.item() - want["l2/loss"][0]) / want["l2/loss"][0] < 1e-6
+    (3.0 * loss).backward()
+    pc = torch.tensor(want["l1/pred"]).requires_grad_(True)
+    (3.0 * OL2()(pc, torch.tensor(want["l1/target"]))).backward()
+    assert rel(_t(pred.grad), _t(pc.grad)) < 1e-6
+    assert torch.isnan(MaskedMSELoss()(pred.detach(), torch.zeros_like(target)))
+    b, h, w = 2, 97, 161
+    m, o = _latefusion_pair(h, w)
+    opt = torch.optim.SGD(o.parameters(), 0.01, momentum=0.9, weight_decay=1e-4)
+    ts = HipTrainStep(m, b, h, w, criterion="l2")
+    for it in range(2):
+        x, t = make_batch(b, h, w, 40 + it, ref_pixels=h * w)
+        lo = OL2()(o(x), t)
+        opt.zero_grad()
+        lo.backward()
+        opt.step()
+        lg, _ = ts.step(x.cuda(), t.cuda())
+        torch.cuda.synchronize()
+        assert abs(lg.item() - lo.item()) / lo.item() < 2e-3, (it, lg.item(), lo.item())
+
+
+# ------------------------------------------------------------------------------------------------ layer-level pins
+class _Holder:
+    pass
+
+
+def _module_plan(mod, kind, n, h, w, cin):
+    from radar_depth_amd.engine import ModulePlan
+    from radar_depth_amd.model.models import ArenaOwner
+
+    class Single(ArenaOwner, torch.nn.Module):
+        def __init__(self, inner):
+            super().__init__()
+            self.mod = inner
+    owner = Single(mod).cuda()
+    return owner, ModulePlan(owner, owner.mod, kind, n, h, w, cin)
+
+
+def test_upproj_module_fwd_bwd_vs_golden():
+    """One UpProjModule(32) (models.py:181-209: unpool -> 5x5 ‖ 5x5 -> BN/ReLU -> 3x3 -> BN -> add -> ReLU) through the plan's own
+    builders -- 4-phase zero-skipping conv, fused BN statistics, joined BN backward, 25-tap dgrad, per-phase wgrad -- against the
+    reference's module output, input gradient and all 10 parameter gradients.  Tolerance 1e-4 of each tensor's max (the
+    kernels are exact-fp32 fmaf chains; differences are summation order)."""
+    from radar_depth_amd.model.models import UpProj
+    from radar_depth_amd.synthetic import procedural_fill_
+    want = np.load(os.path.join(GOLD, "upproj_module.npz"))
+    mod = UpProj.UpProjModule(32)
+    procedural_fill_(mod)
+    n, c, h, w = want["x"].shape
+    owner, plan = _module_plan(mod, "upproj", n, h, w, c)
+    y, dx = plan.run(torch.tensor(want["x"]).cuda(), torch.tensor(want["gy"]).cuda())
+    assert rel(_t(y), want["y"]) < 1e-4
+    assert rel(_t(dx), want["gx"]) < 1e-4
+    checked = 0
+    for name, p in owner.mod.named_parameters():
+        assert rel(_t(owner._grad_view(p)), want["grad/" + name]) < 1e-4, name
+        checked += 1
+    assert checked == 10
+
+
+@pytest.mark.parametrize("tag,cin,cout,stride", [("id", 32, 32, 1), ("ds", 32, 64, 2)])
+def test_basic_block_fwd_bwd_vs_golden(tag, cin, cout, stride):
+    """The reference's own BasicBlock (models.py:75-112), identity-residual and stride-2 + 1x1-downsample forms, through the
+    plan's builders: output, input gradient (residual + conv paths summed in the dgrad epilogue) and every parameter gradient
+    vs vectors generated from the reference; 1e-4 of each tensor's max."""
+    from radar_depth_amd.model.models import BasicBlock, _conv
+    from radar_depth_amd.synthetic import procedural_fill_
+    want = np.load(os.path.join(GOLD, "basic_block.npz"))
+    down = None
+    if stride != 1 or cin != cout:
+        down = torch.nn.Sequential(_conv(cin, cout, 1, stride, pad=0), torch.nn.BatchNorm2d(cout))
+    mod = BasicBlock(cin, cout, stride, down)
+    procedural_fill_(mod)
+    n, c, h, w = want[tag + "/x"].shape
+    owner, plan = _module_plan(mod, "block", n, h, w, c)
+    y, dx = plan.run(torch.tensor(want[tag + "/x"]).cuda(), torch.tensor(want[tag + "/gy"]).cuda())
+    assert rel(_t(y), want[tag + "/y"]) < 1e-4
+    assert rel(_t(dx), want[tag + "/gx"]) < 1e-4
+    for name, p in owner.mod.named_parameters():
+        assert rel(_t(owner._grad_view(p)), want[tag + "/grad/" + name]) < 1e-4, name
+
+
+# ------------------------------------------------------------------------------------------------ robustness
+def test_step_rejects_ragged_batch_and_stale_autograd():
+    from radar_depth_amd.evaluation.criteria_new import MaskedL1Loss
+    from radar_depth_amd.main import HipTrainStep
+    from radar_depth_amd.synthetic import make_batch
+    b, h, w = 2, 97, 161
+    m, _ = _latefusion_pair(h, w)
+    ts = HipTrainStep(m, b, h, w)
+    x, t = make_batch(1, h, w, 3, ref_pixels=h * w)
+    with pytest.raises(ValueError):
+        ts.step(x.cuda(), t.cuda())                       # a last batch of 1 must not be broadcast over the static buffers
+    x, t = make_batch(b, h, w, 3, ref_pixels=h * w)
+    y1 = m(x.cuda())
+    y2 = m(x.cuda())                                      # second training-mode forward overwrites the saved activations
+    with pytest.raises(RuntimeError):
+        MaskedL1Loss()(y1, t.cuda()).backward()
+    MaskedL1Loss()(y2, t.cuda()).backward()               # the latest forward is still differentiable
+
+
+def test_optimizer_state_round_trip():
+    """HipTrainStep.state_dict() is torch.optim.SGD's layout (per-parameter momentum_buffer): loading it into torch's SGD and
+    into a fresh HipTrainStep continues the same trajectory."""
+    from radar_depth_amd.main import HipTrainStep
+    from radar_depth_amd.synthetic import make_batch
+    b, h, w = 2, 97, 161
+    m1, _ = _latefusion_pair(h, w)
+    m2, _ = _latefusion_pair(h, w)
+    t1 = HipTrainStep(m1, b, h, w)
+    batches = [tuple(v.cuda() for v in make_batch(b, h, w, 10 + i, ref_pixels=h * w)) for i in range(3)]
+    for x, t in batches[:2]:
+        t1.step(x, t)
+    sd = t1.state_dict()
+    assert set(sd) == {"state", "param_groups"} and len(sd["state"]) == len(list(m1.parameters()))
+    opt = torch.optim.SGD(m1.parameters(), 0.01, momentum=0.9, weight_decay=1e-4)
+    opt.load_state_dict(sd)                               # torch accepts the layout
+    m2.load_state_dict(m1.state_dict())
+    t2 = HipTrainStep(m2, b, h, w)
+    t2.load_state_dict(sd)
+    l1, _ = t1.step(*batches[2])
+    l2, _ = t2.step(*batches[2])
+    torch.cuda.synchronize()
+    assert l1.item() == l2.item()
+    for p, q in zip(m1.parameters(), m2.parameters()):
+        assert torch.equal(p, q)

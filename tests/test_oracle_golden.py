@@ -78,6 +78,21 @@ def test_upproj_module(golden_dir):
     check_all(got, want, 2e-6)
 
 
+def test_basic_block(golden_dir):
+    want = np.load(os.path.join(golden_dir, "basic_block.npz"))
+    got = mg.block_case(models)
+    check_all(got, want, 2e-6)
+
+
+def test_multistage_full(golden_dir):
+    """BASELINE config 4's geometry (450x800): the oracle reproduces the reference's multistage outputs, losses and gradients."""
+    want = np.load(os.path.join(golden_dir, "multistage_full.npz"))
+    got = mg.multistage_case(multistage_model.ResNet_multistage, criteria.MaskedL1Loss, criteria.SmoothnessLoss,
+                             2, 450, 800, 4242, 8, dense_small=False)
+    assert (got["out/mask"] != want["out/mask"]).mean() == 0
+    check_all(got, want, 1e-5)
+
+
 def test_state_dict_contract():
     m = models.ResNet_latefusion(18, "upproj", [450, 800], 4, False)
     sd = m.state_dict()
