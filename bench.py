@@ -128,7 +128,7 @@ def cpu_baseline(height, width):
     x2, t2 = make_batch(2, height, width, 1234)
     steps(x2, t2, 1)                                        # oneDNN primitive creation
     sweep = {}
-    for nt in sorted({max(1, ncpu // 8), max(1, ncpu // 4), max(1, ncpu // 2)}):
+    for nt in sorted({max(1, ncpu // 32), max(1, ncpu // 16), max(1, ncpu // 8), max(1, ncpu // 4)}):
         torch.set_num_threads(nt)
         sweep[nt] = min(steps(x2, t2, 2))
     nt = min(sweep, key=sweep.get)

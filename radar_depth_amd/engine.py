@@ -788,6 +788,7 @@ class ModulePlan(LateFusionPlan):
     def __init__(self, owner, mod, kind, batch, height, width, cin, bf16=False):
         assert kind in ("block", "upproj")
         self._mod, self._kind, self._cin = mod, kind, cin
+        owner._ensure_arenas()      # parameters move into the flat arena BEFORE any op captures their addresses
         super().__init__(owner, batch, height, width, train=True, bf16=bf16)
 
     def _build(self):

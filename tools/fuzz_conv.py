@@ -51,6 +51,19 @@ for case in range(n_cases):
         poison()
         ops.gconv(d, xs, wp_, out)
         e_f = rel(ops.nhwc_to_nchw(out).cpu(), y.detach())
+        # the same launch with the fused BatchNorm partial sums (what every training-plan forward conv requests)
+        stat = torch.full((ops.gconv_stat_tiles(d), 2, co), float("nan"), device="cuda")
+        out2 = torch.full_like(out, float("nan"))
+        poison()
+        ops.gconv(d, xs, wp_, out2, stat=stat)
+        e_f = max(e_f, rel(ops.nhwc_to_nchw(out2).cpu(), y.detach()))
+        yd = y.detach().double()
+        s_ = stat.double().sum(0).cpu()
+        e_s = max(((s_[0] - yd.sum((0, 2, 3))).abs().max() / (yd ** 2).sum((0, 2, 3)).sqrt().max().clamp_min(1e-30)).item(),
+                  rel(s_[1], (yd ** 2).sum((0, 2, 3))))
+        if not (e_s < 1e-4):
+            e_f = max(e_f, 1.0)
+            print("  stat mismatch %.2e" % e_s, tag)
         slabs = torch.empty(ops.wgrad_workspace_floats(d), device="cuda")
         poison()
         ops.wgrad(d, xs, gys, slabs)
