@@ -363,6 +363,27 @@ int rd_event_destroy(void* event);
 int rd_event_record(void* event, void* stream);
 int rd_stream_wait_event(void* stream, void* event);
 
+/* ---------------------------------------------------------------------------------------
+ * Data-parallel exchange step (the reference itself is single-process, main.py:285-447, so these replace
+ * what a DistributedDataParallel wrapper around its model would do): one process per GPU, RCCL over xGMI.
+ *   rank 0:      rd_comm_unique_id(token)            -> ship the 128-byte token to every rank (any out-of-band channel)
+ *   every rank:  hipSetDevice; rd_comm_init(token, rank, world)                       (collective)
+ *   per step:    after the last backward kernel of a gradient bucket: record an event on the compute stream, make the
+ *                communication stream wait for it, rd_allreduce_bucket(ptr, count, RD_DTYPE_F32, comm_stream); before the
+ *                optimizer step the compute stream waits for an event recorded behind the last bucket.  In-place sum; the
+ *                1/world average is folded into rd_sgd_step's grad_scale.  Nothing synchronises the host.
+ * RCCL is loaded at run time (dlopen): a process that already holds one (PyTorch's) shares it.
+ * ------------------------------------------------------------------------------------- */
+#define RD_DTYPE_F32 0
+#define RD_DTYPE_BF16 1
+int rd_comm_unique_id(void* out128);
+int rd_comm_init(const void* unique_id128, int32_t rank, int32_t world);
+int rd_comm_world(void); /* 0 before rd_comm_init */
+int rd_comm_rank(void);
+int rd_allreduce_bucket(void* ptr, int64_t count, int32_t dtype, void* stream);
+int rd_broadcast(void* ptr, int64_t count, int32_t dtype, int32_t root, void* stream);
+int rd_comm_destroy(void);
+
 /* diagnostics: fill every CU's LDS with NaN bit patterns (LDS is not cleared between kernels): a kernel that consumes an LDS
  * word it never wrote then yields NaN instead of depending on its predecessor's leftovers (tools/fuzz_conv.py --poison) */
 int rd_debug_poison_lds(void* stream);

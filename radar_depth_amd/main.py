@@ -107,8 +107,11 @@ class HipTrainStep:
     torch.autocast(bfloat16) analogue for BASELINE.json configs 2/4; tolerances in tests/test_gpu_bf16.py."""
 
     def __init__(self, model, batch, height, width, lr=0.01, momentum=0.9, weight_decay=1e-4, loss_weights=None, use_graph=False,
-                 operands="fp32", criterion="l1"):
-        """criterion: "l1" (MaskedL1Loss, the default of utils.parse_command) or "l2" (MaskedMSELoss, `-c l2`, main.py:294-305)."""
+                 operands="fp32", criterion="l1", comm="auto"):
+        """criterion: "l1" (MaskedL1Loss, the default of utils.parse_command) or "l2" (MaskedMSELoss, `-c l2`, main.py:294-305).
+        comm: "rccl" = the C ABI's own communicator (radar_depth_amd.comm, rd_allreduce_bucket on a dedicated communication
+        stream, event-chained behind each backward segment); "torch" = torch.distributed.all_reduce (the cross-check);
+        "auto" = rccl when radar_depth_amd.comm is initialised, else torch when torch.distributed is, else single-GPU."""
         from .model.multistage_model import ResNet_multistage
         assert criterion in ("l1", "l2"), criterion
         self.model = model
@@ -130,11 +133,20 @@ class HipTrainStep:
         dev = self.plan.dev
         self.batch, self.height, self.width = batch, height, width
         self.lr, self.momentum, self.wd = lr, momentum, weight_decay
-        self.world = torch.distributed.get_world_size() if torch.distributed.is_available() and torch.distributed.is_initialized() else 1
+        from . import comm as _comm
+        tdist = torch.distributed.is_available() and torch.distributed.is_initialized()
+        assert comm in ("auto", "rccl", "torch"), comm
+        if comm == "auto":
+            comm = "rccl" if _comm.initialised() else "torch"
+        if comm == "rccl" and not _comm.initialised():
+            raise RuntimeError("comm='rccl' needs radar_depth_amd.comm.init_from_torch_distributed() / init_from_file() first")
+        self.comm = comm
+        self.world = _comm.world() if comm == "rccl" else (torch.distributed.get_world_size() if tdist else 1)
+        self.comm_stream = torch.cuda.Stream(device=dev) if comm == "rccl" else None
         if self.world > 1:
             self.sync_state_from_rank0()
         # RD_FORCE_DP=1 runs the data-parallel code path (segmented graphs + bucketed all-reduce) even with one rank (tests)
-        self.dp = self.world > 1 or (os.environ.get("RD_FORCE_DP") == "1" and torch.distributed.is_initialized())
+        self.dp = self.world > 1 or (os.environ.get("RD_FORCE_DP") == "1" and (comm == "rccl" or tdist))
         p = self.plan
         self.n_out = batch * p.Ho * p.Wo
         self.target = torch.zeros(batch, 1, p.Ho, p.Wo, device=dev)
@@ -166,10 +178,13 @@ class HipTrainStep:
         self.side = torch.cuda.Stream(device=dev)   # default priority: raising any stream's priority measured 17-29 % slower
         offs = _param_offsets(model)
         if self.multistage:
-            s1 = [v for k, v in offs.items() if not k.startswith("stage2.")]
-            s2 = [v for k, v in offs.items() if k.startswith("stage2.")]
-            self._buckets = [[(min(v[0] for v in s2), (max(v[1] for v in s2) + 3) // 4 * 4)],
-                             [(min(v[0] for v in s1), (max(v[1] for v in s1) + 3) // 4 * 4)]]
+            # eight buckets in backward-completion order: the four segments of stage 2, then the four of stage 1; the scalar
+            # w_stage1/2 (final right after the loss) ride with the last one
+            self._seg2 = bucket_segments(self.mp.p2, offs, "stage2.")
+            self._seg1 = bucket_segments(self.mp.p1, offs, "stage1.")
+            tops = sorted((v[0], (v[1] + 3) // 4 * 4) for k, v in offs.items() if not k.startswith(("stage1.", "stage2.")))
+            self._buckets = [sl for _, _, sl in self._seg2] + [sl for _, _, sl in self._seg1]
+            self._buckets[-1] = list(self._buckets[-1]) + tops
         else:
             self._segments = bucket_segments(self.plan, offs)
             self._buckets = [sl for _, _, sl in self._segments]
@@ -178,6 +193,12 @@ class HipTrainStep:
         """Data-parallel replicas must start from one state (DDP broadcasts at construction): parameters, momentum and the
         BatchNorm buffers of rank 0 replace every other rank's, so a checkpoint loaded on rank 0 only -- or different seeds --
         cannot silently train divergent replicas whose gradients are still averaged."""
+        if self.comm == "rccl":
+            from . import comm as _comm
+            cur = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+            for tns in [self.st["arena"], self.st["mom"]] + list(self.model.buffers()):
+                _comm.broadcast_(tns, cur, 0)
+            return
         dist = torch.distributed
         dist.broadcast(self.st["arena"], 0)
         dist.broadcast(self.st["mom"], 0)
@@ -257,7 +278,9 @@ class HipTrainStep:
         mp, p1, p2, s = self.mp, self.mp.p1, self.mp.p2, self.plan.stream
         fptr = lambda t, i: C.c_void_p(t.data_ptr() + 4 * i)
 
-        def stage2_part():
+        seg2, seg1 = self._seg2, self._seg1
+
+        def stage2_head():
             p1._run(p1.prep)
             p1._run(p1.fwd)
             mp.filter_op()
@@ -272,14 +295,17 @@ class HipTrainStep:
                                               C.c_float(self.w_smooth), ptr(self.loss4), ptr(self.coefs3), ptr(self.dw1), ptr(self.dw2), s),
                   "uncertainty_total")
             self._l1_bwd(p2.pred, self.sums2, fptr(self.coefs3, 2), p2.dpred, 0)
-            p2._run(p2.bwd)                                   # also writes d(loss)/d(stage-1 prediction) into p1.dpred
+            p2._run(p2.bwd[seg2[0][0]:seg2[0][1]])
 
-        def stage1_part():
+        def stage1_head():
+            # the last segment of stage 2 has written d(loss)/d(stage-1 prediction) into p1.dpred (multistage_model.py:75)
             self._l1_bwd(p1.pred, self.sums, fptr(self.coefs3, 0), p1.dpred, 1)
             if self.uncertainty:
                 check(self.L.rd_smooth_bwd(p1.N, p1.H, p1.W, ptr(self.smooth_ws), fptr(self.coefs3, 1), ptr(p1.dpred), 1, s), "smooth_bwd")
-            p1._run(p1.bwd)
-        return [stage2_part, stage1_part]
+            p1._run(p1.bwd[seg1[0][0]:seg1[0][1]])
+        pieces = [stage2_head] + [(lambda k=k: p2._run(p2.bwd[seg2[k][0]:seg2[k][1]])) for k in range(1, len(seg2))]
+        pieces += [stage1_head] + [(lambda k=k: p1._run(p1.bwd[seg1[k][0]:seg1[k][1]])) for k in range(1, len(seg1))]
+        return pieces
 
     def _sgd(self):
         st = self.st
@@ -335,6 +361,23 @@ class HipTrainStep:
                 pieces[i]()
         if not self.dp:
             launch(0)
+        elif self.comm == "rccl":
+            # piece i completes gradient bucket i: an event behind it on the step's stream releases the bucket's all-reduce on
+            # the communication stream, which runs under pieces i+1..; the SGD kernel waits for the last bucket's event
+            from . import comm as _comm
+            cs = C.c_void_p(self.comm_stream.cuda_stream)
+            grads = self.st["grads"]
+            if not hasattr(self, "_bucket_events"):
+                self._bucket_events = [torch.cuda.Event() for _ in range(len(self._buckets) + 1)]
+            for i, slices in enumerate(self._buckets):
+                launch(i)
+                self._bucket_events[i].record(self.side)
+                self.comm_stream.wait_event(self._bucket_events[i])
+                for lo, hi in slices:
+                    _comm.allreduce_(grads, cs, lo, hi)
+            self._bucket_events[-1].record(self.comm_stream)
+            self.side.wait_event(self._bucket_events[-1])
+            launch(len(self._buckets))
         else:
             # piece i completes gradient bucket i; its all-reduce is enqueued right behind it and overlaps pieces i+1..
             for i, _ in enumerate(reduce_gradient_buckets(self.st["grads"], self._buckets)):

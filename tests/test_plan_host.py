@@ -92,3 +92,31 @@ def test_bucketed_allreduce_gloo_world2():
     for p in procs:
         p.join(60)
     assert res == [(0, True), (1, True)]
+
+
+def test_multistage_buckets_partition_the_arena():
+    """Data-parallel multistage step: eight gradient buckets (four backward segments of stage 2, then four of stage 1; the
+    scalar w_stage1/2 ride with the last) that cover the flat gradient arena exactly once."""
+    import types
+
+    import torch
+
+    from radar_depth_amd import main as hmain
+    from radar_depth_amd.engine import LateFusionPlan
+    args = types.SimpleNamespace(arch="resnet18_multistage_uncertainty_fixs", decoder="upproj", modality="rgbd", pretrained=False)
+    model, _ = hmain.create_model(args, [64, 96])
+    offs = hmain._param_offsets(model)
+    p1 = LateFusionPlan(model.stage1, 1, 64, 96, train=True, dry_run=True)
+    kept = torch.empty(1, 1, 64, 96)
+    p2 = LateFusionPlan(model.stage2, 1, 64, 96, train=True, depth_planes=[kept, p1.pred], x_source=p1.x_in, dense_grad_dst=p1.dpred,
+                        dry_run=True)
+    seg2 = hmain.bucket_segments(p2, offs, "stage2.")
+    seg1 = hmain.bucket_segments(p1, offs, "stage1.")
+    assert len(seg2) == 4 and len(seg1) == 4
+    tops = sorted((v[0], (v[1] + 3) // 4 * 4) for k, v in offs.items() if not k.startswith(("stage1.", "stage2.")))
+    assert [k for k in offs if not k.startswith(("stage1.", "stage2."))] == ["w_stage1", "w_stage2"]
+    covered = sorted(sl for _, _, bk in seg2 + seg1 for sl in bk) + tops
+    covered.sort()
+    total = max(v[1] for v in offs.values())
+    assert covered[0][0] == 0 and covered[-1][1] == (total + 3) // 4 * 4
+    assert all(a[1] == b[0] for a, b in zip(covered, covered[1:]))
