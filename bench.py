@@ -168,6 +168,9 @@ def main():
                     help="conv operand precision.  fp32 (default) is the BASELINE.json configs[1] measurement; bf16 (configs 2/4) runs the "
                          "forward / input-gradient / weight-gradient convolutions on bf16 MFMA with fp32 tensors + accumulation and is reported with "
                          "dtype \"bf16\" and its own metric name -- never as the fp32 headline")
+    ap.add_argument("--comm", default="rccl", choices=["rccl", "torch"],
+                    help="gradient exchange for --gpus > 1: rccl = the C ABI's own communicator (rd_allreduce_bucket on a communication "
+                         "stream, event-chained per backward segment); torch = torch.distributed.all_reduce (cross-check)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     args = ap.parse_args()
@@ -185,6 +188,17 @@ def main():
         os.environ.setdefault("MASTER_PORT", "29533")
         torch.distributed.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
     assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node %d (WORLD_SIZE=%d)" % (args.gpus, world)
+    comm_used = "none"
+    if torch.distributed.is_initialized():
+        comm_used = "torch"
+        if args.comm == "rccl":
+            # torch.distributed only carries the 128-byte RCCL token (and the barrier / max-over-ranks of the timing)
+            try:
+                from radar_depth_amd import comm as rd_comm
+                rd_comm.init_from_torch_distributed()
+                comm_used = "rccl"
+            except Exception as ex:                          # noqa: BLE001 -- never lose the scaling run to the bootstrap
+                print("[bench] native RCCL communicator unavailable (%s); falling back to torch.distributed" % ex, file=sys.stderr)
 
     import types
 
@@ -197,7 +211,8 @@ def main():
     model, loss_weights = made if isinstance(made, tuple) else (made, None)
     model = model.cuda()
     ts = HipTrainStep(model, args.batch, args.height, args.width, lr=0.01, momentum=0.9, weight_decay=1e-4,
-                      loss_weights=loss_weights, use_graph=args.graph, operands=args.operands)
+                      loss_weights=loss_weights, use_graph=args.graph, operands=args.operands,
+                      comm=comm_used if comm_used != "none" else "auto")
     x, t = make_batch(args.batch, args.height, args.width, 1234 + 1000 * rank)
     x, t = x.cuda(), t.cuda()
 
@@ -234,7 +249,7 @@ def main():
         "config": {"workload": "%s --decoder upproj --modality rgbd, b=%d/GPU %dx%d fp32, full step "
                                "(fwd + loss + bwd + SGD momentum .9 wd 1e-4), random init" % (args.arch, args.batch, args.height, args.width),
                    "global_batch": world * args.batch, "parallelism": "dp%d" % world if world > 1 else ("dp1 (forced data-parallel code path)" if os.environ.get("RD_FORCE_DP") == "1" else "single"),
-                   "hipgraph": args.graph, "final_loss": round(final_loss, 5)},
+                   "hipgraph": args.graph, "comm": comm_used, "final_loss": round(final_loss, 5)},
     }
     multistage = args.arch != "resnet18_latefusion"
     bf16 = args.operands == "bf16"
@@ -278,6 +293,9 @@ def main():
         if world == 1 and not args.no_cpu_baseline and not multistage and not bf16:
             out["cpu_baseline"] = cpu_baseline(args.height, args.width)
         print(json.dumps(out), flush=True)
+    if comm_used == "rccl":
+        from radar_depth_amd import comm as rd_comm
+        rd_comm.destroy()
     if torch.distributed.is_available() and torch.distributed.is_initialized():
         torch.distributed.destroy_process_group()
 
