@@ -168,12 +168,17 @@ def main():
                     help="conv operand precision.  fp32 (default) is the BASELINE.json configs[1] measurement; bf16 (configs 2/4) runs the "
                          "forward / input-gradient / weight-gradient convolutions on bf16 MFMA with fp32 tensors + accumulation and is reported with "
                          "dtype \"bf16\" and its own metric name -- never as the fp32 headline")
+    ap.add_argument("--storage", default="fp32", choices=["fp32", "bf16"],
+                    help="element type of the NHWC activation / gradient tensors in HBM.  bf16 (BASELINE.json configs 3 / 5) implies "
+                         "--operands bf16; statistics, parameters, their gradients and the optimizer stay fp32")
     ap.add_argument("--comm", default="rccl", choices=["rccl", "torch"],
                     help="gradient exchange for --gpus > 1: rccl = the C ABI's own communicator (rd_allreduce_bucket on a communication "
                          "stream, event-chained per backward segment); torch = torch.distributed.all_reduce (cross-check)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     args = ap.parse_args()
+    if args.storage == "bf16":
+        args.operands = "bf16"
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -212,7 +217,7 @@ def main():
     model = model.cuda()
     ts = HipTrainStep(model, args.batch, args.height, args.width, lr=0.01, momentum=0.9, weight_decay=1e-4,
                       loss_weights=loss_weights, use_graph=args.graph, operands=args.operands,
-                      comm=comm_used if comm_used != "none" else "auto")
+                      comm=comm_used if comm_used != "none" else "auto", storage=args.storage)
     x, t = make_batch(args.batch, args.height, args.width, 1234 + 1000 * rank)
     x, t = x.cuda(), t.cuda()
 
@@ -257,6 +262,12 @@ def main():
         out["dtype"] = "bf16"
         out["metric"] = METRIC + " [bf16 conv operands on v_mfma_f32_32x32x16_bf16: forward, input gradients, weight gradients of the >=32-channel layers; stems/head/16-channel weight gradients fp32; fp32 tensors/accumulation]"
         out["config"]["workload"] = out["config"]["workload"].replace(" fp32,", " bf16-operand convs,")
+        if args.storage == "bf16":
+            out["metric"] = METRIC + " [bf16 storage: NHWC activations and gradients bf16 in HBM, bf16 MFMA convolutions incl. every weight gradient, fp32 accumulation / BatchNorm statistics / loss / parameters / SGD]"
+            out["config"]["workload"] = out["config"]["workload"].replace(" bf16-operand convs,", " bf16 storage + bf16 convs,")
+            # HBM-bound configuration: fraction of SURVEY 8(d)'s bf16 bound (0.329 GB/sample at 6.29 TB/s measured copy rate and 8 TB/s spec)
+            out["roofline_note"] = "bf16 bound (SURVEY 8d): 15181 samples/s @6.29 TB/s, 17527 @8 TB/s per GPU at 450x800; this run: %.1f%% / %.1f%%" % (
+                100 * out["value"] / world / (15181 * 360000.0 / (args.height * args.width)), 100 * out["value"] / world / (17527 * 360000.0 / (args.height * args.width)))
     if rank == 0 and not args.no_roofline and not multistage and not bf16:
         agg, fam = instrumented_pass(ts)
         name, (ms, n, flops) = max(agg.items(), key=lambda kv: kv[1][0])

@@ -384,6 +384,40 @@ int rd_allreduce_bucket(void* ptr, int64_t count, int32_t dtype, void* stream);
 int rd_broadcast(void* ptr, int64_t count, int32_t dtype, int32_t root, void* stream);
 int rd_comm_destroy(void);
 
+/* ---------------------------------------------------------------------------------------
+ * Storage-typed forms (bf16-storage plans, BASELINE.json configs 3 / 5): the same operations with the NHWC activation /
+ * gradient tensors stored as fp32 (dtype = RD_DTYPE_F32) or bf16 (RD_DTYPE_BF16) in HBM.  Arithmetic is fp32 in both cases
+ * (bf16 values are widened on load, results rounded to nearest-even on store); per-channel statistics, coefficients, weights'
+ * gradients and every reduction stay fp32 / fp64.  Strides are in elements.  The argument lists are those of the fp32 entry
+ * points above with `dtype` in front and the tensors as void pointers.
+ * ------------------------------------------------------------------------------------- */
+int rd_bn_stats_t(int32_t dtype, const void* x, int64_t M, int32_t C, int32_t ldx, float* stat_partial, int32_t* n_tiles, void* stream);
+int rd_bn_act_t(int32_t dtype, const void* x1, int32_t ldx1, const float* scale1, const float* shift1, const void* x2, int32_t ldx2, const float* scale2, const float* shift2, void* y, int32_t ldy, int64_t M, int32_t C, int32_t act, void* stream);
+int rd_bn_bwd_reduce_t(int32_t dtype, const void* dy, int32_t lddy, const void* y, int32_t ldy, const void* x1, int32_t ldx1, const float* mean1, const void* x2, int32_t ldx2, const float* mean2, void* g, int32_t ldg, int64_t M, int32_t C, int32_t act, float* red_partial, void* stream);
+int rd_bn_bwd_reduce_x_t(int32_t dtype, const void* dy, int32_t lddy, const void* x1, int32_t ldx1, const float* mean1, const float* scale1, const float* shift1, void* g, int32_t ldg, int64_t M, int32_t C, int32_t act, float* red_partial, void* stream);
+int rd_bn_bwd_reduce_x2_t(int32_t dtype, const void* dy, int32_t lddy, const void* x1, int32_t ldx1, const float* mean1, const float* scale1, const float* shift1, const void* x2, int32_t ldx2, const float* mean2, const float* scale2, const float* shift2, int64_t M, int32_t C, int32_t act, float* red_partial, void* stream);
+int rd_bn_bwd_apply_t(int32_t dtype, const void* g, int32_t ldg, const void* x, int32_t ldx, const float* red_partial, int32_t n_tiles, int32_t which, const float* gamma, const float* mean, const float* invstd, float* dgamma, float* dbeta, float* coef_ws, void* dx, int32_t lddx, int64_t M, int32_t C, void* stream);
+int rd_bn_bwd_apply_x2_t(int32_t dtype, const void* dy, int32_t lddy, const void* x1, int32_t ldx1, const void* x2, int32_t ldx2, const float* red_partial, int32_t n_tiles, const float* gamma1, const float* mean1, const float* invstd1, const float* scale1, const float* shift1, const float* gamma2, const float* mean2, const float* invstd2, const float* scale2, const float* shift2, int32_t act, float* dgamma1, float* dbeta1, float* dgamma2, float* dbeta2, float* coef_ws6, void* dx1, int32_t lddx1, void* dx2, int32_t lddx2, int64_t M, int32_t C, void* stream);
+int rd_bn_bwd_apply_x_t(int32_t dtype, const void* dy, int32_t lddy, const void* x, int32_t ldx, const float* red_partial, int32_t n_tiles, const float* gamma, const float* mean, const float* invstd, const float* scale, const float* shift, int32_t act, float* dgamma, float* dbeta, float* coef_ws, void* dx, int32_t lddx, int64_t M, int32_t C, void* stream);
+int rd_bnact_maxpool_fwd_t(int32_t dtype, const void* x, const float* scale, const float* shift, int32_t act, int32_t N, int32_t H, int32_t W, int32_t C, void* y, int32_t ldy, uint8_t* idx, void* stream);
+int rd_bnact_maxpool_bwd_t(int32_t dtype, const void* dy, int32_t lddy, const uint8_t* idx, const void* x, const float* scale, const float* shift, int32_t act, int32_t N, int32_t H, int32_t W, int32_t C, void* g, void* stream);
+int rd_bnact_maxpool_bwd_stats_t(int32_t dtype, const void* dy, int32_t lddy, const uint8_t* idx, const void* x, const float* scale, const float* shift, int32_t act, int32_t N, int32_t H, int32_t W, int32_t C, void* g, const float* mean, float* red_partial, void* stream);
+int rd_gconv_bf16_t(int32_t dtype, const RdConvDesc* d, const void* in, const void* w_packed_bf16, void* out, const float* bias,
+                    int32_t act, int32_t act_cols, const void* addend, int32_t ld_add, float* stat_partial, void* stream);
+int rd_wgrad_bf16_t(int32_t dtype, const RdConvDesc* d, const void* in, const void* dout, float* slabs, void* stream);
+int rd_stem_fwd_t(int32_t dtype, const float* const* planes, const int64_t* strides, int32_t Cin, int32_t N, int32_t H, int32_t W,
+                  const float* w_packed, int32_t Cout, void* out, float* stat_partial, void* stream);
+int rd_stem_fwd_bf16_t(int32_t dtype, const float* const* planes, const int64_t* strides, int32_t Cin, int32_t N, int32_t H,
+                       int32_t W, const float* w_packed, int32_t Cout, void* out, float* stat_partial, void* stream);
+int rd_stem_wgrad_t(int32_t dtype, const float* const* planes, const int64_t* strides, int32_t Cin, int32_t N, int32_t H, int32_t W,
+                    const void* dout, int32_t Cout, float* grad_oihw, float* ws, void* stream);
+int rd_stem_dgrad_channel_t(int32_t dtype, const void* dout, const float* w_packed, int32_t N, int32_t H, int32_t W, int32_t Cin,
+                            int32_t ci, int32_t Cout, float* dx, void* stream);
+int rd_head_conv_fwd_t(int32_t dtype, const void* x, int32_t ldx, const float* w_oihw, int32_t N, int32_t H, int32_t W, int32_t C,
+                       float* d, void* stream);
+int rd_head_conv_bwd_t(int32_t dtype, const void* x, int32_t ldx, const float* w_oihw, const float* dd, int32_t N, int32_t H,
+                       int32_t W, int32_t C, void* dx, int32_t lddx, float* dw_oihw, float* ws, void* stream);
+
 /* diagnostics: fill every CU's LDS with NaN bit patterns (LDS is not cleared between kernels): a kernel that consumes an LDS
  * word it never wrote then yields NaN instead of depending on its predecessor's leftovers (tools/fuzz_conv.py --poison) */
 int rd_debug_poison_lds(void* stream);

@@ -68,6 +68,28 @@ __device__ __forceinline__ void glds16(const float* gsrc, float* lds_wave_base) 
 // is therefore preceded by this explicit wait.
 __device__ __forceinline__ void glds_wait() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 
+// ---- storage types of NHWC activation / gradient tensors: fp32 (float) or bf16 (bf16s: 16-bit storage only -- every kernel
+// computes in fp32 and rounds to nearest-even when it stores).  ld4 / st4 move four consecutive channels.
+struct bf16s { unsigned short v; };
+__device__ __forceinline__ unsigned pack_bf16x2(float lo, float hi) {
+    const __bf16 a = (__bf16)lo, b = (__bf16)hi;
+    return (unsigned)__builtin_bit_cast(unsigned short, a) | ((unsigned)__builtin_bit_cast(unsigned short, b) << 16);
+}
+__device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+__device__ __forceinline__ float4 ld4(const bf16s* p) {
+    const uint2 u = *reinterpret_cast<const uint2*>(p);
+    return make_float4(__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xffff0000u), __uint_as_float(u.y << 16),
+                       __uint_as_float(u.y & 0xffff0000u));
+}
+__device__ __forceinline__ void st4(float* p, const float4 v) { *reinterpret_cast<float4*>(p) = v; }
+__device__ __forceinline__ void st4(bf16s* p, const float4 v) {
+    *reinterpret_cast<uint2*>(p) = make_uint2(pack_bf16x2(v.x, v.y), pack_bf16x2(v.z, v.w));
+}
+__device__ __forceinline__ float ld1(const float* p) { return *p; }
+__device__ __forceinline__ float ld1(const bf16s* p) { return __uint_as_float((unsigned)p->v << 16); }
+__device__ __forceinline__ void st1(float* p, float v) { *p = v; }
+__device__ __forceinline__ void st1(bf16s* p, float v) { p->v = __builtin_bit_cast(unsigned short, (__bf16)v); }
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

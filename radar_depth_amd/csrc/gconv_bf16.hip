@@ -14,6 +14,7 @@
 
 #include <mutex>
 #include <string>
+#include <type_traits>
 #include <unordered_map>
 
 #include "common.h"
@@ -36,10 +37,10 @@ __device__ __forceinline__ void buf_load8(__amdgpu_buffer_rsrc_t r, unsigned off
 
 struct GconvBfArgs {
     RdConvDesc d;
-    const float* in;
+    const void* in;               // NHWC activations: fp32, or bf16 when the kernel is instantiated with IO16
     const unsigned short* w;      // packed bf16 operand
-    float* out;
-    const float* addend;
+    void* out;
+    const void* addend;
     const float* bias;
     float* stat;
     int act, act_cols, ld_add, ldw;
@@ -54,8 +55,13 @@ __device__ __forceinline__ bf16x4 cvt4(const float4 v) {
     return r;
 }
 
-template <int MT, int NT, bool PIPE>
+// IO16: the activation tensors (in, out, addend) are stored as bf16 in HBM (bf16-storage plans): the patch is a straight 16-byte
+// copy per 8-channel unit (half the bytes, no conversion), the epilogue rounds to nearest-even on store; the BatchNorm partial
+// sums are still taken from the fp32 accumulators.
+template <int MT, int NT, bool PIPE, bool IO16>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void gconv_bf16_kernel(const GconvBfArgs a) {
+    typedef typename std::conditional<IO16, bf16s, float>::type io_t;
+    constexpr int ESZ = IO16 ? 2 : 4;
     constexpr int WM = 4;
     constexpr int BM = WM * MT * 32;
     constexpr int BN = NT * 32;
@@ -130,7 +136,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void g
     const int lq8 = 31 - __clz(q8);
     const int welems = ntaps << (lq8 + (NT == 2 ? 6 : 5));   // 16-byte units of the weight slab [tap][q8][BN]
     const int cin8 = D.Cin >> 3;
-    const float* in_n = a.in + (size_t)n * D.Hi * D.Wi * D.ldi;
+    const char* in_n = static_cast<const char*>(a.in) + (size_t)n * D.Hi * D.Wi * D.ldi * ESZ;
     const int lks = lq8 - 1;                  // log2 of the 16-channel MFMA steps per tap
     const int nsteps = ntaps << lks;
 
@@ -190,11 +196,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void g
         const int ih = ih0 + row, iw = iw0 + px;
         const bool ok = seg < nsegs && cu < rowu;
         ldst = ok ? (row * PW + px) * PSB + qq * 16 : -1;
-        goff = (ok && ih >= 0 && ih < D.Hi && iw >= 0 && iw < D.Wi) ? (unsigned)(((ih * D.Wi + iw) * D.ldi + qq * 8) * 4) : RD_OOB;
+        goff = (ok && ih >= 0 && ih < D.Hi && iw >= 0 && iw < D.Wi) ? (unsigned)(((ih * D.Wi + iw) * D.ldi + qq * 8) * ESZ) : RD_OOB;
     };
-    const unsigned img_bytes = (unsigned)(D.Hi * D.Wi * D.ldi) * 4u;
+    const unsigned img_bytes = (unsigned)(D.Hi * D.Wi * D.ldi) * (unsigned)ESZ;
     auto chunk_rsrc = [&](int cb) {           // image n from channel cb on
-        return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(in_n + cb), 0, img_bytes - cb * 4, 0x00020000);
+        return __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(in_n + cb * ESZ), 0, img_bytes - cb * ESZ, 0x00020000);
+    };
+    // one 8-channel unit in flight: two float4 (fp32 storage) or 16 raw bytes in v0 (bf16 storage; v1 unused and dropped)
+    auto load_unit = [&](__amdgpu_buffer_rsrc_t r, unsigned off, float4& v0, float4& v1) {
+        if constexpr (IO16) v0 = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)off, 0, 0));
+        else buf_load8(r, off, v0, v1);
     };
     auto weight_off = [&](int e) -> unsigned {      // byte offset of slab unit e inside the packed weights at input-channel group 0
         const int j = e & (BN - 1), tk = e >> (NT == 2 ? 6 : 5);
@@ -202,7 +213,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void g
         return (e < welems && co0 + j < D.Cout) ? (unsigned)((((unsigned)s_widx[min(t, ntaps - 1)] * cin8 + k8) * a.ldw + co0 + j) * 16) : ~0u;
     };
     auto put_unit = [&](int ldst, const float4 v0, const float4 v1) {
-        if (ldst >= 0) {
+        if constexpr (IO16) {
+            if (ldst >= 0) *reinterpret_cast<float4*>(s_patch + ldst) = v0;
+        } else if (ldst >= 0) {
             bf16x8 r;
             const bf16x4 lo = cvt4(v0), hi = cvt4(v1);
             r[0] = lo[0]; r[1] = lo[1]; r[2] = lo[2]; r[3] = lo[3];
@@ -239,7 +252,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void g
         auto patch_fetch = [&](int cb, float4 (&v0)[UPP], float4 (&v1)[UPP]) {
             const __amdgpu_buffer_rsrc_t r = chunk_rsrc(cb);
 #pragma unroll
-            for (int u = 0; u < UPP; ++u) buf_load8(r, pgo[u], v0[u], v1[u]);
+            for (int u = 0; u < UPP; ++u) load_unit(r, pgo[u], v0[u], v1[u]);
         };
         {
             float4 v0[UPP], v1[UPP];
@@ -291,7 +304,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void g
                 for (int u = 0; u < UP; ++u) {
                     unsigned go;
                     unit_of(k0 + u, go, ld[u]);
-                    buf_load8(r, go, v0[u], v1[u]);
+                    load_unit(r, go, v0[u], v1[u]);
                 }
 #pragma unroll
                 for (int u = 0; u < UP; ++u) put_unit(ld[u], v0[u], v1[u]);
@@ -333,20 +346,20 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void g
                 if (has_add) {
 #pragma unroll
                     for (int i = 0; i < 8; ++i) {
-                        const float* ap = a.addend + (size_t)ro[h8 + i] * a.ld_add + cob;
+                        const io_t* ap = static_cast<const io_t*>(a.addend) + (size_t)ro[h8 + i] * a.ld_add + cob;
 #pragma unroll
-                        for (int nt = 0; nt < NT; ++nt) addv[nt][i] = ap[nt * 32];
+                        for (int nt = 0; nt < NT; ++nt) addv[nt][i] = ld1(ap + nt * 32);
                     }
                 }
 #pragma unroll
                 for (int i = 0; i < 8; ++i) {
-                    float* rp = a.out + (size_t)ro[h8 + i] * D.ldo + cob;
+                    io_t* rp = static_cast<io_t*>(a.out) + (size_t)ro[h8 + i] * D.ldo + cob;
 #pragma unroll
                     for (int nt = 0; nt < NT; ++nt) {
                         float v = acc[mt][nt][h8 + i] + biasv[nt];
                         if (has_add) v += addv[nt][i];
                         if (cob + nt * 32 < a.act_cols) v = act_fwd(v, a.act);
-                        rp[nt * 32] = v;
+                        st1(rp + nt * 32, v);
                         if (want_stat) {
                             ssum[nt] += v;
                             ssq[nt] += v * v;
@@ -363,9 +376,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void g
                 for (int i = 0; i < 16; ++i) {
                     if (cok && ro[i] >= 0) {
                         float v = acc[mt][nt][i] + biasv[nt];
-                        if (has_add) v += a.addend[(size_t)ro[i] * a.ld_add + co];
+                        if (has_add) v += ld1(static_cast<const io_t*>(a.addend) + (size_t)ro[i] * a.ld_add + co);
                         if (co < a.act_cols) v = act_fwd(v, a.act);
-                        a.out[(size_t)ro[i] * D.ldo + co] = v;
+                        st1(static_cast<io_t*>(a.out) + (size_t)ro[i] * D.ldo + co, v);
                         ssum[nt] += v;
                         ssq[nt] += v * v;
                     }
@@ -498,10 +511,10 @@ static bool plan_gconv_bf16(const RdConvDesc& d, GconvBfPlan& best) {
     return best_score > 0;
 }
 
-template <int MT, int NT, bool PIPE>
+template <int MT, int NT, bool PIPE, bool IO16>
 static int launch_bf(const GconvBfArgs& a, int grid, size_t lds, hipStream_t s) {
     static bool attr_set = false;
-    auto k = gconv_bf16_kernel<MT, NT, PIPE>;
+    auto k = gconv_bf16_kernel<MT, NT, PIPE, IO16>;
     if (!attr_set) {
         RD_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr_set = true;
@@ -574,10 +587,10 @@ extern "C" int rd_gconv_bf16_stat_tiles(const RdConvDesc* d) {
     return d->N * pl.tiles_total;
 }
 
-extern "C" int rd_gconv_bf16(const RdConvDesc* d, const float* in, const void* w_packed_bf16, float* out, const float* bias,
-                             int32_t act, int32_t act_cols, const float* addend, int32_t ld_add, float* stat_partial,
-                             void* stream) {
+static int gconv_bf16_impl(bool io16, const RdConvDesc* d, const void* in, const void* w_packed_bf16, void* out, const float* bias,
+                           int32_t act, int32_t act_cols, const void* addend, int32_t ld_add, float* stat_partial, void* stream) {
     RD_CHECK_ARG(in && w_packed_bf16 && out, "gconv_bf16: null tensor");
+    RD_CHECK_ARG(!io16 || (d && d->ldi % 8 == 0), "gconv_bf16: bf16 storage needs the input channel stride to be a multiple of 8");
     GconvBfArgs a;
     GconvBfPlan pl;
     int rc = bf_plan_query(d, pl, a.d);
@@ -603,11 +616,27 @@ extern "C" int rd_gconv_bf16(const RdConvDesc* d, const float* in, const void* w
             a.trace = g_bf_trace;
         }
     }
-#define RD_BF(MT_, NT_)                 \
-    if (pl.MT == MT_ && pl.NT == NT_)   \
-        return pl.pipe ? launch_bf<MT_, NT_, true>(a, grid, pl.lds_bytes, s) : launch_bf<MT_, NT_, false>(a, grid, pl.lds_bytes, s);
+#define RD_BF(MT_, NT_)                                                                                                        \
+    if (pl.MT == MT_ && pl.NT == NT_)                                                                                          \
+        return io16 ? (pl.pipe ? launch_bf<MT_, NT_, true, true>(a, grid, pl.lds_bytes, s)                                     \
+                               : launch_bf<MT_, NT_, false, true>(a, grid, pl.lds_bytes, s))                                   \
+                    : (pl.pipe ? launch_bf<MT_, NT_, true, false>(a, grid, pl.lds_bytes, s)                                    \
+                               : launch_bf<MT_, NT_, false, false>(a, grid, pl.lds_bytes, s));
     RD_BF(2, 2) RD_BF(2, 1) RD_BF(3, 2) RD_BF(1, 2) RD_BF(1, 1)
 #undef RD_BF
     set_error("gconv_bf16: no kernel for tile %dx%d", pl.MT, pl.NT);
     return RD_EINVAL;
+}
+
+extern "C" int rd_gconv_bf16(const RdConvDesc* d, const float* in, const void* w_packed_bf16, float* out, const float* bias,
+                             int32_t act, int32_t act_cols, const float* addend, int32_t ld_add, float* stat_partial,
+                             void* stream) {
+    return gconv_bf16_impl(false, d, in, w_packed_bf16, out, bias, act, act_cols, addend, ld_add, stat_partial, stream);
+}
+// storage-typed form: dtype = RD_DTYPE_BF16 -> in / out / addend are bf16 NHWC tensors (strides in elements)
+extern "C" int rd_gconv_bf16_t(int32_t dtype, const RdConvDesc* d, const void* in, const void* w_packed_bf16, void* out,
+                               const float* bias, int32_t act, int32_t act_cols, const void* addend, int32_t ld_add,
+                               float* stat_partial, void* stream) {
+    RD_CHECK_ARG(dtype == RD_DTYPE_F32 || dtype == RD_DTYPE_BF16, "gconv_bf16_t: bad dtype %d", dtype);
+    return gconv_bf16_impl(dtype == RD_DTYPE_BF16, d, in, w_packed_bf16, out, bias, act, act_cols, addend, ld_add, stat_partial, stream);
 }

@@ -9,8 +9,8 @@ int launch_slab_reduce(const float* slabs, int n_splits, int64_t E, float* tmp, 
                        int O, int I, int co_off, int accumulate, hipStream_t s);
 
 // d[n,h,w] = sum_{kh,kw,c} x[n,h+kh-1,w+kw-1,c] * w[c][kh][kw]      (w: OIHW with O == 1)
-template <int C>
-__global__ __launch_bounds__(256) void head_conv_fwd_kernel(const float* __restrict__ x, int ldx, const float* __restrict__ w,
+template <int C, typename T>
+__global__ __launch_bounds__(256) void head_conv_fwd_kernel(const T* __restrict__ x, int ldx, const float* __restrict__ w,
                                                             int N, int H, int W, float* __restrict__ d) {
     __shared__ float s_w[9 * C];
     for (int e = threadIdx.x; e < 9 * C; e += blockDim.x) {
@@ -32,11 +32,11 @@ __global__ __launch_bounds__(256) void head_conv_fwd_kernel(const float* __restr
             for (int kw = 0; kw < 3; ++kw) {
                 const int iw = wx + kw - 1;
                 if (iw < 0 || iw >= W) continue;
-                const float* px = x + (((size_t)n * H + ih) * W + iw) * ldx;
+                const T* px = x + (((size_t)n * H + ih) * W + iw) * ldx;
                 const float* wt = s_w + (kh * 3 + kw) * C;
 #pragma unroll
                 for (int c = 0; c < C; c += 4) {
-                    const float4 v = *reinterpret_cast<const float4*>(px + c);
+                    const float4 v = ld4(px + c);
                     s = fmaf(v.x, wt[c], s); s = fmaf(v.y, wt[c + 1], s);
                     s = fmaf(v.z, wt[c + 2], s); s = fmaf(v.w, wt[c + 3], s);
                 }
@@ -47,9 +47,9 @@ __global__ __launch_bounds__(256) void head_conv_fwd_kernel(const float* __restr
 }
 
 // dx[n,h,w,c] = sum_{kh,kw} dd[n,h-kh+1,w-kw+1] * w[c][kh][kw]
-template <int C>
+template <int C, typename T>
 __global__ __launch_bounds__(256) void head_conv_dgrad_kernel(const float* __restrict__ dd, const float* __restrict__ w, int N,
-                                                              int H, int W, float* __restrict__ dx, int lddx) {
+                                                              int H, int W, T* __restrict__ dx, int lddx) {
     __shared__ float s_w[9 * C];
     for (int e = threadIdx.x; e < 9 * C; e += blockDim.x) {
         const int t = e / C, c = e - t * C;
@@ -77,14 +77,14 @@ __global__ __launch_bounds__(256) void head_conv_dgrad_kernel(const float* __res
                 s.x = fmaf(g, wt[0], s.x); s.y = fmaf(g, wt[1], s.y); s.z = fmaf(g, wt[2], s.z); s.w = fmaf(g, wt[3], s.w);
             }
         }
-        *reinterpret_cast<float4*>(dx + (((size_t)n * H + h) * W + wx) * lddx + c) = s;
+        st4(dx + (((size_t)n * H + h) * W + wx) * lddx + c, s);
     }
 }
 
 // partial[block][t][c] = sum over the block's pixels of x[pix + tap t][c] * dd[pix]
 // thread = (tap, channel quad, pixel lane); pixel lanes are reduced through LDS.
-template <int C>
-__global__ __launch_bounds__(256) void head_conv_wgrad_kernel(const float* __restrict__ x, int ldx, const float* __restrict__ dd,
+template <int C, typename T>
+__global__ __launch_bounds__(256) void head_conv_wgrad_kernel(const T* __restrict__ x, int ldx, const float* __restrict__ dd,
                                                               int N, int H, int W, int64_t pix_per_block,
                                                               float* __restrict__ partial) {
     constexpr int Q = C / 4, COMBOS = 9 * Q, PL = 256 / COMBOS;
@@ -104,7 +104,7 @@ __global__ __launch_bounds__(256) void head_conv_wgrad_kernel(const float* __res
             const int ih = h + kh - 1, iw = wx + kw - 1;
             if (ih < 0 || ih >= H || iw < 0 || iw >= W) continue;
             const float g = dd[p];
-            const float4 v = *reinterpret_cast<const float4*>(x + (p + (int64_t)(kh - 1) * W + (kw - 1)) * ldx + c);
+            const float4 v = ld4(x + (p + (int64_t)(kh - 1) * W + (kw - 1)) * ldx + c);
             acc.x = fmaf(g, v.x, acc.x); acc.y = fmaf(g, v.y, acc.y); acc.z = fmaf(g, v.z, acc.z); acc.w = fmaf(g, v.w, acc.w);
         }
         s_red[pl * COMBOS + combo] = acc;
@@ -200,13 +200,25 @@ static int head_wgrad_blocks(int64_t pixels) {
 }  // namespace rd
 using namespace rd;
 
-extern "C" int rd_head_conv_fwd(const float* x, int32_t ldx, const float* w_oihw, int32_t N, int32_t H, int32_t W, int32_t C,
-                                float* d, void* stream) {
+template <typename T>
+static int head_conv_fwd_T(const T* x, int32_t ldx, const float* w_oihw, int32_t N, int32_t H, int32_t W, int32_t C, float* d, void* stream) {
     RD_CHECK_ARG(x && w_oihw && d && C == 16 && ldx % 4 == 0, "head_conv_fwd: bad arguments (C must be 16)");
-    hipLaunchKernelGGL(head_conv_fwd_kernel<16>, dim3(ew_grid64((int64_t)N * H * W)), dim3(256), 0,
+    hipLaunchKernelGGL((head_conv_fwd_kernel<16, T>), dim3(ew_grid64((int64_t)N * H * W)), dim3(256), 0,
                        static_cast<hipStream_t>(stream), x, ldx, w_oihw, N, H, W, d);
     RD_CHECK_LAUNCH("head_conv_fwd_kernel");
     return RD_OK;
+}
+extern "C" int rd_head_conv_fwd(const float* x, int32_t ldx, const float* w_oihw, int32_t N, int32_t H, int32_t W, int32_t C,
+                                float* d, void* stream) {
+    return head_conv_fwd_T<float>(x, ldx, w_oihw, N, H, W, C, d, stream);
+}
+// storage-typed form: x is an fp32 (RD_DTYPE_F32) or bf16 (RD_DTYPE_BF16) NHWC tensor; the depth map d stays fp32
+extern "C" int rd_head_conv_fwd_t(int32_t dtype, const void* x, int32_t ldx, const float* w_oihw, int32_t N, int32_t H, int32_t W,
+                                  int32_t C, float* d, void* stream) {
+    if (dtype == RD_DTYPE_F32) return head_conv_fwd_T<float>(static_cast<const float*>(x), ldx, w_oihw, N, H, W, C, d, stream);
+    if (dtype == RD_DTYPE_BF16) return head_conv_fwd_T<bf16s>(static_cast<const bf16s*>(x), ldx, w_oihw, N, H, W, C, d, stream);
+    rd::set_error("head_conv_fwd_t: bad dtype %d", dtype);
+    return RD_EINVAL;
 }
 
 extern "C" int64_t rd_head_conv_bwd_workspace_floats(int32_t N, int32_t H, int32_t W, int32_t C) {
@@ -214,20 +226,34 @@ extern "C" int64_t rd_head_conv_bwd_workspace_floats(int32_t N, int32_t H, int32
     return (int64_t)(blocks + 16) * 9 * C;
 }
 
-extern "C" int rd_head_conv_bwd(const float* x, int32_t ldx, const float* w_oihw, const float* dd, int32_t N, int32_t H, int32_t W,
-                                int32_t C, float* dx, int32_t lddx, float* dw_oihw, float* ws, void* stream) {
+template <typename T>
+static int head_conv_bwd_T(const T* x, int32_t ldx, const float* w_oihw, const float* dd, int32_t N, int32_t H, int32_t W, int32_t C,
+                           T* dx, int32_t lddx, float* dw_oihw, float* ws, void* stream) {
     RD_CHECK_ARG(x && w_oihw && dd && dx && dw_oihw && ws && C == 16 && ldx % 4 == 0 && lddx % 4 == 0,
                  "head_conv_bwd: bad arguments (C must be 16)");
     hipStream_t s = static_cast<hipStream_t>(stream);
-    hipLaunchKernelGGL(head_conv_dgrad_kernel<16>, dim3(ew_grid64((int64_t)N * H * W * 4)), dim3(256), 0, s, dd, w_oihw, N, H, W,
+    hipLaunchKernelGGL((head_conv_dgrad_kernel<16, T>), dim3(ew_grid64((int64_t)N * H * W * 4)), dim3(256), 0, s, dd, w_oihw, N, H, W,
                        dx, lddx);
     RD_CHECK_LAUNCH("head_conv_dgrad_kernel");
     const int64_t pixels = (int64_t)N * H * W;
     const int blocks = head_wgrad_blocks(pixels);
-    hipLaunchKernelGGL(head_conv_wgrad_kernel<16>, dim3(blocks), dim3(256), 0, s, x, ldx, dd, N, H, W, cdiv64(pixels, blocks), ws);
+    hipLaunchKernelGGL((head_conv_wgrad_kernel<16, T>), dim3(blocks), dim3(256), 0, s, x, ldx, dd, N, H, W, cdiv64(pixels, blocks), ws);
     RD_CHECK_LAUNCH("head_conv_wgrad_kernel");
     const int64_t E = 9 * C;
     return launch_slab_reduce(ws, blocks, E, ws + (int64_t)blocks * E, dw_oihw, 9, C, 1, 1, C, 0, 0, s);
+}
+extern "C" int rd_head_conv_bwd(const float* x, int32_t ldx, const float* w_oihw, const float* dd, int32_t N, int32_t H, int32_t W,
+                                int32_t C, float* dx, int32_t lddx, float* dw_oihw, float* ws, void* stream) {
+    return head_conv_bwd_T<float>(x, ldx, w_oihw, dd, N, H, W, C, dx, lddx, dw_oihw, ws, stream);
+}
+extern "C" int rd_head_conv_bwd_t(int32_t dtype, const void* x, int32_t ldx, const float* w_oihw, const float* dd, int32_t N, int32_t H,
+                                  int32_t W, int32_t C, void* dx, int32_t lddx, float* dw_oihw, float* ws, void* stream) {
+    if (dtype == RD_DTYPE_F32)
+        return head_conv_bwd_T<float>(static_cast<const float*>(x), ldx, w_oihw, dd, N, H, W, C, static_cast<float*>(dx), lddx, dw_oihw, ws, stream);
+    if (dtype == RD_DTYPE_BF16)
+        return head_conv_bwd_T<bf16s>(static_cast<const bf16s*>(x), ldx, w_oihw, dd, N, H, W, C, static_cast<bf16s*>(dx), lddx, dw_oihw, ws, stream);
+    rd::set_error("head_conv_bwd_t: bad dtype %d", dtype);
+    return RD_EINVAL;
 }
 
 extern "C" int rd_bilinear_fwd(const float* d, int32_t N, int32_t Hs, int32_t Ws, float* out, int32_t Ho, int32_t Wo, void* stream) {

@@ -107,7 +107,8 @@ __device__ __forceinline__ void block_reduce_store(float4 (&acc)[NS], int Q, int
     }
 }
 
-__global__ __launch_bounds__(256) void bn_stats_kernel(const float* __restrict__ x, int64_t M, int C, int ldx, int RPB,
+template <typename T>
+__global__ __launch_bounds__(256) void bn_stats_kernel(const T* __restrict__ x, int64_t M, int C, int ldx, int RPB,
                                                        float* __restrict__ part) {
     extern __shared__ float sm[];
     const int Q = C >> 2, RL = 256 / Q;
@@ -117,7 +118,7 @@ __global__ __launch_bounds__(256) void bn_stats_kernel(const float* __restrict__
     float4 acc[2] = {make_float4(0, 0, 0, 0), make_float4(0, 0, 0, 0)};
     if (active)
         for (int64_t r = r0 + rl; r < r1; r += RL) {
-            const float4 v = *reinterpret_cast<const float4*>(x + r * ldx + q * 4);
+            const float4 v = ld4(x + r * ldx + q * 4);
             acc[0].x += v.x; acc[0].y += v.y; acc[0].z += v.z; acc[0].w += v.w;
             acc[1].x += v.x * v.x; acc[1].y += v.y * v.y; acc[1].z += v.z * v.z; acc[1].w += v.w * v.w;
         }
@@ -125,21 +126,22 @@ __global__ __launch_bounds__(256) void bn_stats_kernel(const float* __restrict__
 }
 
 // y = act(s1*x1 + t1 [+ (s2*x2 + t2 | x2)])
-__global__ __launch_bounds__(256) void bn_act_kernel(const float* __restrict__ x1, int ldx1, const float* __restrict__ s1,
-                                                     const float* __restrict__ t1, const float* __restrict__ x2, int ldx2,
+template <typename T>
+__global__ __launch_bounds__(256) void bn_act_kernel(const T* __restrict__ x1, int ldx1, const float* __restrict__ s1,
+                                                     const float* __restrict__ t1, const T* __restrict__ x2, int ldx2,
                                                      const float* __restrict__ s2, const float* __restrict__ t2,
-                                                     float* __restrict__ y, int ldy, int64_t M, int C, int act) {
+                                                     T* __restrict__ y, int ldy, int64_t M, int C, int act) {
     const int Q = C >> 2;
     const int64_t total = M * Q;
     for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
         const int64_t r = e / Q;
         const int c = (int)(e - r * Q) * 4;
-        const float4 v = *reinterpret_cast<const float4*>(x1 + r * ldx1 + c);
+        const float4 v = ld4(x1 + r * ldx1 + c);
         const float4 a = *reinterpret_cast<const float4*>(s1 + c);
         const float4 b = *reinterpret_cast<const float4*>(t1 + c);
         float4 z = make_float4(fmaf(a.x, v.x, b.x), fmaf(a.y, v.y, b.y), fmaf(a.z, v.z, b.z), fmaf(a.w, v.w, b.w));
         if (x2) {
-            float4 u = *reinterpret_cast<const float4*>(x2 + r * ldx2 + c);
+            float4 u = ld4(x2 + r * ldx2 + c);
             if (s2) {
                 const float4 a2 = *reinterpret_cast<const float4*>(s2 + c);
                 const float4 b2 = *reinterpret_cast<const float4*>(t2 + c);
@@ -148,17 +150,18 @@ __global__ __launch_bounds__(256) void bn_act_kernel(const float* __restrict__ x
             z.x += u.x; z.y += u.y; z.z += u.z; z.w += u.w;
         }
         z.x = act_fwd(z.x, act); z.y = act_fwd(z.y, act); z.z = act_fwd(z.z, act); z.w = act_fwd(z.w, act);
-        *reinterpret_cast<float4*>(y + r * ldy + c) = z;
+        st4(y + r * ldy + c, z);
     }
 }
 
 // backward pass 1: g = dy * act'(y); sums of g, g*(x1-m1), g*(x2-m2).
 // y == nullptr with an activation: the output was act(s1*x1 + t1) alone (no second operand), so its sign is recomputed from
 // x1 -- which the kernel reads anyway -- with the forward kernel's own fmaf, instead of reading the activation tensor.
-__global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restrict__ dy, int lddy, const float* __restrict__ y,
-                                                            int ldy, const float* __restrict__ x1, int ldx1,
-                                                            const float* __restrict__ m1, const float* __restrict__ x2, int ldx2,
-                                                            const float* __restrict__ m2, float* __restrict__ g, int ldg,
+template <typename T>
+__global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* __restrict__ dy, int lddy, const T* __restrict__ y,
+                                                            int ldy, const T* __restrict__ x1, int ldx1,
+                                                            const float* __restrict__ m1, const T* __restrict__ x2, int ldx2,
+                                                            const float* __restrict__ m2, T* __restrict__ g, int ldg,
                                                             int64_t M, int C, int act, int RPB, float* __restrict__ part,
                                                             const float* __restrict__ s1, const float* __restrict__ t1,
                                                             const float* __restrict__ s2, const float* __restrict__ t2) {
@@ -179,10 +182,10 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restr
         const float4 sa2 = from_x2 ? *reinterpret_cast<const float4*>(s2 + c) : make_float4(0, 0, 0, 0);
         const float4 sb2 = from_x2 ? *reinterpret_cast<const float4*>(t2 + c) : make_float4(0, 0, 0, 0);
         for (int64_t r = r0 + rl; r < r1; r += RL) {
-            float4 gv = *reinterpret_cast<const float4*>(dy + r * lddy + c);
+            float4 gv = ld4(dy + r * lddy + c);
             float4 v = make_float4(0, 0, 0, 0), v2 = make_float4(0, 0, 0, 0);
-            if (x1) v = *reinterpret_cast<const float4*>(x1 + r * ldx1 + c);
-            if (x2) v2 = *reinterpret_cast<const float4*>(x2 + r * ldx2 + c);
+            if (x1) v = ld4(x1 + r * ldx1 + c);
+            if (x2) v2 = ld4(x2 + r * ldx2 + c);
             if (act != RD_ACT_NONE) {
                 float4 yv;
                 if (from_x) {
@@ -191,11 +194,11 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restr
                         yv.x += fmaf(sa2.x, v2.x, sb2.x); yv.y += fmaf(sa2.y, v2.y, sb2.y);
                         yv.z += fmaf(sa2.z, v2.z, sb2.z); yv.w += fmaf(sa2.w, v2.w, sb2.w);
                     }
-                } else yv = *reinterpret_cast<const float4*>(y + r * ldy + c);
+                } else yv = ld4(y + r * ldy + c);
                 gv.x *= act_grad_from_out(yv.x, act); gv.y *= act_grad_from_out(yv.y, act);
                 gv.z *= act_grad_from_out(yv.z, act); gv.w *= act_grad_from_out(yv.w, act);
             }
-            if (g) *reinterpret_cast<float4*>(g + r * ldg + c) = gv;
+            if (g) st4(g + r * ldg + c, gv);
             acc[0].x += gv.x; acc[0].y += gv.y; acc[0].z += gv.z; acc[0].w += gv.w;
             if (x1) {
                 acc[1].x += gv.x * (v.x - mu1.x); acc[1].y += gv.y * (v.y - mu1.y);
@@ -253,17 +256,18 @@ __global__ __launch_bounds__(256) void bn_bwd_coeffs_kernel(const float* __restr
 
 // s1 != nullptr: g is the raw output gradient dy of act(s1*x + t1); the activation factor is applied here (the reduce pass then
 // does not have to write the masked gradient)
-__global__ __launch_bounds__(256) void bn_bwd_dx_kernel(const float* __restrict__ g, int ldg, const float* __restrict__ x, int ldx,
+template <typename T>
+__global__ __launch_bounds__(256) void bn_bwd_dx_kernel(const T* __restrict__ g, int ldg, const T* __restrict__ x, int ldx,
                                                         const float* __restrict__ mean, const float* __restrict__ coef,
-                                                        float* __restrict__ dx, int lddx, int64_t M, int C,
+                                                        T* __restrict__ dx, int lddx, int64_t M, int C,
                                                         const float* __restrict__ s1, const float* __restrict__ t1, int act) {
     const int Q = C >> 2;
     const int64_t total = M * Q;
     for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
         const int64_t r = e / Q;
         const int c = (int)(e - r * Q) * 4;
-        float4 gv = *reinterpret_cast<const float4*>(g + r * ldg + c);
-        const float4 xv = *reinterpret_cast<const float4*>(x + r * ldx + c);
+        float4 gv = ld4(g + r * ldg + c);
+        const float4 xv = ld4(x + r * ldx + c);
         if (s1) {
             const float4 sa = *reinterpret_cast<const float4*>(s1 + c), sb = *reinterpret_cast<const float4*>(t1 + c);
             gv.x *= act_grad_from_out(fmaf(sa.x, xv.x, sb.x), act); gv.y *= act_grad_from_out(fmaf(sa.y, xv.y, sb.y), act);
@@ -278,26 +282,27 @@ __global__ __launch_bounds__(256) void bn_bwd_dx_kernel(const float* __restrict_
         o.y = fmaf(A.y, gv.y, fmaf(B.y, xv.y - mu.y, K.y));
         o.z = fmaf(A.z, gv.z, fmaf(B.z, xv.z - mu.z, K.z));
         o.w = fmaf(A.w, gv.w, fmaf(B.w, xv.w - mu.w, K.w));
-        *reinterpret_cast<float4*>(dx + r * lddx + c) = o;
+        st4(dx + r * lddx + c, o);
     }
 }
 
 // out = act(bn1(x1) + bn2(x2)): both input gradients in one pass from the raw output gradient (the masked gradient is never
 // materialised, dy is read once): dx_i = A_i*g + B_i*(x_i - mean_i) + K_i with g = dy * act'(s1*x1+t1 + s2*x2+t2)
-__global__ __launch_bounds__(256) void bn_bwd_dx2_kernel(const float* __restrict__ dy, int lddy, const float* __restrict__ x1, int ldx1,
-                                                         const float* __restrict__ x2, int ldx2, const float* __restrict__ m1,
+template <typename T>
+__global__ __launch_bounds__(256) void bn_bwd_dx2_kernel(const T* __restrict__ dy, int lddy, const T* __restrict__ x1, int ldx1,
+                                                         const T* __restrict__ x2, int ldx2, const float* __restrict__ m1,
                                                          const float* __restrict__ m2, const float* __restrict__ coef1,
                                                          const float* __restrict__ coef2, const float* __restrict__ s1,
                                                          const float* __restrict__ t1, const float* __restrict__ s2,
-                                                         const float* __restrict__ t2, int act, float* __restrict__ dx1, int lddx1,
-                                                         float* __restrict__ dx2, int lddx2, int64_t M, int C) {
+                                                         const float* __restrict__ t2, int act, T* __restrict__ dx1, int lddx1,
+                                                         T* __restrict__ dx2, int lddx2, int64_t M, int C) {
     const int Q = C >> 2;
     const int64_t total = M * Q;
     for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
         const int64_t r = e / Q;
         const int c = (int)(e - r * Q) * 4;
-        float4 gv = *reinterpret_cast<const float4*>(dy + r * lddy + c);
-        const float4 v1 = *reinterpret_cast<const float4*>(x1 + r * ldx1 + c), v2 = *reinterpret_cast<const float4*>(x2 + r * ldx2 + c);
+        float4 gv = ld4(dy + r * lddy + c);
+        const float4 v1 = ld4(x1 + r * ldx1 + c), v2 = ld4(x2 + r * ldx2 + c);
         const float4 a1 = *reinterpret_cast<const float4*>(s1 + c), b1 = *reinterpret_cast<const float4*>(t1 + c);
         const float4 a2 = *reinterpret_cast<const float4*>(s2 + c), b2 = *reinterpret_cast<const float4*>(t2 + c);
         gv.x *= act_grad_from_out(fmaf(a1.x, v1.x, b1.x) + fmaf(a2.x, v2.x, b2.x), act);
@@ -312,18 +317,19 @@ __global__ __launch_bounds__(256) void bn_bwd_dx2_kernel(const float* __restrict
         float4 o;
         o.x = fmaf(A1.x, gv.x, fmaf(B1.x, v1.x - mu1.x, K1.x)); o.y = fmaf(A1.y, gv.y, fmaf(B1.y, v1.y - mu1.y, K1.y));
         o.z = fmaf(A1.z, gv.z, fmaf(B1.z, v1.z - mu1.z, K1.z)); o.w = fmaf(A1.w, gv.w, fmaf(B1.w, v1.w - mu1.w, K1.w));
-        *reinterpret_cast<float4*>(dx1 + r * lddx1 + c) = o;
+        st4(dx1 + r * lddx1 + c, o);
         o.x = fmaf(A2.x, gv.x, fmaf(B2.x, v2.x - mu2.x, K2.x)); o.y = fmaf(A2.y, gv.y, fmaf(B2.y, v2.y - mu2.y, K2.y));
         o.z = fmaf(A2.z, gv.z, fmaf(B2.z, v2.z - mu2.z, K2.z)); o.w = fmaf(A2.w, gv.w, fmaf(B2.w, v2.w - mu2.w, K2.w));
-        *reinterpret_cast<float4*>(dx2 + r * lddx2 + c) = o;
+        st4(dx2 + r * lddx2 + c, o);
     }
 }
 
 // ------------------------------------------------------------------------------------------------
 // stem: y = maxpool3x3/2/1(act(scale*x+shift)), argmax position saved (first max wins, like ATen's CPU kernel)
-__global__ __launch_bounds__(256) void bnact_maxpool_fwd_kernel(const float* __restrict__ x, const float* __restrict__ scale,
+template <typename T>
+__global__ __launch_bounds__(256) void bnact_maxpool_fwd_kernel(const T* __restrict__ x, const float* __restrict__ scale,
                                                                 const float* __restrict__ shift, int act, int N, int H, int W,
-                                                                int C, int Ho, int Wo, float* __restrict__ y, int ldy,
+                                                                int C, int Ho, int Wo, T* __restrict__ y, int ldy,
                                                                 uint8_t* __restrict__ idx) {
     const int Q = C >> 2;
     const int64_t total = (int64_t)N * Ho * Wo * Q;
@@ -344,7 +350,7 @@ __global__ __launch_bounds__(256) void bnact_maxpool_fwd_kernel(const float* __r
             for (int kw = 0; kw < 3; ++kw) {
                 const int iw = 2 * ow - 1 + kw;
                 if (iw < 0 || iw >= W) continue;
-                const float4 v = *reinterpret_cast<const float4*>(x + (((size_t)n * H + ih) * W + iw) * C + c);
+                const float4 v = ld4(x + (((size_t)n * H + ih) * W + iw) * C + c);
                 const float z[4] = {act_fwd(fmaf(a.x, v.x, b.x), act), act_fwd(fmaf(a.y, v.y, b.y), act),
                                     act_fwd(fmaf(a.z, v.z, b.z), act), act_fwd(fmaf(a.w, v.w, b.w), act)};
 #pragma unroll
@@ -354,7 +360,7 @@ __global__ __launch_bounds__(256) void bnact_maxpool_fwd_kernel(const float* __r
             }
         }
         const size_t o = ((size_t)n * Ho + oh) * Wo + ow;
-        *reinterpret_cast<float4*>(y + o * ldy + c) = make_float4(best[0], best[1], best[2], best[3]);
+        st4(y + o * ldy + c, make_float4(best[0], best[1], best[2], best[3]));
         *reinterpret_cast<uchar4*>(idx + o * C + c) = make_uchar4(bi[0], bi[1], bi[2], bi[3]);
     }
 }
@@ -363,11 +369,12 @@ __global__ __launch_bounds__(256) void bnact_maxpool_fwd_kernel(const float* __r
 // part != nullptr: also the BatchNorm-backward sums of the stem (sum g, sum g*(x - mean)) per block, [block][3][C] like
 // bn_bwd_reduce_kernel -- g and x are in registers here, so the separate reduce pass over both (the largest tensors of the
 // network) disappears.  Needs 256 % (C/4) == 0 so that a thread keeps its channel quad across the grid-stride loop.
-__global__ __launch_bounds__(256) void bnact_maxpool_bwd_kernel(const float* __restrict__ dy, int lddy,
-                                                                const uint8_t* __restrict__ idx, const float* __restrict__ x,
+template <typename T>
+__global__ __launch_bounds__(256) void bnact_maxpool_bwd_kernel(const T* __restrict__ dy, int lddy,
+                                                                const uint8_t* __restrict__ idx, const T* __restrict__ x,
                                                                 const float* __restrict__ scale, const float* __restrict__ shift,
                                                                 int act, int N, int H, int W, int C, int Ho, int Wo,
-                                                                float* __restrict__ g, const float* __restrict__ mean,
+                                                                T* __restrict__ g, const float* __restrict__ mean,
                                                                 float* __restrict__ part) {
     extern __shared__ float sm[];
     const int Q = C >> 2;
@@ -391,7 +398,7 @@ __global__ __launch_bounds__(256) void bnact_maxpool_bwd_kernel(const float* __r
                 const int kw = w - (2 * ow - 1);
                 const size_t o = ((size_t)n * Ho + oh) * Wo + ow;
                 const uchar4 id = *reinterpret_cast<const uchar4*>(idx + o * C + c);
-                const float4 d = *reinterpret_cast<const float4*>(dy + o * lddy + c);
+                const float4 d = ld4(dy + o * lddy + c);
                 const int pos = kh * 3 + kw;
                 if (id.x == pos) s[0] += d.x;
                 if (id.y == pos) s[1] += d.y;
@@ -400,7 +407,7 @@ __global__ __launch_bounds__(256) void bnact_maxpool_bwd_kernel(const float* __r
             }
         }
         const size_t i = (((size_t)n * H + h) * W + w) * C + c;
-        const float4 v = *reinterpret_cast<const float4*>(x + i);
+        const float4 v = ld4(x + i);
         const float4 a = *reinterpret_cast<const float4*>(scale + c);
         const float4 b = *reinterpret_cast<const float4*>(shift + c);
         float4 o4;
@@ -408,7 +415,7 @@ __global__ __launch_bounds__(256) void bnact_maxpool_bwd_kernel(const float* __r
         o4.y = s[1] * act_grad_from_out(fmaf(a.y, v.y, b.y), act);
         o4.z = s[2] * act_grad_from_out(fmaf(a.z, v.z, b.z), act);
         o4.w = s[3] * act_grad_from_out(fmaf(a.w, v.w, b.w), act);
-        *reinterpret_cast<float4*>(g + i) = o4;
+        st4(g + i, o4);
         if (part) {
             acc[0].x += o4.x; acc[0].y += o4.y; acc[0].z += o4.z; acc[0].w += o4.w;
             acc[1].x += o4.x * (v.x - mu.x); acc[1].y += o4.y * (v.y - mu.y);
@@ -459,31 +466,51 @@ extern "C" int rd_bn_eval_coeffs_batched(const void* jobs_dev, int32_t n_jobs, f
 extern "C" int rd_bn_stats_tiles(int64_t M) { return (int)cdiv64(M, rows_per_block(M)); }
 extern "C" int rd_bn_bwd_tiles(int64_t M) { return (int)cdiv64(M, rows_per_block(M)); }
 
-extern "C" int rd_bn_stats(const float* x, int64_t M, int32_t C, int32_t ldx, float* stat_partial, int32_t* n_tiles,
-                           void* stream) {
+template <typename T>
+static int rd_bn_stats_T(const T* x, int64_t M, int32_t C, int32_t ldx, float* stat_partial, int32_t* n_tiles, void* stream) {
     RD_CHECK_ARG(x && stat_partial && M > 0 && C >= 4 && C % 4 == 0 && C <= 1024 && ldx % 4 == 0, "bn_stats: bad arguments");
     const int RPB = rows_per_block(M), grid = (int)cdiv64(M, RPB);
     const int Q = C / 4, RL = 256 / Q;
-    hipLaunchKernelGGL(bn_stats_kernel, dim3(grid), dim3(256), (size_t)RL * 2 * C * sizeof(float),
+    hipLaunchKernelGGL((bn_stats_kernel<T>), dim3(grid), dim3(256), (size_t)RL * 2 * C * sizeof(float),
                        static_cast<hipStream_t>(stream), x, M, C, ldx, RPB, stat_partial);
     RD_CHECK_LAUNCH("bn_stats_kernel");
     if (n_tiles) *n_tiles = grid;
     return RD_OK;
 }
+extern "C" int rd_bn_stats(const float* x, int64_t M, int32_t C, int32_t ldx, float* stat_partial, int32_t* n_tiles, void* stream) {
+    return rd_bn_stats_T<float>(x, M, C, ldx, stat_partial, n_tiles, stream);
+}
+// storage-typed form: dtype = RD_DTYPE_F32 / RD_DTYPE_BF16 selects the element type of the NHWC tensors (strides in elements)
+extern "C" int rd_bn_stats_t(int32_t dtype, const void* x, int64_t M, int32_t C, int32_t ldx, float* stat_partial, int32_t* n_tiles, void* stream) {
+    if (dtype == RD_DTYPE_F32) return rd_bn_stats_T<float>(static_cast<const float*>(x), M, C, ldx, stat_partial, n_tiles, stream);
+    if (dtype == RD_DTYPE_BF16) return rd_bn_stats_T<bf16s>(static_cast<const bf16s*>(x), M, C, ldx, stat_partial, n_tiles, stream);
+    rd::set_error("rd_bn_stats_t: bad dtype %d", dtype);
+    return RD_EINVAL;
+}
 
-extern "C" int rd_bn_act(const float* x1, int32_t ldx1, const float* scale1, const float* shift1, const float* x2, int32_t ldx2,
-                         const float* scale2, const float* shift2, float* y, int32_t ldy, int64_t M, int32_t C, int32_t act,
-                         void* stream) {
+template <typename T>
+static int rd_bn_act_T(const T* x1, int32_t ldx1, const float* scale1, const float* shift1, const T* x2, int32_t ldx2, const float* scale2, const float* shift2, T* y, int32_t ldy, int64_t M, int32_t C, int32_t act, void* stream) {
     RD_CHECK_ARG(x1 && scale1 && shift1 && y && M > 0 && C % 4 == 0 && ldx1 % 4 == 0 && ldy % 4 == 0 && (!x2 || ldx2 % 4 == 0),
                  "bn_act: bad arguments");
-    hipLaunchKernelGGL(bn_act_kernel, dim3(ew_grid(M * (C / 4))), dim3(256), 0, static_cast<hipStream_t>(stream), x1, ldx1,
+    hipLaunchKernelGGL((bn_act_kernel<T>), dim3(ew_grid(M * (C / 4))), dim3(256), 0, static_cast<hipStream_t>(stream), x1, ldx1,
                        scale1, shift1, x2, ldx2, scale2, shift2, y, ldy, M, C, act);
     RD_CHECK_LAUNCH("bn_act_kernel");
     return RD_OK;
 }
+extern "C" int rd_bn_act(const float* x1, int32_t ldx1, const float* scale1, const float* shift1, const float* x2, int32_t ldx2, const float* scale2, const float* shift2, float* y, int32_t ldy, int64_t M, int32_t C, int32_t act, void* stream) {
+    return rd_bn_act_T<float>(x1, ldx1, scale1, shift1, x2, ldx2, scale2, shift2, y, ldy, M, C, act, stream);
+}
+// storage-typed form: dtype = RD_DTYPE_F32 / RD_DTYPE_BF16 selects the element type of the NHWC tensors (strides in elements)
+extern "C" int rd_bn_act_t(int32_t dtype, const void* x1, int32_t ldx1, const float* scale1, const float* shift1, const void* x2, int32_t ldx2, const float* scale2, const float* shift2, void* y, int32_t ldy, int64_t M, int32_t C, int32_t act, void* stream) {
+    if (dtype == RD_DTYPE_F32) return rd_bn_act_T<float>(static_cast<const float*>(x1), ldx1, scale1, shift1, static_cast<const float*>(x2), ldx2, scale2, shift2, static_cast<float*>(y), ldy, M, C, act, stream);
+    if (dtype == RD_DTYPE_BF16) return rd_bn_act_T<bf16s>(static_cast<const bf16s*>(x1), ldx1, scale1, shift1, static_cast<const bf16s*>(x2), ldx2, scale2, shift2, static_cast<bf16s*>(y), ldy, M, C, act, stream);
+    rd::set_error("rd_bn_act_t: bad dtype %d", dtype);
+    return RD_EINVAL;
+}
 
-static int bn_bwd_reduce_impl(const float* dy, int32_t lddy, const float* y, int32_t ldy, const float* x1, int32_t ldx1,
-                              const float* mean1, const float* x2, int32_t ldx2, const float* mean2, float* g, int32_t ldg,
+template <typename T>
+static int bn_bwd_reduce_impl(const T* dy, int32_t lddy, const T* y, int32_t ldy, const T* x1, int32_t ldx1,
+                              const float* mean1, const T* x2, int32_t ldx2, const float* mean2, T* g, int32_t ldg,
                               int64_t M, int32_t C, int32_t act, float* red_partial, const float* scale1, const float* shift1,
                               void* stream, const float* scale2 = nullptr, const float* shift2 = nullptr) {
     RD_CHECK_ARG(dy && red_partial && M > 0 && C >= 4 && C % 4 == 0 && C <= 1024, "bn_bwd_reduce: bad arguments");
@@ -498,48 +525,80 @@ static int bn_bwd_reduce_impl(const float* dy, int32_t lddy, const float* y, int
     RD_CHECK_LAUNCH("bn_bwd_reduce_kernel");
     return RD_OK;
 }
-extern "C" int rd_bn_bwd_reduce(const float* dy, int32_t lddy, const float* y, int32_t ldy, const float* x1, int32_t ldx1,
-                                const float* mean1, const float* x2, int32_t ldx2, const float* mean2, float* g, int32_t ldg,
-                                int64_t M, int32_t C, int32_t act, float* red_partial, void* stream) {
-    return bn_bwd_reduce_impl(dy, lddy, y, ldy, x1, ldx1, mean1, x2, ldx2, mean2, g, ldg, M, C, act, red_partial, nullptr, nullptr, stream);
+template <typename T>
+static int rd_bn_bwd_reduce_T(const T* dy, int32_t lddy, const T* y, int32_t ldy, const T* x1, int32_t ldx1, const float* mean1, const T* x2, int32_t ldx2, const float* mean2, T* g, int32_t ldg, int64_t M, int32_t C, int32_t act, float* red_partial, void* stream) {
+    return bn_bwd_reduce_impl<T>(dy, lddy, y, ldy, x1, ldx1, mean1, x2, ldx2, mean2, g, ldg, M, C, act, red_partial, nullptr, nullptr, stream);
+}
+extern "C" int rd_bn_bwd_reduce(const float* dy, int32_t lddy, const float* y, int32_t ldy, const float* x1, int32_t ldx1, const float* mean1, const float* x2, int32_t ldx2, const float* mean2, float* g, int32_t ldg, int64_t M, int32_t C, int32_t act, float* red_partial, void* stream) {
+    return rd_bn_bwd_reduce_T<float>(dy, lddy, y, ldy, x1, ldx1, mean1, x2, ldx2, mean2, g, ldg, M, C, act, red_partial, stream);
+}
+// storage-typed form: dtype = RD_DTYPE_F32 / RD_DTYPE_BF16 selects the element type of the NHWC tensors (strides in elements)
+extern "C" int rd_bn_bwd_reduce_t(int32_t dtype, const void* dy, int32_t lddy, const void* y, int32_t ldy, const void* x1, int32_t ldx1, const float* mean1, const void* x2, int32_t ldx2, const float* mean2, void* g, int32_t ldg, int64_t M, int32_t C, int32_t act, float* red_partial, void* stream) {
+    if (dtype == RD_DTYPE_F32) return rd_bn_bwd_reduce_T<float>(static_cast<const float*>(dy), lddy, static_cast<const float*>(y), ldy, static_cast<const float*>(x1), ldx1, mean1, static_cast<const float*>(x2), ldx2, mean2, static_cast<float*>(g), ldg, M, C, act, red_partial, stream);
+    if (dtype == RD_DTYPE_BF16) return rd_bn_bwd_reduce_T<bf16s>(static_cast<const bf16s*>(dy), lddy, static_cast<const bf16s*>(y), ldy, static_cast<const bf16s*>(x1), ldx1, mean1, static_cast<const bf16s*>(x2), ldx2, mean2, static_cast<bf16s*>(g), ldg, M, C, act, red_partial, stream);
+    rd::set_error("rd_bn_bwd_reduce_t: bad dtype %d", dtype);
+    return RD_EINVAL;
 }
 // out = act(scale1 * x1 + shift1): the activation's sign is recomputed from x1 (one tensor read less than rd_bn_bwd_reduce)
-extern "C" int rd_bn_bwd_reduce_x(const float* dy, int32_t lddy, const float* x1, int32_t ldx1, const float* mean1,
-                                  const float* scale1, const float* shift1, float* g, int32_t ldg, int64_t M, int32_t C,
-                                  int32_t act, float* red_partial, void* stream) {
-    return bn_bwd_reduce_impl(dy, lddy, nullptr, 0, x1, ldx1, mean1, nullptr, 0, nullptr, g, ldg, M, C, act, red_partial, scale1, shift1, stream);
+template <typename T>
+static int rd_bn_bwd_reduce_x_T(const T* dy, int32_t lddy, const T* x1, int32_t ldx1, const float* mean1, const float* scale1, const float* shift1, T* g, int32_t ldg, int64_t M, int32_t C, int32_t act, float* red_partial, void* stream) {
+    return bn_bwd_reduce_impl<T>(dy, lddy, nullptr, 0, x1, ldx1, mean1, nullptr, 0, nullptr, g, ldg, M, C, act, red_partial, scale1, shift1, stream);
+}
+extern "C" int rd_bn_bwd_reduce_x(const float* dy, int32_t lddy, const float* x1, int32_t ldx1, const float* mean1, const float* scale1, const float* shift1, float* g, int32_t ldg, int64_t M, int32_t C, int32_t act, float* red_partial, void* stream) {
+    return rd_bn_bwd_reduce_x_T<float>(dy, lddy, x1, ldx1, mean1, scale1, shift1, g, ldg, M, C, act, red_partial, stream);
+}
+// storage-typed form: dtype = RD_DTYPE_F32 / RD_DTYPE_BF16 selects the element type of the NHWC tensors (strides in elements)
+extern "C" int rd_bn_bwd_reduce_x_t(int32_t dtype, const void* dy, int32_t lddy, const void* x1, int32_t ldx1, const float* mean1, const float* scale1, const float* shift1, void* g, int32_t ldg, int64_t M, int32_t C, int32_t act, float* red_partial, void* stream) {
+    if (dtype == RD_DTYPE_F32) return rd_bn_bwd_reduce_x_T<float>(static_cast<const float*>(dy), lddy, static_cast<const float*>(x1), ldx1, mean1, scale1, shift1, static_cast<float*>(g), ldg, M, C, act, red_partial, stream);
+    if (dtype == RD_DTYPE_BF16) return rd_bn_bwd_reduce_x_T<bf16s>(static_cast<const bf16s*>(dy), lddy, static_cast<const bf16s*>(x1), ldx1, mean1, scale1, shift1, static_cast<bf16s*>(g), ldg, M, C, act, red_partial, stream);
+    rd::set_error("rd_bn_bwd_reduce_x_t: bad dtype %d", dtype);
+    return RD_EINVAL;
 }
 
-extern "C" int rd_bn_bwd_apply(const float* g, int32_t ldg, const float* x, int32_t ldx, const float* red_partial, int32_t n_tiles,
-                               int32_t which, const float* gamma, const float* mean, const float* invstd, float* dgamma,
-                               float* dbeta, float* coef_ws, float* dx, int32_t lddx, int64_t M, int32_t C, void* stream) {
+template <typename T>
+static int rd_bn_bwd_apply_T(const T* g, int32_t ldg, const T* x, int32_t ldx, const float* red_partial, int32_t n_tiles, int32_t which, const float* gamma, const float* mean, const float* invstd, float* dgamma, float* dbeta, float* coef_ws, T* dx, int32_t lddx, int64_t M, int32_t C, void* stream) {
     RD_CHECK_ARG(g && x && red_partial && gamma && mean && invstd && coef_ws && dx && (which == 1 || which == 2) && M > 0 &&
                      C % 4 == 0, "bn_bwd_apply: bad arguments");
     hipStream_t s = static_cast<hipStream_t>(stream);
     hipLaunchKernelGGL(bn_bwd_coeffs_kernel, dim3(C), dim3(256), 0, s, red_partial, n_tiles, C, which, (double)M, gamma, invstd,
                        dgamma, dbeta, coef_ws);
     RD_CHECK_LAUNCH("bn_bwd_coeffs_kernel");
-    hipLaunchKernelGGL(bn_bwd_dx_kernel, dim3(ew_grid(M * (C / 4))), dim3(256), 0, s, g, ldg, x, ldx, mean, coef_ws, dx, lddx, M, C,
+    hipLaunchKernelGGL((bn_bwd_dx_kernel<T>), dim3(ew_grid(M * (C / 4))), dim3(256), 0, s, g, ldg, x, ldx, mean, coef_ws, dx, lddx, M, C,
                        (const float*)nullptr, (const float*)nullptr, RD_ACT_NONE);
     RD_CHECK_LAUNCH("bn_bwd_dx_kernel");
     return RD_OK;
 }
+extern "C" int rd_bn_bwd_apply(const float* g, int32_t ldg, const float* x, int32_t ldx, const float* red_partial, int32_t n_tiles, int32_t which, const float* gamma, const float* mean, const float* invstd, float* dgamma, float* dbeta, float* coef_ws, float* dx, int32_t lddx, int64_t M, int32_t C, void* stream) {
+    return rd_bn_bwd_apply_T<float>(g, ldg, x, ldx, red_partial, n_tiles, which, gamma, mean, invstd, dgamma, dbeta, coef_ws, dx, lddx, M, C, stream);
+}
+// storage-typed form: dtype = RD_DTYPE_F32 / RD_DTYPE_BF16 selects the element type of the NHWC tensors (strides in elements)
+extern "C" int rd_bn_bwd_apply_t(int32_t dtype, const void* g, int32_t ldg, const void* x, int32_t ldx, const float* red_partial, int32_t n_tiles, int32_t which, const float* gamma, const float* mean, const float* invstd, float* dgamma, float* dbeta, float* coef_ws, void* dx, int32_t lddx, int64_t M, int32_t C, void* stream) {
+    if (dtype == RD_DTYPE_F32) return rd_bn_bwd_apply_T<float>(static_cast<const float*>(g), ldg, static_cast<const float*>(x), ldx, red_partial, n_tiles, which, gamma, mean, invstd, dgamma, dbeta, coef_ws, static_cast<float*>(dx), lddx, M, C, stream);
+    if (dtype == RD_DTYPE_BF16) return rd_bn_bwd_apply_T<bf16s>(static_cast<const bf16s*>(g), ldg, static_cast<const bf16s*>(x), ldx, red_partial, n_tiles, which, gamma, mean, invstd, dgamma, dbeta, coef_ws, static_cast<bf16s*>(dx), lddx, M, C, stream);
+    rd::set_error("rd_bn_bwd_apply_t: bad dtype %d", dtype);
+    return RD_EINVAL;
+}
 
 // out = act(bn1(x1) + bn2(x2)) (downsample blocks, UpProj joins): sums and both input gradients straight from the raw output
 // gradient -- the activation output is not read, the masked gradient is not written, dy is read once per pass.
-extern "C" int rd_bn_bwd_reduce_x2(const float* dy, int32_t lddy, const float* x1, int32_t ldx1, const float* mean1, const float* scale1,
-                                   const float* shift1, const float* x2, int32_t ldx2, const float* mean2, const float* scale2,
-                                   const float* shift2, int64_t M, int32_t C, int32_t act, float* red_partial, void* stream) {
+template <typename T>
+static int rd_bn_bwd_reduce_x2_T(const T* dy, int32_t lddy, const T* x1, int32_t ldx1, const float* mean1, const float* scale1, const float* shift1, const T* x2, int32_t ldx2, const float* mean2, const float* scale2, const float* shift2, int64_t M, int32_t C, int32_t act, float* red_partial, void* stream) {
     RD_CHECK_ARG(x1 && x2 && scale1 && shift1 && scale2 && shift2 && act != RD_ACT_NONE, "bn_bwd_reduce_x2: bad arguments");
-    return bn_bwd_reduce_impl(dy, lddy, nullptr, 0, x1, ldx1, mean1, x2, ldx2, mean2, nullptr, 0, M, C, act, red_partial, scale1, shift1, stream,
+    return bn_bwd_reduce_impl<T>(dy, lddy, nullptr, 0, x1, ldx1, mean1, x2, ldx2, mean2, nullptr, 0, M, C, act, red_partial, scale1, shift1, stream,
                               scale2, shift2);
 }
-extern "C" int rd_bn_bwd_apply_x2(const float* dy, int32_t lddy, const float* x1, int32_t ldx1, const float* x2, int32_t ldx2,
-                                  const float* red_partial, int32_t n_tiles, const float* gamma1, const float* mean1, const float* invstd1,
-                                  const float* scale1, const float* shift1, const float* gamma2, const float* mean2, const float* invstd2,
-                                  const float* scale2, const float* shift2, int32_t act, float* dgamma1, float* dbeta1, float* dgamma2,
-                                  float* dbeta2, float* coef_ws6, float* dx1, int32_t lddx1, float* dx2, int32_t lddx2, int64_t M,
-                                  int32_t C, void* stream) {
+extern "C" int rd_bn_bwd_reduce_x2(const float* dy, int32_t lddy, const float* x1, int32_t ldx1, const float* mean1, const float* scale1, const float* shift1, const float* x2, int32_t ldx2, const float* mean2, const float* scale2, const float* shift2, int64_t M, int32_t C, int32_t act, float* red_partial, void* stream) {
+    return rd_bn_bwd_reduce_x2_T<float>(dy, lddy, x1, ldx1, mean1, scale1, shift1, x2, ldx2, mean2, scale2, shift2, M, C, act, red_partial, stream);
+}
+// storage-typed form: dtype = RD_DTYPE_F32 / RD_DTYPE_BF16 selects the element type of the NHWC tensors (strides in elements)
+extern "C" int rd_bn_bwd_reduce_x2_t(int32_t dtype, const void* dy, int32_t lddy, const void* x1, int32_t ldx1, const float* mean1, const float* scale1, const float* shift1, const void* x2, int32_t ldx2, const float* mean2, const float* scale2, const float* shift2, int64_t M, int32_t C, int32_t act, float* red_partial, void* stream) {
+    if (dtype == RD_DTYPE_F32) return rd_bn_bwd_reduce_x2_T<float>(static_cast<const float*>(dy), lddy, static_cast<const float*>(x1), ldx1, mean1, scale1, shift1, static_cast<const float*>(x2), ldx2, mean2, scale2, shift2, M, C, act, red_partial, stream);
+    if (dtype == RD_DTYPE_BF16) return rd_bn_bwd_reduce_x2_T<bf16s>(static_cast<const bf16s*>(dy), lddy, static_cast<const bf16s*>(x1), ldx1, mean1, scale1, shift1, static_cast<const bf16s*>(x2), ldx2, mean2, scale2, shift2, M, C, act, red_partial, stream);
+    rd::set_error("rd_bn_bwd_reduce_x2_t: bad dtype %d", dtype);
+    return RD_EINVAL;
+}
+template <typename T>
+static int rd_bn_bwd_apply_x2_T(const T* dy, int32_t lddy, const T* x1, int32_t ldx1, const T* x2, int32_t ldx2, const float* red_partial, int32_t n_tiles, const float* gamma1, const float* mean1, const float* invstd1, const float* scale1, const float* shift1, const float* gamma2, const float* mean2, const float* invstd2, const float* scale2, const float* shift2, int32_t act, float* dgamma1, float* dbeta1, float* dgamma2, float* dbeta2, float* coef_ws6, T* dx1, int32_t lddx1, T* dx2, int32_t lddx2, int64_t M, int32_t C, void* stream) {
     RD_CHECK_ARG(dy && x1 && x2 && red_partial && gamma1 && gamma2 && mean1 && mean2 && invstd1 && invstd2 && scale1 && shift1 && scale2 &&
                      shift2 && coef_ws6 && dx1 && dx2 && M > 0 && C % 4 == 0, "bn_bwd_apply_x2: bad arguments");
     hipStream_t s = static_cast<hipStream_t>(stream);
@@ -549,49 +608,86 @@ extern "C" int rd_bn_bwd_apply_x2(const float* dy, int32_t lddy, const float* x1
     hipLaunchKernelGGL(bn_bwd_coeffs_kernel, dim3(C), dim3(256), 0, s, red_partial, n_tiles, C, 2, (double)M, gamma2, invstd2, dgamma2, dbeta2,
                        coef_ws6 + 3 * C);
     RD_CHECK_LAUNCH("bn_bwd_coeffs_kernel");
-    hipLaunchKernelGGL(bn_bwd_dx2_kernel, dim3(ew_grid(M * (C / 4))), dim3(256), 0, s, dy, lddy, x1, ldx1, x2, ldx2, mean1, mean2, coef_ws6,
+    hipLaunchKernelGGL((bn_bwd_dx2_kernel<T>), dim3(ew_grid(M * (C / 4))), dim3(256), 0, s, dy, lddy, x1, ldx1, x2, ldx2, mean1, mean2, coef_ws6,
                        coef_ws6 + 3 * C, scale1, shift1, scale2, shift2, act, dx1, lddx1, dx2, lddx2, M, C);
     RD_CHECK_LAUNCH("bn_bwd_dx2_kernel");
     return RD_OK;
 }
+extern "C" int rd_bn_bwd_apply_x2(const float* dy, int32_t lddy, const float* x1, int32_t ldx1, const float* x2, int32_t ldx2, const float* red_partial, int32_t n_tiles, const float* gamma1, const float* mean1, const float* invstd1, const float* scale1, const float* shift1, const float* gamma2, const float* mean2, const float* invstd2, const float* scale2, const float* shift2, int32_t act, float* dgamma1, float* dbeta1, float* dgamma2, float* dbeta2, float* coef_ws6, float* dx1, int32_t lddx1, float* dx2, int32_t lddx2, int64_t M, int32_t C, void* stream) {
+    return rd_bn_bwd_apply_x2_T<float>(dy, lddy, x1, ldx1, x2, ldx2, red_partial, n_tiles, gamma1, mean1, invstd1, scale1, shift1, gamma2, mean2, invstd2, scale2, shift2, act, dgamma1, dbeta1, dgamma2, dbeta2, coef_ws6, dx1, lddx1, dx2, lddx2, M, C, stream);
+}
+// storage-typed form: dtype = RD_DTYPE_F32 / RD_DTYPE_BF16 selects the element type of the NHWC tensors (strides in elements)
+extern "C" int rd_bn_bwd_apply_x2_t(int32_t dtype, const void* dy, int32_t lddy, const void* x1, int32_t ldx1, const void* x2, int32_t ldx2, const float* red_partial, int32_t n_tiles, const float* gamma1, const float* mean1, const float* invstd1, const float* scale1, const float* shift1, const float* gamma2, const float* mean2, const float* invstd2, const float* scale2, const float* shift2, int32_t act, float* dgamma1, float* dbeta1, float* dgamma2, float* dbeta2, float* coef_ws6, void* dx1, int32_t lddx1, void* dx2, int32_t lddx2, int64_t M, int32_t C, void* stream) {
+    if (dtype == RD_DTYPE_F32) return rd_bn_bwd_apply_x2_T<float>(static_cast<const float*>(dy), lddy, static_cast<const float*>(x1), ldx1, static_cast<const float*>(x2), ldx2, red_partial, n_tiles, gamma1, mean1, invstd1, scale1, shift1, gamma2, mean2, invstd2, scale2, shift2, act, dgamma1, dbeta1, dgamma2, dbeta2, coef_ws6, static_cast<float*>(dx1), lddx1, static_cast<float*>(dx2), lddx2, M, C, stream);
+    if (dtype == RD_DTYPE_BF16) return rd_bn_bwd_apply_x2_T<bf16s>(static_cast<const bf16s*>(dy), lddy, static_cast<const bf16s*>(x1), ldx1, static_cast<const bf16s*>(x2), ldx2, red_partial, n_tiles, gamma1, mean1, invstd1, scale1, shift1, gamma2, mean2, invstd2, scale2, shift2, act, dgamma1, dbeta1, dgamma2, dbeta2, coef_ws6, static_cast<bf16s*>(dx1), lddx1, static_cast<bf16s*>(dx2), lddx2, M, C, stream);
+    rd::set_error("rd_bn_bwd_apply_x2_t: bad dtype %d", dtype);
+    return RD_EINVAL;
+}
 
 // Apply pass paired with rd_bn_bwd_reduce_x(g = NULL): dy is the raw output gradient, the activation factor is recomputed from x.
-extern "C" int rd_bn_bwd_apply_x(const float* dy, int32_t lddy, const float* x, int32_t ldx, const float* red_partial, int32_t n_tiles,
-                                 const float* gamma, const float* mean, const float* invstd, const float* scale, const float* shift,
-                                 int32_t act, float* dgamma, float* dbeta, float* coef_ws, float* dx, int32_t lddx, int64_t M, int32_t C,
-                                 void* stream) {
+template <typename T>
+static int rd_bn_bwd_apply_x_T(const T* dy, int32_t lddy, const T* x, int32_t ldx, const float* red_partial, int32_t n_tiles, const float* gamma, const float* mean, const float* invstd, const float* scale, const float* shift, int32_t act, float* dgamma, float* dbeta, float* coef_ws, T* dx, int32_t lddx, int64_t M, int32_t C, void* stream) {
     RD_CHECK_ARG(dy && x && red_partial && gamma && mean && invstd && scale && shift && coef_ws && dx && M > 0 && C % 4 == 0,
                  "bn_bwd_apply_x: bad arguments");
     hipStream_t s = static_cast<hipStream_t>(stream);
     hipLaunchKernelGGL(bn_bwd_coeffs_kernel, dim3(C), dim3(256), 0, s, red_partial, n_tiles, C, 1, (double)M, gamma, invstd, dgamma,
                        dbeta, coef_ws);
     RD_CHECK_LAUNCH("bn_bwd_coeffs_kernel");
-    hipLaunchKernelGGL(bn_bwd_dx_kernel, dim3(ew_grid(M * (C / 4))), dim3(256), 0, s, dy, lddy, x, ldx, mean, coef_ws, dx, lddx, M, C,
+    hipLaunchKernelGGL((bn_bwd_dx_kernel<T>), dim3(ew_grid(M * (C / 4))), dim3(256), 0, s, dy, lddy, x, ldx, mean, coef_ws, dx, lddx, M, C,
                        scale, shift, act);
     RD_CHECK_LAUNCH("bn_bwd_dx_kernel");
     return RD_OK;
 }
+extern "C" int rd_bn_bwd_apply_x(const float* dy, int32_t lddy, const float* x, int32_t ldx, const float* red_partial, int32_t n_tiles, const float* gamma, const float* mean, const float* invstd, const float* scale, const float* shift, int32_t act, float* dgamma, float* dbeta, float* coef_ws, float* dx, int32_t lddx, int64_t M, int32_t C, void* stream) {
+    return rd_bn_bwd_apply_x_T<float>(dy, lddy, x, ldx, red_partial, n_tiles, gamma, mean, invstd, scale, shift, act, dgamma, dbeta, coef_ws, dx, lddx, M, C, stream);
+}
+// storage-typed form: dtype = RD_DTYPE_F32 / RD_DTYPE_BF16 selects the element type of the NHWC tensors (strides in elements)
+extern "C" int rd_bn_bwd_apply_x_t(int32_t dtype, const void* dy, int32_t lddy, const void* x, int32_t ldx, const float* red_partial, int32_t n_tiles, const float* gamma, const float* mean, const float* invstd, const float* scale, const float* shift, int32_t act, float* dgamma, float* dbeta, float* coef_ws, void* dx, int32_t lddx, int64_t M, int32_t C, void* stream) {
+    if (dtype == RD_DTYPE_F32) return rd_bn_bwd_apply_x_T<float>(static_cast<const float*>(dy), lddy, static_cast<const float*>(x), ldx, red_partial, n_tiles, gamma, mean, invstd, scale, shift, act, dgamma, dbeta, coef_ws, static_cast<float*>(dx), lddx, M, C, stream);
+    if (dtype == RD_DTYPE_BF16) return rd_bn_bwd_apply_x_T<bf16s>(static_cast<const bf16s*>(dy), lddy, static_cast<const bf16s*>(x), ldx, red_partial, n_tiles, gamma, mean, invstd, scale, shift, act, dgamma, dbeta, coef_ws, static_cast<bf16s*>(dx), lddx, M, C, stream);
+    rd::set_error("rd_bn_bwd_apply_x_t: bad dtype %d", dtype);
+    return RD_EINVAL;
+}
 
-extern "C" int rd_bnact_maxpool_fwd(const float* x, const float* scale, const float* shift, int32_t act, int32_t N, int32_t H,
-                                    int32_t W, int32_t C, float* y, int32_t ldy, uint8_t* idx, void* stream) {
+template <typename T>
+static int rd_bnact_maxpool_fwd_T(const T* x, const float* scale, const float* shift, int32_t act, int32_t N, int32_t H, int32_t W, int32_t C, T* y, int32_t ldy, uint8_t* idx, void* stream) {
     RD_CHECK_ARG(x && scale && shift && y && idx && C % 4 == 0 && ldy % 4 == 0, "bnact_maxpool_fwd: bad arguments");
     const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
-    hipLaunchKernelGGL(bnact_maxpool_fwd_kernel, dim3(ew_grid((int64_t)N * Ho * Wo * (C / 4))), dim3(256), 0,
+    hipLaunchKernelGGL((bnact_maxpool_fwd_kernel<T>), dim3(ew_grid((int64_t)N * Ho * Wo * (C / 4))), dim3(256), 0,
                        static_cast<hipStream_t>(stream), x, scale, shift, act, N, H, W, C, Ho, Wo, y, ldy, idx);
     RD_CHECK_LAUNCH("bnact_maxpool_fwd_kernel");
     return RD_OK;
 }
+extern "C" int rd_bnact_maxpool_fwd(const float* x, const float* scale, const float* shift, int32_t act, int32_t N, int32_t H, int32_t W, int32_t C, float* y, int32_t ldy, uint8_t* idx, void* stream) {
+    return rd_bnact_maxpool_fwd_T<float>(x, scale, shift, act, N, H, W, C, y, ldy, idx, stream);
+}
+// storage-typed form: dtype = RD_DTYPE_F32 / RD_DTYPE_BF16 selects the element type of the NHWC tensors (strides in elements)
+extern "C" int rd_bnact_maxpool_fwd_t(int32_t dtype, const void* x, const float* scale, const float* shift, int32_t act, int32_t N, int32_t H, int32_t W, int32_t C, void* y, int32_t ldy, uint8_t* idx, void* stream) {
+    if (dtype == RD_DTYPE_F32) return rd_bnact_maxpool_fwd_T<float>(static_cast<const float*>(x), scale, shift, act, N, H, W, C, static_cast<float*>(y), ldy, idx, stream);
+    if (dtype == RD_DTYPE_BF16) return rd_bnact_maxpool_fwd_T<bf16s>(static_cast<const bf16s*>(x), scale, shift, act, N, H, W, C, static_cast<bf16s*>(y), ldy, idx, stream);
+    rd::set_error("rd_bnact_maxpool_fwd_t: bad dtype %d", dtype);
+    return RD_EINVAL;
+}
 
-extern "C" int rd_bnact_maxpool_bwd(const float* dy, int32_t lddy, const uint8_t* idx, const float* x, const float* scale,
-                                    const float* shift, int32_t act, int32_t N, int32_t H, int32_t W, int32_t C, float* g,
-                                    void* stream) {
+template <typename T>
+static int rd_bnact_maxpool_bwd_T(const T* dy, int32_t lddy, const uint8_t* idx, const T* x, const float* scale, const float* shift, int32_t act, int32_t N, int32_t H, int32_t W, int32_t C, T* g, void* stream) {
     RD_CHECK_ARG(dy && idx && x && scale && shift && g && C % 4 == 0 && lddy % 4 == 0, "bnact_maxpool_bwd: bad arguments");
     const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
-    hipLaunchKernelGGL(bnact_maxpool_bwd_kernel, dim3(ew_grid((int64_t)N * H * W * (C / 4))), dim3(256), 0,
+    hipLaunchKernelGGL((bnact_maxpool_bwd_kernel<T>), dim3(ew_grid((int64_t)N * H * W * (C / 4))), dim3(256), 0,
                        static_cast<hipStream_t>(stream), dy, lddy, idx, x, scale, shift, act, N, H, W, C, Ho, Wo, g,
                        (const float*)nullptr, (float*)nullptr);
     RD_CHECK_LAUNCH("bnact_maxpool_bwd_kernel");
     return RD_OK;
+}
+extern "C" int rd_bnact_maxpool_bwd(const float* dy, int32_t lddy, const uint8_t* idx, const float* x, const float* scale, const float* shift, int32_t act, int32_t N, int32_t H, int32_t W, int32_t C, float* g, void* stream) {
+    return rd_bnact_maxpool_bwd_T<float>(dy, lddy, idx, x, scale, shift, act, N, H, W, C, g, stream);
+}
+// storage-typed form: dtype = RD_DTYPE_F32 / RD_DTYPE_BF16 selects the element type of the NHWC tensors (strides in elements)
+extern "C" int rd_bnact_maxpool_bwd_t(int32_t dtype, const void* dy, int32_t lddy, const uint8_t* idx, const void* x, const float* scale, const float* shift, int32_t act, int32_t N, int32_t H, int32_t W, int32_t C, void* g, void* stream) {
+    if (dtype == RD_DTYPE_F32) return rd_bnact_maxpool_bwd_T<float>(static_cast<const float*>(dy), lddy, idx, static_cast<const float*>(x), scale, shift, act, N, H, W, C, static_cast<float*>(g), stream);
+    if (dtype == RD_DTYPE_BF16) return rd_bnact_maxpool_bwd_T<bf16s>(static_cast<const bf16s*>(dy), lddy, idx, static_cast<const bf16s*>(x), scale, shift, act, N, H, W, C, static_cast<bf16s*>(g), stream);
+    rd::set_error("rd_bnact_maxpool_bwd_t: bad dtype %d", dtype);
+    return RD_EINVAL;
 }
 
 // Same, and the stem BatchNorm's backward sums in the same pass: red_partial [rd_bnact_maxpool_bwd_tiles(...)][3][C]
@@ -599,17 +695,26 @@ extern "C" int rd_bnact_maxpool_bwd(const float* dy, int32_t lddy, const uint8_t
 extern "C" int rd_bnact_maxpool_bwd_tiles(int32_t N, int32_t H, int32_t W, int32_t C) {
     return ew_grid((int64_t)N * H * W * (C / 4));
 }
-extern "C" int rd_bnact_maxpool_bwd_stats(const float* dy, int32_t lddy, const uint8_t* idx, const float* x, const float* scale,
-                                          const float* shift, int32_t act, int32_t N, int32_t H, int32_t W, int32_t C, float* g,
-                                          const float* mean, float* red_partial, void* stream) {
+template <typename T>
+static int rd_bnact_maxpool_bwd_stats_T(const T* dy, int32_t lddy, const uint8_t* idx, const T* x, const float* scale, const float* shift, int32_t act, int32_t N, int32_t H, int32_t W, int32_t C, T* g, const float* mean, float* red_partial, void* stream) {
     RD_CHECK_ARG(dy && idx && x && scale && shift && g && mean && red_partial && C % 4 == 0 && lddy % 4 == 0,
                  "bnact_maxpool_bwd_stats: bad arguments");
     RD_CHECK_ARG(C >= 4 && 256 % (C / 4) == 0, "bnact_maxpool_bwd_stats: C/4 = %d must divide 256", C / 4);
     const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
     const int Q = C / 4, RL = 256 / Q;
-    hipLaunchKernelGGL(bnact_maxpool_bwd_kernel, dim3(ew_grid((int64_t)N * H * W * (C / 4))), dim3(256),
+    hipLaunchKernelGGL((bnact_maxpool_bwd_kernel<T>), dim3(ew_grid((int64_t)N * H * W * (C / 4))), dim3(256),
                        (size_t)RL * 3 * C * sizeof(float), static_cast<hipStream_t>(stream), dy, lddy, idx, x, scale, shift, act, N, H,
                        W, C, Ho, Wo, g, mean, red_partial);
     RD_CHECK_LAUNCH("bnact_maxpool_bwd_kernel");
     return RD_OK;
+}
+extern "C" int rd_bnact_maxpool_bwd_stats(const float* dy, int32_t lddy, const uint8_t* idx, const float* x, const float* scale, const float* shift, int32_t act, int32_t N, int32_t H, int32_t W, int32_t C, float* g, const float* mean, float* red_partial, void* stream) {
+    return rd_bnact_maxpool_bwd_stats_T<float>(dy, lddy, idx, x, scale, shift, act, N, H, W, C, g, mean, red_partial, stream);
+}
+// storage-typed form: dtype = RD_DTYPE_F32 / RD_DTYPE_BF16 selects the element type of the NHWC tensors (strides in elements)
+extern "C" int rd_bnact_maxpool_bwd_stats_t(int32_t dtype, const void* dy, int32_t lddy, const uint8_t* idx, const void* x, const float* scale, const float* shift, int32_t act, int32_t N, int32_t H, int32_t W, int32_t C, void* g, const float* mean, float* red_partial, void* stream) {
+    if (dtype == RD_DTYPE_F32) return rd_bnact_maxpool_bwd_stats_T<float>(static_cast<const float*>(dy), lddy, idx, static_cast<const float*>(x), scale, shift, act, N, H, W, C, static_cast<float*>(g), mean, red_partial, stream);
+    if (dtype == RD_DTYPE_BF16) return rd_bnact_maxpool_bwd_stats_T<bf16s>(static_cast<const bf16s*>(dy), lddy, idx, static_cast<const bf16s*>(x), scale, shift, act, N, H, W, C, static_cast<bf16s*>(g), mean, red_partial, stream);
+    rd::set_error("rd_bnact_maxpool_bwd_stats_t: bad dtype %d", dtype);
+    return RD_EINVAL;
 }

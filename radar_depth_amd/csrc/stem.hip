@@ -16,9 +16,10 @@ struct StemArgs {
     const float* plane[3];
     long long stride[3];  // elements between consecutive images of each plane
     const float* w;       // packed [49][Cin][Cout]
-    const float* dout;    // wgrad: NHWC [N,Ho,Wo,Cout]
-    float* out;
+    const void* dout;     // wgrad: NHWC [N,Ho,Wo,Cout], fp32 or (io16) bf16
+    void* out;            // forward: NHWC [N,Ho,Wo,Cout], fp32 or (io16) bf16
     float* stat;
+    int io16;             // bf16-storage plans: the NHWC tensors are bf16 (the network input planes stay fp32)
     int Cin, N, H, W, Ho, Wo, Cout, tiles_h, tiles_w;
     int total_tiles, tiles_per_split;  // wgrad
 };
@@ -148,7 +149,9 @@ __global__ __launch_bounds__(256) void stem_fwd_kernel(const StemArgs a) {
                     const int co = nt * 32 + l31;
                     if (co < a.Cout) {
                         const float v = acc[mt][nt][i];
-                        a.out[(((size_t)n * a.Ho + oh) * a.Wo + ow) * a.Cout + co] = v;
+                        const size_t o = (((size_t)n * a.Ho + oh) * a.Wo + ow) * a.Cout + co;
+                        if (a.io16) st1(static_cast<bf16s*>(a.out) + o, v);
+                        else static_cast<float*>(a.out)[o] = v;
                         ssum[nt] += v;
                         ssq[nt] += v * v;
                     }
@@ -245,7 +248,8 @@ __global__ __launch_bounds__(256) void stem_wgrad_kernel(const StemArgs a, float
                 const int oh = r0 + (p >> 5), ow = c0 + (p & 31);
                 v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
                 if (e < NPIX * (BN / 4) && oh < a.Ho && ow < a.Wo && j < a.Cout)
-                    v[u] = *reinterpret_cast<const float4*>(a.dout + (((size_t)n * a.Ho + oh) * a.Wo + ow) * a.Cout + j);
+                    v[u] = a.io16 ? ld4(static_cast<const bf16s*>(a.dout) + (((size_t)n * a.Ho + oh) * a.Wo + ow) * a.Cout + j)
+                                  : ld4(static_cast<const float*>(a.dout) + (((size_t)n * a.Ho + oh) * a.Wo + ow) * a.Cout + j);
             }
 #pragma unroll
             for (int u = 0; u < U; ++u) {
@@ -307,7 +311,8 @@ __global__ __launch_bounds__(256) void stem_wgrad_kernel(const StemArgs a, float
 }
 
 // dx[n,h,w] = sum_{co,kh,kw} dout[n,(h+3-kh)/2,(w+3-kw)/2,co] * w[(kh*7+kw)][ci][co]  over taps of matching parity
-__global__ __launch_bounds__(256) void stem_dgrad_channel_kernel(const float* __restrict__ dout, const float* __restrict__ wp,
+template <typename T>
+__global__ __launch_bounds__(256) void stem_dgrad_channel_kernel(const T* __restrict__ dout, const float* __restrict__ wp,
                                                                  int N, int H, int W, int Ho, int Wo, int Cin, int ci, int Cout,
                                                                  float* __restrict__ dx) {
     __shared__ float s_w[49 * 64];
@@ -328,10 +333,10 @@ __global__ __launch_bounds__(256) void stem_dgrad_channel_kernel(const float* __
             for (int kw = (w + 3) & 1; kw < 7; kw += 2) {
                 const int ow = (w + 3 - kw) >> 1;
                 if (ow < 0 || ow >= Wo) continue;
-                const float* d = dout + (((size_t)n * Ho + oh) * Wo + ow) * Cout;
+                const T* d = dout + (((size_t)n * Ho + oh) * Wo + ow) * Cout;
                 const float* wv = s_w + (kh * 7 + kw) * Cout;
                 for (int co = 0; co < Cout; co += 4) {
-                    const float4 dv = *reinterpret_cast<const float4*>(d + co);
+                    const float4 dv = ld4(d + co);
                     s = fmaf(dv.x, wv[co], s); s = fmaf(dv.y, wv[co + 1], s);
                     s = fmaf(dv.z, wv[co + 2], s); s = fmaf(dv.w, wv[co + 3], s);
                 }
@@ -368,9 +373,10 @@ extern "C" int rd_stem_stat_tiles(int32_t N, int32_t H, int32_t W) {
     return N * cdiv(Ho, 8) * cdiv(Wo, ST_TW);
 }
 
-extern "C" int rd_stem_fwd(const float* const* planes, const int64_t* strides, int32_t Cin, int32_t N, int32_t H, int32_t W,
-                           const float* w_packed, int32_t Cout, float* out, float* stat_partial, void* stream) {
+static int stem_fwd_impl(int io16, const float* const* planes, const int64_t* strides, int32_t Cin, int32_t N, int32_t H, int32_t W,
+                         const float* w_packed, int32_t Cout, void* out, float* stat_partial, void* stream) {
     StemArgs a;
+    a.io16 = io16;
     int rc = stem_fill(a, planes, strides, Cin, N, H, W, Cout);
     if (rc != RD_OK) return rc;
     RD_CHECK_ARG(w_packed && out, "stem_fwd: null tensor");
@@ -394,6 +400,17 @@ extern "C" int rd_stem_fwd(const float* const* planes, const int64_t* strides, i
     return RD_OK;
 }
 
+extern "C" int rd_stem_fwd(const float* const* planes, const int64_t* strides, int32_t Cin, int32_t N, int32_t H, int32_t W,
+                           const float* w_packed, int32_t Cout, float* out, float* stat_partial, void* stream) {
+    return stem_fwd_impl(0, planes, strides, Cin, N, H, W, w_packed, Cout, out, stat_partial, stream);
+}
+// storage-typed forms: dtype selects the element type of the NHWC output / output-gradient tensor (the input planes stay fp32)
+extern "C" int rd_stem_fwd_t(int32_t dtype, const float* const* planes, const int64_t* strides, int32_t Cin, int32_t N, int32_t H,
+                             int32_t W, const float* w_packed, int32_t Cout, void* out, float* stat_partial, void* stream) {
+    RD_CHECK_ARG(dtype == RD_DTYPE_F32 || dtype == RD_DTYPE_BF16, "stem_fwd_t: bad dtype %d", dtype);
+    return stem_fwd_impl(dtype == RD_DTYPE_BF16, planes, strides, Cin, N, H, W, w_packed, Cout, out, stat_partial, stream);
+}
+
 extern "C" int64_t rd_stem_wgrad_workspace_floats(int32_t N, int32_t H, int32_t W, int32_t Cin, int32_t Cout) {
     const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
     const int total = N * cdiv(Ho, 4) * cdiv(Wo, ST_TW);
@@ -404,9 +421,10 @@ extern "C" int64_t rd_stem_wgrad_workspace_floats(int32_t N, int32_t H, int32_t 
     return (int64_t)(n_splits + J) * 49 * Cin * Cout;
 }
 
-extern "C" int rd_stem_wgrad(const float* const* planes, const int64_t* strides, int32_t Cin, int32_t N, int32_t H, int32_t W,
-                             const float* dout, int32_t Cout, float* grad_oihw, float* ws, void* stream) {
+static int stem_wgrad_impl(int io16, const float* const* planes, const int64_t* strides, int32_t Cin, int32_t N, int32_t H, int32_t W,
+                           const void* dout, int32_t Cout, float* grad_oihw, float* ws, void* stream) {
     StemArgs a;
+    a.io16 = io16;
     int rc = stem_fill(a, planes, strides, Cin, N, H, W, Cout);
     if (rc != RD_OK) return rc;
     RD_CHECK_ARG(dout && grad_oihw && ws, "stem_wgrad: null tensor");
@@ -434,14 +452,36 @@ extern "C" int rd_stem_wgrad(const float* const* planes, const int64_t* strides,
     return launch_slab_reduce(ws, n_splits, E, ws + (int64_t)n_splits * E, grad_oihw, 49, Cin, Cout, Cout, Cin, 0, 0, s);
 }
 
-extern "C" int rd_stem_dgrad_channel(const float* dout, const float* w_packed, int32_t N, int32_t H, int32_t W, int32_t Cin,
-                                     int32_t ci, int32_t Cout, float* dx, void* stream) {
+extern "C" int rd_stem_wgrad(const float* const* planes, const int64_t* strides, int32_t Cin, int32_t N, int32_t H, int32_t W,
+                             const float* dout, int32_t Cout, float* grad_oihw, float* ws, void* stream) {
+    return stem_wgrad_impl(0, planes, strides, Cin, N, H, W, dout, Cout, grad_oihw, ws, stream);
+}
+extern "C" int rd_stem_wgrad_t(int32_t dtype, const float* const* planes, const int64_t* strides, int32_t Cin, int32_t N, int32_t H,
+                               int32_t W, const void* dout, int32_t Cout, float* grad_oihw, float* ws, void* stream) {
+    RD_CHECK_ARG(dtype == RD_DTYPE_F32 || dtype == RD_DTYPE_BF16, "stem_wgrad_t: bad dtype %d", dtype);
+    return stem_wgrad_impl(dtype == RD_DTYPE_BF16, planes, strides, Cin, N, H, W, dout, Cout, grad_oihw, ws, stream);
+}
+
+template <typename T>
+static int stem_dgrad_channel_T(const T* dout, const float* w_packed, int32_t N, int32_t H, int32_t W, int32_t Cin,
+                                int32_t ci, int32_t Cout, float* dx, void* stream) {
     RD_CHECK_ARG(dout && w_packed && dx && ci >= 0 && ci < Cin && Cout % 4 == 0 && Cout <= 64, "stem_dgrad_channel: bad arguments");
     const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
     int64_t g = cdiv64((int64_t)N * H * W, 256);
     if (g > (int64_t)num_cus() * 16) g = (int64_t)num_cus() * 16;
-    hipLaunchKernelGGL(stem_dgrad_channel_kernel, dim3((int)g), dim3(256), 0, static_cast<hipStream_t>(stream), dout, w_packed, N,
+    hipLaunchKernelGGL(stem_dgrad_channel_kernel<T>, dim3((int)g), dim3(256), 0, static_cast<hipStream_t>(stream), dout, w_packed, N,
                        H, W, Ho, Wo, Cin, ci, Cout, dx);
     RD_CHECK_LAUNCH("stem_dgrad_channel_kernel");
     return RD_OK;
+}
+extern "C" int rd_stem_dgrad_channel(const float* dout, const float* w_packed, int32_t N, int32_t H, int32_t W, int32_t Cin,
+                                     int32_t ci, int32_t Cout, float* dx, void* stream) {
+    return stem_dgrad_channel_T<float>(dout, w_packed, N, H, W, Cin, ci, Cout, dx, stream);
+}
+extern "C" int rd_stem_dgrad_channel_t(int32_t dtype, const void* dout, const float* w_packed, int32_t N, int32_t H, int32_t W,
+                                       int32_t Cin, int32_t ci, int32_t Cout, float* dx, void* stream) {
+    if (dtype == RD_DTYPE_F32) return stem_dgrad_channel_T<float>(static_cast<const float*>(dout), w_packed, N, H, W, Cin, ci, Cout, dx, stream);
+    if (dtype == RD_DTYPE_BF16) return stem_dgrad_channel_T<bf16s>(static_cast<const bf16s*>(dout), w_packed, N, H, W, Cin, ci, Cout, dx, stream);
+    rd::set_error("stem_dgrad_channel_t: bad dtype %d", dtype);
+    return RD_EINVAL;
 }

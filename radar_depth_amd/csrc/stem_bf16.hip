@@ -21,8 +21,9 @@ struct StemBfArgs {
     const float* plane[3];
     long long stride[3];  // elements between consecutive images of each plane
     const float* w;       // packed fp32 [49][Cin][Cout]
-    float* out;
+    void* out;            // NHWC [N,Ho,Wo,Cout]: fp32, or bf16 when io16
     float* stat;
+    int io16;
     int Cin, N, H, W, Ho, Wo, Cout, tiles_h, tiles_w;
 };
 
@@ -130,14 +131,15 @@ __global__ __launch_bounds__(256) void stem_fwd_bf16_kernel(const StemBfArgs a) 
     for (int mt = 0; mt < MT; ++mt) {
         const int r = r0 + wave * MT + mt;
         if (full) {
-            float* rowp = a.out + (((size_t)n * a.Ho + r) * a.Wo + c0 + 4 * hh) * a.Cout + l31;
+            const size_t rowo = (((size_t)n * a.Ho + r) * a.Wo + c0 + 4 * hh) * a.Cout + l31;
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
-                float* p = rowp + (size_t)((i & 3) + 8 * (i >> 2)) * a.Cout;
+                const size_t po = rowo + (size_t)((i & 3) + 8 * (i >> 2)) * a.Cout;
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt) {
                     const float v = acc[mt][nt][i];
-                    p[nt * 32] = v;
+                    if (a.io16) st1(static_cast<bf16s*>(a.out) + po + nt * 32, v);
+                    else static_cast<float*>(a.out)[po + nt * 32] = v;
                     ssum[nt] += v;
                     ssq[nt] += v * v;
                 }
@@ -152,7 +154,9 @@ __global__ __launch_bounds__(256) void stem_fwd_bf16_kernel(const StemBfArgs a) 
                 const int c = c0 + (i & 3) + 8 * (i >> 2) + 4 * hh;
                 if (r < a.Ho && c < a.Wo && co < a.Cout) {
                     const float v = acc[mt][nt][i];
-                    a.out[(((size_t)n * a.Ho + r) * a.Wo + c) * a.Cout + co] = v;
+                    const size_t o = (((size_t)n * a.Ho + r) * a.Wo + c) * a.Cout + co;
+                    if (a.io16) st1(static_cast<bf16s*>(a.out) + o, v);
+                    else static_cast<float*>(a.out)[o] = v;
                     ssum[nt] += v;
                     ssq[nt] += v * v;
                 }
@@ -187,8 +191,8 @@ __global__ __launch_bounds__(256) void stem_fwd_bf16_kernel(const StemBfArgs a) 
 
 using namespace rd;
 
-extern "C" int rd_stem_fwd_bf16(const float* const* planes, const int64_t* strides, int32_t Cin, int32_t N, int32_t H, int32_t W,
-                                const float* w_packed, int32_t Cout, float* out, float* stat_partial, void* stream) {
+static int stem_fwd_bf16_impl(int io16, const float* const* planes, const int64_t* strides, int32_t Cin, int32_t N, int32_t H, int32_t W,
+                              const float* w_packed, int32_t Cout, void* out, float* stat_partial, void* stream) {
     RD_CHECK_ARG(planes && strides && Cin >= 1 && Cin <= 3 && N > 0 && H > 6 && W > 6, "stem_bf16: bad arguments");
     RD_CHECK_ARG(Cout == 64 || Cout == 16 || Cout == 32, "stem_bf16: Cout=%d unsupported", Cout);
     RD_CHECK_ARG(w_packed && out, "stem_bf16: null tensor");
@@ -198,7 +202,7 @@ extern "C" int rd_stem_fwd_bf16(const float* const* planes, const int64_t* strid
         a.stride[i] = i < Cin ? strides[i] : 0;
         RD_CHECK_ARG(i >= Cin || planes[i], "stem_bf16: null plane %d", i);
     }
-    a.w = w_packed; a.out = out; a.stat = stat_partial;
+    a.w = w_packed; a.out = out; a.stat = stat_partial; a.io16 = io16;
     a.Cin = Cin; a.N = N; a.H = H; a.W = W; a.Cout = Cout;
     a.Ho = (H - 1) / 2 + 1; a.Wo = (W - 1) / 2 + 1;
     a.tiles_h = cdiv(a.Ho, SB_TH); a.tiles_w = cdiv(a.Wo, SB_TW);
@@ -213,4 +217,15 @@ extern "C" int rd_stem_fwd_bf16(const float* const* planes, const int64_t* strid
     else hipLaunchKernelGGL(stem_fwd_bf16_kernel<1>, dim3(grid), dim3(256), lds, s, a);
     RD_CHECK_LAUNCH("stem_fwd_bf16_kernel");
     return RD_OK;
+}
+
+extern "C" int rd_stem_fwd_bf16(const float* const* planes, const int64_t* strides, int32_t Cin, int32_t N, int32_t H, int32_t W,
+                                const float* w_packed, int32_t Cout, float* out, float* stat_partial, void* stream) {
+    return stem_fwd_bf16_impl(0, planes, strides, Cin, N, H, W, w_packed, Cout, out, stat_partial, stream);
+}
+// storage-typed form: dtype selects the element type of the NHWC output tensor
+extern "C" int rd_stem_fwd_bf16_t(int32_t dtype, const float* const* planes, const int64_t* strides, int32_t Cin, int32_t N, int32_t H,
+                                  int32_t W, const float* w_packed, int32_t Cout, void* out, float* stat_partial, void* stream) {
+    RD_CHECK_ARG(dtype == RD_DTYPE_F32 || dtype == RD_DTYPE_BF16, "stem_fwd_bf16_t: bad dtype %d", dtype);
+    return stem_fwd_bf16_impl(dtype == RD_DTYPE_BF16, planes, strides, Cin, N, H, W, w_packed, Cout, out, stat_partial, stream);
 }

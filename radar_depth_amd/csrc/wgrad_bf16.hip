@@ -40,8 +40,8 @@ typedef __bf16 wbf16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned int wu32x4 __attribute__((ext_vector_type(4)));
 
 struct WgradBfArgs {
-    const float* x;
-    const float* dy;
+    const void* x;        // NHWC activations / output gradients: fp32, or bf16 when the kernel is instantiated with IO16
+    const void* dy;
     float* slabs;
     int N, Hx, Wx, Hy, Wy, lh, lw, Cin, Cout, ldi, ldo, IS, OS, S;
     int tiles_h, tiles_w, total_tiles, tiles_per_split, n_splits;
@@ -77,8 +77,11 @@ __device__ __forceinline__ unsigned pack2(float lo, float hi) {
 }
 
 // FULL: all nine taps present (stride-1 3x3, UpProj phase 0) -> no tap tests in the MFMA phase; NK: k-parts = 4 / tile pairs
-template <bool FULL, int NK>
+// IO16: x and dy are bf16 tensors (bf16-storage plans): a unit is one 16-byte load per pixel and the staging waves only interleave
+// the pixel pair (no conversion) -- the staging waves are this kernel's critical path, so this is where bf16 storage pays twice.
+template <bool FULL, int NK, bool IO16>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void wgrad_bf16_kernel(const WgradBfArgs a) {
+    constexpr int ESZ = IO16 ? 2 : 4;
     extern __shared__ __attribute__((aligned(16))) unsigned wsm[];
     // eight waves, two roles: waves 0-3 own the accumulators and issue the MFMAs, waves 4-7 stage the NEXT tile meanwhile
     // (global loads -> registers -> bf16 -> LDS); one barrier per tile hands the buffers over
@@ -148,10 +151,15 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         const int n = tile / tiles_img, tr = tile - n * tiles_img;
         const int th = tr / a.tiles_w, tw = tr - th * a.tiles_w;
         const int r0 = th * WB_R, c0 = tw * WB_TW;
-        const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.x + (size_t)n * a.Hx * a.Wx * a.ldi), 0,
-                                                                            a.Hx * a.Wx * a.ldi * 4, 0x00020000);
-        const __amdgpu_buffer_rsrc_t yr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.dy + (size_t)n * a.Hy * a.Wy * a.ldo), 0,
-                                                                            a.Hy * a.Wy * a.ldo * 4, 0x00020000);
+        const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<char*>(static_cast<const char*>(a.x) + (size_t)n * a.Hx * a.Wx * a.ldi * ESZ), 0, a.Hx * a.Wx * a.ldi * ESZ, 0x00020000);
+        const __amdgpu_buffer_rsrc_t yr = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<char*>(static_cast<const char*>(a.dy) + (size_t)n * a.Hy * a.Wy * a.ldo * ESZ), 0, a.Hy * a.Wy * a.ldo * ESZ, 0x00020000);
+        // one pixel's 8 channels: two float4 (fp32 storage) or 16 raw bytes in the first slot (bf16 storage)
+        auto load_px = [&](__amdgpu_buffer_rsrc_t r, unsigned off, float4& v0, float4& v1) {
+            if constexpr (IO16) v0 = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)off, 0, 0));
+            else wb_load8(r, off, v0, v1);
+        };
 #pragma unroll
         for (int q = 0; q < UX; ++q) {
             int cg, rr, pp;
@@ -162,7 +170,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             for (int px = 0; px < 2; ++px) {
                 const int iw = a.IS * (c0 + 2 * pp - 8 + px) + xb;
                 const bool ok = rowok && iw >= 0 && iw < a.Wx;
-                wb_load8(xr, ok ? (unsigned)(((ih * a.Wx + iw) * a.ldi + c) * 4) : WB_OOB, vx[q][2 * px], vx[q][2 * px + 1]);
+                load_px(xr, ok ? (unsigned)(((ih * a.Wx + iw) * a.ldi + c) * ESZ) : WB_OOB, vx[q][2 * px], vx[q][2 * px + 1]);
             }
         }
 #pragma unroll
@@ -175,11 +183,21 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             for (int px = 0; px < 2; ++px) {
                 const int qc = c0 + 2 * pp + px, iw = a.OS * qc + yb;
                 const bool ok = rowok && qc < a.lw && iw < a.Wy;
-                wb_load8(yr, ok ? (unsigned)(((ih * a.Wy + iw) * a.ldo + c) * 4) : WB_OOB, vy[q][2 * px], vy[q][2 * px + 1]);
+                load_px(yr, ok ? (unsigned)(((ih * a.Wy + iw) * a.ldo + c) * ESZ) : WB_OOB, vy[q][2 * px], vy[q][2 * px + 1]);
             }
         }
     };
     auto put8 = [&](unsigned* d, int plane, const float4 (&v)[4]) {
+        if constexpr (IO16) {
+            // v[0] / v[2]: the two pixels' eight bf16 channels as stored; dword k of the plane = (pixel 0 ch k, pixel 1 ch k)
+            const wu32x4 p0 = __builtin_bit_cast(wu32x4, v[0]), p1 = __builtin_bit_cast(wu32x4, v[2]);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                d[(2 * j) * plane] = (p0[j] & 0xffffu) | (p1[j] << 16);
+                d[(2 * j + 1) * plane] = (p0[j] >> 16) | (p1[j] & 0xffff0000u);
+            }
+            return;
+        }
         d[0 * plane] = pack2(v[0].x, v[2].x);
         d[1 * plane] = pack2(v[0].y, v[2].y);
         d[2 * plane] = pack2(v[0].z, v[2].z);
@@ -406,8 +424,9 @@ extern "C" int rd_wgrad_bf16_plan_info(const RdConvDesc* d, int32_t* out) {
     return RD_OK;
 }
 
-extern "C" int rd_wgrad_bf16(const RdConvDesc* d, const float* in, const float* dout, float* slabs, void* stream) {
+static int wgrad_bf16_impl(bool io16, const RdConvDesc* d, const void* in, const void* dout, float* slabs, void* stream) {
     RD_CHECK_ARG(d && in && dout && slabs, "wgrad_bf16: null argument");
+    RD_CHECK_ARG(!io16 || (d->ldi % 8 == 0 && d->ldo % 8 == 0), "wgrad_bf16: bf16 storage needs channel strides that are multiples of 8");
     WgradBfPlan pl;
     if (!wgrad_bf16_plan(d, pl)) { set_error("wgrad_bf16: unsupported descriptor"); return RD_EINVAL; }
     WgradBfArgs a;
@@ -437,10 +456,11 @@ extern "C" int rd_wgrad_bf16(const RdConvDesc* d, const float* in, const float* 
     const int nk = 4 / (pl.cpi * pl.cpo);
     const dim3 grid(pl.n_cib * pl.n_cob * pl.n_splits * pl.n_pass);
     hipStream_t st = static_cast<hipStream_t>(stream);
-#define RD_WB(FULL_, NK_)                                                                                                       \
-    if (full == FULL_ && nk == NK_) {                                                                                           \
+#define RD_WB(FULL_, NK_) RD_WB2(FULL_, NK_, false) RD_WB2(FULL_, NK_, true)
+#define RD_WB2(FULL_, NK_, IO_)                                                                                                 \
+    if (full == FULL_ && nk == NK_ && io16 == IO_) {                                                                            \
         static bool attr_set = false;                                                                                           \
-        auto k = wgrad_bf16_kernel<FULL_, NK_>;                                                                                 \
+        auto k = wgrad_bf16_kernel<FULL_, NK_, IO_>;                                                                            \
         if (!attr_set) {                                                                                                        \
             RD_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); \
             attr_set = true;                                                                                                    \
@@ -451,8 +471,17 @@ extern "C" int rd_wgrad_bf16(const RdConvDesc* d, const float* in, const float* 
     }
     RD_WB(true, 1) RD_WB(true, 2) RD_WB(true, 4) RD_WB(false, 1) RD_WB(false, 2) RD_WB(false, 4)
 #undef RD_WB
+#undef RD_WB2
     set_error("wgrad_bf16: no kernel for %d k-parts", nk);
     return RD_EINVAL;
+}
+extern "C" int rd_wgrad_bf16(const RdConvDesc* d, const float* in, const float* dout, float* slabs, void* stream) {
+    return wgrad_bf16_impl(false, d, in, dout, slabs, stream);
+}
+// storage-typed form: dtype = RD_DTYPE_BF16 -> in / dout are bf16 NHWC tensors (strides in elements); slabs stay fp32
+extern "C" int rd_wgrad_bf16_t(int32_t dtype, const RdConvDesc* d, const void* in, const void* dout, float* slabs, void* stream) {
+    RD_CHECK_ARG(dtype == RD_DTYPE_F32 || dtype == RD_DTYPE_BF16, "wgrad_bf16_t: bad dtype %d", dtype);
+    return wgrad_bf16_impl(dtype == RD_DTYPE_BF16, d, in, dout, slabs, stream);
 }
 
 extern "C" int rd_wgrad_bf16_reduce(const RdConvDesc* d, const float* slabs, float* grad_oihw, int32_t O, int32_t I, int32_t KH,

@@ -30,7 +30,7 @@ BN_MOMENTUM = 0.1
 
 
 class Act:
-    """A channel slice [c0, c0+C) of an NHWC fp32 buffer t[N,H,W,ld]."""
+    """A channel slice [c0, c0+C) of an NHWC buffer t[N,H,W,ld] (fp32, or bf16 in bf16-storage plans)."""
     __slots__ = ("t", "c0", "C")
 
     def __init__(self, t, c0=0, C_=None):
@@ -59,7 +59,7 @@ class Act:
 
     @property
     def ptr(self):
-        return C.c_void_p(self.t.data_ptr() + 4 * self.c0)
+        return C.c_void_p(self.t.data_ptr() + self.t.element_size() * self.c0)
 
     def chan(self, c0, C_):
         return Act(self.t, self.c0 + c0, C_)
@@ -74,7 +74,7 @@ def _p(t):
 
 class LateFusionPlan:
     def __init__(self, module, batch, height, width, train=True, depth_planes=None, x_source=None, dense_grad_dst=None,
-                 dry_run=False, bf16=False):
+                 dry_run=False, bf16=False, storage="fp32"):
         """module: a radar_depth_amd ResNet_latefusion(2); bf16: run the gconv-lowered convolutions with bf16 operands on
         v_mfma_f32_32x32x16_bf16 (fp32 tensors, fp32 accumulation -- BASELINE.json configs 3/5, opt-in; in train plans the
         forward and input-gradient convolutions and the weight gradients of the >= 32-channel layers -- wgrad_bf16.hip; the
@@ -85,7 +85,13 @@ class LateFusionPlan:
         self.m = module
         self.N, self.H, self.W = batch, height, width
         self.train = train
-        self.bf16 = bool(bf16)
+        # storage: element type of the NHWC activation / gradient tensors in HBM.  "bf16" (BASELINE.json configs 3 / 5) halves the
+        # bytes of every HBM-bound kernel; it implies bf16 conv operands.  Statistics, parameters, gradients of parameters stay fp32.
+        assert storage in ("fp32", "bf16")
+        self.storage = storage
+        self.adt = torch.bfloat16 if storage == "bf16" else torch.float32
+        self.dt = 1 if storage == "bf16" else 0            # RD_DTYPE_BF16 / RD_DTYPE_F32
+        self.bf16 = bool(bf16) or storage == "bf16"
         self.dev = next(module.parameters()).device
         # dry_run: record the op lists against host buffers without ever launching (CPU tests of the host logic)
         assert dry_run or self.dev.type == "cuda", "the HIP path needs the module on a GPU"
@@ -135,7 +141,7 @@ class LateFusionPlan:
         return t
 
     def act(self, N, H, W, Cc):
-        return Act(self.buf(N, H, W, Cc))
+        return Act(self.buf(N, H, W, Cc, dtype=self.adt))
 
     def op(self, lst, name, fn, *args):
         lst.append((name, fn, args))
@@ -214,7 +220,7 @@ class LateFusionPlan:
         stat = self.buf(tiles, 2, cout) if self.train else None
         self.keep.append(d)
         if self.bf16:
-            self.op(lst, name, self.L.rd_gconv_bf16, C.byref(d), x.ptr, _p(wp), out.ptr, C.c_void_p(0), 0, 0, C.c_void_p(0), 0,
+            self.op(lst, name, self.L.rd_gconv_bf16_t, self.dt, C.byref(d), x.ptr, _p(wp), out.ptr, C.c_void_p(0), 0, 0, C.c_void_p(0), 0,
                     _p(stat), self.stream)
         else:
             ws = self._gconv_ws(d, name)
@@ -239,6 +245,12 @@ class LateFusionPlan:
         # (32-wide MFMA tiles: the 16-channel layers are faster on the fp32 kernel -- 42 vs 55 us for the depth encoder's layer1)
         wg_bf16 = (self.bf16 and os.environ.get("RD_WGRAD_BF16", "1") == "1" and min(cin, cout) >= int(os.environ.get("RD_WGRAD_BF16_MINC", "32"))
                    and self.L.rd_wgrad_bf16_supported(C.byref(dwd)) == 1)
+        if self.storage == "bf16":
+            # bf16 tensors: only the bf16 weight-gradient kernel reads them (the 16-channel layers included: a half-empty
+            # 32-wide tile, but half the bytes and no conversion in its staging waves)
+            wg_bf16 = True
+            if self.L.rd_wgrad_bf16_supported(C.byref(dwd)) != 1:
+                raise NotImplementedError("bf16 storage: no bf16 weight-gradient decomposition for %s" % name)
         f_ws, f_wgrad, f_reduce, fam = ((self.L.rd_wgrad_bf16_workspace_floats, self.L.rd_wgrad_bf16, self.L.rd_wgrad_bf16_reduce, "wgrad_bf16")
                                         if wg_bf16 else (self.L.rd_wgrad_workspace_floats, self.L.rd_wgrad, self.L.rd_wgrad_reduce, "wgrad"))
         nws = f_ws(C.byref(dwd))
@@ -253,7 +265,10 @@ class LateFusionPlan:
         def launch_wgrad():
             self.edge(self.bwd, name + ".fork_wgrad", cur, wst)
             with self.on(wst):
-                self.op(self.bwd, name + ".wgrad", f_wgrad, C.byref(dwd), x.ptr, dout.ptr, _p(ws), self.stream)
+                if wg_bf16:
+                    self.op(self.bwd, name + ".wgrad", self.L.rd_wgrad_bf16_t, self.dt, C.byref(dwd), x.ptr, dout.ptr, _p(ws), self.stream)
+                else:
+                    self.op(self.bwd, name + ".wgrad", f_wgrad, C.byref(dwd), x.ptr, dout.ptr, _p(ws), self.stream)
                 self.meta[name + ".wgrad"] = (fam, dwd)
                 for w, off in sorted(ctx["weights"], key=lambda t: t[1]):
                     o, i, kh, kw = w.shape
@@ -277,12 +292,13 @@ class LateFusionPlan:
         self.keep.append(dd)
         if zero_fill:
             assert dx.C == dx.ld, "zero-filled dgrad target must be a whole buffer"
-            self.op(self.bwd, name + ".zero", self.L.rd_fill, dx.ptr, C.c_int64(dx.t.numel()), C.c_float(0.0), self.stream)
+            self.op(self.bwd, name + ".zero", self.L.rd_fill, dx.ptr, C.c_int64(dx.t.numel() * dx.t.element_size() // 4), C.c_float(0.0),
+                    self.stream)
             if addend is not None:
                 raise NotImplementedError("addend with a zero-filled stride-2 dgrad")
         self.meta[name + ".dgrad"] = ("gconv_bf16" if self.bf16 else "gconv", dd)
         if self.bf16:
-            self.op(self.bwd, name + ".dgrad", self.L.rd_gconv_bf16, C.byref(dd), dout.ptr, _p(ctx["wd"]), dx.ptr, C.c_void_p(0), 0, 0,
+            self.op(self.bwd, name + ".dgrad", self.L.rd_gconv_bf16_t, self.dt, C.byref(dd), dout.ptr, _p(ctx["wd"]), dx.ptr, C.c_void_p(0), 0, 0,
                     addend.ptr if addend is not None else C.c_void_p(0), addend.ld if addend is not None else 0,
                     C.c_void_p(0), self.stream)
         else:
@@ -314,7 +330,7 @@ class LateFusionPlan:
             self.pack_jobs.append((w, wp, o, i, kh * kw, cout, off, i, 0, scale[off:off + o], 2 if self.bf16 else 1))
         self.keep += [d, scale]
         if self.bf16:
-            self.op(self.fwd, name, self.L.rd_gconv_bf16, C.byref(d), x.ptr, _p(wp), out.ptr, _p(bias), act,
+            self.op(self.fwd, name, self.L.rd_gconv_bf16_t, self.dt, C.byref(d), x.ptr, _p(wp), out.ptr, _p(bias), act,
                     cout if act_cols is None else act_cols, addend.ptr if addend is not None else C.c_void_p(0),
                     addend.ld if addend is not None else 0, C.c_void_p(0), self.stream)
             self.meta[name] = ("gconv_bf16", d)
@@ -345,7 +361,7 @@ class LateFusionPlan:
         """out = act(bn1(x1) [+ bn2(x2) | + x2])."""
         if out is None:
             out = self.act(x1.N, x1.H, x1.W, x1.C)
-        self.op(self.fwd, name, self.L.rd_bn_act, x1.ptr, x1.ld, _p(co1["scale"]), _p(co1["shift"]),
+        self.op(self.fwd, name, self.L.rd_bn_act_t, self.dt, x1.ptr, x1.ld, _p(co1["scale"]), _p(co1["shift"]),
                 x2.ptr if x2 is not None else C.c_void_p(0), x2.ld if x2 is not None else 0,
                 _p(co2["scale"]) if co2 is not None else C.c_void_p(0), _p(co2["shift"]) if co2 is not None else C.c_void_p(0),
                 out.ptr, out.ld, C.c_int64(x1.M), x1.C, act, self.stream)
@@ -361,14 +377,14 @@ class LateFusionPlan:
         if lone and x2 is None and act != ACT_NONE:
             # lone act(bn(x1)): the activation's sign is recomputed from x1 in both passes -- y is not read and the masked
             # gradient is never materialised
-            self.op(self.bwd, name + ".bwd_reduce", self.L.rd_bn_bwd_reduce_x, dy.ptr, dy.ld, x1.ptr, x1.ld, _p(co1["mean"]),
+            self.op(self.bwd, name + ".bwd_reduce", self.L.rd_bn_bwd_reduce_x_t, self.dt, dy.ptr, dy.ld, x1.ptr, x1.ld, _p(co1["mean"]),
                     _p(co1["scale"]), _p(co1["shift"]), C.c_void_p(0), 0, C.c_int64(M), Cc, act, _p(red), self.stream)
             dx1 = self.act(x1.N, x1.H, x1.W, Cc)
             self._bn_apply_x(name + ".bn1", dy, x1, red, tiles, co1, act, dx1)
             return dx1, None
         if co2 is not None and act != ACT_NONE:
             # act(bn1(x1) + bn2(x2)): same idea for both operands at once (y not read, g not materialised, dy read once per pass)
-            self.op(self.bwd, name + ".bwd_reduce", self.L.rd_bn_bwd_reduce_x2, dy.ptr, dy.ld, x1.ptr, x1.ld, _p(co1["mean"]),
+            self.op(self.bwd, name + ".bwd_reduce", self.L.rd_bn_bwd_reduce_x2_t, self.dt, dy.ptr, dy.ld, x1.ptr, x1.ld, _p(co1["mean"]),
                     _p(co1["scale"]), _p(co1["shift"]), x2.ptr, x2.ld, _p(co2["mean"]), _p(co2["scale"]), _p(co2["shift"]),
                     C.c_int64(M), Cc, act, _p(red), self.stream)
             dx1 = self.act(x1.N, x1.H, x1.W, Cc)
@@ -376,7 +392,7 @@ class LateFusionPlan:
                 dx2 = self.act(x2.N, x2.H, x2.W, Cc)
             b1, b2 = co1["bn"], co2["bn"]
             coef = self.buf(6 * Cc)
-            self.op(self.bwd, name + ".bwd_apply", self.L.rd_bn_bwd_apply_x2, dy.ptr, dy.ld, x1.ptr, x1.ld, x2.ptr, x2.ld, _p(red), tiles,
+            self.op(self.bwd, name + ".bwd_apply", self.L.rd_bn_bwd_apply_x2_t, self.dt, dy.ptr, dy.ld, x1.ptr, x1.ld, x2.ptr, x2.ld, _p(red), tiles,
                     _p(b1.weight), _p(co1["mean"]), _p(co1["invstd"]), _p(co1["scale"]), _p(co1["shift"]),
                     _p(b2.weight), _p(co2["mean"]), _p(co2["invstd"]), _p(co2["scale"]), _p(co2["shift"]), act,
                     _p(self.grad_of(b1.weight)), _p(self.grad_of(b1.bias)), _p(self.grad_of(b2.weight)), _p(self.grad_of(b2.bias)),
@@ -385,7 +401,7 @@ class LateFusionPlan:
         # with no activation g == dy: skip the copy and let the apply pass read dy directly
         g = self.act(x1.N, x1.H, x1.W, Cc) if act != ACT_NONE else dy
         if True:
-            self.op(self.bwd, name + ".bwd_reduce", self.L.rd_bn_bwd_reduce, dy.ptr, dy.ld, y.ptr if y is not None else C.c_void_p(0),
+            self.op(self.bwd, name + ".bwd_reduce", self.L.rd_bn_bwd_reduce_t, self.dt, dy.ptr, dy.ld, y.ptr if y is not None else C.c_void_p(0),
                     y.ld if y is not None else 0, x1.ptr, x1.ld, _p(co1["mean"]),
                     x2.ptr if co2 is not None else C.c_void_p(0), x2.ld if co2 is not None else 0,
                     _p(co2["mean"]) if co2 is not None else C.c_void_p(0), g.ptr if act != ACT_NONE else C.c_void_p(0), g.ld,
@@ -402,14 +418,14 @@ class LateFusionPlan:
     def _bn_apply(self, name, g, x, red, tiles, which, co, dx):
         bn = co["bn"]
         coef = self.buf(3 * co["C"])
-        self.op(self.bwd, name + ".bwd_apply", self.L.rd_bn_bwd_apply, g.ptr, g.ld, x.ptr, x.ld, _p(red), tiles, which,
+        self.op(self.bwd, name + ".bwd_apply", self.L.rd_bn_bwd_apply_t, self.dt, g.ptr, g.ld, x.ptr, x.ld, _p(red), tiles, which,
                 _p(bn.weight), _p(co["mean"]), _p(co["invstd"]), _p(self.grad_of(bn.weight)), _p(self.grad_of(bn.bias)),
                 _p(coef), dx.ptr, dx.ld, C.c_int64(x.M), co["C"], self.stream)
 
     def _bn_apply_x(self, name, dy, x, red, tiles, co, act, dx):
         bn = co["bn"]
         coef = self.buf(3 * co["C"])
-        self.op(self.bwd, name + ".bwd_apply", self.L.rd_bn_bwd_apply_x, dy.ptr, dy.ld, x.ptr, x.ld, _p(red), tiles,
+        self.op(self.bwd, name + ".bwd_apply", self.L.rd_bn_bwd_apply_x_t, self.dt, dy.ptr, dy.ld, x.ptr, x.ld, _p(red), tiles,
                 _p(bn.weight), _p(co["mean"]), _p(co["invstd"]), _p(co["scale"]), _p(co["shift"]), act,
                 _p(self.grad_of(bn.weight)), _p(self.grad_of(bn.bias)), _p(coef), dx.ptr, dx.ld, C.c_int64(x.M), co["C"], self.stream)
 
@@ -429,13 +445,13 @@ class LateFusionPlan:
         self.keep += [pl, st]
         # bf16 plans: the 64-channel RGB stem forward runs on the bf16 matrix cores too (220 vs 574 us at b=16; its weight
         # gradient stays fp32); the 16-channel depth stem is faster on the fp32 kernel (175 vs 330 us)
-        self.op(self.fwd, name, self.L.rd_stem_fwd_bf16 if (self.bf16 and cout >= 64) else self.L.rd_stem_fwd, pl, st, cin, N, H, W, _p(wp), cout,
-                raw.ptr, _p(stat), self.stream)
+        self.op(self.fwd, name, self.L.rd_stem_fwd_bf16_t if (self.bf16 and cout >= 64) else self.L.rd_stem_fwd_t, self.dt, pl, st, cin, N, H, W,
+                _p(wp), cout, raw.ptr, _p(stat), self.stream)
         co = self.bn_coeffs(name + ".bn", bn, stat, tiles, cout, 0, N * Hc * Wc)
         Hp, Wp = (Hc - 1) // 2 + 1, (Wc - 1) // 2 + 1
         pooled = self.act(N, Hp, Wp, cout)
         idx = self.buf(N, Hp, Wp, cout, dtype=torch.uint8)
-        self.op(self.fwd, name + ".bnact_pool", self.L.rd_bnact_maxpool_fwd, raw.ptr, _p(co["scale"]), _p(co["shift"]), act, N, Hc, Wc,
+        self.op(self.fwd, name + ".bnact_pool", self.L.rd_bnact_maxpool_fwd_t, self.dt, raw.ptr, _p(co["scale"]), _p(co["shift"]), act, N, Hc, Wc,
                 cout, pooled.ptr, pooled.ld, _p(idx), self.stream)
         self.taps[out_name] = pooled
         return pooled, dict(name=name, pl=pl, st=st, cin=cin, cout=cout, raw=raw, wp=wp, co=co, idx=idx, act=act, conv=conv,
@@ -449,7 +465,7 @@ class LateFusionPlan:
         # (g and x are in registers there): no separate reduce pass over the two largest tensors of the network
         tiles = self.L.rd_bnact_maxpool_bwd_tiles(N, ctx["Hc"], ctx["Wc"], cout)
         red = self.buf(tiles, 3, cout)
-        self.op(self.bwd, ctx["name"] + ".pool_bwd", self.L.rd_bnact_maxpool_bwd_stats, dpooled.ptr, dpooled.ld, _p(ctx["idx"]), raw.ptr,
+        self.op(self.bwd, ctx["name"] + ".pool_bwd", self.L.rd_bnact_maxpool_bwd_stats_t, self.dt, dpooled.ptr, dpooled.ld, _p(ctx["idx"]), raw.ptr,
                 _p(co["scale"]), _p(co["shift"]), ctx["act"], N, ctx["Hc"], ctx["Wc"], cout, g.ptr, _p(co["mean"]), _p(red), self.stream)
         dx = self.act(raw.N, raw.H, raw.W, cout)
         self._bn_apply(ctx["name"] + ".bn.bn1", g, raw, red, tiles, 1, co, dx)
@@ -459,11 +475,11 @@ class LateFusionPlan:
         wst = 2 if cur == 0 else cur
         self.edge(self.bwd, ctx["name"] + ".fork_wgrad", cur, wst)
         with self.on(wst):
-            self.op(self.bwd, ctx["name"] + ".wgrad", self.L.rd_stem_wgrad, ctx["pl"], ctx["st"], cin, N, H, W, dx.ptr, cout,
+            self.op(self.bwd, ctx["name"] + ".wgrad", self.L.rd_stem_wgrad_t, self.dt, ctx["pl"], ctx["st"], cin, N, H, W, dx.ptr, cout,
                     _p(self.grad_of(ctx["conv"].weight)), _p(ws), self.stream)
         if dgrad_channel is not None:
             ci, dst = dgrad_channel
-            self.op(self.bwd, ctx["name"] + ".dgrad_ch", self.L.rd_stem_dgrad_channel, dx.ptr, _p(ctx["wp"]), N, H, W, cin, ci, cout,
+            self.op(self.bwd, ctx["name"] + ".dgrad_ch", self.L.rd_stem_dgrad_channel_t, self.dt, dx.ptr, _p(ctx["wp"]), N, H, W, cin, ci, cout,
                     _p(dst), self.stream)
 
     def _block(self, name, blk, x, out=None):
@@ -544,7 +560,7 @@ class LateFusionPlan:
         M, tiles = R.M, self.L.rd_bn_bwd_tiles(C.c_int64(R.M))
         red = self.buf(tiles, 3, half)
         x1, co = R.chan(0, half), ctx["co_u1"]
-        self.op(self.bwd, name + ".bn1.bwd_reduce", self.L.rd_bn_bwd_reduce_x, dy1.ptr, dy1.ld, x1.ptr, x1.ld, _p(co["mean"]),
+        self.op(self.bwd, name + ".bn1.bwd_reduce", self.L.rd_bn_bwd_reduce_x_t, self.dt, dy1.ptr, dy1.ld, x1.ptr, x1.ld, _p(co["mean"]),
                 _p(co["scale"]), _p(co["shift"]), C.c_void_p(0), 0, C.c_int64(M), half, ACT_RELU, _p(red), self.stream)
         self._bn_apply_x(name + ".bn1", dy1, x1, red, tiles, co, ACT_RELU, dR.chan(0, half))
         dx = self.conv_bwd(ctx["cR"], dR)
@@ -635,7 +651,7 @@ class LateFusionPlan:
         m, N = self.m, self.N
         self.z = z
         self.dmap = self.buf(N, z.H, z.W)
-        self.op(self.fwd, "conv3", self.L.rd_head_conv_fwd, z.ptr, z.ld, _p(m.conv3.weight), N, z.H, z.W, z.C, _p(self.dmap), self.stream)
+        self.op(self.fwd, "conv3", self.L.rd_head_conv_fwd_t, self.dt, z.ptr, z.ld, _p(m.conv3.weight), N, z.H, z.W, z.C, _p(self.dmap), self.stream)
         self.pred = self.buf(N, 1, self.Ho, self.Wo)
         self.op(self.fwd, "bilinear", self.L.rd_bilinear_fwd, _p(self.dmap), N, z.H, z.W, _p(self.pred), self.Ho, self.Wo, self.stream)
 
@@ -696,7 +712,7 @@ class LateFusionPlan:
         self.op(self.bwd, "bilinear.bwd", self.L.rd_bilinear_bwd, _p(self.dpred), N, self.Ho, self.Wo, _p(ddm), z.H, z.W, self.stream)
         dz = self.act(N, z.H, z.W, z.C)
         ws = self.buf(int(self.L.rd_head_conv_bwd_workspace_floats(N, z.H, z.W, z.C)))
-        self.op(self.bwd, "conv3.bwd", self.L.rd_head_conv_bwd, z.ptr, z.ld, _p(m.conv3.weight), _p(ddm), N, z.H, z.W, z.C, dz.ptr, dz.ld,
+        self.op(self.bwd, "conv3.bwd", self.L.rd_head_conv_bwd_t, self.dt, z.ptr, z.ld, _p(m.conv3.weight), _p(ddm), N, z.H, z.W, z.C, dz.ptr, dz.ld,
                 _p(self.grad_of(m.conv3.weight)), _p(ws), self.stream)
         for ctx in reversed(self.ups):
             dz = self._upproj_bwd(ctx, dz)

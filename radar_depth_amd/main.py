@@ -107,13 +107,19 @@ class HipTrainStep:
     torch.autocast(bfloat16) analogue for BASELINE.json configs 2/4; tolerances in tests/test_gpu_bf16.py."""
 
     def __init__(self, model, batch, height, width, lr=0.01, momentum=0.9, weight_decay=1e-4, loss_weights=None, use_graph=False,
-                 operands="fp32", criterion="l1", comm="auto"):
+                 operands="fp32", criterion="l1", comm="auto", storage="fp32"):
         """criterion: "l1" (MaskedL1Loss, the default of utils.parse_command) or "l2" (MaskedMSELoss, `-c l2`, main.py:294-305).
         comm: "rccl" = the C ABI's own communicator (radar_depth_amd.comm, rd_allreduce_bucket on a dedicated communication
         stream, event-chained behind each backward segment); "torch" = torch.distributed.all_reduce (the cross-check);
         "auto" = rccl when radar_depth_amd.comm is initialised, else torch when torch.distributed is, else single-GPU."""
         from .model.multistage_model import ResNet_multistage
         assert criterion in ("l1", "l2"), criterion
+        # storage="bf16": NHWC activations and their gradients live in HBM as bf16 (implies bf16 conv operands); BatchNorm
+        # statistics, losses, parameters, their gradients and the optimizer stay fp32 -- BASELINE.json configs 3 / 5
+        assert storage in ("fp32", "bf16"), storage
+        if storage == "bf16":
+            operands = "bf16"
+        self.operands, self.storage = operands, storage
         self.model = model
         self.L = lib()
         self._f_sums, self._f_bwd = ((self.L.rd_masked_l1_sums, self.L.rd_masked_l1_bwd) if criterion == "l1" else
@@ -121,12 +127,12 @@ class HipTrainStep:
         model.train()
         self.multistage = isinstance(model, ResNet_multistage)
         if self.multistage:
-            self.mp = model._plans(batch, height, width, True, bf16=operands == "bf16")
+            self.mp = model._plans(batch, height, width, True, bf16=operands == "bf16", storage=storage)
             self.plans = [self.mp.p1, self.mp.p2]
         else:
             assert isinstance(model, ResNet_latefusion)
             self.mp = None
-            self.plans = [model._plan(batch, height, width, True, bf16=operands == "bf16")]
+            self.plans = [model._plan(batch, height, width, True, bf16=operands == "bf16", storage=storage)]
         self.plan = self.plans[0]
         self.st = model._ensure_arenas()
         self._arena_version = self.st["version"]
@@ -390,21 +396,21 @@ class HipInference:
     """Eval-mode forward of the validate() body (main.py:564-595: model.eval(), no_grad, batch 1) as one hipGraph:
     BatchNorm folded into the convolutions (scale in the packed weights, shift/ReLU/residual in the conv epilogue)."""
 
-    def __init__(self, model, batch, height, width, use_graph=True, operands="fp32"):
+    def __init__(self, model, batch, height, width, use_graph=True, operands="fp32", storage="fp32"):
         """operands: "fp32" (default; the parity path, within 1e-3 of the reference) or "bf16" (conv operands rounded to bf16,
         fp32 accumulation and tensors: csrc/gconv_bf16.hip; tolerance stated in tests/test_gpu_bf16.py)."""
         from .model.multistage_model import ResNet_multistage
-        assert operands in ("fp32", "bf16")
-        bf16 = operands == "bf16"
+        assert operands in ("fp32", "bf16") and storage in ("fp32", "bf16")
+        bf16 = operands == "bf16" or storage == "bf16"
         self.L = lib()
         model.eval()
         self.multistage = isinstance(model, ResNet_multistage)
         if self.multistage:
-            self.mp = model._plans(batch, height, width, False, bf16=bf16)
+            self.mp = model._plans(batch, height, width, False, bf16=bf16, storage=storage)
             self.plans = [self.mp.p1, self.mp.p2]
         else:
             self.mp = None
-            self.plans = [model._plan(batch, height, width, False, bf16=bf16)]
+            self.plans = [model._plan(batch, height, width, False, bf16=bf16, storage=storage)]
         self.use_graph = use_graph
         self.graph = None
         self.calls = 0

@@ -81,10 +81,23 @@ def test_bf16_plan_flag_reaches_the_plan(tmp_path):
     def fn_names(ops):
         return [getattr(fn, "__name__", str(fn)) for _, fn, _ in ops]
     fwd, bwd = fn_names(plan.fwd), fn_names(plan.bwd)
-    assert "rd_gconv_bf16" in fwd and "rd_gconv_ws" not in fwd and "rd_gconv_ws" not in bwd
-    assert fwd.count("rd_stem_fwd_bf16") == 1 and fwd.count("rd_stem_fwd") == 1          # RGB stem bf16, depth stem fp32
-    assert "rd_wgrad_bf16" in bwd and "rd_wgrad" in bwd                                   # >= 32 channels vs 16-channel layers
+    assert "rd_gconv_bf16_t" in fwd and "rd_gconv_ws" not in fwd and "rd_gconv_ws" not in bwd
+    assert fwd.count("rd_stem_fwd_bf16_t") == 1 and fwd.count("rd_stem_fwd_t") == 1      # RGB stem bf16, depth stem fp32
+    assert "rd_wgrad_bf16_t" in bwd and "rd_wgrad" in bwd                                 # >= 32 channels vs 16-channel layers
     fam = {k: v[0] for k, v in plan.meta.items()}
     assert fam["layer1.0.conv1.wgrad"] == "wgrad_bf16" and fam["layer1_depth.0.conv1.wgrad"] == "wgrad"
+    assert plan.dt == 0 and plan.cat.t.dtype == torch.float32                             # bf16 OPERANDS: tensors stay fp32
     plan32 = LateFusionPlan(m, 2, 97, 161, train=True, dry_run=True)
-    assert not any(n.endswith("bf16") for n in fn_names(plan32.fwd) + fn_names(plan32.bwd))
+    assert not any("bf16" in n for n in fn_names(plan32.fwd) + fn_names(plan32.bwd))
+    # bf16 STORAGE: every NHWC tensor is bf16, every weight gradient runs on the bf16 kernel (nothing else reads bf16 tensors),
+    # every storage-typed op carries dtype 1 as its first argument
+    plan16 = LateFusionPlan(m, 2, 97, 161, train=True, dry_run=True, storage="bf16")
+    assert plan16.bf16 and plan16.dt == 1 and plan16.cat.t.dtype == torch.bfloat16 and plan16.z.t.dtype == torch.bfloat16
+    assert plan16.pred.dtype == torch.float32 and plan16.x_in.dtype == torch.float32
+    bwd16 = fn_names(plan16.bwd)
+    assert "rd_wgrad" not in bwd16 and "rd_wgrad_reduce" not in bwd16 and bwd16.count("rd_wgrad_bf16_t") == bwd.count("rd_wgrad_bf16_t") + bwd.count("rd_wgrad")
+    for _, fn, args in plan16.fwd + plan16.bwd:
+        if getattr(fn, "__name__", "").endswith("_t"):
+            assert args[0] == 1
+    assert plan16.taps["layer1.0"].ptr.value - plan16.taps["layer1.0"].t.data_ptr() == 0
+    assert plan16.cat.chan(512, 128).ptr.value - plan16.cat.t.data_ptr() == 2 * 512
