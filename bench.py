@@ -296,6 +296,12 @@ def main():
                                                   for k, v in sorted(agg.items(), key=lambda kv: -kv[1][0])}}
     if world > 1:
         torch.distributed.barrier()
+    # communicator teardown BEFORE the result line, and C stdio flushed around it: RCCL writes its version banner through C
+    # stdio, which would otherwise land after the JSON line when the buffers drain at exit
+    if comm_used == "rccl":
+        from radar_depth_amd import comm as rd_comm
+        rd_comm.destroy()
+    C.CDLL(None).fflush(None)
     if rank == 0:
         if multistage:
             out["metric"] = "training samples/sec, %s b=%d %dx%d rgbd" % (args.arch, args.batch, args.height, args.width)
@@ -304,9 +310,6 @@ def main():
         if world == 1 and not args.no_cpu_baseline and not multistage and not bf16:
             out["cpu_baseline"] = cpu_baseline(args.height, args.width)
         print(json.dumps(out), flush=True)
-    if comm_used == "rccl":
-        from radar_depth_amd import comm as rd_comm
-        rd_comm.destroy()
     if torch.distributed.is_available() and torch.distributed.is_initialized():
         torch.distributed.destroy_process_group()
 
