@@ -39,8 +39,24 @@ def desc_flops(d):
     return 2.0 * f * d.N * d.Cin * d.Cout
 
 
-def kernel_identity(L, kind, d):
+def desc_bytes(kind, d, esz):
+    """Algorithmic HBM bytes of one launch: every operand tensor read once, the result written once (weights and halos ignored,
+    SURVEY.md 8d / appendix B).  Convolution: non-zero input + output; weight gradient: input + output gradient."""
+    return float(esz) * d.N * (d.Hi * d.Wi * d.Cin + d.Ho * d.Wo * d.Cout)
+
+
+def kernel_identity(L, kind, d, io16=False):
     """Kernel name as rocprofv3 prints it (spaces removed), from the library's own plan for the descriptor."""
+    tb_ = lambda v: "true" if v else "false"
+    if kind == "gconv_bf16":
+        info = (C.c_int32 * 8)()
+        L.rd_gconv_bf16_plan_info(C.byref(d), info)           # MT, NT, pipe*1000 + CKP, ...
+        return "gconv_bf16_kernel<%d,%d,%s,%s>" % (info[0], info[1], tb_(info[2] >= 1000), tb_(io16))
+    if kind == "wgrad_bf16":
+        info = (C.c_int32 * 8)()
+        L.rd_wgrad_bf16_plan_info(C.byref(d), info)           # cpi, cpo, ...
+        full = d.n_phases == 1 and d.in_stride == 1 and d.phase[0].n_taps == 9
+        return "wgrad_bf16_kernel<%s,%d,%s>" % (tb_(full), 4 // (info[0] * info[1]), tb_(io16))
     if kind == "gconv":
         info = (C.c_int32 * 10)()
         L.rd_gconv_plan_info(C.byref(d), info)                 # info[4] = pipelined*10000 + ksplit*100 + CKW
@@ -92,11 +108,12 @@ def instrumented_pass(ts):
             fam[family] = fam.get(family, 0.0) + ms
             if name in plan.meta:
                 kind, d = plan.meta[name]
-                k = kernel_identity(L, kind, d)
-                a = agg.setdefault(k, [0.0, 0, 0.0])
+                k = kernel_identity(L, kind, d, plan.storage == "bf16")
+                a = agg.setdefault(k, [0.0, 0, 0.0, 0.0])
                 a[0] += ms
                 a[1] += 1
                 a[2] += desc_flops(d)
+                a[3] += desc_bytes(kind, d, 2 if plan.storage == "bf16" else 4)
     return agg, fam
 
 
@@ -270,7 +287,7 @@ def main():
                 100 * out["value"] / world / (15181 * 360000.0 / (args.height * args.width)), 100 * out["value"] / world / (17527 * 360000.0 / (args.height * args.width)))
     if rank == 0 and not args.no_roofline and not multistage and not bf16:
         agg, fam = instrumented_pass(ts)
-        name, (ms, n, flops) = max(agg.items(), key=lambda kv: kv[1][0])
+        name, (ms, n, flops, _) = max(agg.items(), key=lambda kv: kv[1][0])
         achieved = flops / (ms * 1e-3) / 1e12
         # algorithmic work of one training sample (UpProj zero-skipped, stem dgrads omitted): 104.57 GFLOP at 450x800
         alg_gflop = 104.57 * (args.height * args.width) / (450.0 * 800.0)
@@ -279,7 +296,8 @@ def main():
         # profiles/r01_pmc_traffic.json; collected with tools described in DESIGN.md, not re-measured on every run)
         traffic = None
         try:
-            tj = json.load(open(os.path.join(REPO, "profiles", "r01_pmc_traffic.json")))["kernels"]
+            pmc = "r02_pmc_traffic.json" if os.path.exists(os.path.join(REPO, "profiles", "r02_pmc_traffic.json")) else "r01_pmc_traffic.json"
+            tj = json.load(open(os.path.join(REPO, "profiles", pmc)))["kernels"]
             key = name.replace(" ", "")
             if key in tj:
                 traffic = tj[key]["hbm_read_bytes_per_launch"] + tj[key]["hbm_write_bytes_per_launch"]
@@ -293,6 +311,27 @@ def main():
                            "step_frac_of_peak": round(step_flops * args.steps / dt / 1e12 / PEAK_FP32_TFLOPS, 4),
                            "eager_ms_by_family": {k: round(v, 3) for k, v in sorted(fam.items(), key=lambda kv: -kv[1])},
                            "eager_ms_by_kernel": {k: [round(v[0], 3), v[1], round(v[2] / (v[0] * 1e-3) / 1e12, 1)]
+                                                  for k, v in sorted(agg.items(), key=lambda kv: -kv[1][0])}}
+    if rank == 0 and not args.no_roofline and not multistage and bf16:
+        # bf16 configurations are HBM-bound (arithmetic intensity ~ the ridge): the roofline of the dominant kernel is
+        # algorithmic bytes per launch (operand tensors once in, result once out) / its average duration against 8 TB/s
+        agg, fam = instrumented_pass(ts)
+        name, (ms, n, flops, nbytes) = max(agg.items(), key=lambda kv: kv[1][0])
+        achieved = nbytes / (ms * 1e-3) / 1e9
+        traffic = None
+        try:
+            tj = json.load(open(os.path.join(REPO, "profiles", "r02_pmc_traffic_bf16_storage.json" if args.storage == "bf16"
+                                             else "r02_pmc_traffic_bf16_operands.json")))["kernels"]
+            if name in tj:
+                traffic = tj[name]["hbm_read_bytes_per_launch"] + tj[name]["hbm_write_bytes_per_launch"]
+        except (OSError, KeyError, ValueError):
+            pass
+        out["roofline"] = {"bound": "hbm", "kernel": name, "launches_per_step": n, "avg_launch_us": round(1e3 * ms / n, 2),
+                           "achieved": round(achieved, 1), "peak": 8000.0, "unit": "GB/s", "frac": round(achieved / 8000.0, 4),
+                           "traffic": traffic, "algorithmic_bytes_per_launch": int(nbytes / n),
+                           "kernel_tflops": round(flops / (ms * 1e-3) / 1e12, 1),
+                           "eager_ms_by_family": {k: round(v, 3) for k, v in sorted(fam.items(), key=lambda kv: -kv[1])},
+                           "eager_ms_by_kernel": {k: [round(v[0], 3), v[1], round(v[3] / (v[0] * 1e-3) / 1e9, 0)]
                                                   for k, v in sorted(agg.items(), key=lambda kv: -kv[1][0])}}
     if world > 1:
         torch.distributed.barrier()
