@@ -74,7 +74,7 @@ def _p(t):
 
 class LateFusionPlan:
     def __init__(self, module, batch, height, width, train=True, depth_planes=None, x_source=None, dense_grad_dst=None,
-                 dry_run=False, bf16=False, storage="fp32"):
+                 dry_run=False, bf16=False, storage="fp32", segment_joins=True):
         """module: a radar_depth_amd ResNet_latefusion(2); bf16: run the gconv-lowered convolutions with bf16 operands on
         v_mfma_f32_32x32x16_bf16 (fp32 tensors, fp32 accumulation -- BASELINE.json configs 3/5, opt-in; in train plans the
         forward and input-gradient convolutions and the weight gradients of the >= 32-channel layers -- wgrad_bf16.hip; the
@@ -85,6 +85,11 @@ class LateFusionPlan:
         self.m = module
         self.N, self.H, self.W = batch, height, width
         self.train = train
+        # segment_joins=False: the backward's bucket boundaries do not join the side streams into the main one (the main chain
+        # keeps running ahead of the weight-gradient stream); each boundary instead records one event per side stream in
+        # self.segment_events, which a data-parallel caller makes its communication stream wait for.  Only the end of backward joins.
+        self.segment_joins = bool(segment_joins)
+        self.segment_events = []
         # storage: element type of the NHWC activation / gradient tensors in HBM.  "bf16" (BASELINE.json configs 3 / 5) halves the
         # bytes of every HBM-bound kernel; it implies bf16 conv operands.  Statistics, parameters, gradients of parameters stay fp32.
         assert storage in ("fp32", "bf16")
@@ -702,9 +707,18 @@ class LateFusionPlan:
         self.dx_dense = None
         self.bwd_segments = []
 
-        def end_segment(prefixes):
-            self.edge(self.bwd, "join1", 1, 0)
-            self.edge(self.bwd, "join2", 2, 0)
+        def end_segment(prefixes, last=False):
+            evs = []
+            if last or self.segment_joins:
+                self.edge(self.bwd, "join1", 1, 0)
+                self.edge(self.bwd, "join2", 2, 0)
+            elif self.multi_stream:
+                for q in (1, 2):
+                    if (self.stream_mask >> (q - 1)) & 1:
+                        ev = self._event()
+                        self.op(self.bwd, "segment_end%d.record" % q, self.L.rd_event_record, ev, self.streams[q])
+                        evs.append(ev)
+            self.segment_events.append(evs)
             begin = self.bwd_segments[-1][1] if self.bwd_segments else 0
             self.bwd_segments.append((begin, len(self.bwd), prefixes))
 
@@ -747,7 +761,7 @@ class LateFusionPlan:
             for ctx in reversed(self.blocks_d[0:4]):
                 gd = self._block_bwd(ctx, gd)
             self._stem_bwd(self.c_stem_d, gd, dgrad_channel=dense)
-        end_segment(("conv1", "bn1", "layer1", "layer2", "conv1_depth", "bn1_depth", "layer1_depth", "layer2_depth"))
+        end_segment(("conv1", "bn1", "layer1", "layer2", "conv1_depth", "bn1_depth", "layer1_depth", "layer2_depth"), last=True)
 
     # ------------------------------------------------------------------ execution
     def _run(self, ops):

@@ -121,18 +121,26 @@ class HipTrainStep:
             operands = "bf16"
         self.operands, self.storage = operands, storage
         self.model = model
+        # The backward is built in bucket-aligned segments.  Segment-granular hipGraphs and torch.distributed's all_reduce (which
+        # orders itself behind the CURRENT stream) need every segment to end with all plan streams joined; plain launches with the
+        # native communicator -- and single-GPU runs -- do not: the communication stream waits for per-stream events instead and
+        # the main chain keeps running ahead of the weight-gradient stream (+1 % fp32, +2 % bf16 storage).
+        from . import comm as _comm0
+        tdist0 = torch.distributed.is_available() and torch.distributed.is_initialized()
+        native = comm == "rccl" or (comm == "auto" and (_comm0.initialised() or not tdist0))
+        joins = bool(use_graph) or not native
         self.L = lib()
         self._f_sums, self._f_bwd = ((self.L.rd_masked_l1_sums, self.L.rd_masked_l1_bwd) if criterion == "l1" else
                                      (self.L.rd_masked_l2_sums, self.L.rd_masked_l2_bwd))
         model.train()
         self.multistage = isinstance(model, ResNet_multistage)
         if self.multistage:
-            self.mp = model._plans(batch, height, width, True, bf16=operands == "bf16", storage=storage)
+            self.mp = model._plans(batch, height, width, True, bf16=operands == "bf16", storage=storage, segment_joins=joins)
             self.plans = [self.mp.p1, self.mp.p2]
         else:
             assert isinstance(model, ResNet_latefusion)
             self.mp = None
-            self.plans = [model._plan(batch, height, width, True, bf16=operands == "bf16", storage=storage)]
+            self.plans = [model._plan(batch, height, width, True, bf16=operands == "bf16", storage=storage, segment_joins=joins)]
         self.plan = self.plans[0]
         self.st = model._ensure_arenas()
         self._arena_version = self.st["version"]
@@ -191,9 +199,11 @@ class HipTrainStep:
             tops = sorted((v[0], (v[1] + 3) // 4 * 4) for k, v in offs.items() if not k.startswith(("stage1.", "stage2.")))
             self._buckets = [sl for _, _, sl in self._seg2] + [sl for _, _, sl in self._seg1]
             self._buckets[-1] = list(self._buckets[-1]) + tops
+            self._bucket_side_events = list(self.mp.p2.segment_events) + list(self.mp.p1.segment_events)
         else:
             self._segments = bucket_segments(self.plan, offs)
             self._buckets = [sl for _, _, sl in self._segments]
+            self._bucket_side_events = list(self.plan.segment_events)
 
     def sync_state_from_rank0(self):
         """Data-parallel replicas must start from one state (DDP broadcasts at construction): parameters, momentum and the
@@ -379,6 +389,8 @@ class HipTrainStep:
                 launch(i)
                 self._bucket_events[i].record(self.side)
                 self.comm_stream.wait_event(self._bucket_events[i])
+                for ev in self._bucket_side_events[i]:          # the segment's tails on the depth / weight-gradient streams
+                    check(self.L.rd_stream_wait_event(cs, ev), "stream_wait_event")
                 for lo, hi in slices:
                     _comm.allreduce_(grads, cs, lo, hi)
             self._bucket_events[-1].record(self.comm_stream)
