@@ -239,6 +239,9 @@ def main():
     x, t = x.cuda(), t.cuda()
 
     def sync():
+        # drain this rank's own work first: the step's all-reduces (own communicator, communication stream) are then complete
+        # before the barrier's collective (torch's communicator) is enqueued -- collectives of two communicators never interleave
+        torch.cuda.synchronize()
         if world > 1:
             torch.distributed.barrier()
         torch.cuda.synchronize()

@@ -422,7 +422,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MT * NT <= 
     float biasv[NT];
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) biasv[nt] = (has_bias && cob + nt * 32 < D.Cout) ? a.bias[cob + nt * 32] : 0.f;
-    const bool cols_full = co0 + wn * NT * 32 + NT * 32 <= D.Cout;       // wave-uniform
+    // column validity is lane-constant (channel = cob + nt*32): the fast path keeps its unrolled, branch-free shape and lets the
+    // stores / addend loads of lanes beyond Cout be masked off (the 16-channel layers fill half a 32-wide tile: they used to fall
+    // into the per-element path below, whose epilogue took longer than the layer's MFMAs)
+    bool cok[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) cok[nt] = cob + nt * 32 < D.Cout;
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
         __builtin_amdgcn_sched_barrier(0);   // keep one M-tile's row offsets / addends live at a time
@@ -433,7 +438,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MT * NT <= 
             ro[i] = s_opix[(wm * MT + mt) * 32 + (i & 3) + 8 * (i >> 2) + 4 * hh];   // -1: no such pixel
             rows_ok = rows_ok && ro[i] >= 0;
         }
-        if (!fused && cols_full && __all(rows_ok)) {
+        if (!fused && __all(rows_ok)) {
             // two batches of 8 accumulator rows: enough loads in flight to hide the addend latency without pushing the
             // kernel past 256 registers (arch + accumulation), which would halve the waves per SIMD
 #pragma unroll
@@ -444,7 +449,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MT * NT <= 
                     for (int i = 0; i < 8; ++i) {
                         const float* ap = a.addend + (size_t)ro[h8 + i] * a.ld_add + cob;
 #pragma unroll
-                        for (int nt = 0; nt < NT; ++nt) addv[nt][i] = ap[nt * 32];
+                        for (int nt = 0; nt < NT; ++nt) addv[nt][i] = cok[nt] ? ap[nt * 32] : 0.f;
                     }
                 }
 #pragma unroll
@@ -454,7 +459,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MT * NT <= 
                     for (int nt = 0; nt < NT; ++nt) {
                         float v = acc[mt][nt][h8 + i];
                         if (has_add) v += addv[nt][i];
-                        rp[nt * 32] = v;
+                        if (cok[nt]) rp[nt * 32] = v;
                         ssum[nt] += v;
                         ssq[nt] += v * v;
                     }

@@ -328,7 +328,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void g
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) biasv[nt] = (has_bias && cob + nt * 32 < D.Cout) ? a.bias[cob + nt * 32] : 0.f;
     const bool want_stat = a.stat != nullptr;
-    const bool cols_full = co0 + NT * 32 <= D.Cout;       // wave-uniform
+    // lane-constant column validity: partial N tiles (the 16-channel layers) stay on the branch-free path with masked stores
+    bool cok[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) cok[nt] = cob + nt * 32 < D.Cout;
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
         int ro[16];
@@ -338,7 +341,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void g
             ro[i] = s_opix[(wm * MT + mt) * 32 + (i & 3) + 8 * (i >> 2) + 4 * hh];   // -1: no such pixel
             rows_ok = rows_ok && ro[i] >= 0;
         }
-        if (cols_full && __all(rows_ok)) {
+        if (__all(rows_ok)) {
             // full M-tile (almost all of them): no exec masking; the addends of eight rows are gathered before their first use
 #pragma unroll
             for (int h8 = 0; h8 < 16; h8 += 8) {
@@ -348,7 +351,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void g
                     for (int i = 0; i < 8; ++i) {
                         const io_t* ap = static_cast<const io_t*>(a.addend) + (size_t)ro[h8 + i] * a.ld_add + cob;
 #pragma unroll
-                        for (int nt = 0; nt < NT; ++nt) addv[nt][i] = ld1(ap + nt * 32);
+                        for (int nt = 0; nt < NT; ++nt) addv[nt][i] = cok[nt] ? ld1(ap + nt * 32) : 0.f;
                     }
                 }
 #pragma unroll
@@ -359,7 +362,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void g
                         float v = acc[mt][nt][h8 + i] + biasv[nt];
                         if (has_add) v += addv[nt][i];
                         if (cob + nt * 32 < a.act_cols) v = act_fwd(v, a.act);
-                        st1(rp + nt * 32, v);
+                        if (cok[nt]) st1(rp + nt * 32, v);
                         if (want_stat) {
                             ssum[nt] += v;
                             ssq[nt] += v * v;

@@ -574,7 +574,8 @@ static int plan_wgrad(const RdConvDesc& d_in, WgradPlan& pl, WgradArgs* out, int
         // column-strip kernel: 25-pixel strips, row segments sized so that every CU gets two workgroups
         WgradStripArgs& sa = pl.sa;
         const int groups = pl.n_cib * pl.n_cob;
-        int want = cdiv(2 * num_cus(), groups);
+        static const char* wpc_env = getenv("RD_WGRAD_WG_PER_CU_X2");   // diagnostics: workgroups per CU, times two (default 4 = two per CU)
+        int want = cdiv((wpc_env ? atoi(wpc_env) : 4) * num_cus() / 2, groups);
         if (want < 1) want = 1;
         sa.n_strips = cdiv(P0.lw, 25);
         const int base_units = d.N * sa.n_strips;
@@ -642,7 +643,8 @@ static int plan_wgrad(const RdConvDesc& d_in, WgradPlan& pl, WgradArgs* out, int
     pl.tiles_w = cdiv(P0.lw, pl.TW);
     pl.total_tiles = d.N * pl.tiles_h * pl.tiles_w;
     const int groups = pl.n_cib * pl.n_cob * pl.n_tg;
-    int want = cdiv(2 * num_cus(), groups);
+    static const char* wpc_env2 = getenv("RD_WGRAD_WG_PER_CU_X2");
+    int want = cdiv((wpc_env2 ? atoi(wpc_env2) : 4) * num_cus() / 2, groups);
     if (want < 1) want = 1;
     if (want > pl.total_tiles) want = pl.total_tiles;
     pl.tiles_per_split = cdiv(pl.total_tiles, want);

@@ -7,17 +7,27 @@ sys.path.insert(0, ".")
 import numpy as np, torch
 from radar_depth_amd import convdesc as cd, ops
 from radar_depth_amd._lib import lib
+IO16 = "--io16" in sys.argv          # bf16-storage form (rd_gconv_bf16_t with RD_DTYPE_BF16)
+sys.argv = [a for a in sys.argv if a != "--io16"]
 sys.argv, idx = sys.argv[:1], int(sys.argv[1])
 from tools.bench_ops import CONVS
 from tools.bench_ops_bf16 import plan
 B = 16
 name, cnt, ci, co, k, s, p, h, w = CONVS[idx]
 d = cd.conv_fwd(B, h, w, ci, co, k, s, p)
-x = torch.randn(B, h, w, ci, device="cuda")
+from radar_depth_amd._lib import current_stream, ptr
+adt = torch.bfloat16 if IO16 else torch.float32
+x = torch.randn(B, h, w, ci, device="cuda").to(adt)
 wp = ops.pack_weights_bf16(torch.randn(co, ci, k, k, device="cuda"))
-y = torch.empty(B, d.Ho, d.Wo, co, device="cuda")
-for _ in range(200):
-    ops.gconv_bf16(d, x, wp, y)
+y = torch.empty(B, d.Ho, d.Wo, co, device="cuda", dtype=adt)
+ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+for it in range(200):
+    if it == 100:
+        ev0.record()
+    assert lib().rd_gconv_bf16_t(1 if IO16 else 0, C.byref(d), ptr(x), ptr(wp), ptr(y), None, 0, 0, None, 0, None, current_stream()) == 0
+ev1.record()
+torch.cuda.synchronize()
+print("io16" if IO16 else "fp32 io", "avg launch %.1f us" % (ev0.elapsed_time(ev1) * 10.0))
 torch.cuda.synchronize()
 info = (C.c_int32 * 8)()
 lib().rd_gconv_bf16_plan_info(C.byref(d), info)
