@@ -59,9 +59,11 @@ def kernel_identity(L, kind, d, io16=False):
         return "wgrad_bf16_kernel<%s,%d,%s>" % (tb_(full), 4 // (info[0] * info[1]), tb_(io16))
     if kind == "gconv":
         info = (C.c_int32 * 10)()
-        L.rd_gconv_plan_info(C.byref(d), info)                 # info[4] = pipelined*10000 + ksplit*100 + CKW
-        return "gconv_kernel<%d,%d,%d,%d,%d,%s,%s>" % (info[0], info[1], info[2], info[3], info[4] % 100,
-                                                       "true" if d.in_stride == 2 else "false", "true" if info[4] >= 10000 else "false")
+        L.rd_gconv_plan_info(C.byref(d), info)                 # info[4] = grouped*1000000 + pipelined*10000 + ksplit*100 + CKW
+        grouped = info[4] >= 1000000                          # in_stride == 2 run as input-parity groups: SWZ = false instantiation
+        return "gconv_kernel<%d,%d,%d,%d,%d,%s,%s,%s>" % (info[0], info[1], info[2], info[3], info[4] % 100,
+                                                          "true" if (d.in_stride == 2 and not grouped) else "false",
+                                                          "true" if info[4] % 1000000 >= 10000 else "false", "true" if grouped else "false")
     w = (C.c_int32 * 9)()
     L.rd_wgrad_plan_info(C.byref(d), w)
     tb = lambda v: "true" if v else "false"

@@ -50,13 +50,25 @@ struct GconvArgs {
     // per phase and tap: offset of the tap inside the LDS halo patch -- bytes for the padded layout, pixels for the swizzled
     // one.  Read through the scalar unit (s_load_dword), so the per-step address arithmetic costs no VALU issue.
     int tapoff[RD_MAX_PHASES][RD_MAX_TAPS + 1];
+    // Input-parity groups of an in_stride == 2 (single-phase) descriptor.  The taps are split by the parity of their input offset;
+    // group g reads the DECIMATED sub-image in[ih0 + g_oh + 2*y, iw0 + g_ow + 2*x], on which its taps are unit-stride: the patch of
+    // a group has the size of an ordinary 3x3 halo patch instead of the 4x interleaved one, the padded LDS layout / scalar tap
+    // offsets / pipelined chunk loop of the stride-1 path apply, and two workgroups fit a CU.  The chunk loop runs once per
+    // group, all groups accumulate into the same registers.  ngroups == 0: ordinary descriptor.
+    int ngroups;
+    int g_ntaps[4], g_oh[4], g_ow[4], g_tbase[4];
+    int g_sh_max, g_sw_max;      // largest sub-patch tap offset over all groups (sub-patch = (TH + sh_max) x (TW + sw_max))
+    short g_widx[32];            // weight slab index of every tap, groups concatenated (g_tbase)
     int lds_floats;              // floats of LDS in use before the trace stamps
     unsigned long long* trace;   // diagnostics (RD_GCONV_TRACE=1): per-workgroup cycle-counter stamps, 64 per workgroup
     int debug;         // ablation bits (RD_GCONV_DEBUG env): 1 skip patch staging, 2 skip weight staging, 4 skip MFMA loop
 };
 
-template <int MT, int NT, int WM, int WN, int CKW, bool SWZ, bool PIPE>
+// GRP: the descriptor runs as input-parity groups (GconvArgs::ngroups).  A template parameter, not a run-time flag: the large
+// register tiles sit exactly at 256 registers and the group bookkeeping as run-time state made the ordinary kernels spill (67 VGPRs).
+template <int MT, int NT, int WM, int WN, int CKW, bool SWZ, bool PIPE, bool GRP = false>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MT * NT <= 6 ? 2 : 1))) void gconv_kernel(const GconvArgs a) {
+    static_assert(!(GRP && SWZ), "input-parity groups use the padded patch layout");
     constexpr int BM = WM * MT * 32;
     constexpr int BN = WN * NT * 32;
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -88,8 +100,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MT * NT <= 
     const int r0 = (tloc / tiles_w) * a.TH, c0 = (tloc % tiles_w) * a.TW;
     const int th_n = min(a.TH, P.lh - r0), tw_n = min(a.TW, P.lw - c0);
     const int IS = D.in_stride, OS = D.out_stride;
-    const int PW = (a.TW - 1) * IS + (P.dw_max - P.dw_min) + 1;
-    const int PH = (th_n - 1) * IS + (P.dh_max - P.dh_min) + 1;
+    constexpr bool grouped = GRP;
+    const int ISl = grouped ? 1 : IS;            // pixel step of neighbouring outputs inside the LDS patch
+    const int PW = grouped ? a.TW + a.g_sw_max : (a.TW - 1) * IS + (P.dw_max - P.dw_min) + 1;
+    const int PH = grouped ? th_n + a.g_sh_max : (th_n - 1) * IS + (P.dh_max - P.dh_min) + 1;
     const int ih0 = r0 * IS + P.dh_min, iw0 = c0 * IS + P.dw_min;
     const int CKP = a.CKP;
     // Patch pixel layout in LDS, two forms (float offset of channel cq of patch pixel px = paddr(px, cq)):
@@ -100,7 +114,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MT * NT <= 
     const int PS = SWZ ? CKP : CKP + 4;
     const int QPM = (CKP >> 2) - 1, SWS = CKP == 16 ? 2 : 1;
     auto paddr = [&](int px, int cq) { return SWZ ? ((px * CKP + (((px >> SWS) & QPM) << 2)) ^ cq) : px * PS + cq; };
-    const int ntaps = P.n_taps;
+    int ntaps = grouped ? a.g_ntaps[0] : P.n_taps;   // (per group when grouped)
+    int tsel = grouped ? 0 : ph;                       // row of a.tapoff in use
+    int tb = 0;                                        // first entry of the group's taps in s_widx
     const int co0 = cot * BN;
 
     // LDS carve-up
@@ -114,9 +130,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MT * NT <= 
         const int r = m / a.TW, c = m - r * a.TW;
         const bool ok = (r < th_n) && (c < tw_n);
         s_opix[m] = ok ? ((n * D.Ho + (r0 + r) * OS + P.out_off_h) * D.Wo + (c0 + c) * OS + P.out_off_w) : -1;
-        s_apix[m] = ok ? ((r * IS) * PW + c * IS) : 0;
+        s_apix[m] = ok ? ((r * ISl) * PW + c * ISl) : 0;
     }
-    if (tid < ntaps) {
+    if (grouped) {
+        if (tid < 32) s_widx[tid] = a.g_widx[tid];
+    } else if (tid < ntaps) {
         s_widx[tid] = P.widx[tid];
     }
     __syncthreads();
@@ -167,7 +185,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MT * NT <= 
     // (tap, k-quantum) of the step whose fragments are loaded next: wave-uniform, kept in SGPRs.  tap_nxt is fetched
     // one step early so that its s_load is covered by the wait the MFMAs need anyway.
     int t_n = 0, kqA = 0, kqB = 0;
-    int tap_cur = a.tapoff[ph][0], tap_nxt = a.tapoff[ph][ntaps > 1 ? 1 : 0];
+    int tap_cur = a.tapoff[tsel][0], tap_nxt = a.tapoff[tsel][ntaps > 1 ? 1 : 0];
     const char* const wbase = reinterpret_cast<const char*>(s_w) + boffB + wsel;
     const char* const pbase = reinterpret_cast<const char*>(s_patch);
 #define RD_GC_LOAD(AV, BV)                                                                     \
@@ -186,7 +204,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MT * NT <= 
         ++t_n;                                                                         \
         if (t_n == ntaps) { t_n = 0; kqA += CKW * 4; kqB += (CKW >> 2) * BN * 16; }    \
         tap_cur = tap_nxt;                                                             \
-        tap_nxt = a.tapoff[ph][t_n + 1 == ntaps ? 0 : t_n + 1];                        \
+        tap_nxt = a.tapoff[tsel][t_n + 1 == ntaps ? 0 : t_n + 1];                      \
     }
 #define RD_GC_MFMA(AV, BV)                                                                     \
     _Pragma("unroll") for (int kk = 0; kk < KK; ++kk)                                  \
@@ -225,6 +243,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MT * NT <= 
     const int cin_per = D.Cin / a.ksplit;
     const int cb_lo = ksl * cin_per, cb_hi = cb_lo + cin_per;
     float* const outp = a.out + (size_t)ksl * a.split_stride;
+    const int ngr = GRP ? a.ngroups : 1;
+    for (int grp = 0; grp < ngr; ++grp) {
+    // sub-image origin and step of this pass (ordinary descriptors: one pass over the dense patch)
+    int gih0 = ih0, giw0 = iw0, gst = 1;
+    if (grouped) {
+        ntaps = a.g_ntaps[grp]; tsel = grp; tb = a.g_tbase[grp];
+        gih0 = ih0 + a.g_oh[grp]; giw0 = iw0 + a.g_ow[grp]; gst = 2;
+        if (grp > 0) __syncthreads();     // every wave is done with the previous group's patch and slabs
+    }
     if constexpr (PIPE) {
         // ---- software-pipelined chunk loop (the whole patch chunk is one batch of <= UPP loads per thread and a weight slab
         // <= UWP): the weight slabs alternate between two LDS buffers and are fetched with global_load_lds one slab ahead (no
@@ -241,7 +268,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MT * NT <= 
             const int e = tid + u * 256;
             const int pix = e / q4, qq = e - pix * q4;
             const int py = pix / PW, px = pix - py * PW;
-            const int ih = ih0 + py, iw = iw0 + px;
+            const int ih = gih0 + gst * py, iw = giw0 + gst * px;
             pdst[u] = e < patch_elems ? paddr(pix, qq * 4) : -1;
             pgo[u] = (e < patch_elems && ih >= 0 && ih < D.Hi && iw >= 0 && iw < D.Wi) ? (unsigned)(((ih * D.Wi + iw) * D.ldi + qq * 4) * 4) : ~0u;
         }
@@ -251,7 +278,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MT * NT <= 
             const int e = tid + u * 256;
             const int j = e % BN, tk = e / BN;
             const int k4 = tk % W4, t = min(tk / W4, ntaps - 1);
-            woff[u] = (e < welems && co0 + j < D.Cout) ? (unsigned)((((unsigned)s_widx[t] * (D.Cin >> 2) + k4) * a.ldw + co0 + j) * 16) : ~0u;
+            woff[u] = (e < welems && co0 + j < D.Cout) ? (unsigned)((((unsigned)s_widx[tb + t] * (D.Cin >> 2) + k4) * a.ldw + co0 + j) * 16) : ~0u;
         }
         auto issue_slab = [&](int buf, int cq0) {          // cq0: first input-channel quad of the slab
             const char* src = reinterpret_cast<const char*>(a.w) + (size_t)cq0 * a.ldw * 16;
@@ -337,7 +364,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MT * NT <= 
                 const int row = nseg == 1 ? seg : seg / nseg;
                 const int cu = ((seg - row * nseg) << 6) + lane;
                 const int px = cu >> lq4, qq = cu & (q4 - 1);
-                const int ih = ih0 + row, iw = iw0 + px;
+                const int ih = gih0 + gst * row, iw = giw0 + gst * px;
                 const bool ok = seg < nsegs && cu < rowu;
                 ld[u] = ok ? paddr(row * PW + px, qq * 4) : -1;
                 const unsigned go = (ok && ih >= 0 && ih < D.Hi && iw >= 0 && iw < D.Wi && cb + qq * 4 < D.Cin)
@@ -365,7 +392,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MT * NT <= 
                 const int co = co0 + j;
                 v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
                 if (e < we && co < D.Cout)
-                    v[u] = *reinterpret_cast<const float4*>(a.w + (((size_t)s_widx[t] * cinq + cq0 + k4) * a.ldw + co) * 4);
+                    v[u] = *reinterpret_cast<const float4*>(a.w + (((size_t)s_widx[tb + t] * cinq + cq0 + k4) * a.ldw + co) * 4);
             }
         };
         auto w_store = [&](int base, int ks, auto& v) {
@@ -405,6 +432,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MT * NT <= 
             RD_STAMP()
         }
     }
+    }   // input-parity groups
 
     // ---- epilogue.  Row validity is uniform per half-wave and almost always true, so full M-tiles take a wave-uniform
     // fast path: no exec masking, one row pointer per accumulator row with the N-tile as an immediate offset, and the
@@ -584,7 +612,39 @@ struct GconvPlan {
     int MT, NT, WM, WN, CKW, CKP, TH, TW, PP, tiles_total, n_cotiles, taps_max, WSD, ksplit;
     size_t lds_bytes;
     int pipe;      // software-pipelined chunk loop (double-buffered weight slabs via global_load_lds)
+    int grouped;   // input-parity groups (in_stride == 2, one phase): see GconvArgs::ngroups
 };
+
+// Input-parity decomposition of a single-phase in_stride == 2 descriptor.
+struct ParityGroups {
+    int n = 0;
+    int ntaps[4], oh[4], ow[4], tbase[4];
+    int sh[32], sw[32], widx[32];     // per tap (groups concatenated): offset inside the decimated sub-image, weight slab
+    int sh_max = 0, sw_max = 0, taps_max = 0;
+};
+static bool build_parity_groups(const RdConvDesc& d, ParityGroups& G) {
+    static const char* off = getenv("RD_GCONV_NOGROUP");      // diagnostics: keep the interleaved 4x patch
+    if (off || d.in_stride != 2 || d.n_phases != 1 || d.phase[0].n_taps > 32) return false;
+    const RdPhase& p = d.phase[0];
+    int k = 0;
+    for (int ra = 0; ra < 2; ++ra)
+        for (int rb = 0; rb < 2; ++rb) {
+            const int k0 = k;
+            for (int t = 0; t < p.n_taps; ++t) {
+                const int a = p.dh[t] - p.dh_min, b = p.dw[t] - p.dw_min;
+                if ((a & 1) != ra || (b & 1) != rb) continue;
+                G.sh[k] = a >> 1; G.sw[k] = b >> 1; G.widx[k] = p.widx[t];
+                G.sh_max = G.sh_max > G.sh[k] ? G.sh_max : G.sh[k];
+                G.sw_max = G.sw_max > G.sw[k] ? G.sw_max : G.sw[k];
+                ++k;
+            }
+            if (k == k0) continue;
+            G.ntaps[G.n] = k - k0; G.oh[G.n] = ra; G.ow[G.n] = rb; G.tbase[G.n] = k0;
+            G.taps_max = G.taps_max > k - k0 ? G.taps_max : k - k0;
+            ++G.n;
+        }
+    return G.n >= 1;
+}
 
 static int patch_pixels(const RdConvDesc& d, const RdPhase& p, int TH, int TW) {
     const int th = TH < p.lh ? TH : p.lh;
@@ -616,6 +676,9 @@ static bool plan_gconv(const RdConvDesc& d, GconvPlan& best, bool allow_split = 
     static const Cfg cfgs[] = {{2, 2, 4, 1, 0.93}, {2, 1, 4, 1, 0.82}, {3, 2, 4, 1, 1.0}, {1, 2, 4, 1, 0.78}, {1, 1, 4, 1, 0.76}};
     int taps_max = 0;
     for (int i = 0; i < d.n_phases; ++i) taps_max = taps_max > d.phase[i].n_taps ? taps_max : d.phase[i].n_taps;
+    ParityGroups PG;
+    const bool grouped = build_parity_groups(d, PG);
+    if (grouped) taps_max = PG.taps_max;          // a weight slab holds one group's taps
     const int CKW = taps_max > 9 ? 4 : 8;
     double best_score = -1;
     // reference phase for tile selection: the one with the largest logical grid
@@ -645,18 +708,19 @@ static bool plan_gconv(const RdConvDesc& d, GconvPlan& best, bool allow_split = 
                 TH = cdiv(P.lh, cdiv(P.lh, TH));
                 int PP = 0;
                 for (int i = 0; i < d.n_phases; ++i) {
-                    const int pp = patch_pixels(d, d.phase[i], TH, TW);
+                    const int pp = grouped ? (TH + PG.sh_max) * (TW + PG.sw_max) : patch_pixels(d, d.phase[i], TH, TW);
                     PP = PP > pp ? PP : pp;
                 }
                 // pipelined chunk loop: the patch chunk must be one batch of loads per thread, a weight slab at most seven
                 static const char* nopipe = getenv("RD_GCONV_NOPIPE");
                 const int upp = c.MT * c.NT >= 4 ? 8 : 4;
                 const int wsd_p = pick_wsd(taps_max, BN, CKW, ckp, true);
-                const bool pipe = !nopipe && PP * (ckp / 4) <= upp * 256 && taps_max * (wsd_p / 4) * BN <= 7 * 256;
-                const size_t lds = lds_need(BM, BN, CKW, ckp, PP, taps_max, d.in_stride == 2, pipe);
+                static const char* gnopipe = getenv("RD_GCONV_GROUP_NOPIPE");   // diagnostics
+                const bool pipe = !nopipe && !(grouped && gnopipe) && PP * (ckp / 4) <= upp * 256 && taps_max * (wsd_p / 4) * BN <= 7 * 256;
+                const size_t lds = lds_need(BM, BN, CKW, ckp, PP, taps_max, d.in_stride == 2 && !grouped, pipe);
                 if (lds > 160 * 1024 - 512) continue;
                 const double m_util = (double)P.lh * P.lw / ((double)cdiv(P.lh, TH) * cdiv(P.lw, TW) * BM);
-                const double halo = (double)PP / (TH * TW * d.in_stride * d.in_stride);
+                const double halo = grouped ? (double)PP / (TH * TW) : (double)PP / (TH * TW * d.in_stride * d.in_stride);
                 double score = c.prior * m_util * n_util / (1.0 + 0.04 * (halo - 1.0));
                 if (lds > 80 * 1024) score *= 0.85;          // one workgroup per CU only
                 if (ckp == 16 && d.Cin >= 32) score *= 0.97;  // half-line loads
@@ -682,7 +746,8 @@ static bool plan_gconv(const RdConvDesc& d, GconvPlan& best, bool allow_split = 
                             (wgs < 2 * ncu && lds <= 80 * 1024 ? 0.9 : 1.0);   // (a > 80 KB tile already paid for single residency)
                     if (score > best_score) {
                         best_score = score;
-                        best = GconvPlan{c.MT, c.NT, c.WM, c.WN, CKW, ckp, TH, TW, PP, 0, n_cot, taps_max, pick_wsd(taps_max, BN, CKW, ckp, pipe), ksp, lds, pipe ? 1 : 0};
+                        best = GconvPlan{c.MT, c.NT, c.WM, c.WN, CKW, ckp, TH, TW, PP, 0, n_cot, taps_max, pick_wsd(taps_max, BN, CKW, ckp, pipe), ksp, lds, pipe ? 1 : 0,
+                                         grouped ? 1 : 0};
                     }
                 }
             }
@@ -691,10 +756,10 @@ static bool plan_gconv(const RdConvDesc& d, GconvPlan& best, bool allow_split = 
     return best_score > 0;
 }
 
-template <int MT, int NT, int WM, int WN, int CKW, bool SWZ, bool PIPE>
+template <int MT, int NT, int WM, int WN, int CKW, bool SWZ, bool PIPE, bool GRP = false>
 static int launch_cfg(const GconvArgs& a, int grid, size_t lds, hipStream_t s) {
     static bool attr_set = false;
-    auto k = gconv_kernel<MT, NT, WM, WN, CKW, SWZ, PIPE>;
+    auto k = gconv_kernel<MT, NT, WM, WN, CKW, SWZ, PIPE, GRP>;
     if (!attr_set) {
         RD_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr_set = true;
@@ -743,7 +808,8 @@ extern "C" int rd_gconv_plan_info(const RdConvDesc* d, int32_t* out) {
     if (!plan_gconv(dd, pl, true)) { set_error("gconv: no feasible tiling"); return RD_EINVAL; }
     fill_tiles(dd, pl);
     // (reports the plan used WITH a workspace; CKW slot carries pipe*10000 + ksplit*100 + CKW)
-    const int v[10] = {pl.MT, pl.NT, pl.WM, pl.WN, pl.pipe * 10000 + pl.ksplit * 100 + pl.CKW, pl.CKP, pl.TH, pl.TW, (int)pl.lds_bytes,
+    // (CKW slot: + 1000000 when the in_stride == 2 descriptor runs as input-parity groups, i.e. on the SWZ = false instantiation)
+    const int v[10] = {pl.MT, pl.NT, pl.WM, pl.WN, pl.grouped * 1000000 + pl.pipe * 10000 + pl.ksplit * 100 + pl.CKW, pl.CKP, pl.TH, pl.TW, (int)pl.lds_bytes,
                        d->N * pl.tiles_total * pl.n_cotiles * pl.ksplit};
     for (int i = 0; i < 10; ++i) out[i] = v[i];
     return RD_OK;
@@ -769,7 +835,7 @@ extern "C" int rd_gconv_occupancy(const RdConvDesc* d) {
 #define RD_OCC(MT_, NT_, WM_, WN_) \
     if (pl.MT == MT_ && pl.NT == NT_ && pl.WM == WM_ && pl.WN == WN_) \
         return pl.pipe ? RD_OCC2(MT_, NT_, WM_, WN_, true) : RD_OCC2(MT_, NT_, WM_, WN_, false);
-    const bool swz = d->in_stride == 2;
+    const bool swz = d->in_stride == 2 && !pl.grouped;
     RD_OCC(2, 2, 4, 1) RD_OCC(2, 1, 4, 1) RD_OCC(3, 2, 4, 1) RD_OCC(1, 2, 4, 1) RD_OCC(1, 1, 4, 1)
 #undef RD_OCC
 #undef RD_OCC2
@@ -848,7 +914,24 @@ static int gconv_impl(const RdConvDesc* d, const float* in, const float* w_packe
     a.TH = pl.TH; a.TW = pl.TW; a.PP = pl.PP; a.CKP = pl.CKP;
     a.tiles_total = pl.tiles_total; a.n_cotiles = pl.n_cotiles; a.taps_max = pl.taps_max; a.WSD = pl.WSD;
     a.ksplit = pl.ksplit;
-    {
+    a.ngroups = 0;
+    if (pl.grouped) {
+        ParityGroups PG;
+        build_parity_groups(*d, PG);
+        a.ngroups = PG.n;
+        a.g_sh_max = PG.sh_max; a.g_sw_max = PG.sw_max;
+        const int PWg = pl.TW + PG.sw_max, PSg = pl.CKP + 4;
+        for (int t = 0; t < 32; ++t) a.g_widx[t] = 0;
+        for (int g = 0; g < 4; ++g) { a.g_ntaps[g] = a.g_oh[g] = a.g_ow[g] = a.g_tbase[g] = 0; }
+        for (int g = 0; g < PG.n; ++g) {
+            a.g_ntaps[g] = PG.ntaps[g]; a.g_oh[g] = PG.oh[g]; a.g_ow[g] = PG.ow[g]; a.g_tbase[g] = PG.tbase[g];
+            for (int t = 0; t < PG.ntaps[g]; ++t) {
+                const int k = PG.tbase[g] + t;
+                a.g_widx[k] = (short)PG.widx[k];
+                a.tapoff[g][t] = (PG.sh[k] * PWg + PG.sw[k]) * PSg * 4;
+            }
+        }
+    } else {
         const bool swz_ = d->in_stride == 2;
         const int PS_ = swz_ ? pl.CKP : pl.CKP + 4;
         for (int i = 0; i < d->n_phases; ++i) {
@@ -880,6 +963,8 @@ static int gconv_impl(const RdConvDesc* d, const float* in, const float* w_packe
 #define RD_LAUNCH2(MT_, NT_, WM_, WN_, P_)                                                           \
     (swz ? (pl.CKW == 8 ? launch_cfg<MT_, NT_, WM_, WN_, 8, true, P_>(a, grid, lds_launch, s)             \
                         : launch_cfg<MT_, NT_, WM_, WN_, 4, true, P_>(a, grid, lds_launch, s))            \
+         : pl.grouped ? (pl.CKW == 8 ? launch_cfg<MT_, NT_, WM_, WN_, 8, false, P_, true>(a, grid, lds_launch, s)   \
+                                     : launch_cfg<MT_, NT_, WM_, WN_, 4, false, P_, true>(a, grid, lds_launch, s))  \
          : (pl.CKW == 8 ? launch_cfg<MT_, NT_, WM_, WN_, 8, false, P_>(a, grid, lds_launch, s)            \
                         : launch_cfg<MT_, NT_, WM_, WN_, 4, false, P_>(a, grid, lds_launch, s)))
 #define RD_TRY(MT_, NT_, WM_, WN_)                                                                  \
@@ -887,7 +972,7 @@ static int gconv_impl(const RdConvDesc* d, const float* in, const float* w_packe
         launched = true;                                                                            \
         rc = pl.pipe ? RD_LAUNCH2(MT_, NT_, WM_, WN_, true) : RD_LAUNCH2(MT_, NT_, WM_, WN_, false);              \
     }
-    const bool swz = d->in_stride == 2;
+    const bool swz = d->in_stride == 2 && !pl.grouped;
     const size_t lds_launch = (size_t)a.lds_floats * 4 + (a.trace ? 512 : 0);
     RD_TRY(2, 2, 4, 1)
     RD_TRY(2, 1, 4, 1)
