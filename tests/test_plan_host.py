@@ -120,3 +120,47 @@ def test_multistage_buckets_partition_the_arena():
     total = max(v[1] for v in offs.values())
     assert covered[0][0] == 0 and covered[-1][1] == (total + 3) // 4 * 4
     assert all(a[1] == b[0] for a, b in zip(covered, covered[1:]))
+
+
+def test_plan_cache_is_a_small_lru():
+    """A plan owns ~11 GB of buffers at b=16 450x800: the per-module cache keeps the PLAN_CACHE_SIZE most recently used keys,
+    drops plans of a rebuilt parameter arena first, and closes what it drops (frees HBM, destroys the hipEvents)."""
+    from radar_depth_amd.model import models
+
+    class FakePlan:
+        def __init__(self):
+            self.closed = False
+
+        def close(self):
+            self.closed = True
+    cap = models.PLAN_CACHE_SIZE
+    cache, plans = {}, []
+    for i in range(cap + 2):
+        models._evict_plans(cache, version=1)
+        p = FakePlan()
+        plans.append(p)
+        cache[(i, 450, 800, True, 1, None, False, "fp32", True)] = p
+        assert len(cache) <= cap
+    assert [p.closed for p in plans] == [True, True] + [False] * cap            # oldest first
+    # a rebuilt arena (new version): every plan of the old version goes, whatever its age
+    models._evict_plans(cache, version=2)
+    assert not cache and all(p.closed for p in plans)
+
+
+def test_segment_events_replace_joins():
+    """segment_joins=False (native communicator / single GPU): the three inner bucket boundaries record one event per side
+    stream instead of joining the streams; only the end of backward joins.  The op lists are otherwise identical."""
+    import torch
+
+    from radar_depth_amd.engine import LateFusionPlan
+    from radar_depth_amd.model.models import ResNet_latefusion
+    m = ResNet_latefusion(18, "upproj", [64, 96], 4, False)
+    pj = LateFusionPlan(m, 1, 64, 96, train=True, dry_run=True, segment_joins=True)
+    pe = LateFusionPlan(m, 1, 64, 96, train=True, dry_run=True, segment_joins=False)
+    assert [len(e) for e in pj.segment_events] == [0, 0, 0, 0]
+    assert [len(e) for e in pe.segment_events] == [2, 2, 2, 0]
+    names = lambda plan: [n for n, _, _ in plan.bwd]
+    strip = lambda ns: [n for n in ns if not n.startswith(("join", "segment_end"))]
+    assert strip(names(pj)) == strip(names(pe))
+    assert names(pj).count("join1.record") == 4 and names(pe).count("join1.record") == 1
+    assert [s[2] for s in pj.bwd_segments] == [s[2] for s in pe.bwd_segments]

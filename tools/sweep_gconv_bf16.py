@@ -23,8 +23,16 @@ if len(sys.argv) > 2 and sys.argv[1] == "--one":
         x = torch.randn(B, h, w, c, device="cuda")
         wp = ops.pack_weights_bf16(torch.randn(c, c, 5, 5, device="cuda"))
         y = torch.empty(B, 2 * h, 2 * w, c, device="cuda")
+    IO16 = os.environ.get("RD_SWEEP_IO16") == "1"        # bf16-storage form of the kernel
+    if IO16:
+        import ctypes as C
+        from radar_depth_amd._lib import current_stream, lib, ptr
+        x, y = x.to(torch.bfloat16), y.to(torch.bfloat16)
+        run = lambda: lib().rd_gconv_bf16_t(1, C.byref(d), ptr(x), ptr(wp), ptr(y), None, 0, 0, None, 0, None, current_stream())
+    else:
+        run = lambda: ops.gconv_bf16(d, x, wp, y)
     try:
-        t = timeit(lambda: ops.gconv_bf16(d, x, wp, y))
+        t = timeit(run)
         print("%-18s %8.1f us  %s" % (name, t * 1e6, plan(d)))
     except Exception as e:
         print("%-18s infeasible (%s)" % (name, str(e)[:60]))
