@@ -38,11 +38,7 @@ __global__ __launch_bounds__(256) void stem_fwd_kernel(const StemArgs a) {
     int* s_koff = reinterpret_cast<int*>(smem);        // [Kq]
     float* s_w = smem + ((Kq + 3) & ~3);               // [Kq][BN]
     float* s_patch = s_w + (size_t)Kq * BN;            // [Cin][PH][PW]
-
-    const int bid = xcd_remap(blockIdx.x, gridDim.x);
-    const int n = bid / (a.tiles_h * a.tiles_w);
-    const int trem = bid - n * (a.tiles_h * a.tiles_w);
-    const int r0 = (trem / a.tiles_w) * TH, c0 = (trem % a.tiles_w) * ST_TW;
+    float* s_red = s_patch + (size_t)a.Cin * PLANE;    // [4][2][BN] statistics scratch (the weights stay resident)
 
     for (int k = tid; k < Kq; k += 256) {
         int off = 0;
@@ -69,7 +65,16 @@ __global__ __launch_bounds__(256) void stem_fwd_kernel(const StemArgs a) {
             if (e < Kq * (BN / 4)) *reinterpret_cast<float4*>(s_w + (size_t)e * 4) = v[u];
         }
     }
+    // PERSISTENT workgroups: the k->offset table and the weight operand (38 KB for the RGB stem -- more than twice the patch of
+    // a tile, for 4.8 MFLOP of work) are staged once per workgroup, not once per tile; the grid is two workgroups per CU and each
+    // walks the tiles bid, bid + grid, ...
+    const int total_tiles = a.N * a.tiles_h * a.tiles_w;
+    for (int bid = blockIdx.x; bid < total_tiles; bid += gridDim.x) {
+    const int n = bid / (a.tiles_h * a.tiles_w);
+    const int trem = bid - n * (a.tiles_h * a.tiles_w);
+    const int r0 = (trem / a.tiles_w) * TH, c0 = (trem % a.tiles_w) * ST_TW;
     const int ih0 = 2 * r0 - 3, iw0 = 2 * c0 - 3;
+    __syncthreads();          // the previous tile's MFMAs are done with the patch (and its statistics with s_red)
     for (int base = tid; base < a.Cin * PLANE; base += 256 * U) {
         float v[U];
 #pragma unroll
@@ -161,7 +166,7 @@ __global__ __launch_bounds__(256) void stem_fwd_kernel(const StemArgs a) {
     }
     if (a.stat) {
         __syncthreads();
-        float* red = s_w;  // [4][2][BN]
+        float* red = s_red;  // [4][2][BN]
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
             const float s = ssum[nt] + __shfl_xor(ssum[nt], 32, 64);
@@ -179,6 +184,7 @@ __global__ __launch_bounds__(256) void stem_fwd_kernel(const StemArgs a) {
             if (j < a.Cout) a.stat[((size_t)bid * 2 + which) * a.Cout + j] = s;
         }
     }
+    }   // tiles of this workgroup
 }
 
 // wgrad: D[k][co] += sum_pixels patch(k, pixel) * dout[pixel][co];  MTK = ceil(K/32) row tiles
@@ -382,11 +388,12 @@ static int stem_fwd_impl(int io16, const float* const* planes, const int64_t* st
     RD_CHECK_ARG(w_packed && out, "stem_fwd: null tensor");
     a.w = w_packed; a.out = out; a.stat = stat_partial; a.dout = nullptr;
     a.tiles_h = cdiv(a.Ho, 8); a.tiles_w = cdiv(a.Wo, ST_TW);
-    const int grid = N * a.tiles_h * a.tiles_w;
+    const int total = N * a.tiles_h * a.tiles_w;
+    const int grid = total < 2 * num_cus() ? total : 2 * num_cus();     // persistent: two workgroups per CU walk the tiles
     const int NT = Cout > 32 ? 2 : 1, BN = NT * 32;
     const int Kp = (49 * Cin + 1) & ~1;
     const int Kq = Kp + 4;
-    const size_t lds = ((size_t)((Kq + 3) & ~3) + (size_t)Kq * BN + (size_t)Cin * 21 * ST_PW) * 4;
+    const size_t lds = ((size_t)((Kq + 3) & ~3) + (size_t)Kq * BN + (size_t)Cin * 21 * ST_PW + (size_t)8 * BN) * 4;
     hipStream_t s = static_cast<hipStream_t>(stream);
     static bool attr = false;
     if (!attr) {

@@ -294,3 +294,55 @@ def test_bf16_storage_geometries(geom):
     loss, pred = ts.step(x, t)
     torch.cuda.synchronize()
     assert torch.isfinite(loss).all() and torch.isfinite(pred).all() and all(torch.isfinite(p).all() for p in m.parameters())
+
+
+def test_config3_per_gpu_workload_b16_450x800_bf16_storage():
+    """BASELINE configs[2]'s per-GPU workload exactly (resnet18_latefusion, b=16, 450x800) under bf16 storage: the training step's
+    loss against the oracle with the plan's rounding points (2e-3), the forward map to the chaos floor of the quantised network
+    (0.15 max / 0.12 rms, see test_bf16_storage_train_step_vs_emulated_oracle), everything finite after the update."""
+    from oracle import train as otrain
+    from radar_depth_amd.main import HipTrainStep
+    from radar_depth_amd.synthetic import make_batch
+    b, h, w = 16, 450, 800
+    args, hm, hw_, om, ow = _pair("resnet18_latefusion", h, w)
+    assert _emulate_bf16_storage(om) == 52
+    x, t = make_batch(b, h, w, 1234)
+    crit = otrain.make_criterion(args.arch)
+    with torch.no_grad():
+        lo, po, _ = otrain.compute_loss(args.arch, om, crit, x, t, ow)
+    ts = HipTrainStep(hm, b, h, w, storage="bf16")
+    loss, pred = ts.step(x.cuda(), t.cuda())
+    torch.cuda.synchronize()
+    e_loss = abs(loss.item() - lo.item()) / abs(lo.item())
+    e_max = ((pred.cpu() - po).abs().max() / po.abs().max()).item()
+    e_rms = ((pred.cpu() - po).norm() / po.norm()).item()
+    print("config 3 per-GPU workload, bf16 storage: loss %.3e  map max %.3e rms %.3e" % (e_loss, e_max, e_rms))
+    assert e_loss < 2e-3 and e_max < 0.15 and e_rms < 0.12
+    assert all(torch.isfinite(p).all() for p in hm.parameters())
+
+
+def test_config5_geometry_multistage_900x1600_bf16_storage():
+    """BASELINE configs[4]'s network and geometry (multistage_uncertainty_fixs, 900x1600) under bf16 storage, b=2: the four loss
+    terms of the fused step against the oracle with the plan's rounding points (2e-3); stage-1 map to the chaos floor; finite
+    parameters after the update.  (The per-GPU batch of 8 is what `bench.py --arch ... --batch 8 --height 900 --width 1600
+    --storage bf16` runs: 244 samples/s.)"""
+    from oracle import train as otrain
+    from radar_depth_amd.main import HipTrainStep
+    from radar_depth_amd.synthetic import make_batch
+    b, h, w = 2, 900, 1600
+    args, hm, hw_, om, ow = _pair("resnet18_multistage_uncertainty_fixs", h, w)
+    assert _emulate_bf16_storage(om) == 104
+    x, t = make_batch(b, h, w, 4321)
+    crit = otrain.make_criterion(args.arch)
+    with torch.no_grad():
+        lo, po, ex = otrain.compute_loss(args.arch, om, crit, x, t, ow)
+    ts = HipTrainStep(hm, b, h, w, loss_weights=hw_, storage="bf16")
+    loss, pred = ts.step(x.cuda(), t.cuda())
+    torch.cuda.synchronize()
+    want4 = np.array([ex["d1"].item(), ex["d2"].item(), ex["smooth"].item(), lo.item()])
+    got4 = ts.loss4.cpu().numpy()
+    e_loss = np.abs(got4 - want4).max() / np.abs(want4).max()
+    e1 = ((ts.mp.p1.pred.cpu() - ex["pred1"]).abs().max() / ex["pred1"].abs().max()).item()
+    print("config 5 geometry, bf16 storage: losses %.3e  stage-1 map max %.3e" % (e_loss, e1))
+    assert e_loss < 2e-3 and e1 < 0.15
+    assert all(torch.isfinite(p).all() for p in hm.parameters())
