@@ -1,5 +1,5 @@
 """Race hunt: two identically initialised training steps (latefusion at several geometries, then multistage) must stay
-bit-identical while ~650 kernels run on three streams.   python tools/stress_repro.py [fp32|bf16]"""
+bit-identical while ~650 kernels run on three streams.   python tools/stress_repro.py [fp32|bf16|bf16s]"""
 import sys, types
 import torch
 sys.path.insert(0, ".")
@@ -16,15 +16,17 @@ def build(arch, h, w):
     return m.cuda(), lw
 
 
-OPERANDS = sys.argv[1] if len(sys.argv) > 1 else "fp32"
-print("conv operands:", OPERANDS)
+MODE = sys.argv[1] if len(sys.argv) > 1 else "fp32"          # fp32 | bf16 (operands) | bf16s (bf16 storage)
+assert MODE in ("fp32", "bf16", "bf16s"), MODE
+OPERANDS, STORAGE = ("bf16" if MODE != "fp32" else "fp32"), ("bf16" if MODE == "bf16s" else "fp32")
+print("mode:", MODE)
 bad = 0
 for arch, b, h, w, steps in [("resnet18_latefusion", 16, 450, 800, 6), ("resnet18_latefusion", 3, 225, 401, 6), ("resnet18_latefusion", 1, 450, 800, 6),
                             ("resnet18_latefusion", 5, 97, 161, 8), ("resnet18_multistage_uncertainty_fixs", 4, 225, 400, 5),
                             ("resnet18_multistage_uncertainty_fixs", 8, 450, 800, 3)]:
     (m1, lw1), (m2, lw2) = build(arch, h, w), build(arch, h, w)
-    t1 = HipTrainStep(m1, b, h, w, loss_weights=lw1, operands=OPERANDS)
-    t2 = HipTrainStep(m2, b, h, w, loss_weights=lw2, operands=OPERANDS)
+    t1 = HipTrainStep(m1, b, h, w, loss_weights=lw1, operands=OPERANDS, storage=STORAGE)
+    t2 = HipTrainStep(m2, b, h, w, loss_weights=lw2, operands=OPERANDS, storage=STORAGE)
     ok = True
     for it in range(steps):
         x, t = make_batch(b, h, w, 4000 + it, ref_pixels=h * w)
