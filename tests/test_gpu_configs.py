@@ -523,3 +523,28 @@ def test_native_rccl_two_ranks(tmp_path):
         ref = want[off:off + a.numel()].view(a.shape).cpu()
         assert (a - ref).abs().max().item() <= 1e-6 * max(ref.abs().max().item(), 1e-3)
         off += (a.numel() + 3) // 4 * 4
+
+
+def test_training_loop_checkpoint_and_resume(tmp_path):
+    """The reference's loop shape end to end (tools/train_synthetic.py: parse_command -> create_model -> fused steps -> LR schedule
+    -> on-device metrics -> validate() via the inference graph -> .pth.tar with optimizer state -> --resume): a run of two epochs
+    equals one epoch + resume + one epoch, bit for bit (parameters and momentum restored, LR schedule continued)."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("train_synthetic", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
+                                                                              "tools", "train_synthetic.py"))
+    ts = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(ts)
+    common = ["-a", "resnet18_latefusion", "-d", "upproj", "-m", "rgbd", "--data", "nuscenes", "-b", "2", "--no-pretrain",
+              "--steps-per-epoch", "3", "--height", "97", "--width", "161"]
+    torch.manual_seed(5)
+    m_full, _ = ts.main(common + ["--epochs", "2", "--output", str(tmp_path / "full")])
+    torch.manual_seed(5)
+    ts.main(common + ["--epochs", "1", "--output", str(tmp_path / "part")])
+    torch.manual_seed(77)                                  # a different init: everything must come from the checkpoint
+    m_res, _ = ts.main(common + ["--epochs", "2", "--output", str(tmp_path / "part"), "--resume", str(tmp_path / "part" / "checkpoint-0.pth.tar")])
+    for (k, a), (_, c) in zip(m_full.state_dict().items(), m_res.state_dict().items()):
+        assert torch.equal(a, c), k
+    from radar_depth_amd import utils
+    ck = utils.load_checkpoint(str(tmp_path / "part" / "checkpoint-1.pth.tar"))
+    assert ck["epoch"] == 1 and ck["arch"] == "resnet18_latefusion" and len(ck["optimizer_state_dict"]["state"]) == 163
+    assert ck["args"].decoder == "upproj" and ck["best_result"].rmse < float("inf")
