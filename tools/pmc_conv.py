@@ -1,11 +1,13 @@
 """Tiny driver for rocprofv3 --pmc runs: a few launches of the dominant conv shapes (layer1 3x3 64->64, B=16)."""
 import sys
 import torch
-sys.path.insert(0, ".")
+import os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from radar_depth_amd import convdesc as cd, ops
 B = 16
 dev = "cuda"
-for (ci, co, k, s, p, h, w) in [(64, 64, 3, 1, 1, 113, 200), (128, 128, 3, 1, 1, 57, 100), (512, 512, 3, 1, 1, 15, 25)]:
+# (round 2: + a stride-2 3x3 forward, which runs as input-parity groups)
+for (ci, co, k, s, p, h, w) in [(64, 64, 3, 1, 1, 113, 200), (128, 128, 3, 1, 1, 57, 100), (512, 512, 3, 1, 1, 15, 25), (64, 128, 3, 2, 1, 113, 200)]:
     d = cd.conv_fwd(B, h, w, ci, co, k, s, p)
     x = torch.randn(B, h, w, ci, device=dev)
     wt = torch.randn(co, ci, k, k, device=dev)
@@ -15,5 +17,6 @@ for (ci, co, k, s, p, h, w) in [(64, 64, 3, 1, 1, 113, 200), (128, 128, 3, 1, 1,
     slabs = torch.empty(ops.wgrad_workspace_floats(d), device=dev)
     for _ in range(3):
         ops.gconv(d, x, wp, y, stat=stat)
-        ops.wgrad(d, x, y, slabs)
+        if s == 1:
+            ops.wgrad(d, x, y, slabs)
 torch.cuda.synchronize()
