@@ -738,8 +738,18 @@ static bool plan_gconv(const RdConvDesc& d, GconvPlan& best, bool allow_split = 
                 const bool hole_free = d.n_phases == 1 ? d.out_stride == 1 : covered == (int64_t)d.Ho * d.Wo;
                 const bool can_split = !nosplit && allow_split && hole_free && d.ldo == d.Cout && d.Cout <= 1024;
                 double base = score;
+                // A split slice must still carry enough MFMA work to pay for the combine launch (~10 us) and the partial-sum
+                // round trip: the 1x1 convolutions and the small depth-branch layers ran up to 2x slower split four ways than
+                // unsplit (fusion 1x1 forward 78 -> 52 us, its dgrad 104 -> 53 us), the 512-channel 3x3 layers 1.3x faster.
+                static const char* minmf = getenv("RD_GCONV_SPLIT_MIN_MFLOP");      // diagnostics (default 25)
+                const double min_slice_flops = (minmf ? atof(minmf) : 25.0) * 1e6;
+                double taps_avg = 0;
+                for (int i = 0; i < d.n_phases; ++i) taps_avg += d.phase[i].n_taps;
+                taps_avg /= d.n_phases;
+                const double wg_flops = 2.0 * TH * TW * BN * (double)d.Cin * taps_avg;
                 for (int ksp = 1; ksp <= (can_split ? 4 : 1); ksp *= 2) {
                     if (d.Cin % (ksp * ckp) != 0) continue;
+                    if (ksp > 1 && wg_flops / ksp < min_slice_flops) continue;
                     const double wgs = wgs1 * ksp;
                     // fewer than two workgroups per CU leaves staging/epilogue phases uncovered
                     score = base * (wgs / (ncu * ceil(wgs / ncu))) * (ksp == 1 ? 1.0 : (ksp == 2 ? 0.95 : 0.91)) *
