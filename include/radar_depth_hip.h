@@ -418,6 +418,14 @@ int rd_head_conv_fwd_t(int32_t dtype, const void* x, int32_t ldx, const float* w
 int rd_head_conv_bwd_t(int32_t dtype, const void* x, int32_t ldx, const float* w_oihw, const float* dd, int32_t N, int32_t H,
                        int32_t W, int32_t C, void* dx, int32_t lddx, float* dw_oihw, float* ws, void* stream);
 
+/* Plan tuner for rd_gconv / rd_gconv_ws (the role cudnn.benchmark plays for the reference's convolutions): list the candidate
+ * execution plans of a descriptor (9 ints each: MT, NT, WM, WN, CKP, TH, TW, ksplit, pipelined; best heuristic score first; returns
+ * the count), pin one -- every later call with that descriptor, workspace / statistics-tile queries included, uses it -- or pin
+ * NULL to return to the heuristic.  The caller times rd_gconv_ws under each pinned candidate (radar_depth_amd/autotune.py).
+ * allow_split: 1 for the rd_gconv_ws form (with workspace), 0 for rd_gconv. */
+int rd_gconv_tune_candidates(const RdConvDesc* d, int32_t allow_split, int32_t* out, int32_t max_candidates);
+int rd_gconv_tune_pin(const RdConvDesc* d, int32_t allow_split, const int32_t* candidate);
+
 /* diagnostics: fill every CU's LDS with NaN bit patterns (LDS is not cleared between kernels): a kernel that consumes an LDS
  * word it never wrote then yields NaN instead of depending on its predecessor's leftovers (tools/fuzz_conv.py --poison) */
 int rd_debug_poison_lds(void* stream);

@@ -1,0 +1,102 @@
+"""Plan tuner for the generalised convolution (the role cudnn.benchmark plays for the reference's convolutions).
+
+The planner in csrc/gconv.hip scores tilings with a model fitted to the large layers; for the small-spatial, few-tap and multi-phase
+launches of the network (1x1 convolutions, the depth branch, stride-2 input gradients, the UpProj phases) timing finds plans 5-40 %
+faster (tools/sweep_plan_layers.py).  tune_gconv() times rd_gconv_ws under every candidate plan of a descriptor on scratch tensors,
+checks each candidate's result against the first one (a wrong kernel configuration must never win), and pins the fastest through the C
+ABI (rd_gconv_tune_pin): the plan cache of the library then serves it to every later call with that descriptor.
+
+Results are cached per process, so the second model / plan with the same shapes costs nothing.  Tuning makes the choice of summation
+order depend on timing noise: two PROCESSES may pick different plans and differ in the last bits (two models in one process share the
+pinned plans and stay bit-identical).  Off by default; HipTrainStep(autotune=True), LateFusionPlan(autotune=True) or RD_AUTOTUNE=1."""
+import ctypes as C
+import os
+
+import torch
+
+_TUNED = {}
+MAX_CANDIDATES = 32
+
+
+def enabled_by_default():
+    return os.environ.get("RD_AUTOTUNE", "0") == "1"
+
+
+def _time_launch(fn, iters):
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        fn()
+    e1.record()
+    e1.synchronize()
+    return e0.elapsed_time(e1) * 1e3 / iters          # microseconds
+
+
+def tune_gconv(L, d, device, allow_split=True, verify=True, report=None):
+    """Pin the fastest plan for descriptor d (RdConvDesc) as rd_gconv_ws will run it.  Returns (best_us, heuristic_us) or None when
+    there is nothing to choose from.  report: optional list that receives (us, candidate tuple, ok) rows."""
+    key = bytes(d) + (b"\x01" if allow_split else b"\x00")
+    if key in _TUNED:
+        return _TUNED[key]
+    cand = (C.c_int32 * (9 * MAX_CANDIDATES))()
+    n = L.rd_gconv_tune_candidates(C.byref(d), int(allow_split), cand, MAX_CANDIDATES)
+    if n <= 1:
+        _TUNED[key] = None
+        return None
+    n_slabs = max(d.phase[i].widx[t] for i in range(d.n_phases) for t in range(d.phase[i].n_taps)) + 1
+    g = torch.Generator(device="cpu").manual_seed(1234)
+    x = torch.randn(d.N * d.Hi * d.Wi * d.ldi, generator=g).to(device)
+    w = (torch.randn(n_slabs * d.Cin * d.Cout, generator=g) * (1.0 / (d.Cin * 4.0) ** 0.5)).to(device)
+    out = torch.zeros(d.N * d.Ho * d.Wo * d.ldo, device=device)
+    stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    pv = lambda t: C.c_void_p(t.data_ptr())
+    rows, ref = [], None
+    for i in range(n):
+        c = (C.c_int32 * 9)(*cand[9 * i:9 * i + 9])
+        if L.rd_gconv_tune_pin(C.byref(d), int(allow_split), c) != 0:
+            continue
+        nws = int(L.rd_gconv_workspace_floats(C.byref(d)))
+        ws = torch.empty(nws, device=device) if nws > 0 else None
+
+        def launch():
+            rc = L.rd_gconv_ws(C.byref(d), pv(x), pv(w), pv(out), None, 0, None, pv(ws) if ws is not None else None, stream)
+            if rc != 0:
+                raise RuntimeError("rd_gconv_ws failed under candidate %s: %s" % (tuple(c), L.rd_last_error().decode()))
+        out.zero_()
+        try:
+            launch()
+            if i == 0:                    # let the device clock ramp before the first timing (cold launches read ~13 % slow)
+                _time_launch(launch, 30)
+            ok = True
+            if verify:
+                if ref is None:
+                    ref = out.clone()
+                else:
+                    ok = bool(((out - ref).abs().max() <= 1e-4 * ref.abs().max().clamp_min(1e-20)).item())
+            us = _time_launch(launch, 3)
+            us = min(us, _time_launch(launch, 6))
+        except RuntimeError:
+            ok, us = False, float("inf")
+        rows.append((us, tuple(c), ok))
+        if report is not None:
+            report.append(rows[-1])
+    good = [r for r in rows if r[2]]
+    if not good:
+        L.rd_gconv_tune_pin(C.byref(d), int(allow_split), None)
+        _TUNED[key] = None
+        return None
+    best = min(good)
+    L.rd_gconv_tune_pin(C.byref(d), int(allow_split), (C.c_int32 * 9)(*best[1]))
+    bad = [r for r in rows if not r[2]]
+    if bad:
+        import warnings
+        warnings.warn("radar_depth_amd.autotune: %d gconv plan candidate(s) disagreed with the reference result and were rejected: %s"
+                      % (len(bad), [r[1] for r in bad][:3]))
+    _TUNED[key] = (best[0], rows[0][0])
+    return _TUNED[key]
+
+
+def summary():
+    """(descriptors tuned, sum of heuristic times, sum of tuned times) in microseconds over this process's tuned descriptors."""
+    done = [v for v in _TUNED.values() if v]
+    return len(done), sum(v[1] for v in done), sum(v[0] for v in done)

@@ -19,9 +19,11 @@
 #include <math.h>
 #include <stdlib.h>
 
+#include <algorithm>
 #include <mutex>
 #include <string>
 #include <unordered_map>
+#include <vector>
 
 #include "common.h"
 
@@ -669,7 +671,10 @@ static size_t lds_need(int BM, int BN, int CKW, int CKP, int PP, int taps_max, b
 
 // Choose wave tiling + pixel tile for a descriptor.  Heuristic: maximise useful-MAC fraction of the
 // BM x BN tile, penalise halo re-reads, prefer <= 80 KB of LDS (two workgroups per CU).
-static bool plan_gconv(const RdConvDesc& d, GconvPlan& best, bool allow_split = false) {
+// all: when given, every feasible (score, plan) point of the search is collected (the plan tuner's candidate list); the env overrides
+// RD_GCONV_FORCE / RD_GCONV_CKP / ... are diagnostics of the HEURISTIC and are not applied to a collecting search.
+static bool plan_gconv(const RdConvDesc& d, GconvPlan& best, bool allow_split = false,
+                       std::vector<std::pair<double, GconvPlan>>* all = nullptr) {
     // prior = measured relative efficiency of the register tile on large layers (tools/sweep_gconv.py, B=16 layer1/layer2);
     // WN=2 tilings (2,2,2,2), (4,2,2,2) never won a shape and were dropped.
     struct Cfg { int MT, NT, WM, WN; double prior; };
@@ -690,13 +695,13 @@ static bool plan_gconv(const RdConvDesc& d, GconvPlan& best, bool allow_split = 
     int cfg_i = -1;
     for (const Cfg& c : cfgs) {
         ++cfg_i;
-        if (force && atoi(force) != cfg_i) continue;
+        if (!all && force && atoi(force) != cfg_i) continue;
         const int BM = c.WM * c.MT * 32, BN = c.WN * c.NT * 32;
         const int n_cot = cdiv(d.Cout, BN);
         const double n_util = (double)d.Cout / (n_cot * BN);
         static const char* force_ckp = getenv("RD_GCONV_CKP");   // diagnostics
         for (int ckp = 32; ckp >= 16; ckp -= 16) {
-            if (force_ckp && atoi(force_ckp) != ckp && d.Cin >= 32) continue;
+            if (!all && force_ckp && atoi(force_ckp) != ckp && d.Cin >= 32) continue;
             if (ckp > d.Cin && ckp != 16) continue;
             if (d.Cin % ckp != 0 && !(ckp == 16 && d.Cin % 16 == 0)) continue;
             for (int twt = 1; twt <= cdiv(P.lw, 4); ++twt) {
@@ -716,7 +721,11 @@ static bool plan_gconv(const RdConvDesc& d, GconvPlan& best, bool allow_split = 
                 const int upp = c.MT * c.NT >= 4 ? 8 : 4;
                 const int wsd_p = pick_wsd(taps_max, BN, CKW, ckp, true);
                 static const char* gnopipe = getenv("RD_GCONV_GROUP_NOPIPE");   // diagnostics
-                const bool pipe = !nopipe && !(grouped && gnopipe) && PP * (ckp / 4) <= upp * 256 && taps_max * (wsd_p / 4) * BN <= 7 * 256;
+                const bool pipe_ok = !nopipe && !(grouped && gnopipe) && PP * (ckp / 4) <= upp * 256 && taps_max * (wsd_p / 4) * BN <= 7 * 256;
+                // (a collecting search also lists the plain-loop form of a pipelinable point: the tuner found it faster for some
+                //  small launches)
+                for (int pv = pipe_ok ? 1 : 0; pv >= ((all && pipe_ok) ? 0 : (pipe_ok ? 1 : 0)); --pv) {
+                const bool pipe = pv != 0;
                 const size_t lds = lds_need(BM, BN, CKW, ckp, PP, taps_max, d.in_stride == 2 && !grouped, pipe);
                 if (lds > 160 * 1024 - 512) continue;
                 const double m_util = (double)P.lh * P.lw / ((double)cdiv(P.lh, TH) * cdiv(P.lw, TW) * BM);
@@ -749,17 +758,20 @@ static bool plan_gconv(const RdConvDesc& d, GconvPlan& best, bool allow_split = 
                 const double wg_flops = 2.0 * TH * TW * BN * (double)d.Cin * taps_avg;
                 for (int ksp = 1; ksp <= (can_split ? 4 : 1); ksp *= 2) {
                     if (d.Cin % (ksp * ckp) != 0) continue;
-                    if (ksp > 1 && wg_flops / ksp < min_slice_flops) continue;
+                    if (!all && ksp > 1 && wg_flops / ksp < min_slice_flops) continue;
                     const double wgs = wgs1 * ksp;
                     // fewer than two workgroups per CU leaves staging/epilogue phases uncovered
                     score = base * (wgs / (ncu * ceil(wgs / ncu))) * (ksp == 1 ? 1.0 : (ksp == 2 ? 0.95 : 0.91)) *
                             (wgs < 2 * ncu && lds <= 80 * 1024 ? 0.9 : 1.0);   // (a > 80 KB tile already paid for single residency)
+                    const GconvPlan cand{c.MT, c.NT, c.WM, c.WN, CKW, ckp, TH, TW, PP, 0, n_cot, taps_max, pick_wsd(taps_max, BN, CKW, ckp, pipe), ksp, lds,
+                                         pipe ? 1 : 0, grouped ? 1 : 0};
+                    if (all) all->emplace_back(score, cand);
                     if (score > best_score) {
                         best_score = score;
-                        best = GconvPlan{c.MT, c.NT, c.WM, c.WN, CKW, ckp, TH, TW, PP, 0, n_cot, taps_max, pick_wsd(taps_max, BN, CKW, ckp, pipe), ksp, lds, pipe ? 1 : 0,
-                                         grouped ? 1 : 0};
+                        best = cand;
                     }
                 }
+                }   // pipelined / plain form
             }
         }
     }
@@ -810,13 +822,13 @@ static void fill_tiles(RdConvDesc& d, GconvPlan& pl) {
 
 using namespace rd;
 
+static int plan_query(const RdConvDesc* d, bool allow_split, GconvPlan& pl, RdConvDesc& dd);
+
 // diagnostics: out[0..9] = MT, NT, WM, WN, CKW, CKP, TH, TW, lds_bytes, workgroups
 extern "C" int rd_gconv_plan_info(const RdConvDesc* d, int32_t* out) {
-    if (validate_desc(d) != RD_OK) return RD_EINVAL;
     GconvPlan pl;
-    RdConvDesc dd = *d;
-    if (!plan_gconv(dd, pl, true)) { set_error("gconv: no feasible tiling"); return RD_EINVAL; }
-    fill_tiles(dd, pl);
+    RdConvDesc dd;
+    if (plan_query(d, true, pl, dd) != RD_OK) return RD_EINVAL;       // the cached plan: heuristic, or pinned by the tuner
     // (reports the plan used WITH a workspace; CKW slot carries pipe*10000 + ksplit*100 + CKW)
     // (CKW slot: + 1000000 when the in_stride == 2 descriptor runs as input-parity groups, i.e. on the SWZ = false instantiation)
     const int v[10] = {pl.MT, pl.NT, pl.WM, pl.WN, pl.grouped * 1000000 + pl.pipe * 10000 + pl.ksplit * 100 + pl.CKW, pl.CKP, pl.TH, pl.TW, (int)pl.lds_bytes,
@@ -854,10 +866,14 @@ extern "C" int rd_gconv_occupancy(const RdConvDesc* d) {
 
 // Plans are a pure function of the descriptor: cached, because the step is issued as ~650 plain launches per iteration and the
 // tile search (tens of microseconds) would otherwise be repeated on every one of them.
+struct PlanEntry { GconvPlan pl; RdConvDesc dd; int tuner_owned; };   // tuner_owned == 0: handed out by a plain query -- callers may
+                                                                      // have sized buffers on it, so the tuner must not replace it
+static std::mutex g_plan_mu;
+static std::unordered_map<std::string, PlanEntry> g_plan_cache;
 static int plan_query(const RdConvDesc* d, bool allow_split, GconvPlan& pl, RdConvDesc& dd) {
-    struct Entry { GconvPlan pl; RdConvDesc dd; };
-    static std::mutex mu;
-    static std::unordered_map<std::string, Entry> cache;
+    std::mutex& mu = g_plan_mu;
+    std::unordered_map<std::string, PlanEntry>& cache = g_plan_cache;
+    typedef PlanEntry Entry;
     RD_CHECK_ARG(d != nullptr, "gconv: null descriptor");
     std::string key(reinterpret_cast<const char*>(d), sizeof(RdConvDesc));
     key.push_back(allow_split ? 1 : 0);
@@ -872,13 +888,91 @@ static int plan_query(const RdConvDesc* d, bool allow_split, GconvPlan& pl, RdCo
     if (!plan_gconv(dd, pl, allow_split)) { set_error("gconv: no feasible tiling"); return RD_EINVAL; }
     fill_tiles(dd, pl);
     std::lock_guard<std::mutex> lk(mu);
-    cache.emplace(std::move(key), Entry{pl, dd});
+    cache.emplace(std::move(key), Entry{pl, dd, 0});
     return RD_OK;
+}
+
+// ---- plan tuner (cudnn.benchmark's role): the heuristic above is fitted to the large layers; for the small-spatial, few-tap and
+// multi-phase launches the best (register tile, channel chunk, split, pipelined / plain loop) point is found by timing.  The
+// caller lists the candidate plans of a descriptor, times rd_gconv_ws with each one pinned, and pins the winner; every later
+// call with that descriptor (workspace / statistics-tile queries included) uses the pinned plan.  Candidate = 9 ints:
+// MT, NT, WM, WN, CKP, TH, TW, ksplit, pipelined.
+static bool same_point(const GconvPlan& p, const int32_t* c) {
+    return p.MT == c[0] && p.NT == c[1] && p.WM == c[2] && p.WN == c[3] && p.CKP == c[4] && p.TH == c[5] && p.TW == c[6] && p.ksplit == c[7] &&
+           p.pipe == c[8];
+}
+extern "C" int rd_gconv_tune_candidates(const RdConvDesc* d, int32_t allow_split, int32_t* out, int32_t max_candidates) {
+    if (validate_desc(d) != RD_OK) return RD_EINVAL;
+    RD_CHECK_ARG(out && max_candidates > 0, "gconv_tune_candidates: bad arguments");
+    {   // a descriptor somebody already planned without the tuner keeps its plan (its buffers were sized on it): nothing to tune
+        std::string key(reinterpret_cast<const char*>(d), sizeof(RdConvDesc));
+        key.push_back(allow_split ? 1 : 0);
+        std::lock_guard<std::mutex> lk(g_plan_mu);
+        auto it = g_plan_cache.find(key);
+        if (it != g_plan_cache.end() && !it->second.tuner_owned) return 0;
+    }
+    std::vector<std::pair<double, GconvPlan>> all;
+    GconvPlan best;
+    RdConvDesc dd = *d;
+    if (!plan_gconv(dd, best, allow_split != 0, &all)) { set_error("gconv: no feasible tiling"); return RD_EINVAL; }
+    // one point per (register tile, chunk, split, loop form): the best-scoring pixel tile of each; best score first
+    std::stable_sort(all.begin(), all.end(), [](const auto& a, const auto& b) { return a.first > b.first; });
+    std::vector<GconvPlan> pick;
+    for (const auto& sp : all) {
+        const GconvPlan& p = sp.second;
+        bool dup = false;
+        for (const GconvPlan& q : pick)
+            dup = dup || (q.MT == p.MT && q.NT == p.NT && q.CKP == p.CKP && q.ksplit == p.ksplit && q.pipe == p.pipe);
+        if (!dup) pick.push_back(p);
+    }
+    int n = 0;
+    for (const GconvPlan& p : pick) {
+        if (n == max_candidates) break;
+        const int v[9] = {p.MT, p.NT, p.WM, p.WN, p.CKP, p.TH, p.TW, p.ksplit, p.pipe};
+        for (int i = 0; i < 9; ++i) out[n * 9 + i] = v[i];
+        ++n;
+    }
+    return n;
+}
+// cand == NULL: back to the heuristic plan
+extern "C" int rd_gconv_tune_pin(const RdConvDesc* d, int32_t allow_split, const int32_t* cand) {
+    if (validate_desc(d) != RD_OK) return RD_EINVAL;
+    std::string key(reinterpret_cast<const char*>(d), sizeof(RdConvDesc));
+    key.push_back(allow_split ? 1 : 0);
+    GconvPlan pl;
+    RdConvDesc dd = *d;
+    if (!cand) {
+        if (!plan_gconv(dd, pl, allow_split != 0)) { set_error("gconv: no feasible tiling"); return RD_EINVAL; }
+    } else {
+        std::vector<std::pair<double, GconvPlan>> all;
+        GconvPlan best;
+        if (!plan_gconv(dd, best, allow_split != 0, &all)) { set_error("gconv: no feasible tiling"); return RD_EINVAL; }
+        bool found = false;
+        for (const auto& sp : all)
+            if (!found && same_point(sp.second, cand)) { pl = sp.second; found = true; }
+        RD_CHECK_ARG(found, "gconv_tune_pin: not a feasible plan of this descriptor");
+    }
+    fill_tiles(dd, pl);
+    std::lock_guard<std::mutex> lk(g_plan_mu);
+    auto it = g_plan_cache.find(key);
+    RD_CHECK_ARG(it == g_plan_cache.end() || it->second.tuner_owned, "gconv_tune_pin: this descriptor is already planned and in use");
+    g_plan_cache[key] = PlanEntry{pl, dd, 1};
+    return RD_OK;
+}
+
+// The plan a launch uses.  With a workspace: the split-allowed plan.  Without one: the split-allowed plan when it does not split
+// (callers size the statistics tiles with the _ws query and pass no workspace when it asks for none -- the tuner may have pinned a
+// plan under that key that differs from the no-split heuristic), otherwise the no-split plan.  The heuristic gives the same plan
+// under both keys whenever its split-allowed choice does not split, so this only matters for pinned plans.
+static int plan_lookup(const RdConvDesc* d, bool has_ws, GconvPlan& pl, RdConvDesc& dd) {
+    int rc = plan_query(d, true, pl, dd);
+    if (rc != RD_OK || has_ws || pl.ksplit == 1) return rc;
+    return plan_query(d, false, pl, dd);
 }
 
 extern "C" int rd_gconv_stat_tiles(const RdConvDesc* d) {
     GconvPlan pl; RdConvDesc dd;
-    if (plan_query(d, false, pl, dd) != RD_OK) return RD_EINVAL;
+    if (plan_lookup(d, false, pl, dd) != RD_OK) return RD_EINVAL;
     return d->N * pl.tiles_total;
 }
 
@@ -910,7 +1004,7 @@ static int gconv_impl(const RdConvDesc* d, const float* in, const float* w_packe
     RD_CHECK_ARG(in && w_packed && out, "gconv: null tensor");
     GconvArgs a;
     GconvPlan pl;
-    int rc = plan_query(d, ws != nullptr, pl, a.d);
+    int rc = plan_lookup(d, ws != nullptr, pl, a.d);
     if (rc != RD_OK) return rc;
     const bool split = pl.ksplit > 1;
     a.in = in; a.w = w_packed;

@@ -74,7 +74,7 @@ def _p(t):
 
 class LateFusionPlan:
     def __init__(self, module, batch, height, width, train=True, depth_planes=None, x_source=None, dense_grad_dst=None,
-                 dry_run=False, bf16=False, storage="fp32", segment_joins=True):
+                 dry_run=False, bf16=False, storage="fp32", segment_joins=True, autotune=None):
         """module: a radar_depth_amd ResNet_latefusion(2); bf16: run the gconv-lowered convolutions with bf16 operands on
         v_mfma_f32_32x32x16_bf16 (fp32 tensors, fp32 accumulation -- BASELINE.json configs 3/5, opt-in; in train plans the
         forward and input-gradient convolutions and the weight gradients of the >= 32-channel layers -- wgrad_bf16.hip; the
@@ -88,6 +88,9 @@ class LateFusionPlan:
         # segment_joins=False: the backward's bucket boundaries do not join the side streams into the main one (the main chain
         # keeps running ahead of the weight-gradient stream); each boundary instead records one event per side stream in
         # self.segment_events, which a data-parallel caller makes its communication stream wait for.  Only the end of backward joins.
+        # autotune: time the candidate execution plans of every fp32 gconv descriptor once and pin the fastest (autotune.py)
+        from . import autotune as _at
+        self.autotune = _at.enabled_by_default() if autotune is None else bool(autotune)
         self.segment_joins = bool(segment_joins)
         self.segment_events = []
         # storage: element type of the NHWC activation / gradient tensors in HBM.  "bf16" (BASELINE.json configs 3 / 5) halves the
@@ -190,8 +193,16 @@ class LateFusionPlan:
         return self.m._grad_view(param)
 
     # ------------------------------------------------------------------ convolution (gconv family)
+    def _tune(self, d):
+        """fp32 gconv descriptors only (the bf16 kernels have their own planner); must run before the descriptor's statistics
+        tiles / workspace are sized, because both depend on the plan."""
+        if self.autotune and not self.dry_run and not self.bf16:
+            from . import autotune as _at
+            _at.tune_gconv(self.L, d, self.dev)
+
     def _gconv_ws(self, d, name):
         """Split-K workspace of a descriptor (None when the library's plan does not split)."""
+        self._tune(d)
         n = self.L.rd_gconv_workspace_floats(C.byref(d))
         if n < 0:
             check(int(n), "rd_gconv_workspace_floats(%s)" % name)
@@ -219,6 +230,7 @@ class LateFusionPlan:
             o, i, kh, kw = w.shape
             self.pack_jobs.append((w, wp, o, i, kh * kw, cout, off, i, 0, None, quad))
             self.pack_jobs.append((w, wd, o, i, kh * kw, cin, off, cout, 1, None, quad))
+        self._tune(d)
         tiles = (self.L.rd_gconv_bf16_stat_tiles if self.bf16 else self.L.rd_gconv_stat_tiles_ws)(C.byref(d))
         if tiles < 0:
             check(tiles, "rd_gconv_stat_tiles(%s)" % name)
@@ -770,12 +782,17 @@ class LateFusionPlan:
         # diagnostics: RD_POISON_LDS=1 (with RD_SINGLE_STREAM=1) NaN-fills every CU's LDS before each op, so that a kernel
         # consuming LDS it never wrote shows up as NaN in the parity tests instead of depending on its predecessor's leftovers
         poison = os.environ.get("RD_POISON_LDS") == "1" and not self.multi_stream
+        trace_ops = os.environ.get("RD_TRACE_OPS") == "1"       # diagnostics: name every op and synchronise behind it
         for name, fn, args in ops:
             if poison:
                 self.L.rd_debug_poison_lds(self.streams[0])
+            if trace_ops:
+                print("[op]", name, getattr(fn, "__name__", fn), flush=True)
             rc = fn(*args)
             if rc != 0:
                 check(rc, name)
+            if trace_ops:
+                torch.cuda.synchronize()
 
     def set_stream(self, serialize=False):
         """Bind stream 0 to torch's current stream and streams 1/2 to the plan's side streams (serialize=True binds all

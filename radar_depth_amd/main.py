@@ -107,7 +107,7 @@ class HipTrainStep:
     torch.autocast(bfloat16) analogue for BASELINE.json configs 2/4; tolerances in tests/test_gpu_bf16.py."""
 
     def __init__(self, model, batch, height, width, lr=0.01, momentum=0.9, weight_decay=1e-4, loss_weights=None, use_graph=False,
-                 operands="fp32", criterion="l1", comm="auto", storage="fp32"):
+                 operands="fp32", criterion="l1", comm="auto", storage="fp32", autotune=None):
         """criterion: "l1" (MaskedL1Loss, the default of utils.parse_command) or "l2" (MaskedMSELoss, `-c l2`, main.py:294-305).
         comm: "rccl" = the C ABI's own communicator (radar_depth_amd.comm, rd_allreduce_bucket on a dedicated communication
         stream, event-chained behind each backward segment); "torch" = torch.distributed.all_reduce (the cross-check);
@@ -135,12 +135,13 @@ class HipTrainStep:
         model.train()
         self.multistage = isinstance(model, ResNet_multistage)
         if self.multistage:
-            self.mp = model._plans(batch, height, width, True, bf16=operands == "bf16", storage=storage, segment_joins=joins)
+            self.mp = model._plans(batch, height, width, True, bf16=operands == "bf16", storage=storage, segment_joins=joins, autotune=autotune)
             self.plans = [self.mp.p1, self.mp.p2]
         else:
             assert isinstance(model, ResNet_latefusion)
             self.mp = None
-            self.plans = [model._plan(batch, height, width, True, bf16=operands == "bf16", storage=storage, segment_joins=joins)]
+            self.plans = [model._plan(batch, height, width, True, bf16=operands == "bf16", storage=storage, segment_joins=joins,
+                                      autotune=autotune)]
         self.plan = self.plans[0]
         self.st = model._ensure_arenas()
         self._arena_version = self.st["version"]

@@ -265,7 +265,7 @@ class ResNet_latefusion(ArenaOwner, nn.Module):
         return 1
 
     # ------------------------------------------------------------------ HIP execution
-    def _plan(self, batch, height, width, train, depth_planes=None, bf16=False, storage="fp32", segment_joins=True):
+    def _plan(self, batch, height, width, train, depth_planes=None, bf16=False, storage="fp32", segment_joins=True, autotune=None):
         from ..engine import LateFusionPlan
         st = self._ensure_arenas()
         key = (batch, height, width, bool(train), st["version"], None if depth_planes is None else tuple(t.data_ptr() for t in depth_planes),
@@ -274,7 +274,7 @@ class ResNet_latefusion(ArenaOwner, nn.Module):
         if key not in plans:
             _evict_plans(plans, st["version"])
             plans[key] = LateFusionPlan(self, batch, height, width, train=train, depth_planes=depth_planes, bf16=bf16, storage=storage,
-                                        segment_joins=segment_joins)
+                                        segment_joins=segment_joins, autotune=autotune)
         else:
             plans[key] = plans.pop(key)          # most recently used last
         return plans[key]

@@ -548,3 +548,49 @@ def test_training_loop_checkpoint_and_resume(tmp_path):
     ck = utils.load_checkpoint(str(tmp_path / "part" / "checkpoint-1.pth.tar"))
     assert ck["epoch"] == 1 and ck["arch"] == "resnet18_latefusion" and len(ck["optimizer_state_dict"]["state"]) == 163
     assert ck["args"].decoder == "upproj" and ck["best_result"].rmse < float("inf")
+
+
+def test_autotuned_plans_keep_parity_and_do_not_disturb_existing_plans():
+    """The gconv plan tuner (radar_depth_amd/autotune.py): (1) a plan built before tuning keeps working -- descriptors that were
+    already planned are never re-pinned under it; (2) a model built with autotune=True at a geometry nobody planned yet reproduces
+    the oracle's forward / loss / gradient norms like the heuristic plans do; (3) every candidate the tuner timed agreed with the
+    reference result (it warns and rejects otherwise)."""
+    import warnings
+    from oracle.criteria import MaskedL1Loss as OL1
+    from radar_depth_amd import autotune
+    from radar_depth_amd.main import HipTrainStep
+    from radar_depth_amd.synthetic import make_batch
+    b, h, w = 2, 97, 161
+    m0, _ = _latefusion_pair(h, w)
+    t0 = HipTrainStep(m0, b, h, w)                        # heuristic plans at this geometry: now in use
+    x, t = make_batch(b, h, w, 11, ref_pixels=h * w)
+    l_before, _ = t0.step(x.cuda(), t.cuda())
+    m1, _ = _latefusion_pair(h, w)
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")                    # a rejected candidate would warn
+        t1 = HipTrainStep(m1, b, h, w, autotune=True)     # same descriptors: nothing may be re-pinned
+        l_same, _ = t1.step(x.cuda(), t.cuda())
+        torch.cuda.synchronize()
+        assert l_before.item() == l_same.item()           # same plans -> bit-identical
+        # a fresh geometry: tuned from scratch
+        b2, h2, w2 = 3, 113, 145
+        n0 = autotune.summary()[0]
+        m2, o2 = _latefusion_pair(h2, w2)
+        x2, tg2 = make_batch(b2, h2, w2, 12, ref_pixels=h2 * w2)
+        yo = o2(x2)
+        lo = OL1()(yo, tg2)
+        lo.backward()
+        init = [p.detach().clone() for p in m2.parameters()]
+        t2 = HipTrainStep(m2, b2, h2, w2, lr=1.0, momentum=0.0, weight_decay=0.0, autotune=True)
+        loss, pred = t2.step(x2.cuda(), tg2.cuda())
+        torch.cuda.synchronize()
+    n1, heur_us, tuned_us = autotune.summary()
+    assert n1 > n0 and tuned_us <= heur_us
+    assert rel(_t(pred), _t(yo)) < 1e-3 and abs(loss.item() - lo.item()) / lo.item() < 1e-4
+    go = np.array([p.grad.double().norm().item() for p in o2.parameters()])
+    gg = np.array([(i0 - p.detach()).double().norm().item() for i0, p in zip(init, m2.parameters())])
+    assert np.abs(go - gg).max() / go.max() < 2e-2
+    l_after, _ = t0.step(x.cuda(), t.cuda())              # the first model's plan still runs (and still agrees with its twin)
+    l_twin, _ = t1.step(x.cuda(), t.cuda())
+    torch.cuda.synchronize()
+    assert l_after.item() == l_twin.item() and np.isfinite(l_after.item())
