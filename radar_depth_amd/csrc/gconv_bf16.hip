@@ -45,6 +45,7 @@ struct GconvBfArgs {
     float* stat;
     int act, act_cols, ld_add, ldw;
     int TH, TW, PP, CKP, tiles_total, n_cotiles, taps_max;
+    int vec4;                     // out / addend / bias allow 4-channel accesses (alignment, strides, Cout, act_cols all multiples of 4)
     int tapoff[RD_MAX_PHASES][RD_MAX_TAPS];   // byte offset of tap t inside the patch
     unsigned long long* trace;                // diagnostics (RD_GCONV_BF16_TRACE=1): 32 cycle-counter stamps per workgroup
 };
@@ -53,6 +54,21 @@ __device__ __forceinline__ bf16x4 cvt4(const float4 v) {
     bf16x4 r;
     r[0] = (__bf16)v.x; r[1] = (__bf16)v.y; r[2] = (__bf16)v.z; r[3] = (__bf16)v.w;
     return r;
+}
+
+// quad exchanges (DPP quad_perm) and the in-register 4x4 transposition used by the epilogue: on entry lane q of a quad holds
+// (row j, column q) in a_j; on exit it holds (row q, column c) in a_c.
+__device__ __forceinline__ float dpp_xor1(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, false));   // quad_perm [1,0,3,2]
+}
+__device__ __forceinline__ float dpp_xor2(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, false));   // quad_perm [2,3,0,1]
+}
+__device__ __forceinline__ void quad_transpose(float& a0, float& a1, float& a2, float& a3, bool odd1, bool odd2) {
+    const float r0 = dpp_xor1(odd1 ? a0 : a1), r1 = dpp_xor1(odd1 ? a2 : a3);
+    const float b0 = odd1 ? r0 : a0, b1 = odd1 ? a1 : r0, b2 = odd1 ? r1 : a2, b3 = odd1 ? a3 : r1;
+    const float u0 = dpp_xor2(odd2 ? b0 : b2), u1 = dpp_xor2(odd2 ? b1 : b3);
+    a0 = odd2 ? u0 : b0; a1 = odd2 ? u1 : b1; a2 = odd2 ? b2 : u0; a3 = odd2 ? b3 : u1;
 }
 
 // IO16: the activation tensors (in, out, addend) are stored as bf16 in HBM (bf16-storage plans): the patch is a straight 16-byte
@@ -328,49 +344,66 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void g
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) biasv[nt] = (has_bias && cob + nt * 32 < D.Cout) ? a.bias[cob + nt * 32] : 0.f;
     const bool want_stat = a.stat != nullptr;
-    // lane-constant column validity: partial N tiles (the 16-channel layers) stay on the branch-free path with masked stores
-    bool cok[NT];
+    // Row-major stores: in the MFMA's C/D layout a lane holds ONE output channel of 16 pixels, so a plain epilogue stores (and
+    // reads the addend) one element per lane and instruction -- 96 two-byte stores per lane for the 3x2 tile, which took 25 % of a
+    // workgroup's lifetime on the 64-channel layers (13.6 k of 54 k clocks, tools/trace_gconv_bf16.py).  Each 4x4 block
+    // (4 accumulator registers x the 4 lanes of a quad = 4 pixels x 4 channels) is transposed in registers with two DPP
+    // exchanges, after which a lane holds FOUR consecutive channels of one pixel: 8-byte (bf16) / 16-byte (fp32) accesses, a
+    // quarter of the instructions.  Needs 4-channel alignment of every pointer and stride (a.vec4, checked by the host).
+    const int q4l = l31 & 3, k4l = l31 >> 2;
+    const bool odd1 = q4l & 1, odd2 = q4l & 2;
+    float4 ssum4[NT], ssq4[NT];
 #pragma unroll
-    for (int nt = 0; nt < NT; ++nt) cok[nt] = cob + nt * 32 < D.Cout;
+    for (int nt = 0; nt < NT; ++nt) ssum4[nt] = ssq4[nt] = make_float4(0.f, 0.f, 0.f, 0.f);
+    bool any4 = false;
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
-        int ro[16];
+        int ro4[4];
         bool rows_ok = true;
 #pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            ro[i] = s_opix[(wm * MT + mt) * 32 + (i & 3) + 8 * (i >> 2) + 4 * hh];   // -1: no such pixel
-            rows_ok = rows_ok && ro[i] >= 0;
+        for (int g = 0; g < 4; ++g) {
+            ro4[g] = s_opix[(wm * MT + mt) * 32 + q4l + 8 * g + 4 * hh];   // this lane's pixel of register group g after the transposition
+            rows_ok = rows_ok && ro4[g] >= 0;
         }
-        if (__all(rows_ok)) {
-            // full M-tile (almost all of them): no exec masking; the addends of eight rows are gathered before their first use
+        if (a.vec4 && __all(rows_ok)) {
+            // full M-tile (almost all of them): no exec masking; the addends are gathered before their first use
+            any4 = true;
+            const int cq = co0 + 4 * k4l;
+            float4 addv[NT][4];
+            if (has_add) {
 #pragma unroll
-            for (int h8 = 0; h8 < 16; h8 += 8) {
-                float addv[NT][8];
-                if (has_add) {
+                for (int g = 0; g < 4; ++g) {
+                    const io_t* ap = static_cast<const io_t*>(a.addend) + (size_t)ro4[g] * a.ld_add + cq;
 #pragma unroll
-                    for (int i = 0; i < 8; ++i) {
-                        const io_t* ap = static_cast<const io_t*>(a.addend) + (size_t)ro[h8 + i] * a.ld_add + cob;
-#pragma unroll
-                        for (int nt = 0; nt < NT; ++nt) addv[nt][i] = cok[nt] ? ld1(ap + nt * 32) : 0.f;
-                    }
+                    for (int nt = 0; nt < NT; ++nt) addv[nt][g] = (cq + nt * 32 < D.Cout) ? ld4(ap + nt * 32) : make_float4(0.f, 0.f, 0.f, 0.f);
                 }
+            }
 #pragma unroll
-                for (int i = 0; i < 8; ++i) {
-                    io_t* rp = static_cast<io_t*>(a.out) + (size_t)ro[h8 + i] * D.ldo + cob;
+            for (int nt = 0; nt < NT; ++nt) {
+                const bool cok4 = cq + nt * 32 < D.Cout;
+                float4 b4 = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (has_bias && cok4) b4 = *reinterpret_cast<const float4*>(a.bias + cq + nt * 32);
 #pragma unroll
-                    for (int nt = 0; nt < NT; ++nt) {
-                        float v = acc[mt][nt][h8 + i] + biasv[nt];
-                        if (has_add) v += addv[nt][i];
-                        if (cob + nt * 32 < a.act_cols) v = act_fwd(v, a.act);
-                        if (cok[nt]) st1(rp + nt * 32, v);
-                        if (want_stat) {
-                            ssum[nt] += v;
-                            ssq[nt] += v * v;
-                        }
+                for (int g = 0; g < 4; ++g) {
+                    float e0 = acc[mt][nt][4 * g], e1 = acc[mt][nt][4 * g + 1], e2 = acc[mt][nt][4 * g + 2], e3 = acc[mt][nt][4 * g + 3];
+                    quad_transpose(e0, e1, e2, e3, odd1, odd2);
+                    float4 v = make_float4(e0 + b4.x, e1 + b4.y, e2 + b4.z, e3 + b4.w);
+                    if (has_add) { v.x += addv[nt][g].x; v.y += addv[nt][g].y; v.z += addv[nt][g].z; v.w += addv[nt][g].w; }
+                    const int cc = cq + nt * 32;
+                    if (cc < a.act_cols) {          // (act_cols is a multiple of 4 whenever vec4 is set)
+                        v.x = act_fwd(v.x, a.act); v.y = act_fwd(v.y, a.act); v.z = act_fwd(v.z, a.act); v.w = act_fwd(v.w, a.act);
+                    }
+                    if (cok4) st4(static_cast<io_t*>(a.out) + (size_t)ro4[g] * D.ldo + cc, v);
+                    if (want_stat) {
+                        ssum4[nt].x += v.x; ssum4[nt].y += v.y; ssum4[nt].z += v.z; ssum4[nt].w += v.w;
+                        ssq4[nt].x += v.x * v.x; ssq4[nt].y += v.y * v.y; ssq4[nt].z += v.z * v.z; ssq4[nt].w += v.w * v.w;
                     }
                 }
             }
         } else {
+            int ro[16];
+#pragma unroll
+            for (int i = 0; i < 16; ++i) ro[i] = s_opix[(wm * MT + mt) * 32 + (i & 3) + 8 * (i >> 2) + 4 * hh];   // -1: no such pixel
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) {
                 const int co = cob + nt * 32;
@@ -387,6 +420,20 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void g
                     }
                 }
             }
+        }
+    }
+    if (want_stat && __any(any4)) {
+        // back to one channel per lane: sum the four pixels of the quad (every lane of it then holds the quad's four channel sums),
+        // lane q keeps channel q
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            float4 s4 = ssum4[nt], q4 = ssq4[nt];
+            s4.x += dpp_xor1(s4.x); s4.y += dpp_xor1(s4.y); s4.z += dpp_xor1(s4.z); s4.w += dpp_xor1(s4.w);
+            q4.x += dpp_xor1(q4.x); q4.y += dpp_xor1(q4.y); q4.z += dpp_xor1(q4.z); q4.w += dpp_xor1(q4.w);
+            s4.x += dpp_xor2(s4.x); s4.y += dpp_xor2(s4.y); s4.z += dpp_xor2(s4.z); s4.w += dpp_xor2(s4.w);
+            q4.x += dpp_xor2(q4.x); q4.y += dpp_xor2(q4.y); q4.z += dpp_xor2(q4.z); q4.w += dpp_xor2(q4.w);
+            ssum[nt] += odd2 ? (odd1 ? s4.w : s4.z) : (odd1 ? s4.y : s4.x);
+            ssq[nt] += odd2 ? (odd1 ? q4.w : q4.z) : (odd1 ? q4.y : q4.x);
         }
     }
     if (a.stat) {
@@ -603,6 +650,13 @@ static int gconv_bf16_impl(bool io16, const RdConvDesc* d, const void* in, const
     a.act = act; a.act_cols = act_cols; a.ld_add = ld_add; a.ldw = d->Cout;
     a.TH = pl.TH; a.TW = pl.TW; a.PP = pl.PP; a.CKP = pl.CKP;
     a.tiles_total = pl.tiles_total; a.n_cotiles = pl.n_cotiles; a.taps_max = pl.taps_max;
+    {
+        const uintptr_t al = io16 ? 8 : 16;     // four channels
+        static const char* novec = getenv("RD_GCONV_BF16_NOVEC4");   // diagnostics: element-wise epilogue
+        a.vec4 = !novec && d->Cout % 4 == 0 && d->ldo % 4 == 0 && reinterpret_cast<uintptr_t>(out) % al == 0 && act_cols % 4 == 0 &&
+                 (!addend || (ld_add % 4 == 0 && reinterpret_cast<uintptr_t>(addend) % al == 0)) &&
+                 (!bias || reinterpret_cast<uintptr_t>(bias) % 16 == 0);
+    }
     const int PSB = (pl.CKP + 8) * 2;
     for (int i = 0; i < d->n_phases; ++i) {
         const RdPhase& p = d->phase[i];
