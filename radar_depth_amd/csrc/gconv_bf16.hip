@@ -180,18 +180,28 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void g
         // Fragment ring of DEPTH steps, statically indexed (the step loop is unrolled by DEPTH): the reads of step s + DEPTH - 1
         // are issued before the MFMAs of step s, unconditionally (past the end they re-read the last step), so the body is
         // straight-line code and the compiler can wait for exactly the oldest outstanding read instead of lgkmcnt(0).
+        // The main loop has NO conditional inside and its order is pinned: with an `if (s < nsteps)` around the MFMAs the wait-count
+        // pass saw a merge of differently loaded paths and emitted s_waitcnt lgkmcnt(0) -- a full drain of the reads in flight --
+        // once per trip; without the scheduling barriers the scheduler sinks the reads below the next step's MFMAs to save
+        // registers and waits for them immediately.  Now every MFMA group waits with lgkmcnt(2 steps of reads).  The remainder
+        // (nsteps mod DEPTH steps, already loaded) follows the loop.
         constexpr int DEPTH = 3;                 // (four sets measured the same; the 3x2 tile has 254 registers with three)
         bf16x8 fa[DEPTH][MT], fb[DEPTH][NT];
         const int last = nsteps - 1;
 #pragma unroll
         for (int j = 0; j < DEPTH - 1; ++j) load(min(j, last), fa[j], fb[j]);
-        for (int s0 = 0; s0 < nsteps; s0 += DEPTH) {
+        int s0 = 0;
+        for (; s0 + DEPTH <= nsteps; s0 += DEPTH) {
 #pragma unroll
             for (int j = 0; j < DEPTH; ++j) {
                 load(min(s0 + j + DEPTH - 1, last), fa[(j + DEPTH - 1) % DEPTH], fb[(j + DEPTH - 1) % DEPTH]);
-                if (s0 + j < nsteps) mma(fa[j], fb[j]);
+                __builtin_amdgcn_sched_barrier(0);
+                mma(fa[j], fb[j]);
+                __builtin_amdgcn_sched_barrier(0);
             }
         }
+        if (s0 < nsteps) mma(fa[0], fb[0]);
+        if (s0 + 1 < nsteps) mma(fa[1], fb[1]);
     };
 
     // ---- staging.  These layers are bound by memory and by the integer work of the staging itself (the bf16 MFMAs of a chunk

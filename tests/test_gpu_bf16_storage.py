@@ -200,7 +200,7 @@ def test_bf16_storage_train_step_vs_emulated_oracle(arch):
     that crosses a bf16 rounding boundary jumps by 2^-8 and batch-statistics BatchNorm over 48 values per channel amplifies it.
     Two correct implementations therefore agree on the map only to that floor; what is pinned tightly is what averages over
     pixels.  Stated tolerances (measured: latefusion / multistage): loss 2e-3 (6.8e-5 / 2.0e-4); gradient norm of EVERY parameter
-    tensor within 3e-2 of the largest (8.1e-3 / 1.1e-2); output map 0.15 max / 0.12 rms = 1.5x the self-sensitivity floor
+    tensor within ~2x the oracle's own sensitivity floor (see the comment at the assertion); output map 0.15 max / 0.12 rms = 1.5x the self-sensitivity floor
     (8.1e-2 / 6.1e-2; stage 2 of the multistage net teacher-forced, see tests/test_gpu_configs.py); latefusion tail
     (decoder.layer4, conv3) gradients element-wise 0.15 norm-wise (5.6e-2)."""
     from oracle import train as otrain
@@ -234,12 +234,20 @@ def test_bf16_storage_train_step_vs_emulated_oracle(arch):
     no = np.array([g_.double().norm().item() for g_ in go])
     ng = np.array([g_.double().norm().item() for g_ in gg])
     e_norm = np.abs(no - ng).max() / no.max()
+    body = [i for i, n in enumerate(names) if not n.endswith(("conv1.weight", "conv1_depth.weight")) or ".layer" in n]   # all but the 7x7 stems
+    e_body = np.abs(no[body] - ng[body]).max() / no.max()
     tail = [i for i, n in enumerate(names) if ("decoder.layer4" in n or "conv3" in n) and not n.startswith("stage1.")]
     e_tail = max((go[i] - gg[i]).norm().item() / max(go[i].norm().item(), 1e-20) for i in tail)
     print("bf16 storage %s: loss %.3e  out max %.3e rms %.3e  grad norms %.3e (%s)  tail elementwise %.3e"
           % (arch, e_loss, e_out, e_rms, e_norm, names[int(np.abs(no - ng).argmax())], e_tail))
     assert all(torch.isfinite(p).all() for p in hm.parameters())
-    assert e_loss < 2e-3 and e_out < 0.15 and e_rms < 0.12 and e_norm < 3e-2
+    # gradient norms: tests/test_conditioning.py::test_bf16_storage_gradient_norm_floor measures how far the emulated oracle's OWN
+    # norms move under a 1e-7 / +-1e-6 relative weight perturbation -- latefusion 1.2e-2 (stem weights; 3.8e-3 elsewhere),
+    # multistage 1.1e-1 (stage-1 stem weights, reached through stage 2 and the radar filter; 3.4e-2 elsewhere).  Tile shapes and
+    # summation orders of correct kernels move the HIP result inside that floor (measured over kernel revisions: latefusion
+    # 8e-3 ... 1.9e-2, multistage 1.1e-2 ... 9.3e-2, always the stem weights), so the bounds are ~2x the floor.
+    tol_all, tol_body = (0.2, 7e-2) if multistage else (4e-2, 1.5e-2)
+    assert e_loss < 2e-3 and e_out < 0.15 and e_rms < 0.12 and e_norm < tol_all and e_body < tol_body, (e_norm, e_body)
     assert multistage or e_tail < 0.15
 
 
