@@ -90,6 +90,21 @@ __device__ __forceinline__ float ld1(const bf16s* p) { return __uint_as_float((u
 __device__ __forceinline__ void st1(float* p, float v) { *p = v; }
 __device__ __forceinline__ void st1(bf16s* p, float v) { p->v = __builtin_bit_cast(unsigned short, (__bf16)v); }
 
+// quad exchanges (DPP quad_perm) and the in-register 4x4 transposition used by the epilogue: on entry lane q of a quad holds
+// (row j, column q) in a_j; on exit it holds (row q, column c) in a_c.
+__device__ __forceinline__ float dpp_xor1(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, false));   // quad_perm [1,0,3,2]
+}
+__device__ __forceinline__ float dpp_xor2(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, false));   // quad_perm [2,3,0,1]
+}
+__device__ __forceinline__ void quad_transpose(float& a0, float& a1, float& a2, float& a3, bool odd1, bool odd2) {
+    const float r0 = dpp_xor1(odd1 ? a0 : a1), r1 = dpp_xor1(odd1 ? a2 : a3);
+    const float b0 = odd1 ? r0 : a0, b1 = odd1 ? a1 : r0, b2 = odd1 ? r1 : a2, b3 = odd1 ? a3 : r1;
+    const float u0 = dpp_xor2(odd2 ? b0 : b2), u1 = dpp_xor2(odd2 ? b1 : b3);
+    a0 = odd2 ? u0 : b0; a1 = odd2 ? u1 : b1; a2 = odd2 ? b2 : u0; a3 = odd2 ? b3 : u1;
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
