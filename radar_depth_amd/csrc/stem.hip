@@ -22,6 +22,8 @@ struct StemArgs {
     int io16;             // bf16-storage plans: the NHWC tensors are bf16 (the network input planes stay fp32)
     int Cin, N, H, W, Ho, Wo, Cout, tiles_h, tiles_w;
     int total_tiles, tiles_per_split;  // wgrad
+    int dephase;          // experiment: the second half of the grid starts this many x 4096 clocks late
+    int debug;            // ablation bits (RD_STEM_DEBUG): 1 stage only the first tile's patch, 2 skip the MFMA walk, 4 skip the stores
 };
 
 constexpr int ST_TW = 32;
@@ -69,12 +71,15 @@ __global__ __launch_bounds__(256) void stem_fwd_kernel(const StemArgs a) {
     // a tile, for 4.8 MFLOP of work) are staged once per workgroup, not once per tile; the grid is two workgroups per CU and each
     // walks the tiles bid, bid + grid, ...
     const int total_tiles = a.N * a.tiles_h * a.tiles_w;
+    if (a.dephase && (a.dephase >= 100 ? (blockIdx.x & 1) : (blockIdx.x >= gridDim.x / 2)))
+        for (int i = 0; i < a.dephase % 100; ++i) __builtin_amdgcn_s_sleep(64);     // 64 x 64 clocks
     for (int bid = blockIdx.x; bid < total_tiles; bid += gridDim.x) {
     const int n = bid / (a.tiles_h * a.tiles_w);
     const int trem = bid - n * (a.tiles_h * a.tiles_w);
     const int r0 = (trem / a.tiles_w) * TH, c0 = (trem % a.tiles_w) * ST_TW;
     const int ih0 = 2 * r0 - 3, iw0 = 2 * c0 - 3;
     __syncthreads();          // the previous tile's MFMAs are done with the patch (and its statistics with s_red)
+    if (!((a.debug & 1) && bid != (int)blockIdx.x))
     for (int base = tid; base < a.Cin * PLANE; base += 256 * U) {
         float v[U];
 #pragma unroll
@@ -109,7 +114,7 @@ __global__ __launch_bounds__(256) void stem_fwd_kernel(const StemArgs a) {
 
     // K walk, two k per MFMA.  Software pipeline pinned with sched_barrier (see gconv.hip): two register sets ping-pong;
     // while one step's MT*NT MFMAs issue, the next step's fragments and the k->offset entry after that are in flight.
-    const int nst = Kp / 2;              // Kp is even; s_koff / s_w have >= 4 slack entries past Kp (host LDS sizing)
+    const int nst = (a.debug & 2) ? 2 : Kp / 2;              // Kp is even; s_koff / s_w have >= 4 slack entries past Kp (host LDS sizing)
     float a0[MT], b0[NT], a1[MT], b1[NT];
     int ko_n = s_koff[hh];
 #define RD_ST_LOAD(AV, BV, STEP)                                                             \
@@ -142,6 +147,51 @@ __global__ __launch_bounds__(256) void stem_fwd_kernel(const StemArgs a) {
     float ssum[NT], ssq[NT];
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) ssum[nt] = ssq[nt] = 0.f;
+    // Full tiles store ROW-MAJOR: in the C/D layout a lane holds one channel of 16 pixels -- 64 four-byte (two-byte) stores per
+    // lane and tile, and the store pipe is issue-bound (this epilogue, not the MFMAs, set the kernel's time: 43 % of the fp32
+    // peak).  Each 4x4 block (4 registers x the 4 lanes of a quad) is transposed with two DPP exchanges (common.h), after which
+    // a lane holds four consecutive channels of one pixel: a quarter of the store instructions.
+    const bool full = r0 + TH <= a.Ho && c0 + ST_TW <= a.Wo && (a.Cout & 3) == 0;      // workgroup-uniform
+    if (full) {
+        const int q4l = l31 & 3, k4l = l31 >> 2;
+        const bool odd1 = q4l & 1, odd2 = q4l & 2;
+        float4 ssum4[NT], ssq4[NT];
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) ssum4[nt] = ssq4[nt] = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            const int oh = r0 + wave * MT + mt;
+            const size_t rowo = (((size_t)n * a.Ho + oh) * a.Wo + c0 + q4l + 4 * hh) * a.Cout + 4 * k4l;
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                const bool cok4 = 4 * k4l + nt * 32 < a.Cout;
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    float e0 = acc[mt][nt][4 * g], e1 = acc[mt][nt][4 * g + 1], e2 = acc[mt][nt][4 * g + 2], e3 = acc[mt][nt][4 * g + 3];
+                    quad_transpose(e0, e1, e2, e3, odd1, odd2);
+                    const float4 v = make_float4(e0, e1, e2, e3);
+                    if (cok4) {
+                        const size_t o = rowo + (size_t)(8 * g) * a.Cout + nt * 32;
+                        if (a.debug & 4) {} else if (a.io16) st4(static_cast<bf16s*>(a.out) + o, v);
+                        else st4(static_cast<float*>(a.out) + o, v);
+                        ssum4[nt].x += v.x; ssum4[nt].y += v.y; ssum4[nt].z += v.z; ssum4[nt].w += v.w;
+                        ssq4[nt].x += v.x * v.x; ssq4[nt].y += v.y * v.y; ssq4[nt].z += v.z * v.z; ssq4[nt].w += v.w * v.w;
+                    }
+                }
+            }
+        }
+        // back to one channel per lane: sum the quad's four pixels, lane q keeps channel q
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            float4 s4 = ssum4[nt], q4 = ssq4[nt];
+            s4.x += dpp_xor1(s4.x); s4.y += dpp_xor1(s4.y); s4.z += dpp_xor1(s4.z); s4.w += dpp_xor1(s4.w);
+            q4.x += dpp_xor1(q4.x); q4.y += dpp_xor1(q4.y); q4.z += dpp_xor1(q4.z); q4.w += dpp_xor1(q4.w);
+            s4.x += dpp_xor2(s4.x); s4.y += dpp_xor2(s4.y); s4.z += dpp_xor2(s4.z); s4.w += dpp_xor2(s4.w);
+            q4.x += dpp_xor2(q4.x); q4.y += dpp_xor2(q4.y); q4.z += dpp_xor2(q4.z); q4.w += dpp_xor2(q4.w);
+            ssum[nt] = odd2 ? (odd1 ? s4.w : s4.z) : (odd1 ? s4.y : s4.x);
+            ssq[nt] = odd2 ? (odd1 ? q4.w : q4.z) : (odd1 ? q4.y : q4.x);
+        }
+    } else
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
         const int oh = r0 + wave * MT + mt;
@@ -387,6 +437,8 @@ static int stem_fwd_impl(int io16, const float* const* planes, const int64_t* st
     if (rc != RD_OK) return rc;
     RD_CHECK_ARG(w_packed && out, "stem_fwd: null tensor");
     a.w = w_packed; a.out = out; a.stat = stat_partial; a.dout = nullptr;
+    { static const char* dbg = getenv("RD_STEM_DEBUG"); a.debug = dbg ? atoi(dbg) : 0; }
+    { static const char* dp = getenv("RD_STEM_DEPHASE"); a.dephase = dp ? atoi(dp) : 0; }
     a.tiles_h = cdiv(a.Ho, 8); a.tiles_w = cdiv(a.Wo, ST_TW);
     const int total = N * a.tiles_h * a.tiles_w;
     const int grid = total < 2 * num_cus() ? total : 2 * num_cus();     // persistent: two workgroups per CU walk the tiles
@@ -436,6 +488,7 @@ static int stem_wgrad_impl(int io16, const float* const* planes, const int64_t* 
     if (rc != RD_OK) return rc;
     RD_CHECK_ARG(dout && grad_oihw && ws, "stem_wgrad: null tensor");
     a.w = nullptr; a.out = nullptr; a.stat = nullptr; a.dout = dout;
+    a.debug = 0; a.dephase = 0;
     a.tiles_h = cdiv(a.Ho, 4); a.tiles_w = cdiv(a.Wo, ST_TW);
     a.total_tiles = N * a.tiles_h * a.tiles_w;
     const int splits = stem_wgrad_splits(a.total_tiles);

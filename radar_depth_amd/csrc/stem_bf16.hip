@@ -127,21 +127,30 @@ __global__ __launch_bounds__(256) void stem_fwd_bf16_kernel(const StemBfArgs a) 
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) ssum[nt] = ssq[nt] = 0.f;
     const bool full = r0 + SB_TH <= a.Ho && c0 + SB_TW <= a.Wo && BN <= a.Cout;      // workgroup-uniform: no masking at all
+    const int q4l = l31 & 3, k4l = l31 >> 2;
+    const bool odd1 = q4l & 1, odd2 = q4l & 2;
+    float4 ssum4[NT], ssq4[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) ssum4[nt] = ssq4[nt] = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
         const int r = r0 + wave * MT + mt;
         if (full) {
-            const size_t rowo = (((size_t)n * a.Ho + r) * a.Wo + c0 + 4 * hh) * a.Cout + l31;
+            // row-major: each 4x4 block (4 registers x the 4 lanes of a quad) transposed with two DPP exchanges, then a lane
+            // stores four consecutive channels of one pixel -- a quarter of the (issue-bound) store instructions
+            const size_t rowo = (((size_t)n * a.Ho + r) * a.Wo + c0 + q4l + 4 * hh) * a.Cout + 4 * k4l;
 #pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                const size_t po = rowo + (size_t)((i & 3) + 8 * (i >> 2)) * a.Cout;
+            for (int nt = 0; nt < NT; ++nt) {
 #pragma unroll
-                for (int nt = 0; nt < NT; ++nt) {
-                    const float v = acc[mt][nt][i];
-                    if (a.io16) st1(static_cast<bf16s*>(a.out) + po + nt * 32, v);
-                    else static_cast<float*>(a.out)[po + nt * 32] = v;
-                    ssum[nt] += v;
-                    ssq[nt] += v * v;
+                for (int g = 0; g < 4; ++g) {
+                    float e0 = acc[mt][nt][4 * g], e1 = acc[mt][nt][4 * g + 1], e2 = acc[mt][nt][4 * g + 2], e3 = acc[mt][nt][4 * g + 3];
+                    quad_transpose(e0, e1, e2, e3, odd1, odd2);
+                    const float4 v = make_float4(e0, e1, e2, e3);
+                    const size_t o = rowo + (size_t)(8 * g) * a.Cout + nt * 32;
+                    if (a.io16) st4(static_cast<bf16s*>(a.out) + o, v);
+                    else st4(static_cast<float*>(a.out) + o, v);
+                    ssum4[nt].x += v.x; ssum4[nt].y += v.y; ssum4[nt].z += v.z; ssum4[nt].w += v.w;
+                    ssq4[nt].x += v.x * v.x; ssq4[nt].y += v.y * v.y; ssq4[nt].z += v.z * v.z; ssq4[nt].w += v.w * v.w;
                 }
             }
             continue;
@@ -161,6 +170,18 @@ __global__ __launch_bounds__(256) void stem_fwd_bf16_kernel(const StemBfArgs a) 
                     ssq[nt] += v * v;
                 }
             }
+        }
+    }
+    if (full) {      // back to one channel per lane: sum the quad's four pixels, lane q keeps channel q
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            float4 s4 = ssum4[nt], q4 = ssq4[nt];
+            s4.x += dpp_xor1(s4.x); s4.y += dpp_xor1(s4.y); s4.z += dpp_xor1(s4.z); s4.w += dpp_xor1(s4.w);
+            q4.x += dpp_xor1(q4.x); q4.y += dpp_xor1(q4.y); q4.z += dpp_xor1(q4.z); q4.w += dpp_xor1(q4.w);
+            s4.x += dpp_xor2(s4.x); s4.y += dpp_xor2(s4.y); s4.z += dpp_xor2(s4.z); s4.w += dpp_xor2(s4.w);
+            q4.x += dpp_xor2(q4.x); q4.y += dpp_xor2(q4.y); q4.z += dpp_xor2(q4.z); q4.w += dpp_xor2(q4.w);
+            ssum[nt] = odd2 ? (odd1 ? s4.w : s4.z) : (odd1 ? s4.y : s4.x);
+            ssq[nt] = odd2 ? (odd1 ? q4.w : q4.z) : (odd1 ? q4.y : q4.x);
         }
     }
     if (a.stat) {
