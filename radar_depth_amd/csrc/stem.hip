@@ -22,7 +22,6 @@ struct StemArgs {
     int io16;             // bf16-storage plans: the NHWC tensors are bf16 (the network input planes stay fp32)
     int Cin, N, H, W, Ho, Wo, Cout, tiles_h, tiles_w;
     int total_tiles, tiles_per_split;  // wgrad
-    int dephase;          // experiment: the second half of the grid starts this many x 4096 clocks late
     int debug;            // ablation bits (RD_STEM_DEBUG): 1 stage only the first tile's patch, 2 skip the MFMA walk, 4 skip the stores
 };
 
@@ -71,8 +70,6 @@ __global__ __launch_bounds__(256) void stem_fwd_kernel(const StemArgs a) {
     // a tile, for 4.8 MFLOP of work) are staged once per workgroup, not once per tile; the grid is two workgroups per CU and each
     // walks the tiles bid, bid + grid, ...
     const int total_tiles = a.N * a.tiles_h * a.tiles_w;
-    if (a.dephase && (a.dephase >= 100 ? (blockIdx.x & 1) : (blockIdx.x >= gridDim.x / 2)))
-        for (int i = 0; i < a.dephase % 100; ++i) __builtin_amdgcn_s_sleep(64);     // 64 x 64 clocks
     for (int bid = blockIdx.x; bid < total_tiles; bid += gridDim.x) {
     const int n = bid / (a.tiles_h * a.tiles_w);
     const int trem = bid - n * (a.tiles_h * a.tiles_w);
@@ -438,7 +435,6 @@ static int stem_fwd_impl(int io16, const float* const* planes, const int64_t* st
     RD_CHECK_ARG(w_packed && out, "stem_fwd: null tensor");
     a.w = w_packed; a.out = out; a.stat = stat_partial; a.dout = nullptr;
     { static const char* dbg = getenv("RD_STEM_DEBUG"); a.debug = dbg ? atoi(dbg) : 0; }
-    { static const char* dp = getenv("RD_STEM_DEPHASE"); a.dephase = dp ? atoi(dp) : 0; }
     a.tiles_h = cdiv(a.Ho, 8); a.tiles_w = cdiv(a.Wo, ST_TW);
     const int total = N * a.tiles_h * a.tiles_w;
     const int grid = total < 2 * num_cus() ? total : 2 * num_cus();     // persistent: two workgroups per CU walk the tiles
@@ -488,7 +484,7 @@ static int stem_wgrad_impl(int io16, const float* const* planes, const int64_t* 
     if (rc != RD_OK) return rc;
     RD_CHECK_ARG(dout && grad_oihw && ws, "stem_wgrad: null tensor");
     a.w = nullptr; a.out = nullptr; a.stat = nullptr; a.dout = dout;
-    a.debug = 0; a.dephase = 0;
+    a.debug = 0;
     a.tiles_h = cdiv(a.Ho, 4); a.tiles_w = cdiv(a.Wo, ST_TW);
     a.total_tiles = N * a.tiles_h * a.tiles_w;
     const int splits = stem_wgrad_splits(a.total_tiles);
