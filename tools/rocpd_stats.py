@@ -13,6 +13,13 @@ cols = [r[1] for r in db.execute("pragma table_info(%s)" % kd)]
 kcols = [r[1] for r in db.execute("pragma table_info(%s)" % ks)]
 name_col = "display_name" if "display_name" in kcols else ("kernel_name" if "kernel_name" in kcols else "name")
 rows = db.execute("select s.%s, d.start, d.end from %s d join %s s on d.kernel_id = s.id" % (name_col, kd, ks)).fetchall()
+steady = ""
+if "--steady" in sys.argv:     # training steps only: drop everything before the first optimizer update (plan building, weight
+    t0 = min((st for name, st, en in rows if "sgd_kernel" in name), default=None)     # packing, the plan tuner's timing launches)
+    if t0 is not None:
+        n_all = len(rows)
+        rows = [r for r in rows if r[1] >= t0]
+        steady = "; steady state only: %d of %d dispatches, from the first sgd_kernel on" % (len(rows), n_all)
 agg = {}
 for name, st, en in rows:
     name = re.sub(r"\(.*$", "", name)
@@ -45,7 +52,7 @@ if "--gaps" in sys.argv:       # which kernels end before / start after the idle
     sys.exit(0)
 if "--timeline" in sys.argv:   # how full is the device: union of kernel intervals vs wall span, over the last 60 % of the trace
     iv = sorted((st, en) for _, st, en in rows)
-    t_lo = iv[0][0] + 0.4 * (iv[-1][1] - iv[0][0])
+    t_lo = iv[0][0] if steady else iv[0][0] + 0.4 * (iv[-1][1] - iv[0][0])
     iv = [(a, b) for a, b in iv if a >= t_lo]
     span = iv[-1][1] - iv[0][0]
     busy, cur_a, cur_b = 0, iv[0][0], iv[0][1]
@@ -65,7 +72,7 @@ if "--timeline" in sys.argv:   # how full is the device: union of kernel interva
               sorted(gaps)[len(gaps) // 2] / 1e3 if gaps else 0.0))
     sys.exit(0)
 tot = sum(a[1] for a in agg.values())
-print("# rocprofv3 --kernel-trace summary of %s (%d dispatches, %.3f ms of kernel time)" % (sys.argv[1], len(rows), tot / 1e6))
+print("# rocprofv3 --kernel-trace summary of %s (%d dispatches, %.3f ms of kernel time%s)" % (sys.argv[1], len(rows), tot / 1e6, steady))
 print("%-72s %8s %12s %10s %7s" % ("kernel", "calls", "total_ms", "avg_us", "share"))
 for name, (n, t) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
     print("%-72s %8d %12.3f %10.2f %6.1f%%" % (name[:72], n, t / 1e6, t / n / 1e3, 100.0 * t / tot))
