@@ -37,7 +37,8 @@ def main(argv=None):
     start_epoch, best = 0, Result()
     best.set_to_worst()
     step = HipTrainStep(model, args.batch_size, h, w, lr=args.lr, momentum=args.momentum, weight_decay=args.weight_decay,
-                        loss_weights=loss_weights, criterion=args.criterion, storage=extra["--storage"])
+                        loss_weights=loss_weights, criterion=args.criterion, storage=extra["--storage"],
+                        autotune=os.environ.get("RD_AUTOTUNE", "1") == "1")     # main.py:11,47 (cudnn.benchmark = True): time the plans once
     if args.resume:                              # main.py:235-266
         ck = utils.load_checkpoint(args.resume)
         model.load_state_dict(ck["model_state_dict"], strict=False)
