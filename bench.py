@@ -61,6 +61,8 @@ def kernel_identity(L, kind, d, io16=False):
         info = (C.c_int32 * 10)()
         L.rd_gconv_plan_info(C.byref(d), info)                 # info[4] = grouped*1000000 + pipelined*10000 + ksplit*100 + CKW
         grouped = info[4] >= 1000000                          # in_stride == 2 run as input-parity groups: SWZ = false instantiation
+        if info[0] == 0:                                      # 16 -> 16 channel 3x3 layers: csrc/conv16.hip (16x16x4 MFMA)
+            return "conv16_kernel<stat|add>"
         return "gconv_kernel<%d,%d,%d,%d,%d,%s,%s,%s>" % (info[0], info[1], info[2], info[3], info[4] % 100,
                                                           "true" if (d.in_stride == 2 and not grouped) else "false",
                                                           "true" if info[4] % 1000000 >= 10000 else "false", "true" if grouped else "false")

@@ -41,6 +41,11 @@ static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 static inline int64_t cdiv64(int64_t a, int64_t b) { return (a + b - 1) / b; }
 
 int num_cus();
+// conv16.hip: the 16 -> 16 channel 3x3 / stride-1 convolutions on the 16x16x4 fp32 MFMA (dispatched from gconv.hip's plans)
+bool conv16_eligible(const RdConvDesc& d);
+int conv16_tiles_per_image(const RdConvDesc& d);
+int launch_conv16(const RdConvDesc& d, const float* in, const float* w_packed, float* out, const float* addend, int ld_add,
+                  float* stat, hipStream_t s);
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));

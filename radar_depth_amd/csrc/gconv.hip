@@ -615,6 +615,7 @@ struct GconvPlan {
     size_t lds_bytes;
     int pipe;      // software-pipelined chunk loop (double-buffered weight slabs via global_load_lds)
     int grouped;   // input-parity groups (in_stride == 2, one phase): see GconvArgs::ngroups
+    int c16;       // served by conv16.hip (16 -> 16 channels, 3x3, unit strides): 16 x 16 pixel tiles, no split, no workspace
 };
 
 // Input-parity decomposition of a single-phase in_stride == 2 descriptor.
@@ -822,7 +823,7 @@ static void fill_tiles(RdConvDesc& d, GconvPlan& pl) {
 
 using namespace rd;
 
-static int plan_query(const RdConvDesc* d, bool allow_split, GconvPlan& pl, RdConvDesc& dd);
+static int plan_query(const RdConvDesc* d, bool allow_split, GconvPlan& pl, RdConvDesc& dd, bool generic_only = false);
 
 // diagnostics: out[0..9] = MT, NT, WM, WN, CKW, CKP, TH, TW, lds_bytes, workgroups
 extern "C" int rd_gconv_plan_info(const RdConvDesc* d, int32_t* out) {
@@ -870,13 +871,14 @@ struct PlanEntry { GconvPlan pl; RdConvDesc dd; int tuner_owned; };   // tuner_o
                                                                       // have sized buffers on it, so the tuner must not replace it
 static std::mutex g_plan_mu;
 static std::unordered_map<std::string, PlanEntry> g_plan_cache;
-static int plan_query(const RdConvDesc* d, bool allow_split, GconvPlan& pl, RdConvDesc& dd) {
+static int plan_query(const RdConvDesc* d, bool allow_split, GconvPlan& pl, RdConvDesc& dd, bool generic_only) {
     std::mutex& mu = g_plan_mu;
     std::unordered_map<std::string, PlanEntry>& cache = g_plan_cache;
     typedef PlanEntry Entry;
     RD_CHECK_ARG(d != nullptr, "gconv: null descriptor");
     std::string key(reinterpret_cast<const char*>(d), sizeof(RdConvDesc));
     key.push_back(allow_split ? 1 : 0);
+    if (generic_only) key.push_back('g');      // the fused (bias / activation) form of a conv16 descriptor: 32x32 kernels
     {
         std::lock_guard<std::mutex> lk(mu);
         auto it = cache.find(key);
@@ -885,8 +887,15 @@ static int plan_query(const RdConvDesc* d, bool allow_split, GconvPlan& pl, RdCo
     int rc = validate_desc(d);
     if (rc != RD_OK) return rc;
     dd = *d;
-    if (!plan_gconv(dd, pl, allow_split)) { set_error("gconv: no feasible tiling"); return RD_EINVAL; }
-    fill_tiles(dd, pl);
+    if (!generic_only && conv16_eligible(*d)) {
+        pl = GconvPlan{};
+        pl.c16 = 1; pl.TH = pl.TW = 16; pl.n_cotiles = 1; pl.ksplit = 1; pl.MT = pl.NT = pl.WM = pl.WN = 0;
+        pl.tiles_total = conv16_tiles_per_image(*d);
+        dd.phase[0].tile_begin = 0;
+    } else {
+        if (!plan_gconv(dd, pl, allow_split)) { set_error("gconv: no feasible tiling"); return RD_EINVAL; }
+        fill_tiles(dd, pl);
+    }
     std::lock_guard<std::mutex> lk(mu);
     cache.emplace(std::move(key), Entry{pl, dd, 0});
     return RD_OK;
@@ -904,6 +913,7 @@ static bool same_point(const GconvPlan& p, const int32_t* c) {
 extern "C" int rd_gconv_tune_candidates(const RdConvDesc* d, int32_t allow_split, int32_t* out, int32_t max_candidates) {
     if (validate_desc(d) != RD_OK) return RD_EINVAL;
     RD_CHECK_ARG(out && max_candidates > 0, "gconv_tune_candidates: bad arguments");
+    if (conv16_eligible(*d)) return 0;          // one kernel, one tiling
     {   // a descriptor somebody already planned without the tuner keeps its plan (its buffers were sized on it): nothing to tune
         std::string key(reinterpret_cast<const char*>(d), sizeof(RdConvDesc));
         key.push_back(allow_split ? 1 : 0);
@@ -937,6 +947,7 @@ extern "C" int rd_gconv_tune_candidates(const RdConvDesc* d, int32_t allow_split
 // cand == NULL: back to the heuristic plan
 extern "C" int rd_gconv_tune_pin(const RdConvDesc* d, int32_t allow_split, const int32_t* cand) {
     if (validate_desc(d) != RD_OK) return RD_EINVAL;
+    RD_CHECK_ARG(!conv16_eligible(*d), "gconv_tune_pin: descriptor is served by the conv16 kernel");
     std::string key(reinterpret_cast<const char*>(d), sizeof(RdConvDesc));
     key.push_back(allow_split ? 1 : 0);
     GconvPlan pl;
@@ -1006,6 +1017,11 @@ static int gconv_impl(const RdConvDesc* d, const float* in, const float* w_packe
     GconvPlan pl;
     int rc = plan_lookup(d, ws != nullptr, pl, a.d);
     if (rc != RD_OK) return rc;
+    if (pl.c16) {
+        if (!bias && act == RD_ACT_NONE) return launch_conv16(*d, in, w_packed, out, addend, ld_add, stat_partial, static_cast<hipStream_t>(stream));
+        rc = plan_query(d, false, pl, a.d, true);      // inference form: bias / activation live in the 32x32 kernels' epilogue
+        if (rc != RD_OK) return rc;
+    }
     const bool split = pl.ksplit > 1;
     a.in = in; a.w = w_packed;
     a.out = split ? ws : out;
