@@ -733,7 +733,13 @@ static bool plan_gconv(const RdConvDesc& d, GconvPlan& best, bool allow_split = 
                 const double halo = grouped ? (double)PP / (TH * TW) : (double)PP / (TH * TW * d.in_stride * d.in_stride);
                 double score = c.prior * m_util * n_util / (1.0 + 0.04 * (halo - 1.0));
                 if (lds > 80 * 1024) score *= 0.85;          // one workgroup per CU only
-                if (ckp == 16 && d.Cin >= 32) score *= 0.97;  // half-line loads
+                // half-line loads cost the large tiles ~3 %; the single-block tile on a 3x3 stencil is the other way round (the
+                // small-spatial depth-branch layers: 28.8 -> 24.7 us, 34.8 -> 30.7 us with 16-channel chunks, tools/sweep_plan_layers.py)
+                // (a long reduction in the plain chunk loop exposes one memory round trip per chunk: the pipelined form of the same
+                //  point, where it exists, or a smaller chunk that makes it exist, measured 1.3-1.45x faster from four chunks on)
+                if (!pipe && d.Cin / ckp >= 4) score *= 0.8;
+                const bool small3 = c.MT * c.NT == 1 && taps_max >= 9;
+                if (ckp == (small3 ? 32 : 16) && d.Cin >= 32) score *= 0.97;
                 // CU load balance: the kernel is MFMA-bound, so the time is set by the CU that owns the most workgroups.
                 // Small-spatial / many-channel layers do not produce enough large tiles: split the input channels over
                 // KS workgroups per tile (partials combined by gconv_combine_kernel).  Only single-phase, hole-free,
@@ -757,13 +763,21 @@ static bool plan_gconv(const RdConvDesc& d, GconvPlan& best, bool allow_split = 
                 for (int i = 0; i < d.n_phases; ++i) taps_avg += d.phase[i].n_taps;
                 taps_avg /= d.n_phases;
                 const double wg_flops = 2.0 * TH * TW * BN * (double)d.Cin * taps_avg;
+                double taps_big = 0;
+                for (int i = 0; i < d.n_phases; ++i) taps_big = taps_big > d.phase[i].n_taps ? taps_big : d.phase[i].n_taps;
                 for (int ksp = 1; ksp <= (can_split ? 4 : 1); ksp *= 2) {
                     if (d.Cin % (ksp * ckp) != 0) continue;
                     if (!all && ksp > 1 && wg_flops / ksp < min_slice_flops) continue;
                     const double wgs = wgs1 * ksp;
+                    // Phases with different tap counts (UpProj 9/6/6/4, the stride-2 input gradient 4/2/2/1) make workgroups of
+                    // different length: with fewer than ~4 of them per CU the long ones set the time (the per-layer sweep: stride-2
+                    // dgrads 216 -> 152, 212 -> 160, 191 -> 167 us and the two small UpProj forwards 237 -> 205, 222 -> 204 us on the
+                    // single-block tile instead of the 3x2 one)
+                    const double phase_balance = (d.n_phases > 1 && wgs < 4 * ncu) ? taps_avg / taps_big : 1.0;
                     // fewer than two workgroups per CU leaves staging/epilogue phases uncovered
                     score = base * (wgs / (ncu * ceil(wgs / ncu))) * (ksp == 1 ? 1.0 : (ksp == 2 ? 0.95 : 0.91)) *
-                            (wgs < 2 * ncu && lds <= 80 * 1024 ? 0.9 : 1.0);   // (a > 80 KB tile already paid for single residency)
+                            (wgs < 2 * ncu && lds <= 80 * 1024 ? 0.9 : 1.0) *   // (a > 80 KB tile already paid for single residency)
+                            phase_balance;
                     const GconvPlan cand{c.MT, c.NT, c.WM, c.WN, CKW, ckp, TH, TW, PP, 0, n_cot, taps_max, pick_wsd(taps_max, BN, CKW, ckp, pipe), ksp, lds,
                                          pipe ? 1 : 0, grouped ? 1 : 0};
                     if (all) all->emplace_back(score, cand);

@@ -61,6 +61,11 @@ def _run_fwd(n, ci, co, k, s, p, h, w, seed=0):
     (2, 32, 16, 3, 1, 1, 40, 1),
     (2, 80, 48, 1, 1, 0, 19, 23),
     (4, 16, 64, 1, 2, 0, 7, 5),
+    # csrc/conv16.hip (16 -> 16 channels on the 16x16x4 MFMA): partial 16x16 tiles on both edges, images smaller than a tile
+    (3, 16, 16, 3, 1, 1, 37, 45),
+    (2, 16, 16, 3, 1, 1, 16, 16),
+    (5, 16, 16, 3, 1, 1, 1, 1),
+    (2, 16, 16, 3, 1, 1, 3, 50),
 ])
 def test_gconv_forward(cfg):
     _run_fwd(*cfg)
@@ -76,6 +81,9 @@ def test_gconv_forward(cfg):
     (2, 48, 80, 3, 1, 1, 31, 17),
     (1, 96, 48, 3, 2, 1, 33, 45),
     (3, 64, 64, 3, 1, 1, 1, 1),
+    (2, 16, 16, 3, 1, 1, 113, 200),   # csrc/conv16.hip: input gradient (flipped taps, transposed operand) + residual addend
+    (3, 16, 16, 3, 1, 1, 37, 45),
+    (2, 16, 16, 3, 1, 1, 1, 7),
 ])
 def test_gconv_dgrad(cfg):
     from radar_depth_amd import convdesc as cd, ops
