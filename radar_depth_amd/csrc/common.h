@@ -44,6 +44,10 @@ int num_cus();
 // conv16.hip: the 16 -> 16 channel 3x3 / stride-1 convolutions on the 16x16x4 fp32 MFMA (dispatched from gconv.hip's plans)
 bool conv16_eligible(const RdConvDesc& d);
 int conv16_tiles_per_image(const RdConvDesc& d);
+// wgrad16.hip: the weight gradient of the same layers (slabs in wgrad.hip's layout)
+bool wgrad16_eligible(const RdConvDesc& d);
+void wgrad16_splits(const RdConvDesc& d, int& total_tiles, int& n_splits);
+int launch_wgrad16(const RdConvDesc& d, const float* x, const float* dout, float* slabs, hipStream_t s);
 int launch_conv16(const RdConvDesc& d, const float* in, const float* w_packed, float* out, const float* addend, int ld_add,
                   float* stat, hipStream_t s);
 

@@ -29,8 +29,7 @@ struct Conv16Args {
     int N, H, W;          // output grid == input grid (unit strides)
     int tiles_h, tiles_w;
     int ih_off, iw_off;   // dh_min, dw_min
-    int tapoff[9];        // patch pixel offset of each tap: (dh - dh_min) * 18 + (dw - dw_min)
-    int widx[9];          // weight slab of each tap
+    int widx_pos[9];      // weight slab of the tap at patch position (pos / 3, pos % 3)
 };
 
 constexpr int C16_T = 16, C16_P = 18, C16_PS = 24;
@@ -47,10 +46,11 @@ __global__ __launch_bounds__(256) void conv16_kernel(const Conv16Args a) {
     const int r0 = (trem / a.tiles_w) * C16_T, c0 = (trem % a.tiles_w) * C16_T;
     const int ih0 = r0 + a.ih_off, iw0 = c0 + a.iw_off;
 
-    // the weight operand: nine quads per lane, straight from the packed layout
+    // the weight operand: nine quads per lane, straight from the packed layout, ordered by PATCH POSITION (pos / 3, pos % 3) so
+    // that every LDS address of the walk is one lane-constant base plus a compile-time offset (an immediate of the ds_read)
     float4 wq[9];
 #pragma unroll
-    for (int t = 0; t < 9; ++t) wq[t] = *reinterpret_cast<const float4*>(a.w + ((size_t)(a.widx[t] * 4 + kq) * 16 + m) * 4);
+    for (int t = 0; t < 9; ++t) wq[t] = *reinterpret_cast<const float4*>(a.w + ((size_t)(a.widx_pos[t] * 4 + kq) * 16 + m) * 4);
 
     // halo patch [18][18][16] -> LDS (zero outside the image), 16-byte units, all loads of a thread in flight before its first write
     const float* in_n = a.in + (size_t)n * a.H * a.W * a.ldi;
@@ -78,13 +78,12 @@ __global__ __launch_bounds__(256) void conv16_kernel(const Conv16Args a) {
     f32x4 acc[4];
 #pragma unroll
     for (int mb = 0; mb < 4; ++mb) acc[mb] = f32x4{0.f, 0.f, 0.f, 0.f};
-    const int abase = ((wave * 4) * C16_P + m) * C16_PS + 4 * kq;
+    const float* al = s_patch + ((wave * 4) * C16_P + m) * C16_PS + 4 * kq;
 #pragma unroll
     for (int t = 0; t < 9; ++t) {
-        const int to = a.tapoff[t] * C16_PS;
 #pragma unroll
         for (int mb = 0; mb < 4; ++mb) {
-            const float4 av = *reinterpret_cast<const float4*>(s_patch + abase + mb * C16_P * C16_PS + to);
+            const float4 av = *reinterpret_cast<const float4*>(al + ((mb + t / 3) * C16_P + t % 3) * C16_PS);
             acc[mb] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.x, wq[t].x, acc[mb], 0, 0, 0);
             acc[mb] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.y, wq[t].y, acc[mb], 0, 0, 0);
             acc[mb] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.z, wq[t].z, acc[mb], 0, 0, 0);
@@ -154,7 +153,9 @@ bool conv16_eligible(const RdConvDesc& d) {
     if (p.n_taps != 9 || p.dh_max - p.dh_min != 2 || p.dw_max - p.dw_min != 2) return false;
     if (p.out_off_h != 0 || p.out_off_w != 0 || p.lh != d.Ho || p.lw != d.Wo || d.Hi != d.Ho || d.Wi != d.Wo) return false;
     if (d.ldi % 4 != 0 || d.ldo % 4 != 0) return false;
-    return true;
+    int seen = 0;
+    for (int t = 0; t < 9; ++t) seen |= 1 << ((p.dh[t] - p.dh_min) * 3 + (p.dw[t] - p.dw_min));
+    return seen == 0x1ff;      // every position of the 3x3 stencil exactly once
 }
 
 int conv16_tiles_per_image(const RdConvDesc& d) { return cdiv(d.Ho, C16_T) * cdiv(d.Wo, C16_T); }
@@ -171,10 +172,7 @@ int launch_conv16(const RdConvDesc& d, const float* in, const float* w_packed, f
     a.tiles_h = cdiv(d.Ho, C16_T); a.tiles_w = cdiv(d.Wo, C16_T);
     const RdPhase& p = d.phase[0];
     a.ih_off = p.dh_min; a.iw_off = p.dw_min;
-    for (int t = 0; t < 9; ++t) {
-        a.tapoff[t] = (p.dh[t] - p.dh_min) * C16_P + (p.dw[t] - p.dw_min);
-        a.widx[t] = p.widx[t];
-    }
+    for (int t = 0; t < 9; ++t) a.widx_pos[(p.dh[t] - p.dh_min) * 3 + (p.dw[t] - p.dw_min)] = p.widx[t];
     const int grid = d.N * a.tiles_h * a.tiles_w;
     if (stat) {
         if (addend) hipLaunchKernelGGL((conv16_kernel<true, true>), dim3(grid), dim3(256), 0, s, a);

@@ -514,6 +514,7 @@ struct WgradPlan {
     int rw;         // taps per stencil row (pitch > 0)
     int per_phase;  // UpProj: one launch per output phase (each a rectangular sub-stencil with a shared dout pixel)
     int strip;      // column-strip kernel with LDS row rings (rectangular stencil, unit input stride, 64-channel blocks)
+    int w16;        // served by wgrad16.hip (16 -> 16 channels, 3x3, unit strides, 16x16x4 MFMA): only S, n_splits, slab_splits, J are used
     WgradStripArgs sa;
     size_t lds;
 };
@@ -552,6 +553,7 @@ static int plan_wgrad(const RdConvDesc& d_in, WgradPlan& pl, WgradArgs* out, int
     RD_CHECK_ARG(ntaps == 1 || ntaps == 9 || ntaps == 25 || k3, "wgrad: %d taps unsupported", ntaps);
     pl.rw = rw;
     pl.per_phase = 0;
+    pl.w16 = 0;
     RD_CHECK_ARG(d.Cin % 4 == 0 && d.Cout % 4 == 0 && d.ldi % 4 == 0 && d.ldo % 4 == 0, "wgrad: channels must be multiples of 4");
     pl.shb = d.n_phases == 1;   // single phase: every tap pairs with the same dout pixel
     pl.TG = ntaps == 25 ? 5 : ntaps;
@@ -735,6 +737,14 @@ static int plan_any(const RdConvDesc& d, WgradPlan& pl) {
     return RD_OK;
 }
 static int plan_any_uncached(const RdConvDesc& d, WgradPlan& pl) {
+    if (wgrad16_eligible(d)) {
+        pl = WgradPlan{};
+        int total_tiles = 0;
+        wgrad16_splits(d, total_tiles, pl.n_splits);
+        pl.w16 = 1; pl.S = 9; pl.slab_splits = pl.n_splits; pl.J = pl.n_splits < 16 ? pl.n_splits : 16;
+        pl.total_tiles = total_tiles; pl.MF = 16;
+        return RD_OK;
+    }
     if (upproj_split(d)) {
         bool ok = plan_wgrad(d, pl, nullptr, 0) == RD_OK && pl.pitch > 0;
         for (int ph = 1; ok && ph < 4; ++ph) {
@@ -796,6 +806,7 @@ extern "C" int rd_wgrad(const RdConvDesc* d, const float* in, const float* dout,
     static const char* dbg = getenv("RD_WGRAD_DEBUG");
     int rc = plan_any(*d, pl);
     if (rc != RD_OK) return rc;
+    if (pl.w16) return launch_wgrad16(*d, in, dout, slabs, s);
     // the launch records (plan + kernel arguments minus the tensor pointers) are cached per descriptor like the plans
     struct Launch { WgradPlan pl; WgradArgs a; };
     static std::mutex mu;

@@ -33,6 +33,11 @@ def _rel(a, b):
     # immediate-offset tiled kernel (short image -> no strip) with ragged tiles
     (2, 64, 96, 3, 1, 1, 7, 33),
     (2, 256, 64, 3, 2, 1, 21, 27),
+    # csrc/wgrad16.hip (16 -> 16 channels on the 16x16x4 MFMA): partial 16x16 tiles, images smaller than a tile, many tiles per split
+    (3, 16, 16, 3, 1, 1, 37, 45),
+    (5, 16, 16, 3, 1, 1, 1, 1),
+    (2, 16, 16, 3, 1, 1, 3, 50),
+    (16, 16, 16, 3, 1, 1, 113, 200),
 ])
 def test_wgrad_conv(cfg):
     from radar_depth_amd import convdesc as cd, ops
