@@ -114,6 +114,18 @@ __device__ __forceinline__ void quad_transpose(float& a0, float& a1, float& a2, 
     a0 = odd2 ? u0 : b0; a1 = odd2 ? u1 : b1; a2 = odd2 ? b2 : u0; a3 = odd2 ? b3 : u1;
 }
 
+// e = r * Q + q for the streaming kernels that walk [row][channel quad] tensors: shifts when Q is a power of two (every layer of
+// these networks), a 64-bit division (~100 instructions per 16-byte element) otherwise.  lq = log2(Q) or -1.
+__device__ __forceinline__ int quad_log2(int Q) { return (Q & (Q - 1)) == 0 ? 31 - __clz(Q) : -1; }
+__device__ __forceinline__ void split_quad(int64_t e, int Q, int lq, int64_t& r, int& c) {
+    if (lq >= 0) {
+        r = e >> lq;
+        c = ((int)e & (Q - 1)) * 4;
+    } else {
+        r = e / Q;
+        c = (int)(e - r * Q) * 4;
+    }
+}
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

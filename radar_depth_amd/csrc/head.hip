@@ -8,6 +8,22 @@ namespace rd {
 int launch_slab_reduce(const float* slabs, int n_splits, int64_t E, float* tmp, float* grad_oihw, int S, int Cin, int Cout,
                        int O, int I, int co_off, int accumulate, hipStream_t s);
 
+// pixel index -> (image, row, column); 32-bit divisions whenever the tensor has fewer than 2^31 pixels (a 64-bit division is
+// ~100 instructions, three of them per pixel were a large part of these streaming kernels)
+__device__ __forceinline__ void split_pixel(int64_t e, bool small, int H, int W, int& n, int& h, int& wx) {
+    if (small) {
+        const unsigned u = (unsigned)e, r = u / (unsigned)W;
+        wx = (int)(u - r * (unsigned)W);
+        n = (int)(r / (unsigned)H);
+        h = (int)(r - (unsigned)n * (unsigned)H);
+    } else {
+        wx = (int)(e % W);
+        const int64_t r = e / W;
+        h = (int)(r % H);
+        n = (int)(r / H);
+    }
+}
+
 // d[n,h,w] = sum_{kh,kw,c} x[n,h+kh-1,w+kw-1,c] * w[c][kh][kw]      (w: OIHW with O == 1)
 template <int C, typename T>
 __global__ __launch_bounds__(256) void head_conv_fwd_kernel(const T* __restrict__ x, int ldx, const float* __restrict__ w,
@@ -19,10 +35,10 @@ __global__ __launch_bounds__(256) void head_conv_fwd_kernel(const T* __restrict_
     }
     __syncthreads();
     const int64_t total = (int64_t)N * H * W;
+    const bool small = total < (1ll << 31);
     for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
-        const int wx = (int)(e % W);
-        const int64_t r = e / W;
-        const int h = (int)(r % H), n = (int)(r / H);
+        int wx, h, n;
+        split_pixel(e, small, H, W, n, h, wx);
         float s = 0.f;
 #pragma unroll
         for (int kh = 0; kh < 3; ++kh) {
@@ -58,11 +74,11 @@ __global__ __launch_bounds__(256) void head_conv_dgrad_kernel(const float* __res
     __syncthreads();
     constexpr int Q = C / 4;
     const int64_t total = (int64_t)N * H * W * Q;
+    const bool small = total < (1ll << 31);
     for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
-        const int c = (int)(e % Q) * 4;
-        int64_t r = e / Q;
-        const int wx = (int)(r % W); r /= W;
-        const int h = (int)(r % H), n = (int)(r / H);
+        const int c = (int)(e % Q) * 4;          // (Q is a power of two)
+        int wx, h, n;
+        split_pixel(e / Q, small, H, W, n, h, wx);
         float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
         for (int kh = 0; kh < 3; ++kh) {
@@ -97,10 +113,14 @@ __global__ __launch_bounds__(256) void head_conv_wgrad_kernel(const T* __restric
     const int64_t p1 = p0 + pix_per_block < total ? p0 + pix_per_block : total;
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
     if (pl < PL) {
-        for (int64_t p = p0 + pl; p < p1; p += PL) {
-            const int wx = (int)(p % W);
-            const int64_t r = p / W;
-            const int h = (int)(r % H);
+        // (column / row of the running pixel are carried along: three 64-bit divisions per pixel and thread were most of this
+        //  kernel's 137 us)
+        int wx = (int)((p0 + pl) % W), h = (int)(((p0 + pl) / W) % H);
+        for (int64_t p = p0 + pl; p < p1; p += PL, wx += PL) {
+            while (wx >= W) {
+                wx -= W;
+                h = h + 1 == H ? 0 : h + 1;
+            }
             const int ih = h + kh - 1, iw = wx + kw - 1;
             if (ih < 0 || ih >= H || iw < 0 || iw >= W) continue;
             const float g = dd[p];
@@ -133,9 +153,8 @@ __global__ __launch_bounds__(256) void bilinear_fwd_kernel(const float* __restri
                                                            float* __restrict__ out, int Ho, int Wo, float sh, float sw) {
     const int64_t total = (int64_t)N * Ho * Wo;
     for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
-        const int ox = (int)(e % Wo);
-        const int64_t r = e / Wo;
-        const int oy = (int)(r % Ho), n = (int)(r / Ho);
+        int ox, oy, n;
+        split_pixel(e, total < (1ll << 31), Ho, Wo, n, oy, ox);
         int y0, y1, x0, x1;
         float ly, lx;
         src_index(oy, sh, Hs, y0, y1, ly);
@@ -152,9 +171,8 @@ __global__ __launch_bounds__(256) void bilinear_bwd_kernel(const float* __restri
     const int64_t total = (int64_t)N * Hs * Ws;
     const float inv_h = sh > 0.f ? 1.f / sh : 0.f, inv_w = sw > 0.f ? 1.f / sw : 0.f;
     for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
-        const int x = (int)(e % Ws);
-        const int64_t r = e / Ws;
-        const int y = (int)(r % Hs), n = (int)(r / Hs);
+        int x, y, n;
+        split_pixel(e, total < (1ll << 31), Hs, Ws, n, y, x);
         int oy_lo = (int)floorf((float)(y - 1) * inv_h) - 1, oy_hi = (int)ceilf((float)(y + 1) * inv_h) + 1;
         int ox_lo = (int)floorf((float)(x - 1) * inv_w) - 1, ox_hi = (int)ceilf((float)(x + 1) * inv_w) + 1;
         if (sh == 0.f) { oy_lo = 0; oy_hi = Ho - 1; }

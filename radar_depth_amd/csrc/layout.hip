@@ -65,20 +65,21 @@ __global__ __launch_bounds__(256) void pack_weights_batched_kernel(const PackJob
     const int64_t base = (int64_t)(blockIdx.x - j.first_block) * PACK_CHUNK;
 #pragma unroll
     for (int u = 0; u < PACK_CHUNK / 256; ++u) {
-        const int64_t e = base + u * 256 + threadIdx.x;
-        if (e >= total) break;
+        const int64_t e64 = base + u * 256 + threadIdx.x;
+        if (e64 >= total) break;
+        const unsigned e = (unsigned)e64;      // one weight tensor has fewer than 2^31 elements (engine.py asserts it when it builds the job table): 32-bit divisions
         if (!j.transpose) {
-            const int o = (int)(e % j.O);
-            const int64_t r = e / j.O;
-            const int i = (int)(r % j.I), t = (int)(r / j.I);
+            const unsigned r = e / (unsigned)j.O;
+            const int o = (int)(e - r * (unsigned)j.O);
+            const int t = (int)(r / (unsigned)j.I), i = (int)(r - (r / (unsigned)j.I) * (unsigned)j.I);
             float v = j.src[((int64_t)o * j.I + i) * j.T + t];
             if (j.scale) v *= j.scale[o];
             if (j.quad == 2) reinterpret_cast<__bf16*>(j.dst)[packed_index_bf16(t, j.I, i, j.ldc, j.off + o)] = (__bf16)v;
             else j.dst[packed_index(j.quad, t, j.I, i, j.ldc, j.off + o)] = v;
         } else {
-            const int i = (int)(e % j.I);
-            const int64_t r = e / j.I;
-            const int o = (int)(r % j.O), t = (int)(r / j.O);
+            const unsigned r = e / (unsigned)j.I;
+            const int i = (int)(e - r * (unsigned)j.I);
+            const int t = (int)(r / (unsigned)j.O), o = (int)(r - (r / (unsigned)j.O) * (unsigned)j.O);
             float v = j.src[((int64_t)o * j.I + i) * j.T + t];
             if (j.scale) v *= j.scale[o];
             if (j.quad == 2) reinterpret_cast<__bf16*>(j.dst)[packed_index_bf16(t, j.rows_total, j.off + o, j.ldc, i)] = (__bf16)v;

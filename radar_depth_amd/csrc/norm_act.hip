@@ -132,10 +132,12 @@ __global__ __launch_bounds__(256) void bn_act_kernel(const T* __restrict__ x1, i
                                                      const float* __restrict__ s2, const float* __restrict__ t2,
                                                      T* __restrict__ y, int ldy, int64_t M, int C, int act) {
     const int Q = C >> 2;
+    const int lq = quad_log2(Q);
     const int64_t total = M * Q;
     for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
-        const int64_t r = e / Q;
-        const int c = (int)(e - r * Q) * 4;
+        int64_t r;
+        int c;
+        split_quad(e, Q, lq, r, c);
         const float4 v = ld4(x1 + r * ldx1 + c);
         const float4 a = *reinterpret_cast<const float4*>(s1 + c);
         const float4 b = *reinterpret_cast<const float4*>(t1 + c);
@@ -262,10 +264,12 @@ __global__ __launch_bounds__(256) void bn_bwd_dx_kernel(const T* __restrict__ g,
                                                         T* __restrict__ dx, int lddx, int64_t M, int C,
                                                         const float* __restrict__ s1, const float* __restrict__ t1, int act) {
     const int Q = C >> 2;
+    const int lq = quad_log2(Q);
     const int64_t total = M * Q;
     for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
-        const int64_t r = e / Q;
-        const int c = (int)(e - r * Q) * 4;
+        int64_t r;
+        int c;
+        split_quad(e, Q, lq, r, c);
         float4 gv = ld4(g + r * ldg + c);
         const float4 xv = ld4(x + r * ldx + c);
         if (s1) {
@@ -297,10 +301,12 @@ __global__ __launch_bounds__(256) void bn_bwd_dx2_kernel(const T* __restrict__ d
                                                          const float* __restrict__ t2, int act, T* __restrict__ dx1, int lddx1,
                                                          T* __restrict__ dx2, int lddx2, int64_t M, int C) {
     const int Q = C >> 2;
+    const int lq = quad_log2(Q);
     const int64_t total = M * Q;
     for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
-        const int64_t r = e / Q;
-        const int c = (int)(e - r * Q) * 4;
+        int64_t r;
+        int c;
+        split_quad(e, Q, lq, r, c);
         float4 gv = ld4(dy + r * lddy + c);
         const float4 v1 = ld4(x1 + r * ldx1 + c), v2 = ld4(x2 + r * ldx2 + c);
         const float4 a1 = *reinterpret_cast<const float4*>(s1 + c), b1 = *reinterpret_cast<const float4*>(t1 + c);
@@ -332,13 +338,23 @@ __global__ __launch_bounds__(256) void bnact_maxpool_fwd_kernel(const T* __restr
                                                                 int C, int Ho, int Wo, T* __restrict__ y, int ldy,
                                                                 uint8_t* __restrict__ idx) {
     const int Q = C >> 2;
+    const int lq = quad_log2(Q);
     const int64_t total = (int64_t)N * Ho * Wo * Q;
     for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
-        const int c = (int)(e % Q) * 4;
-        int64_t r = e / Q;
-        const int ow = (int)(r % Wo); r /= Wo;
-        const int oh = (int)(r % Ho);
-        const int n = (int)(r / Ho);
+        int64_t r;
+        int c;
+        split_quad(e, Q, lq, r, c);
+        int ow, oh, n;
+        if (r < (1ll << 31)) {          // 32-bit divisions (a 64-bit one is ~100 instructions)
+            const unsigned u = (unsigned)r, q1 = u / (unsigned)Wo;
+            ow = (int)(u - q1 * (unsigned)Wo);
+            n = (int)(q1 / (unsigned)Ho);
+            oh = (int)(q1 - (unsigned)n * (unsigned)Ho);
+        } else {
+            ow = (int)(r % Wo); r /= Wo;
+            oh = (int)(r % Ho);
+            n = (int)(r / Ho);
+        }
         const float4 a = *reinterpret_cast<const float4*>(scale + c);
         const float4 b = *reinterpret_cast<const float4*>(shift + c);
         float best[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
@@ -378,15 +394,25 @@ __global__ __launch_bounds__(256) void bnact_maxpool_bwd_kernel(const T* __restr
                                                                 float* __restrict__ part) {
     extern __shared__ float sm[];
     const int Q = C >> 2;
+    const int lq = quad_log2(Q);
     const int64_t total = (int64_t)N * H * W * Q;
     float4 acc[3] = {make_float4(0, 0, 0, 0), make_float4(0, 0, 0, 0), make_float4(0, 0, 0, 0)};
     const float4 mu = part ? *reinterpret_cast<const float4*>(mean + (threadIdx.x % Q) * 4) : make_float4(0, 0, 0, 0);
     for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
-        const int c = (int)(e % Q) * 4;
-        int64_t r = e / Q;
-        const int w = (int)(r % W); r /= W;
-        const int h = (int)(r % H);
-        const int n = (int)(r / H);
+        int64_t r;
+        int c;
+        split_quad(e, Q, lq, r, c);
+        int w, h, n;
+        if (r < (1ll << 31)) {
+            const unsigned u = (unsigned)r, q1 = u / (unsigned)W;
+            w = (int)(u - q1 * (unsigned)W);
+            n = (int)(q1 / (unsigned)H);
+            h = (int)(q1 - (unsigned)n * (unsigned)H);
+        } else {
+            w = (int)(r % W); r /= W;
+            h = (int)(r % H);
+            n = (int)(r / H);
+        }
         float s[4] = {0.f, 0.f, 0.f, 0.f};
         const int oh_lo = h >> 1, oh_hi = (h + 1) >> 1;   // oh with 2*oh-1 <= h <= 2*oh+1
         const int ow_lo = w >> 1, ow_hi = (w + 1) >> 1;

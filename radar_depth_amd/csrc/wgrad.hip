@@ -471,10 +471,20 @@ __global__ __launch_bounds__(256) void wgrad_reduce2_kernel(const float* __restr
                                                             int64_t E, int S, int Cin, int Cout, int O, int I, int co_off,
                                                             int accumulate) {
     const int64_t total = (int64_t)S * I * O;
+    const bool small = total < (1ll << 31);          // 32-bit divisions (a 64-bit one is ~100 instructions, three per element)
     for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
-        const int o = (int)(e % O);
-        const int64_t r = e / O;
-        const int i = (int)(r % I), t = (int)(r / I);
+        int o, i, t;
+        if (small) {
+            const unsigned u = (unsigned)e, r = u / (unsigned)O;
+            o = (int)(u - r * (unsigned)O);
+            t = (int)(r / (unsigned)I);
+            i = (int)(r - (unsigned)t * (unsigned)I);
+        } else {
+            o = (int)(e % O);
+            const int64_t r = e / O;
+            i = (int)(r % I);
+            t = (int)(r / I);
+        }
         const float* src = tmp + ((int64_t)t * Cin + i) * Cout + co_off + o;
         float s = 0.f;
         for (int k = 0; k < J; ++k) s += src[k * E];

@@ -696,6 +696,7 @@ class LateFusionPlan:
         jobs = (Job * len(self.pack_jobs))()
         block_job, nb = [], 0
         for k, (src, dst, o, i, t, ldc, off, rows, tr, scale, quad) in enumerate(self.pack_jobs):
+            assert o * i * t < 2 ** 31, "pack_weights_batched indexes one weight tensor with 32-bit arithmetic"
             n = -(-(o * i * t) // chunk)
             jobs[k] = Job(src.data_ptr(), dst.data_ptr(), scale.data_ptr() if scale is not None else None, o, i, t, ldc, off, rows, tr, nb, quad, 0)
             block_job += [k] * n
