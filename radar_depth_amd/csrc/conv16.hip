@@ -73,7 +73,7 @@ __global__ __launch_bounds__(256) void conv16_kernel(const Conv16Args a) {
             if (e < C16_P * C16_P * 4) *reinterpret_cast<float4*>(s_patch + (e >> 2) * C16_PS + 4 * (e & 3)) = v[u];
         }
     }
-    __syncthreads();
+    rd_sync();
 
     f32x4 acc[4];
 #pragma unroll
@@ -135,7 +135,7 @@ __global__ __launch_bounds__(256) void conv16_kernel(const Conv16Args a) {
             s_red[(wave * 2 + 0) * 16 + m] = ssum;
             s_red[(wave * 2 + 1) * 16 + m] = ssq;
         }
-        __syncthreads();
+        rd_sync();
         if (tid < 32) {
             const int which = tid >> 4, j = tid & 15;
             a.stat[((size_t)bid * 2 + which) * 16 + j] =

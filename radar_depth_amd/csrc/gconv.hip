@@ -139,7 +139,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MT * NT <= 
     } else if (tid < ntaps) {
         s_widx[tid] = P.widx[tid];
     }
-    __syncthreads();
+    rd_sync();
     RD_STAMP()
 
     int abase[MT];
@@ -252,7 +252,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MT * NT <= 
     if (grouped) {
         ntaps = a.g_ntaps[grp]; tsel = grp; tb = a.g_tbase[grp];
         gih0 = ih0 + a.g_oh[grp]; giw0 = iw0 + a.g_ow[grp]; gst = 2;
-        if (grp > 0) __syncthreads();     // every wave is done with the previous group's patch and slabs
+        if (grp > 0) rd_sync();     // every wave is done with the previous group's patch and slabs
     }
     if constexpr (PIPE) {
         // ---- software-pipelined chunk loop (the whole patch chunk is one batch of <= UPP loads per thread and a weight slab
@@ -318,7 +318,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MT * NT <= 
         for (int cb = cb_lo; cb < cb_hi; cb += CKP) {
             for (int ks = 0; ks < nsub; ++ks, ++sidx) {
                 glds_wait();
-                __syncthreads();          // slab sidx and the chunk's patch have landed; slab sidx-1 is fully consumed
+                rd_sync();          // slab sidx and the chunk's patch have landed; slab sidx-1 is fully consumed
                 RD_STAMP()
                 const bool last_ks = ks == nsub - 1;
                 const bool more = !(last_ks && cb + CKP >= cb_hi);
@@ -329,14 +329,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MT * NT <= 
                 run_slab(ks, (sidx & 1) * slab_bytes);
                 RD_STAMP()
                 if (swap) {
-                    __syncthreads();      // every wave is done reading this chunk's patch
+                    rd_sync();      // every wave is done reading this chunk's patch
                     patch_put(vp);
                 }
             }
         }
     } else
     for (int cb = cb_lo; cb < cb_hi; cb += CKP) {
-        __syncthreads();
+        rd_sync();
         // ---- stage the halo patch chunk [PH*PW][CKP] (zero outside the image / beyond Cin) and the first weight slab
         // [taps][WSD/4][BN] quads (a straight copy: the packed operand in HBM has the same quad layout).  All global loads
         // of both are issued before the first LDS write, so a chunk pays ONE memory round trip (a load-wait-store loop
@@ -422,13 +422,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MT * NT <= 
             patch_store(vp, ld);
         }
         for (int ks = 0; ks < nsub; ++ks) {
-            if (ks > 0) __syncthreads();
+            if (ks > 0) rd_sync();
             for (int base = ks > 0 ? tid : tid + 256 * UW; base < welems; base += 256 * UW) {
                 float4 vw[UW];
                 w_load(base, ks, vw);
                 w_store(base, ks, vw);
             }
-            __syncthreads();
+            rd_sync();
             RD_STAMP()
             run_slab(ks, 0);
             RD_STAMP()
@@ -517,7 +517,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MT * NT <= 
         }
     }
     if (a.stat) {
-        __syncthreads();
+        rd_sync();
         float* red = s_w;  // [WM][2][BN]
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
@@ -528,7 +528,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MT * NT <= 
                 red[(wm * 2 + 1) * BN + wn * NT * 32 + nt * 32 + l31] = q;
             }
         }
-        __syncthreads();
+        rd_sync();
         if (tid < 2 * BN) {
             const int which = tid / BN, j = tid - which * BN;
             float s = 0.f;
@@ -595,7 +595,7 @@ __global__ __launch_bounds__(256) void gconv_combine_kernel(const float* __restr
             *reinterpret_cast<float4*>(sm + ((size_t)(rl * 2 + 0) * Q + q) * 4) = s1;
             *reinterpret_cast<float4*>(sm + ((size_t)(rl * 2 + 1) * Q + q) * 4) = s2;
         }
-        __syncthreads();
+        rd_sync();
         for (int e = threadIdx.x; e < 2 * C; e += blockDim.x) {
             const int w = e / C, c = e - w * C;
             float v = 0.f;
@@ -737,8 +737,10 @@ static bool plan_gconv(const RdConvDesc& d, GconvPlan& best, bool allow_split = 
                 // small-spatial depth-branch layers: 28.8 -> 24.7 us, 34.8 -> 30.7 us with 16-channel chunks, tools/sweep_plan_layers.py)
                 // (a long reduction in the plain chunk loop exposes one memory round trip per chunk: the pipelined form of the same
                 //  point, where it exists, or a smaller chunk that makes it exist, measured 1.3-1.45x faster from four chunks on)
-                if (!pipe && d.Cin / ckp >= 4) score *= 0.8;
-                const bool small3 = c.MT * c.NT == 1 && taps_max >= 9;
+                static const char* no_rules = getenv("RD_GCONV_NO_RULES");      // diagnostics: bit 1 pipelining preference, 2 chunk size of the
+                const int nr = no_rules ? atoi(no_rules) : 0;                   //              single-block tile, 4 phase balance
+                if (!(nr & 1) && !pipe && d.Cin / ckp >= 4) score *= 0.8;
+                const bool small3 = !(nr & 2) && c.MT * c.NT == 1 && taps_max >= 9;
                 if (ckp == (small3 ? 32 : 16) && d.Cin >= 32) score *= 0.97;
                 // CU load balance: the kernel is MFMA-bound, so the time is set by the CU that owns the most workgroups.
                 // Small-spatial / many-channel layers do not produce enough large tiles: split the input channels over
@@ -773,7 +775,7 @@ static bool plan_gconv(const RdConvDesc& d, GconvPlan& best, bool allow_split = 
                     // different length: with fewer than ~4 of them per CU the long ones set the time (the per-layer sweep: stride-2
                     // dgrads 216 -> 152, 212 -> 160, 191 -> 167 us and the two small UpProj forwards 237 -> 205, 222 -> 204 us on the
                     // single-block tile instead of the 3x2 one)
-                    const double phase_balance = (d.n_phases > 1 && wgs < 4 * ncu) ? taps_avg / taps_big : 1.0;
+                    const double phase_balance = (!(nr & 4) && d.n_phases > 1 && wgs < 4 * ncu) ? taps_avg / taps_big : 1.0;
                     // fewer than two workgroups per CU leaves staging/epilogue phases uncovered
                     score = base * (wgs / (ncu * ceil(wgs / ncu))) * (ksp == 1 ? 1.0 : (ksp == 2 ? 0.95 : 0.91)) *
                             (wgs < 2 * ncu && lds <= 80 * 1024 ? 0.9 : 1.0) *   // (a > 80 KB tile already paid for single residency)

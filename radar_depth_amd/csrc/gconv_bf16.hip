@@ -117,7 +117,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void g
         s_apix[m] = ok ? ((r * IS) * PW + c * IS) : 0;
     }
     if (tid < ntaps) s_widx[tid] = P.widx[tid];
-    __syncthreads();
+    rd_sync();
     RD_STAMP()
 
     int aoffB[MT];
@@ -275,7 +275,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void g
         int idx = 0;
         for (int cb = 0; cb < D.Cin; cb += CKP, ++idx) {
             glds_wait();
-            __syncthreads();          // slab idx and the chunk's patch have landed; slab idx-1 is fully consumed
+            rd_sync();          // slab idx and the chunk's patch have landed; slab idx-1 is fully consumed
             RD_STAMP()
             const bool more = cb + CKP < D.Cin;
             float4 v0[UPP], v1[UPP];
@@ -286,7 +286,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void g
             run_chunk(s_w + (idx & 1) * slab_bytes);
             RD_STAMP()
             if (more) {
-                __syncthreads();      // every wave is done reading this chunk's patch
+                rd_sync();      // every wave is done reading this chunk's patch
 #pragma unroll
                 for (int u = 0; u < UPP; ++u) put_unit(pdst[u], v0[u], v1[u]);
             }
@@ -298,7 +298,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void g
         constexpr int UP = 8;
         const int nk = (nsegs + 3) >> 2;            // row segments per wave
         for (int cb = 0; cb < D.Cin; cb += CKP) {
-            __syncthreads();
+            rd_sync();
             {
                 const char* src = reinterpret_cast<const char*>(a.w) + (size_t)(cb >> 3) * a.ldw * 16;
                 for (int e = tid; e < welems; e += 256) {
@@ -321,7 +321,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void g
                 for (int u = 0; u < UP; ++u) put_unit(ld[u], v0[u], v1[u]);
             }
             glds_wait();
-            __syncthreads();
+            rd_sync();
             RD_STAMP()
             run_chunk(s_w);
             RD_STAMP()
@@ -432,7 +432,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void g
         }
     }
     if (a.stat) {
-        __syncthreads();
+        rd_sync();
         float* red = reinterpret_cast<float*>(s_w);  // [WM][2][BN]
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
@@ -443,7 +443,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void g
                 red[(wm * 2 + 1) * BN + nt * 32 + l31] = q;
             }
         }
-        __syncthreads();
+        rd_sync();
         if (tid < 2 * BN) {
             const int which = tid / BN, j = tid - which * BN;
             float s = 0.f;

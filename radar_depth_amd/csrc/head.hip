@@ -33,7 +33,7 @@ __global__ __launch_bounds__(256) void head_conv_fwd_kernel(const T* __restrict_
         const int t = e / C, c = e - t * C;
         s_w[e] = w[c * 9 + t];
     }
-    __syncthreads();
+    rd_sync();
     const int64_t total = (int64_t)N * H * W;
     const bool small = total < (1ll << 31);
     for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
@@ -71,7 +71,7 @@ __global__ __launch_bounds__(256) void head_conv_dgrad_kernel(const float* __res
         const int t = e / C, c = e - t * C;
         s_w[e] = w[c * 9 + t];
     }
-    __syncthreads();
+    rd_sync();
     constexpr int Q = C / 4;
     const int64_t total = (int64_t)N * H * W * Q;
     const bool small = total < (1ll << 31);
@@ -141,9 +141,9 @@ __global__ __launch_bounds__(256) void head_conv_wgrad_kernel(const T* __restric
     }
 #pragma unroll
     for (int t = 0; t < 9; ++t) {
-        __syncthreads();
+        rd_sync();
         s_red[pl * Q + q] = acc[t];
-        __syncthreads();
+        rd_sync();
         if (threadIdx.x < Q) {
             float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
             for (int k = 0; k < PL; ++k) {

@@ -103,7 +103,7 @@ __global__ void transpose_kernel(const float* __restrict__ src, float* __restric
         const int r = r0 + j, c = c0 + threadIdx.x;
         if (r < rows && c < cols) tile[j][threadIdx.x] = src[(size_t)r * cols + c];
     }
-    __syncthreads();
+    rd_sync();
     for (int j = threadIdx.y; j < 32; j += blockDim.y) {
         const int c = c0 + j, r = r0 + threadIdx.x;
         if (r < rows && c < cols) dst[(size_t)c * rows + r] = tile[threadIdx.x][j];

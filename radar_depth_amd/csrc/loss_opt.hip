@@ -11,9 +11,9 @@ constexpr int RED_BLOCKS = 1024;
 __device__ __forceinline__ double block_sum_d(double v, double* sh) {
     v = wave_sum_d(v);
     const int w = threadIdx.x >> 6;
-    __syncthreads();
+    rd_sync();
     if ((threadIdx.x & 63) == 0) sh[w] = v;
-    __syncthreads();
+    rd_sync();
     double s = 0.0;
     for (int i = 0; i < (int)(blockDim.x >> 6); ++i) s += sh[i];
     return s;

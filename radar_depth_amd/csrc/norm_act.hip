@@ -36,7 +36,7 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restric
     q = wave_sum_d(q);
     const int w = threadIdx.x >> 6;
     if ((threadIdx.x & 63) == 0) { sh[0][w] = s; sh[1][w] = q; }
-    __syncthreads();
+    rd_sync();
     if (threadIdx.x == 0) {
         s = sh[0][0] + sh[0][1] + sh[0][2] + sh[0][3];
         q = sh[1][0] + sh[1][1] + sh[1][2] + sh[1][3];
@@ -98,7 +98,7 @@ __device__ __forceinline__ void block_reduce_store(float4 (&acc)[NS], int Q, int
 #pragma unroll
         for (int s = 0; s < NS; ++s) *reinterpret_cast<float4*>(sm + ((size_t)(rl * NS + s) * Q + q) * 4) = acc[s];
     }
-    __syncthreads();
+    rd_sync();
     for (int e = threadIdx.x; e < NS * Q * 4; e += blockDim.x) {
         const int s = e / (Q * 4), c = e - s * (Q * 4);
         float v = 0.f;
@@ -242,7 +242,7 @@ __global__ __launch_bounds__(256) void bn_bwd_coeffs_kernel(const float* __restr
     s1 = wave_sum_d(s1);
     const int w = threadIdx.x >> 6;
     if ((threadIdx.x & 63) == 0) { sh[0][w] = s0; sh[1][w] = s1; }
-    __syncthreads();
+    rd_sync();
     if (threadIdx.x == 0) {
         s0 = sh[0][0] + sh[0][1] + sh[0][2] + sh[0][3];
         s1 = sh[1][0] + sh[1][1] + sh[1][2] + sh[1][3];

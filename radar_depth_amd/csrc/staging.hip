@@ -20,7 +20,7 @@ __global__ __launch_bounds__(256) void stage_frames_kernel(const uint8_t* __rest
                                                            float* __restrict__ labels, const StageLut lut) {
     __shared__ float s_lut[256];
     s_lut[threadIdx.x] = lut.v[threadIdx.x];
-    __syncthreads();
+    rd_sync();
     const int W4 = (W + 3) >> 2;                 // four consecutive output pixels per thread
     const int64_t total = (int64_t)B * H * W4;
     const int64_t plane = (int64_t)H * W;

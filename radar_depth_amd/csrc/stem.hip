@@ -75,7 +75,7 @@ __global__ __launch_bounds__(256) void stem_fwd_kernel(const StemArgs a) {
     const int trem = bid - n * (a.tiles_h * a.tiles_w);
     const int r0 = (trem / a.tiles_w) * TH, c0 = (trem % a.tiles_w) * ST_TW;
     const int ih0 = 2 * r0 - 3, iw0 = 2 * c0 - 3;
-    __syncthreads();          // the previous tile's MFMAs are done with the patch (and its statistics with s_red)
+    rd_sync();          // the previous tile's MFMAs are done with the patch (and its statistics with s_red)
     if (!((a.debug & 1) && bid != (int)blockIdx.x))
     for (int base = tid; base < a.Cin * PLANE; base += 256 * U) {
         float v[U];
@@ -95,7 +95,7 @@ __global__ __launch_bounds__(256) void stem_fwd_kernel(const StemArgs a) {
             if (e < a.Cin * PLANE) s_patch[e] = v[u];
         }
     }
-    __syncthreads();
+    rd_sync();
 
     // wave w owns output rows 2w, 2w+1 of the tile (two 32-pixel M tiles)
     int abase[MT];
@@ -212,7 +212,7 @@ __global__ __launch_bounds__(256) void stem_fwd_kernel(const StemArgs a) {
         }
     }
     if (a.stat) {
-        __syncthreads();
+        rd_sync();
         float* red = s_red;  // [4][2][BN]
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
@@ -223,7 +223,7 @@ __global__ __launch_bounds__(256) void stem_fwd_kernel(const StemArgs a) {
                 red[(wave * 2 + 1) * BN + nt * 32 + l31] = q;
             }
         }
-        __syncthreads();
+        rd_sync();
         if (tid < 2 * BN) {
             const int which = tid / BN, j = tid - which * BN;
             const float s = red[(0 * 2 + which) * BN + j] + red[(1 * 2 + which) * BN + j] + red[(2 * 2 + which) * BN + j] +
@@ -271,7 +271,7 @@ __global__ __launch_bounds__(256) void stem_wgrad_kernel(const StemArgs a, float
         const int n = tile / (a.tiles_h * a.tiles_w);
         const int trem = tile - n * (a.tiles_h * a.tiles_w);
         const int r0 = (trem / a.tiles_w) * TH, c0 = (trem % a.tiles_w) * ST_TW;
-        __syncthreads();
+        rd_sync();
         const int ih0 = 2 * r0 - 3, iw0 = 2 * c0 - 3;
         constexpr int U = 8;
         for (int base = tid; base < a.Cin * PLANE; base += 256 * U) {
@@ -310,7 +310,7 @@ __global__ __launch_bounds__(256) void stem_wgrad_kernel(const StemArgs a, float
                 if (e < NPIX * (BN / 4)) *reinterpret_cast<float4*>(s_do + (size_t)e * 4) = v[u];
             }
         }
-        __syncthreads();
+        rd_sync();
         // pixel walk (two pixels per MFMA), pipelined like the forward K walk; NPIX/2/4 = 16 steps per wave (even)
         {
             float a0[MTK], b0[NT], a1[MTK], b1[NT];
@@ -347,10 +347,10 @@ __global__ __launch_bounds__(256) void stem_wgrad_kernel(const StemArgs a, float
     for (int mt = 0; mt < MTK; ++mt)
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
-            __syncthreads();
+            rd_sync();
 #pragma unroll
             for (int i = 0; i < 16; ++i) red[(wave * 16 + i) * 64 + lane] = acc[mt][nt][i];
-            __syncthreads();
+            rd_sync();
 #pragma unroll
             for (int ii = 0; ii < 4; ++ii) {
                 const int i = ii * 4 + wave;
@@ -373,7 +373,7 @@ __global__ __launch_bounds__(256) void stem_dgrad_channel_kernel(const T* __rest
         const int t = e / Cout, co = e - t * Cout;
         s_w[e] = wp[((size_t)t * Cin + ci) * Cout + co];
     }
-    __syncthreads();
+    rd_sync();
     const int64_t total = (int64_t)N * H * W;
     for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
         const int w = (int)(e % W);

@@ -69,7 +69,7 @@ __global__ __launch_bounds__(256) void stem_fwd_bf16_kernel(const StemBfArgs a) 
     for (int tile = blockIdx.x; tile < total_tiles; tile += gridDim.x) {
     const int n = tile / tiles_img, trem = tile - n * tiles_img;
     const int r0 = (trem / a.tiles_w) * SB_TH, c0 = (trem % a.tiles_w) * SB_TW;
-    __syncthreads();                         // the previous tile's MFMAs / partial sums are done with the patch
+    rd_sync();                         // the previous tile's MFMAs / partial sums are done with the patch
     // ---- halo patch (zero outside the image), lanes along the columns: coalesced plane reads, six loads in flight per thread
     const int ih0 = 2 * r0 - 3, iw0 = 2 * c0 - 3;
     const int npatch = a.Cin * SB_PH * SB_PW;
@@ -93,7 +93,7 @@ __global__ __launch_bounds__(256) void stem_fwd_bf16_kernel(const StemBfArgs a) 
             if (u < npatch) s_patch[u] = __builtin_bit_cast(unsigned short, b);
         }
     }
-    __syncthreads();
+    rd_sync();
 
     // ---- MFMA walk.  Wave w owns tile rows 2w, 2w+1 (M-tile = one tile row, lane l31 = column); lane half hh takes group 2s+hh.
     f32x16 acc[MT][NT];
@@ -185,7 +185,7 @@ __global__ __launch_bounds__(256) void stem_fwd_bf16_kernel(const StemBfArgs a) 
         }
     }
     if (a.stat) {
-        __syncthreads();
+        rd_sync();
         float* red = reinterpret_cast<float*>(ssm);       // [4 waves][2][BN] (over the patch: every wave is past its MFMAs)
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
@@ -196,7 +196,7 @@ __global__ __launch_bounds__(256) void stem_fwd_bf16_kernel(const StemBfArgs a) 
                 red[(wave * 2 + 1) * BN + nt * 32 + l31] = q;
             }
         }
-        __syncthreads();
+        rd_sync();
         if (tid < 2 * BN) {
             const int which = tid / BN, j = tid - which * BN;
             float s = 0.f;

@@ -121,7 +121,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void w
         const int th_n = min(a.TH, a.lh - r0), tw_n = min(a.TW, a.lw - c0);
         const int npix = th_n * tw_n;
         const int npad = ((npix + 2 * KP * WLP - 1) / (2 * KP * WLP)) * (2 * KP * WLP);   // even number of steps
-        __syncthreads();  // previous tile fully consumed
+        rd_sync();  // previous tile fully consumed
         if (!((a.debug & 1) && tile > tile_begin)) {
         for (int p = tid; p < npad + 3 * KP * WLP; p += 256) {
             int2 e = make_int2(0, SHB ? zero_row * COB : 0);  // padding: A reads a valid location, B reads zeros (SHB) or is masked
@@ -172,7 +172,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void w
         }
         }
         glds_wait();
-        __syncthreads();
+        rd_sync();
         // Software pipeline pinned with sched_barrier (hipcc otherwise sinks every ds_read next to its MFMA and waits
         // lgkmcnt(0) per instruction).  Two register sets ping-pong (no copy moves): while one set's TG MFMAs issue, the
         // other set's fragments are in flight from LDS and the pixel-table entry of the step after is being fetched.
@@ -265,10 +265,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void w
         float* red = smem;  // [4][NACC][64]
 #pragma unroll
         for (int t = 0; t < TG; ++t) {
-            __syncthreads();
+            rd_sync();
 #pragma unroll
             for (int i = 0; i < NACC; ++i) red[(wave * NACC + i) * 64 + lane] = acc[t][i];
-            __syncthreads();
+            rd_sync();
             float* dst = slab + (size_t)G.widx[t] * a.Cin * a.Cout;
 #pragma unroll
             for (int ii = 0; ii < NACC / 4; ++ii) {
@@ -379,13 +379,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void w
                 }
             }
         };
-        __syncthreads();                                   // the previous unit's walk is over: the rings are free
+        rd_sync();                                   // the previous unit's walk is over: the rings are free
         for (int p = 0; p <= RH; ++p) stage_patch_row(p);
         stage_dout_row(0);
         stage_dout_row(1);
         for (int it = 0; it < niter; ++it) {
             glds_wait();
-            __syncthreads();                               // rows of iteration `it` have landed; iteration it-1 is fully consumed
+            rd_sync();                               // rows of iteration `it` have landed; iteration it-1 is fully consumed
             if (it + 1 < niter && !(a.debug & 1)) {
                 stage_patch_row(2 * it + RH + 1);
                 stage_patch_row(2 * it + RH + 2);

@@ -46,7 +46,7 @@ __global__ __launch_bounds__(256) void wgrad16_kernel(const Wgrad16Args a) {
         const int ih0 = r0 + a.ih_off, iw0 = c0 + a.iw_off;
         const float* x_n = a.x + (size_t)n * a.H * a.W * a.ldi;
         const float* d_n = a.dout + (size_t)n * a.H * a.W * a.ldo;
-        __syncthreads();          // the previous tile's reads are done
+        rd_sync();          // the previous tile's reads are done
         {
             float4 vx[6], vd[4];
 #pragma unroll
@@ -75,7 +75,7 @@ __global__ __launch_bounds__(256) void wgrad16_kernel(const Wgrad16Args a) {
 #pragma unroll
             for (int u = 0; u < 4; ++u) *reinterpret_cast<float4*>(s_d + (tid + u * 256) * 4) = vd[u];
         }
-        __syncthreads();
+        rd_sync();
         // accumulators are indexed by PATCH POSITION (the slab index of the tap sitting there is looked up when the slab is
         // written): every LDS address below is one lane-constant base plus a compile-time offset, i.e. an immediate of the
         // ds_read -- with runtime tap offsets the compiler kept 160 address registers and the kernel ran one wave per SIMD
@@ -94,12 +94,12 @@ __global__ __launch_bounds__(256) void wgrad16_kernel(const Wgrad16Args a) {
     }
 
     // sum the four waves' accumulators (C/D layout: lane = co, registers = ci 4 kq .. 4 kq + 3) and write the slab [tap][ci][co]
-    __syncthreads();
+    rd_sync();
 #pragma unroll
     for (int t = 0; t < 9; ++t)
 #pragma unroll
         for (int v = 0; v < 4; ++v) s_mem[wave * 9 * 256 + (t * 16 + 4 * kq + v) * 16 + m] = acc[t][v];
-    __syncthreads();
+    rd_sync();
     float* slab = a.slabs + (size_t)blockIdx.x * 9 * 256;
     for (int e = tid; e < 9 * 256; e += 256) {
         const int t = e >> 8, rest = e & 255;

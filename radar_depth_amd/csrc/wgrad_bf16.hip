@@ -231,7 +231,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         }
         int bs = 0;
         for (int tile = t_lo; tile < t_hi; ++tile, bs ^= 1) {
-            __syncthreads();
+            rd_sync();
             WB_STAMP()
             if (tile + 1 < t_hi) {
                 float4 vx[UX][4], vy[UY][4];
@@ -254,7 +254,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 
     int bsel = 0;
     for (int tile = t_lo; tile < t_hi; ++tile, bsel ^= 1) {
-        __syncthreads();      // buffer `bsel` is complete; the MFMAs of the previous tile are done with the other one
+        rd_sync();      // buffer `bsel` is complete; the MFMAs of the previous tile are done with the other one
         WB_STAMP()
         const unsigned* XTc = XT + bsel * buf_dwords;
         const unsigned* YTc = YT + bsel * buf_dwords;

@@ -146,3 +146,36 @@ def test_gconv_upproj(c, h, w):
     assert _rel(stat.sum(0)[0].cpu().double(), y.detach().double().sum((0, 2, 3))) < 1e-3
     gotx = dx.permute(0, 3, 1, 2).cpu()
     assert _rel(gotx, gx_want) < 2e-5
+
+
+def test_gconv_launches_are_bitwise_reproducible():
+    """Race regression (round 2): the single-block tile with 16-channel chunks in the pipelined loop -- the plan the heuristic picks
+    for a 64 -> 64 channel 3x3 layer at b=2, 113x200 -- produced two wrong output pixels per launch in 1.7 % of the launches: hipcc
+    had dropped the lgkmcnt(0) wait in front of the loop-header barrier, so a wave could read patch pixels another wave had stored
+    but not committed (csrc/common.h rd_sync / glds_wait).  600 launches on the same inputs must agree bit for bit, output and
+    BatchNorm partial sums; tools/stress_plans.py does the same for every candidate plan of a descriptor."""
+    import ctypes as C
+    from radar_depth_amd import convdesc as cd
+    from radar_depth_amd._lib import check, current_stream, lib, ptr
+    L = lib()
+    for n, h, w, ci, co in ((2, 113, 200, 64, 64), (2, 57, 100, 128, 128)):
+        d = cd.conv_fwd(n, h, w, ci, co, 3, 1, 1)
+        g = torch.Generator(device="cuda").manual_seed(1)
+        x = torch.randn(n * h * w * ci, device="cuda", generator=g)
+        wp = torch.randn(9 * ci * co, device="cuda", generator=g)
+        out = torch.zeros(n * h * w * co, device="cuda")
+        stat = torch.zeros(L.rd_gconv_stat_tiles_ws(C.byref(d)) * 2 * co, device="cuda")
+        L.rd_gconv_workspace_floats.restype = C.c_int64
+        nws = int(L.rd_gconv_workspace_floats(C.byref(d)))
+        ws = torch.empty(max(nws, 1), device="cuda")
+        ref = None
+        for it in range(600):
+            out.fill_(float("nan"))
+            check(L.rd_gconv_ws(C.byref(d), ptr(x), ptr(wp), ptr(out), None, 0, ptr(stat), ptr(ws) if nws else None, current_stream()), "gconv")
+            if it % 50 == 0 or it == 599:
+                torch.cuda.synchronize()
+            cur = (out.clone(), stat.clone())
+            if ref is None:
+                ref = cur
+            else:
+                assert torch.equal(ref[0], cur[0]) and torch.equal(ref[1], cur[1]), (n, h, w, ci, co, it)

@@ -396,3 +396,35 @@ def test_geometries_forward_backward_vs_oracle(b, h, w):
     tail = [i for i, n in enumerate(names) if n.startswith(("decoder.layer4", "decoder.layer3", "conv3"))]
     assert np.abs(go[tail] - gg[tail]).max() / go[tail].max() < 1e-3
     assert np.abs(go - gg).max() / go.max() < 0.1
+
+
+def test_eager_multistage_forward_backward_is_bitwise_reproducible():
+    """The autograd (eager plan) path of the multistage network at config 4's geometry, repeated in one process: outputs (the radar
+    filter's mask included -- it turns a one-ulp difference of stage 1 into a percent-level change of stage 2) and every parameter
+    gradient must be bit-identical every time.  This is the detector that found the missing LDS wait in front of the pipelined
+    gconv loop's barrier (tools/stress_eager.py is the long form)."""
+    import types
+    from radar_depth_amd.main import create_model
+    from radar_depth_amd.synthetic import make_batch, procedural_fill_
+    b, h, w = 2, 450, 800
+    args = types.SimpleNamespace(arch="resnet18_multistage_uncertainty_fixs", decoder="upproj", modality="rgbd", pretrained=False)
+    torch.manual_seed(0)
+    m, _ = create_model(args, [h, w])
+    procedural_fill_(m)
+    m = m.cuda().train()
+    x, _ = make_batch(b, h, w, 77, ref_pixels=h * w)
+    x = x.cuda()
+    ref = None
+    for it in range(12):
+        m.zero_grad(set_to_none=True)
+        o = m(x)
+        keys = [k for k in sorted(o) if torch.is_tensor(o[k])]
+        sum(o[k].float().mean() for k in keys if o[k].dtype.is_floating_point).backward()
+        torch.cuda.synchronize()
+        cur = [o[k].detach().clone() for k in keys] + [p.grad.detach().clone() for p in m.parameters() if p.grad is not None]
+        if ref is None:
+            ref = cur
+        else:
+            assert all(torch.equal(a_, b_) for a_, b_ in zip(ref, cur)), "repetition %d differs" % it
+        junk = [torch.empty(int(1e6 * (1 + (it * 7 + k) % 5)), device="cuda") for k in range(3)]      # shuffle the allocator
+        del junk
