@@ -1,9 +1,19 @@
 """Golden vectors for the input-staging row, produced HERE from /root/reference.
 
-The reference's dataset class cannot be constructed in this container (h5py, the nuScenes devkit and the data are absent), but
-its transform classes import: the vectors below run the literal statement sequence of get_data / transform_val
-(dataset/nuscenes_dataset_torch_new.py:191-195, 417-456, 498-512) with the reference's OWN ``transforms.CenterCrop`` and
-``transforms.ToTensor`` objects on seeded frames.      python tests/golden/make_golden_staging.py"""
+The vectors come from the reference's OWN ``nuscenes_dataset_torch.transform_val`` (dataset/nuscenes_dataset_torch_new.py:415-530),
+called unbound on seeded frames with a namespace standing in for ``self`` (it only reads transform_mode / sparsifier / modality /
+max_depth / t_cfg.crop_size_*).  The dataset class itself cannot be constructed in this container -- h5py, attrdict, matplotlib,
+the nuScenes devkit and the data are absent -- so the module is imported with EMPTY stand-in modules for those packages (none of
+them is touched by transform_val, which is numpy / torch and the reference's own ``transforms`` classes), plus the two aliases the
+reference's 2019-era code expects (``np.int``, ``collections.Iterable``).  The only statements restated here are get_data's two
+decompression lines (:193,:195: ``int16 / 256.``), because get_data reads its input through h5py.  ``reference_val_frame`` -- the
+statement sequence the first version of this script restated -- is kept as a cross-check: both must agree bit for bit.
+    python tests/golden/make_golden_staging.py"""
+import collections
+import collections.abc
+import importlib
+import importlib.abc
+import importlib.machinery
 import os
 import sys
 import types
@@ -11,9 +21,50 @@ import types
 import numpy as np
 import torch
 
-sys.modules.setdefault("torchvision", types.ModuleType("torchvision"))      # dataset/transforms.py only needs the name
+
+class _Empty(types.ModuleType):
+    """Stand-in for a package the image lacks: any attribute is another empty stand-in, calling it returns one."""
+
+    def __getattr__(self, name):
+        if name.startswith("__"):
+            raise AttributeError(name)
+        d = _Empty(self.__name__ + "." + name)
+        setattr(self, name, d)
+        return d
+
+    def __call__(self, *a, **k):
+        return _Empty("call")
+
+
+class _MissingPackages(importlib.abc.MetaPathFinder, importlib.abc.Loader):
+    NAMES = ("h5py", "nuscenes", "matplotlib", "pyquaternion", "cv2", "PIL", "torchvision", "skimage", "ipdb", "attrdict")
+
+    def find_spec(self, name, path, target=None):
+        if name.split(".")[0] in self.NAMES:
+            return importlib.machinery.ModuleSpec(name, self, is_package=True)
+
+    def create_module(self, spec):
+        return _Empty(spec.name)
+
+    def exec_module(self, module):
+        module.__path__ = []
+
+
+sys.meta_path.insert(0, _MissingPackages())
+collections.Iterable = collections.abc.Iterable       # removed in Python 3.10; dataset/transforms.py:313 uses it
+np.int = int                                          # removed in numpy 1.24; used on the (unused here) index-map path
 sys.path.insert(0, "/root/reference")
 from dataset import transforms  # noqa: E402
+ref_dataset = importlib.import_module("dataset.nuscenes_dataset_torch_new")
+
+
+def reference_transform_val(image, lidar_i16, radar_i16, crop_size_val, max_depth):
+    """get_data's decompression (:193,:195) + the reference's own transform_val for modality rgbd / sparsifier radar."""
+    self = types.SimpleNamespace(transform_mode="sparse-to-dense", sparsifier="radar", modality="rgbd", max_depth=max_depth,
+                                 t_cfg=types.SimpleNamespace(crop_size_train=tuple(crop_size_val), crop_size_val=tuple(crop_size_val)))
+    data = {"image": image, "lidar_depth": lidar_i16 / 256., "radar_depth": radar_i16 / 256.}
+    out = ref_dataset.nuscenes_dataset_torch.transform_val(self, data)
+    return out["inputs"].numpy(), out["labels"].numpy()
 
 to_tensor = transforms.ToTensor()
 
@@ -40,7 +91,10 @@ def main():
         img = rng.randint(0, 256, size=(B, H0, W0, 3)).astype(np.uint8)
         lidar = (rng.rand(B, H0, W0) * 120.0 * 256 * (rng.rand(B, H0, W0) < 0.3)).astype(np.int16)
         radar = (rng.rand(B, H0, W0) * 120.0 * 256 * (rng.rand(B, H0, W0) < 0.2)).astype(np.int16)
-        outs = [reference_val_frame(img[b], lidar[b], radar[b], crop, md) for b in range(B)]
+        outs = [reference_transform_val(img[b], lidar[b], radar[b], crop, md) for b in range(B)]
+        for b in range(B):          # the restated sequence agrees with the reference's method bit for bit
+            chk = reference_val_frame(img[b], lidar[b], radar[b], crop, md)
+            assert np.array_equal(outs[b][0], chk[0]) and np.array_equal(outs[b][1], chk[1])
         cases[name + "_image"], cases[name + "_lidar"], cases[name + "_radar"] = img, lidar, radar
         cases[name + "_crop"], cases[name + "_max_depth"] = np.array(crop), np.array(md, dtype=np.float64)
         cases[name + "_inputs"] = np.stack([o[0] for o in outs])
@@ -48,7 +102,7 @@ def main():
     # every byte value through the /255 path
     img = np.arange(256, dtype=np.uint8).reshape(1, 16, 16, 1).repeat(3, axis=3)
     z = np.zeros((1, 16, 16), dtype=np.int16)
-    i, l = reference_val_frame(img[0], z[0], z[0], (16, 16), np.inf)
+    i, l = reference_transform_val(img[0], z[0], z[0], (16, 16), np.inf)
     cases["bytes_inputs"] = i[None]
     out = os.path.join(os.path.dirname(os.path.abspath(__file__)), "staging.npz")
     np.savez_compressed(out, **cases)
