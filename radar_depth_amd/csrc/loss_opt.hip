@@ -143,7 +143,7 @@ __global__ __launch_bounds__(256) void smooth_main_kernel(const float* __restric
     const float inx = 1.f / ((float)N * H * (W - 1)), iny = 1.f / ((float)N * (H - 1) * W);
     double lx = 0.0, ly = 0.0, tq = 0.0;
     for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < hw; e += (int64_t)gridDim.x * blockDim.x) {
-        const int x = (int)(e % W), y = (int)(e / W);
+        const int y = (int)((unsigned)e / (unsigned)W), x = (int)((unsigned)e - (unsigned)y * (unsigned)W);   // (one image: e < 2^31, checked by the host)
         const float d = p[e] * inv;
         float qq = 0.f;
         if (x + 1 < W) {
@@ -359,6 +359,7 @@ static void smooth_carve(float* ws, int N, int H, int W, float*& q, float*& sden
 extern "C" int rd_smooth_fwd(const float* pred, const float* image, int32_t N, int32_t C, int32_t H, int32_t W, float* ws,
                              double* out, void* stream) {
     RD_CHECK_ARG(pred && image && ws && out && N > 0 && C > 0 && H > 1 && W > 1 && ((uintptr_t)ws & 7) == 0, "smooth_fwd: bad arguments");
+    RD_CHECK_ARG((int64_t)H * W < (1ll << 31), "smooth_fwd: one image must have fewer than 2^31 pixels");
     hipStream_t s = static_cast<hipStream_t>(stream);
     float *q, *sden;
     double *tsum, *part;

@@ -376,9 +376,18 @@ __global__ __launch_bounds__(256) void stem_dgrad_channel_kernel(const T* __rest
     rd_sync();
     const int64_t total = (int64_t)N * H * W;
     for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
-        const int w = (int)(e % W);
-        const int64_t r = e / W;
-        const int h = (int)(r % H), n = (int)(r / H);
+        int w, h, n;
+        if (total < (1ll << 31)) {          // 32-bit divisions (a 64-bit one is ~100 instructions)
+            const unsigned u = (unsigned)e, r = u / (unsigned)W;
+            w = (int)(u - r * (unsigned)W);
+            n = (int)(r / (unsigned)H);
+            h = (int)(r - (unsigned)n * (unsigned)H);
+        } else {
+            w = (int)(e % W);
+            const int64_t r = e / W;
+            h = (int)(r % H);
+            n = (int)(r / H);
+        }
         float s = 0.f;
         for (int kh = (h + 3) & 1; kh < 7; kh += 2) {
             const int oh = (h + 3 - kh) >> 1;
