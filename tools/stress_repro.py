@@ -16,14 +16,19 @@ def build(arch, h, w):
     return m.cuda(), lw
 
 
-MODE = sys.argv[1] if len(sys.argv) > 1 else "fp32"          # fp32 | bf16 (operands) | bf16s (bf16 storage)
+MODE = ([a_ for a_ in sys.argv[1:] if not a_.startswith("--")] or ["fp32"])[0]          # fp32 | bf16 (operands) | bf16s (bf16 storage)
 assert MODE in ("fp32", "bf16", "bf16s"), MODE
 OPERANDS, STORAGE = ("bf16" if MODE != "fp32" else "fp32"), ("bf16" if MODE == "bf16s" else "fp32")
 print("mode:", MODE)
 bad = 0
-for arch, b, h, w, steps in [("resnet18_latefusion", 16, 450, 800, 6), ("resnet18_latefusion", 3, 225, 401, 6), ("resnet18_latefusion", 1, 450, 800, 6),
-                            ("resnet18_latefusion", 5, 97, 161, 8), ("resnet18_multistage_uncertainty_fixs", 4, 225, 400, 5),
-                            ("resnet18_multistage_uncertainty_fixs", 8, 450, 800, 3)]:
+CASES = [("resnet18_latefusion", 16, 450, 800, 6), ("resnet18_latefusion", 3, 225, 401, 6), ("resnet18_latefusion", 1, 450, 800, 6),
+         ("resnet18_latefusion", 5, 97, 161, 8), ("resnet18_multistage_uncertainty_fixs", 4, 225, 400, 5),
+         ("resnet18_multistage_uncertainty_fixs", 8, 450, 800, 3)]
+if "--long" in sys.argv:       # the geometry that exposed the LDS race of round 2 (b=2, 450x800) and more steps everywhere
+    CASES = [(a_, b_, h_, w_, 4 * s_) for a_, b_, h_, w_, s_ in CASES] + [("resnet18_multistage_uncertainty_fixs", 2, 450, 800, 30),
+                                                                          ("resnet18_latefusion", 2, 450, 800, 30),
+                                                                          ("resnet18_latefusion", 2, 900, 1600, 10)]
+for arch, b, h, w, steps in CASES:
     (m1, lw1), (m2, lw2) = build(arch, h, w), build(arch, h, w)
     t1 = HipTrainStep(m1, b, h, w, loss_weights=lw1, operands=OPERANDS, storage=STORAGE)
     t2 = HipTrainStep(m2, b, h, w, loss_weights=lw2, operands=OPERANDS, storage=STORAGE)
