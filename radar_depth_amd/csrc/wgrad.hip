@@ -587,7 +587,10 @@ static int plan_wgrad(const RdConvDesc& d_in, WgradPlan& pl, WgradArgs* out, int
         WgradStripArgs& sa = pl.sa;
         const int groups = pl.n_cib * pl.n_cob;
         static const char* wpc_env = getenv("RD_WGRAD_WG_PER_CU_X2");   // diagnostics: workgroups per CU, times two (default 4 = two per CU)
-        int want = cdiv((wpc_env ? atoi(wpc_env) : 4) * num_cus() / 2, groups);
+        // (the four phase launches of an UpProj layer each write their own slabs: with one workgroup per CU instead of two the
+        //  slab traffic halves, which pays there -- dec1 327 -> 270 us, dec2 259 -> 251, dec3 260 -> 250, tools/sweep_wgrad_knobs.py --
+        //  and nowhere else)
+        int want = cdiv((wpc_env ? atoi(wpc_env) : (ph >= 0 ? 2 : 4)) * num_cus() / 2, groups);
         if (want < 1) want = 1;
         sa.n_strips = cdiv(P0.lw, 25);
         const int base_units = d.N * sa.n_strips;
@@ -656,7 +659,9 @@ static int plan_wgrad(const RdConvDesc& d_in, WgradPlan& pl, WgradArgs* out, int
     pl.total_tiles = d.N * pl.tiles_h * pl.tiles_w;
     const int groups = pl.n_cib * pl.n_cob * pl.n_tg;
     static const char* wpc_env2 = getenv("RD_WGRAD_WG_PER_CU_X2");
-    int want = cdiv((wpc_env2 ? atoi(wpc_env2) : 4) * num_cus() / 2, groups);
+    // (UpProj phase launches with many channel blocks -- dec1: 16 -- are slab-traffic-bound like the strip ones: 327 -> 269 us with
+    //  one workgroup per CU; the 32-channel stage has one block and needs the two: 257 vs 301 us)
+    int want = cdiv((wpc_env2 ? atoi(wpc_env2) : (ph >= 0 && groups >= 8 ? 2 : 4)) * num_cus() / 2, groups);
     if (want < 1) want = 1;
     if (want > pl.total_tiles) want = pl.total_tiles;
     pl.tiles_per_split = cdiv(pl.total_tiles, want);
