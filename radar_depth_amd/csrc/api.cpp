@@ -71,7 +71,7 @@ extern "C" int rd_graph_destroy(void* graph_exec) {
 __global__ __launch_bounds__(256) void poison_lds_kernel(unsigned* sink, int words) {
     extern __shared__ unsigned lds_words[];
     for (int i = threadIdx.x; i < words; i += 256) lds_words[i] = 0xFFFFFFFFu;
-    __syncthreads();
+    rd::rd_sync();
     if (sink && lds_words[(threadIdx.x * 97) % words] == 0u) sink[0] = 1;      // keep the stores alive
 }
 extern "C" int rd_debug_poison_lds(void* stream) {

@@ -161,3 +161,23 @@ def test_result_container_semantics():
     am.update(r, 1.5, 0.75, n=2)
     avg = am.average()
     assert avg.rmse == 4 and avg.delta3 == 10 and avg.gpu_time == 1.0 and avg.data_time == 0.5
+
+
+def test_every_kernel_barrier_goes_through_rd_sync():
+    """Source lint for the LDS race fixed in round 2 (csrc/common.h): hipcc's wait-count pass dropped the lgkmcnt(0) in front of a
+    loop-header s_barrier, so a bare __syncthreads() is not a safe LDS barrier in this library.  Every barrier in the kernels must be
+    rd_sync() (explicit s_waitcnt lgkmcnt(0) + __syncthreads()); the only __syncthreads() left is the one inside rd_sync itself."""
+    import glob
+    import os
+    import re
+    root = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "radar_depth_amd", "csrc")
+    offenders = []
+    for f in sorted(glob.glob(os.path.join(root, "*.hip")) + glob.glob(os.path.join(root, "*.h")) + glob.glob(os.path.join(root, "*.cpp"))):
+        for n, line in enumerate(open(f), 1):
+            code = line.split("//")[0]
+            if re.search(r"\b__syncthreads\s*\(", code):
+                offenders.append("%s:%d" % (os.path.basename(f), n))
+    assert len(offenders) == 1 and offenders[0].startswith("common.h:"), offenders
+    common = open(os.path.join(root, "common.h")).read()
+    assert re.search(r"void rd_sync\(\)\s*\{\s*asm volatile\(\"s_waitcnt lgkmcnt\(0\)\"[^;]*;\s*__syncthreads\(\);", common)
+    assert 'asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)"' in common          # glds_wait
