@@ -33,7 +33,8 @@ def _time_launch(fn, iters):
 
 
 def tune_gconv(L, d, device, allow_split=True, verify=True, report=None):
-    """Pin the fastest plan for descriptor d (RdConvDesc) as rd_gconv_ws will run it.  Returns (best_us, heuristic_us) or None when
+    """Pin the fastest plan for descriptor d (RdConvDesc) as rd_gconv_ws will run it.  Returns (best_us, heuristic_us, best plan,
+    heuristic plan) or None when
     there is nothing to choose from.  report: optional list that receives (us, candidate tuple, ok) rows."""
     key = bytes(d) + (b"\x01" if allow_split else b"\x00")
     if key in _TUNED:
@@ -51,6 +52,21 @@ def tune_gconv(L, d, device, allow_split=True, verify=True, report=None):
     stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
     pv = lambda t: C.c_void_p(t.data_ptr())
     rows, ref = [], None
+    # the heuristic plan itself (pin NULL): the candidate list is sorted by score but, unlike the planner, it also contains the
+    # split-K points the planner's minimum-work rule excludes, so its first row is not necessarily what the heuristic would run
+    heur_us, heur_plan = float("inf"), None
+    if L.rd_gconv_tune_pin(C.byref(d), int(allow_split), None) == 0:
+        info = (C.c_int32 * 10)()
+        L.rd_gconv_plan_info(C.byref(d), info)
+        heur_plan = (info[0], info[1], info[2], info[3], info[5], info[6], info[7], (info[4] // 100) % 100, (info[4] // 10000) % 100)
+        nws0 = int(L.rd_gconv_workspace_floats(C.byref(d)))
+        ws0 = torch.empty(nws0, device=device) if nws0 > 0 else None
+
+        def launch0():
+            if L.rd_gconv_ws(C.byref(d), pv(x), pv(w), pv(out), None, 0, None, pv(ws0) if ws0 is not None else None, stream) != 0:
+                raise RuntimeError("rd_gconv_ws failed under the heuristic plan: %s" % L.rd_last_error().decode())
+        _time_launch(launch0, 30)           # (also lets the device clock ramp: cold launches read ~13 % slow)
+        heur_us = min(_time_launch(launch0, 3), _time_launch(launch0, 6))
     for i in range(n):
         c = (C.c_int32 * 9)(*cand[9 * i:9 * i + 9])
         if L.rd_gconv_tune_pin(C.byref(d), int(allow_split), c) != 0:
@@ -92,7 +108,10 @@ def tune_gconv(L, d, device, allow_split=True, verify=True, report=None):
         import warnings
         warnings.warn("radar_depth_amd.autotune: %d gconv plan candidate(s) disagreed with the reference result and were rejected: %s"
                       % (len(bad), [r[1] for r in bad][:3]))
-    _TUNED[key] = (best[0], rows[0][0])
+    if heur_us <= best[0] and heur_plan is not None:      # nothing beats the heuristic: keep it (and its exact tile shape)
+        L.rd_gconv_tune_pin(C.byref(d), int(allow_split), None)
+        best = (heur_us, heur_plan, True)
+    _TUNED[key] = (best[0], heur_us, best[1], heur_plan)      # tuned us, heuristic us, tuned plan, heuristic plan
     return _TUNED[key]
 
 

@@ -777,7 +777,12 @@ static bool plan_gconv(const RdConvDesc& d, GconvPlan& best, bool allow_split = 
                     // single-block tile instead of the 3x2 one)
                     const double phase_balance = (!(nr & 4) && d.n_phases > 1 && wgs < 4 * ncu) ? taps_avg / taps_big : 1.0;
                     // fewer than two workgroups per CU leaves staging/epilogue phases uncovered
-                    score = base * (wgs / (ncu * ceil(wgs / ncu))) * (ksp == 1 ? 1.0 : (ksp == 2 ? 0.95 : 0.91)) *
+                    static const char* kspen = getenv("RD_GCONV_KS_PEN");      // diagnostics: "p2,p4" score factors of a 2- / 4-way split
+                    // (0.85 / 0.72: a split costs the partial-sum round trip and the combine launch; with the 0.95 / 0.91 of round 1 the
+                    //  planner split layers at b=8 that the tuner ran 12-20 % faster unsplit on smaller tiles -- multistage b=8 312 -> 319,
+                    //  latefusion b=16 741 -> 746 samples/s, tools/tune_report.py)
+                    static const double p2 = kspen ? atof(kspen) : 0.85, p4 = kspen && strchr(kspen, ',') ? atof(strchr(kspen, ',') + 1) : 0.72;
+                    score = base * (wgs / (ncu * ceil(wgs / ncu))) * (ksp == 1 ? 1.0 : (ksp == 2 ? p2 : p4)) *
                             (wgs < 2 * ncu && lds <= 80 * 1024 ? 0.9 : 1.0) *   // (a > 80 KB tile already paid for single residency)
                             phase_balance;
                     const GconvPlan cand{c.MT, c.NT, c.WM, c.WN, CKW, ckp, TH, TW, PP, 0, n_cot, taps_max, pick_wsd(taps_max, BN, CKW, ckp, pipe), ksp, lds,
