@@ -69,33 +69,60 @@ __global__ __launch_bounds__(256) void stem_fwd_kernel(const StemArgs a) {
     // PERSISTENT workgroups: the k->offset table and the weight operand (38 KB for the RGB stem -- more than twice the patch of
     // a tile, for 4.8 MFLOP of work) are staged once per workgroup, not once per tile; the grid is two workgroups per CU and each
     // walks the tiles bid, bid + grid, ...
+    // The patch of the NEXT tile is fetched into registers before the MFMA walk of the current tile and written to LDS after it
+    // (the RD_STEM_DEBUG ablation charged 140 of the kernel's 411 us to staging: three exposed memory round trips per tile plus
+    // ~40 VALU instructions of index arithmetic per element on the lanes the co-resident workgroup's fp32 MFMAs need).  A thread's
+    // elements are (plane ci, slot u): patch pixel e = tid + 256 u of EVERY plane, so (row, column) are computed once per
+    // workgroup, the plane is compile-time, and each plane is read through its own buffer descriptor (out-of-range -> 0).
     const int total_tiles = a.N * a.tiles_h * a.tiles_w;
+    constexpr int UP = (PH * ST_PW + 255) / 256;          // 6 patch pixels per thread and plane
+    int prel[UP];                                         // py * W + px, or a huge value for slots past the plane
+    short ppy[UP], ppx[UP];
+#pragma unroll
+    for (int u = 0; u < UP; ++u) {
+        const int e = tid + u * 256;
+        const int py = e / ST_PW, px = e - py * ST_PW;
+        ppy[u] = (short)(e < PLANE ? py : 30000);
+        ppx[u] = (short)px;
+        prel[u] = py * a.W + px;
+    }
+    auto fetch_patch = [&](int bid_, float (&v)[3][UP]) {
+        const int n_ = bid_ / (a.tiles_h * a.tiles_w);
+        const int trem_ = bid_ - n_ * (a.tiles_h * a.tiles_w);
+        const int ih0_ = 2 * (trem_ / a.tiles_w) * TH - 3, iw0_ = 2 * (trem_ % a.tiles_w) * ST_TW - 3;
+        const int org = ih0_ * a.W + iw0_;
+#pragma unroll
+        for (int ci = 0; ci < 3; ++ci) {
+            if (ci < a.Cin) {
+                const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc(
+                    const_cast<float*>(a.plane[ci] + (size_t)n_ * a.stride[ci]), 0, (unsigned)(a.H * a.W) * 4u, 0x00020000);
+#pragma unroll
+                for (int u = 0; u < UP; ++u) {
+                    const int ih = ih0_ + ppy[u], iw = iw0_ + ppx[u];
+                    const unsigned off = (ih >= 0 && ih < a.H && iw >= 0 && iw < a.W) ? (unsigned)(org + prel[u]) * 4u : 0x80000000u;
+                    v[ci][u] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, (int)off, 0, 0));
+                }
+            }
+        }
+    };
+    float vnext[3][UP];
+    if ((int)blockIdx.x < total_tiles) fetch_patch(blockIdx.x, vnext);
     for (int bid = blockIdx.x; bid < total_tiles; bid += gridDim.x) {
     const int n = bid / (a.tiles_h * a.tiles_w);
     const int trem = bid - n * (a.tiles_h * a.tiles_w);
     const int r0 = (trem / a.tiles_w) * TH, c0 = (trem % a.tiles_w) * ST_TW;
-    const int ih0 = 2 * r0 - 3, iw0 = 2 * c0 - 3;
     rd_sync();          // the previous tile's MFMAs are done with the patch (and its statistics with s_red)
-    if (!((a.debug & 1) && bid != (int)blockIdx.x))
-    for (int base = tid; base < a.Cin * PLANE; base += 256 * U) {
-        float v[U];
+    if (!((a.debug & 1) && bid != (int)blockIdx.x)) {
 #pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const int e = base + u * 256;
-            const int ci = min(e / PLANE, a.Cin - 1), rem = e - (e / PLANE) * PLANE;
-            const int py = rem / ST_PW, px = rem - py * ST_PW;
-            const int ih = ih0 + py, iw = iw0 + px;
-            v[u] = 0.f;
-            if (e < a.Cin * PLANE && ih >= 0 && ih < a.H && iw >= 0 && iw < a.W)
-                v[u] = a.plane[ci][(size_t)n * a.stride[ci] + (size_t)ih * a.W + iw];
-        }
+        for (int ci = 0; ci < 3; ++ci)
+            if (ci < a.Cin) {
 #pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const int e = base + u * 256;
-            if (e < a.Cin * PLANE) s_patch[e] = v[u];
-        }
+                for (int u = 0; u < UP; ++u)
+                    if (tid + u * 256 < PLANE) s_patch[ci * PLANE + tid + u * 256] = vnext[ci][u];
+            }
     }
     rd_sync();
+    if (bid + (int)gridDim.x < total_tiles) fetch_patch(bid + gridDim.x, vnext);      // in flight during the walk and the epilogue
 
     // wave w owns output rows 2w, 2w+1 of the tile (two 32-pixel M tiles)
     int abase[MT];
@@ -236,7 +263,7 @@ __global__ __launch_bounds__(256) void stem_fwd_kernel(const StemArgs a) {
 
 // wgrad: D[k][co] += sum_pixels patch(k, pixel) * dout[pixel][co];  MTK = ceil(K/32) row tiles
 template <int MTK, int NT>
-__global__ __launch_bounds__(256) void stem_wgrad_kernel(const StemArgs a, float* __restrict__ slabs) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void stem_wgrad_kernel(const StemArgs a, float* __restrict__ slabs) {
     constexpr int TH = 4, PH = 2 * TH + 5, BN = NT * 32, NPIX = TH * ST_TW;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, hh = lane >> 5;
@@ -267,31 +294,50 @@ __global__ __launch_bounds__(256) void stem_wgrad_kernel(const StemArgs a, float
     const int split = blockIdx.x;
     const int tile_begin = split * a.tiles_per_split;
     const int tile_end = min(tile_begin + a.tiles_per_split, a.total_tiles);
+    // The input patch of the NEXT tile is fetched into registers before the pixel walk of the current one (same scheme as the
+    // forward kernel: slot u of a thread is patch pixel tid + 256 u of every plane, (row, column) computed once, one buffer
+    // descriptor per plane with out-of-range -> 0); the dout tile is staged per tile as before (16-byte loads, shifts only).
+    constexpr int UPW = (PH * ST_PW + 255) / 256;          // 4 patch pixels per thread and plane
+    int pyx[UPW];                                          // py << 16 | px, py = 30000 for slots past the plane
+#pragma unroll
+    for (int u = 0; u < UPW; ++u) {
+        const int e = tid + u * 256;
+        const int py = e / ST_PW, px = e - py * ST_PW;
+        pyx[u] = ((e < PLANE ? py : 30000) << 16) | px;
+    }
+    auto fetch_patch = [&](int tile_, float (&v)[3][UPW]) {
+        const int n_ = tile_ / (a.tiles_h * a.tiles_w);
+        const int trem_ = tile_ - n_ * (a.tiles_h * a.tiles_w);
+        const int ih0_ = 2 * (trem_ / a.tiles_w) * TH - 3, iw0_ = 2 * (trem_ % a.tiles_w) * ST_TW - 3;
+#pragma unroll
+        for (int ci = 0; ci < 3; ++ci) {
+            if (ci < a.Cin) {
+                const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc(
+                    const_cast<float*>(a.plane[ci] + (size_t)n_ * a.stride[ci]), 0, (unsigned)(a.H * a.W) * 4u, 0x00020000);
+#pragma unroll
+                for (int u = 0; u < UPW; ++u) {
+                    const int ih = ih0_ + (pyx[u] >> 16), iw = iw0_ + (pyx[u] & 0xffff);
+                    const unsigned off = (ih >= 0 && ih < a.H && iw >= 0 && iw < a.W) ? (unsigned)(ih * a.W + iw) * 4u : 0x80000000u;
+                    v[ci][u] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, (int)off, 0, 0));
+                }
+            }
+        }
+    };
+    float vnext[3][UPW];
+    if (tile_begin < tile_end) fetch_patch(tile_begin, vnext);
     for (int tile = tile_begin; tile < tile_end; ++tile) {
         const int n = tile / (a.tiles_h * a.tiles_w);
         const int trem = tile - n * (a.tiles_h * a.tiles_w);
         const int r0 = (trem / a.tiles_w) * TH, c0 = (trem % a.tiles_w) * ST_TW;
         rd_sync();
-        const int ih0 = 2 * r0 - 3, iw0 = 2 * c0 - 3;
         constexpr int U = 8;
-        for (int base = tid; base < a.Cin * PLANE; base += 256 * U) {
-            float v[U];
 #pragma unroll
-            for (int u = 0; u < U; ++u) {
-                const int e = base + u * 256;
-                const int ci = min(e / PLANE, a.Cin - 1), rem = e - (e / PLANE) * PLANE;
-                const int py = rem / ST_PW, px = rem - py * ST_PW;
-                const int ih = ih0 + py, iw = iw0 + px;
-                v[u] = 0.f;
-                if (e < a.Cin * PLANE && ih >= 0 && ih < a.H && iw >= 0 && iw < a.W)
-                    v[u] = a.plane[ci][(size_t)n * a.stride[ci] + (size_t)ih * a.W + iw];
-            }
+        for (int ci = 0; ci < 3; ++ci)
+            if (ci < a.Cin) {
 #pragma unroll
-            for (int u = 0; u < U; ++u) {
-                const int e = base + u * 256;
-                if (e < a.Cin * PLANE) s_patch[e] = v[u];
+                for (int u = 0; u < UPW; ++u)
+                    if (tid + u * 256 < PLANE) s_patch[ci * PLANE + tid + u * 256] = vnext[ci][u];
             }
-        }
         for (int base = tid; base < NPIX * (BN / 4); base += 256 * U) {
             float4 v[U];
 #pragma unroll
@@ -311,6 +357,7 @@ __global__ __launch_bounds__(256) void stem_wgrad_kernel(const StemArgs a, float
             }
         }
         rd_sync();
+        if (tile + 1 < tile_end) fetch_patch(tile + 1, vnext);          // in flight during the pixel walk
         // pixel walk (two pixels per MFMA), pipelined like the forward K walk; NPIX/2/4 = 16 steps per wave (even)
         {
             float a0[MTK], b0[NT], a1[MTK], b1[NT];
