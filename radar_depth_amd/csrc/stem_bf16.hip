@@ -66,34 +66,51 @@ __global__ __launch_bounds__(256) void stem_fwd_bf16_kernel(const StemBfArgs a) 
         goff[s] = (c * SB_PH + kh) * SB_PW + 2 * l31;
     }
 
+    // ---- halo patch (zero outside the image).  The NEXT tile's patch is fetched into registers before the MFMA walk of the current
+    // one (stem.hip's scheme: slot q of a thread is patch element tid + 256 q of every plane, (row, column) computed once per
+    // workgroup, one buffer descriptor per plane with out-of-range -> 0) and rounded to bf16 when it is written to LDS.
+    constexpr int UPB = (SB_PH * SB_PW + 255) / 256;      // 6 patch elements per thread and plane
+    int pyx[UPB];                                         // row << 16 | column, row = 30000 for slots past the plane
+#pragma unroll
+    for (int q = 0; q < UPB; ++q) {
+        const int u = tid + q * 256;
+        const int row = u / SB_PW, col = u - row * SB_PW;
+        pyx[q] = ((u < SB_PH * SB_PW ? row : 30000) << 16) | col;
+    }
+    auto fetch_patch = [&](int tile_, float (&f)[3][UPB]) {
+        const int n_ = tile_ / tiles_img, trem_ = tile_ - n_ * tiles_img;
+        const int ih0_ = 2 * (trem_ / a.tiles_w) * SB_TH - 3, iw0_ = 2 * (trem_ % a.tiles_w) * SB_TW - 3;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            if (c < a.Cin) {
+                const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc(
+                    const_cast<float*>(a.plane[c] + (size_t)n_ * a.stride[c]), 0, (unsigned)(a.H * a.W) * 4u, 0x00020000);
+#pragma unroll
+                for (int q = 0; q < UPB; ++q) {
+                    const int ih = ih0_ + (pyx[q] >> 16), iw = iw0_ + (pyx[q] & 0xffff);
+                    const unsigned off = (ih >= 0 && ih < a.H && iw >= 0 && iw < a.W) ? (unsigned)(ih * a.W + iw) * 4u : 0x80000000u;
+                    f[c][q] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, (int)off, 0, 0));
+                }
+            }
+        }
+    };
+    float fnext[3][UPB];
+    if ((int)blockIdx.x < total_tiles) fetch_patch(blockIdx.x, fnext);
     for (int tile = blockIdx.x; tile < total_tiles; tile += gridDim.x) {
     const int n = tile / tiles_img, trem = tile - n * tiles_img;
     const int r0 = (trem / a.tiles_w) * SB_TH, c0 = (trem % a.tiles_w) * SB_TW;
     rd_sync();                         // the previous tile's MFMAs / partial sums are done with the patch
-    // ---- halo patch (zero outside the image), lanes along the columns: coalesced plane reads, six loads in flight per thread
-    const int ih0 = 2 * r0 - 3, iw0 = 2 * c0 - 3;
-    const int npatch = a.Cin * SB_PH * SB_PW;
-    for (int u0 = tid; u0 < npatch; u0 += 6 * 256) {
-        float f[6];
 #pragma unroll
-        for (int q = 0; q < 6; ++q) {
-            const int u = u0 + q * 256;
-            const int c = u / (SB_PH * SB_PW), rem = u - c * (SB_PH * SB_PW);
-            const int row = rem / SB_PW, col = rem - row * SB_PW;
-            const int ih = ih0 + row, iw = iw0 + col;
-            const bool ok = u < npatch && ih >= 0 && ih < a.H && iw >= 0 && iw < a.W;
-            // (clamped address + select instead of a branch: a branch per element makes the loads wait for one another)
-            const float v = a.plane[ok ? c : 0][(size_t)n * a.stride[ok ? c : 0] + (ok ? (size_t)ih * a.W + iw : 0)];
-            f[q] = ok ? v : 0.f;
-        }
+    for (int c = 0; c < 3; ++c)
+        if (c < a.Cin) {
 #pragma unroll
-        for (int q = 0; q < 6; ++q) {
-            const int u = u0 + q * 256;
-            const __bf16 b = (__bf16)f[q];
-            if (u < npatch) s_patch[u] = __builtin_bit_cast(unsigned short, b);
+            for (int q = 0; q < UPB; ++q) {
+                const __bf16 b = (__bf16)fnext[c][q];
+                if (tid + q * 256 < SB_PH * SB_PW) s_patch[c * SB_PH * SB_PW + tid + q * 256] = __builtin_bit_cast(unsigned short, b);
+            }
         }
-    }
     rd_sync();
+    if (tile + (int)gridDim.x < total_tiles) fetch_patch(tile + gridDim.x, fnext);      // in flight during the walk and the epilogue
 
     // ---- MFMA walk.  Wave w owns tile rows 2w, 2w+1 (M-tile = one tile row, lane l31 = column); lane half hh takes group 2s+hh.
     f32x16 acc[MT][NT];
