@@ -79,99 +79,197 @@ def kernel_identity(L, kind, d, io16=False):
 
 
 def instrumented_pass(ts):
-    """One eager step with every conv launch bracketed by events on the step's stream.
-    Returns {kernel: [total_ms, launches, total_flops]} and the per-step op breakdown by family."""
-    plan = ts.plan
+    """One eager step with every op bracketed by events on the step's stream (all plan streams bound to it).
+    Returns {kernel: [total_ms, launches, total_flops, total_bytes]} and the per-step op breakdown by family.  Walks the step's own
+    marshalled op list (HipTrainStep._ops: both stages of the multistage net, the losses and the SGD update included)."""
     L = ts.L
+    if ts._ops is None:
+        ts._build_table()
+    meta = {}
+    for plan in ts.plans:
+        for name, _, a in plan.prep + plan.fwd + plan.bwd:
+            if name in plan.meta:
+                meta[id(a)] = plan.meta[name]
+    io16 = ts.plan.storage == "bf16"
     agg, fam = {}, {}
     with torch.cuda.stream(ts.side):
-        plan.set_stream(serialize=True)      # all plan streams -> this stream, so per-op event pairs bracket the op
+        for plan in ts.plans:
+            plan.set_stream(serialize=True)      # all plan streams -> this stream, so per-op event pairs bracket the op
         recs = []
         # three un-instrumented passes first, back to back with the measured one: the device is then at its sustained
         # (power-managed) clock like in the timed region, not at the boost clock it reaches after an idle gap
         for _ in range(3):
-            for lst in (plan.prep, plan.fwd, plan.bwd):
-                for name, fn, args in lst:
-                    assert fn(*args) == 0, name
-        for lst in (plan.prep, plan.fwd, plan.bwd):
-            for name, fn, args in lst:
-                e0 = torch.cuda.Event(enable_timing=True)
-                e1 = torch.cuda.Event(enable_timing=True)
-                e0.record()
-                rc = fn(*args)
-                e1.record()
-                assert rc == 0, name
-                recs.append((name, e0, e1))
+            for name, fn, args in ts._ops:
+                assert fn(*args) == 0, name
+        for name, fn, args in ts._ops:
+            e0 = torch.cuda.Event(enable_timing=True)
+            e1 = torch.cuda.Event(enable_timing=True)
+            e0.record()
+            rc = fn(*args)
+            e1.record()
+            assert rc == 0, name
+            recs.append((name, id(args), e0, e1))
         torch.cuda.synchronize()
-        for name, e0, e1 in recs:
+        for name, key, e0, e1 in recs:
             ms = e0.elapsed_time(e1)
             tag = name.rsplit(".", 1)[-1]
             if tag in ("record", "wait"):
                 continue
-            family = {"wgrad": "wgrad", "dgrad": "dgrad", "wreduce": "wgrad_reduce", "pack": "pack", "packT": "pack"}.get(tag)
+            family = {"wgrad": "wgrad", "dgrad": "dgrad", "wreduce": "wgrad_reduce", "wreduce_all": "wgrad_reduce", "pack_all": "pack"}.get(tag)
             if family is None:
-                family = "conv_fwd" if name in plan.meta else ("bn/act/pool/head" if True else "other")
+                family = "conv_fwd" if key in meta else "bn/act/pool/head/loss/sgd"
             fam[family] = fam.get(family, 0.0) + ms
-            if name in plan.meta:
-                kind, d = plan.meta[name]
-                k = kernel_identity(L, kind, d, plan.storage == "bf16")
+            if key in meta:
+                kind, d = meta[key]
+                k = kernel_identity(L, kind, d, io16)
                 a = agg.setdefault(k, [0.0, 0, 0.0, 0.0])
                 a[0] += ms
                 a[1] += 1
                 a[2] += desc_flops(d)
-                a[3] += desc_bytes(kind, d, 2 if plan.storage == "bf16" else 4)
+                a[3] += desc_bytes(kind, d, 2 if io16 else 4)
     return agg, fam
 
 
-def cpu_baseline(height, width):
+def cpu_baseline(arch, batch, height, width):
     """Oracle (CPU restatement of the reference, pinned to it by golden vectors) full SGD steps on this box's host cores, per
-    SURVEY.md 8(d): the C2 shape (b=16) and b=2, 2 warm-up + 5 timed steps each, best and median; the thread count is chosen by
-    a quick sweep at b=2 (oversubscribing the host makes oneDNN slower, not faster)."""
+    SURVEY.md 8(d): the configuration's own shape (and, for the headline, b=2 as well), warm-up + timed steps, best and median;
+    the thread count is chosen by a quick sweep at b=2 (oversubscribing the host makes oneDNN slower, not faster).  The sample
+    is bounded to about 30 s of CPU work: the number of timed steps shrinks with the step time."""
     import statistics
+    import types
 
-    from oracle.criteria import MaskedL1Loss
-    from oracle.models import ResNet_latefusion
+    from oracle import train as otrain
     from radar_depth_amd.synthetic import make_batch
     torch.manual_seed(0)
-    m = ResNet_latefusion(18, "upproj", [height, width], 4, False).train()
+    made = otrain.create_model(types.SimpleNamespace(arch=arch, decoder="upproj", modality="rgbd", pretrained=False), [height, width])
+    m, lw = made if isinstance(made, tuple) else (made, None)
+    m.train()
     opt = torch.optim.SGD(m.parameters(), 0.01, momentum=0.9, weight_decay=1e-4)
-    crit = MaskedL1Loss()
+    crit = otrain.make_criterion(arch)
 
     def steps(x, t, n):
         out = []
         for _ in range(n):
             t0 = time.perf_counter()
-            loss = crit(m(x), t)
-            opt.zero_grad()
-            loss.backward()
-            opt.step()
+            otrain.train_step(arch, m, crit, opt, x, t, lw)
             out.append(time.perf_counter() - t0)
         return out
     ncpu = os.cpu_count() or 1
-    x2, t2 = make_batch(2, height, width, 1234)
+    big = height * width > 450 * 800
+    x2, t2 = make_batch(1 if big else 2, height, width, 1234)
     steps(x2, t2, 1)                                        # oneDNN primitive creation
     sweep = {}
     for nt in sorted({max(1, ncpu // 32), max(1, ncpu // 16), max(1, ncpu // 8), max(1, ncpu // 4)}):
         torch.set_num_threads(nt)
-        sweep[nt] = min(steps(x2, t2, 2))
+        sweep[nt] = min(steps(x2, t2, 1 if big else 2))
     nt = min(sweep, key=sweep.get)
     torch.set_num_threads(nt)
-    res = {}
-    for b in (2, 16):
-        x, t = (x2, t2) if b == 2 else make_batch(b, height, width, 1234)
-        tt = steps(x, t, 7)[2:]
+    res, plan_txt = {}, []
+    for b in sorted({x2.shape[0], batch}):
+        x, t = (x2, t2) if b == x2.shape[0] else make_batch(b, height, width, 1234)
+        first = steps(x, t, 1)[0]
+        n_warm = 1 if first > 6 else 2
+        n_timed = max(1, min(5, int(20.0 / max(first, 1e-3)) - n_warm))
+        tt = steps(x, t, n_warm - 1 + n_timed)[n_warm - 1:]
         res[b] = (b / min(tt), b / statistics.median(tt), min(tt))
+        plan_txt.append("b=%d: %d warm-up + %d timed steps" % (b, n_warm, n_timed))
     try:
         cpu = [ln.split(":", 1)[1].strip() for ln in open("/proc/cpuinfo") if ln.startswith("model name")][0]
     except (OSError, IndexError):
         cpu = "unknown"
-    return {"value": round(res[16][0], 3), "median": round(res[16][1], 3), "unit": "samples/s", "cores": nt, "kind": "port",
-            "b2_value": round(res[2][0], 3), "b2_median": round(res[2][1], 3),
-            "thread_sweep_b2_step_s": {str(k): round(v, 3) for k, v in sweep.items()}, "cpu": cpu, "host_cpus": ncpu,
-            "sample": "oracle (PyTorch CPU restatement pinned to the reference by golden vectors), resnet18_latefusion full SGD "
-                      "step, %dx%d fp32: b=16 (the C2 shape) and b=2, 2 warm-up + 5 timed steps each, best (value) and median; "
-                      "best b=16 step %.2f s; %d threads (fastest of the sweep) on %d host cpus (%s)"
-                      % (height, width, res[16][2], nt, ncpu, cpu)}
+    bs = x2.shape[0]
+    return {"value": round(res[batch][0], 3), "median": round(res[batch][1], 3), "unit": "samples/s", "cores": nt, "kind": "port",
+            "b%d_value" % bs: round(res[bs][0], 3), "b%d_median" % bs: round(res[bs][1], 3),
+            "thread_sweep_b%d_step_s" % bs: {str(k): round(v, 3) for k, v in sweep.items()}, "cpu": cpu, "host_cpus": ncpu,
+            "sample": "oracle (PyTorch CPU restatement pinned to the reference by golden vectors), %s full SGD step, %dx%d fp32 "
+                      "(the reference has no reduced-precision path: the fp32 CPU step is the baseline of every configuration): %s, "
+                      "best (value) and median; best b=%d step %.2f s; %d threads (fastest of the sweep) on %d host cpus (%s)"
+                      % (arch, height, width, "; ".join(plan_txt), batch, res[batch][2], nt, ncpu, cpu)}
+
+
+# BASELINE.json configs (index as in the file): (arch, per-GPU batch, height, width, storage)
+CONFIGS = {
+    2: ("resnet18_latefusion", 16, 450, 800, "fp32"),
+    3: ("resnet18_latefusion", 16, 450, 800, "bf16"),
+    4: ("resnet18_multistage_uncertainty_fixs", 8, 450, 800, "fp32"),
+    5: ("resnet18_multistage_uncertainty_fixs", 8, 900, 1600, "bf16"),
+}
+# SURVEY.md 8(d) / BASELINE.md section 4: sum-over-layers roofline bound in samples/s per GPU and algorithmic work per sample;
+# bf16 bounds at 6.29 TB/s measured copy rate / 8 TB/s spec.  Other sizes scale with the pixel count.
+BOUNDS = {
+    ("resnet18_latefusion", 450, 800): {"fp32": 1494.0, "bf16": (15181.0, 17527.0), "gflop": 104.57, "gb": (0.658, 0.329)},
+    ("resnet18_latefusion", 900, 1600): {"fp32": 381.0, "bf16": (3861.0, 4461.0), "gflop": 410.42, "gb": (2.593, 1.296)},
+    ("resnet18_multistage_uncertainty_fixs", 450, 800): {"fp32": 746.0, "bf16": (7545.0, 8715.0), "gflop": 209.57, "gb": (1.326, 0.663)},
+    ("resnet18_multistage_uncertainty_fixs", 900, 1600): {"fp32": 190.0, "bf16": (1919.0, 2218.0), "gflop": 822.53, "gb": (5.226, 2.613)},
+}
+
+
+def bound_for(arch, height, width):
+    b = BOUNDS.get((arch, height, width))
+    if b is not None:
+        return b
+    r = 360000.0 / (height * width)
+    b0 = BOUNDS[(arch, 450, 800)]
+    return {"fp32": b0["fp32"] * r, "bf16": (b0["bf16"][0] * r, b0["bf16"][1] * r), "gflop": b0["gflop"] / r,
+            "gb": (b0["gb"][0] / r, b0["gb"][1] / r)}
+
+
+def free_port():
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
+def self_launch(n):
+    """`python bench.py --gpus N` without a launcher: become `torch.distributed.run --nproc-per-node N bench.py ...` (one rank
+    per GPU, rendezvous on 127.0.0.1).  Rank 0 of the relaunched job prints the one JSON line."""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    sys.stdout.flush()
+    os.execvp(cmd[0], cmd)
+
+
+def dry_run(args, world, rank):
+    """No GPU: the multi-rank plumbing of this script (rendezvous, per-rank seeds, bucketed gradient exchange of the plan's own
+    bucket map, barrier + max-over-ranks timing, the single JSON line) over gloo on CPU.  Nothing is launched or measured."""
+    import types
+
+    import torch.distributed as dist
+
+    from radar_depth_amd.engine import LateFusionPlan
+    from radar_depth_amd.main import _param_offsets, bucket_segments, create_model, reduce_gradient_buckets
+    if world > 1:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.manual_seed(0)
+    made = create_model(types.SimpleNamespace(arch="resnet18_latefusion", decoder="upproj", modality="rgbd", pretrained=False), [64, 96])
+    model = made[0] if isinstance(made, tuple) else made
+    plan = LateFusionPlan(model, 1, 64, 96, train=True, dry_run=True, segment_joins=False)
+    offs = _param_offsets(model)
+    buckets = [sl for _, _, sl in bucket_segments(plan, offs)]
+    total = max(v[1] for v in offs.values())
+    grads = torch.full(((total + 3) // 4 * 4,), float(rank + 1))
+    t0 = time.perf_counter()
+    if world > 1:
+        for _ in reduce_gradient_buckets(grads, buckets):
+            pass
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    want = world * (world + 1) / 2.0
+    covered = sum(hi - lo for bk in buckets for lo, hi in bk)
+    ok = bool((grads == want).all().item()) and covered == grads.numel()
+    per_rank = [dt]
+    if world > 1:
+        box = [None] * world
+        dist.all_gather_object(box, dt)
+        per_rank = box
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps({"metric": METRIC, "value": None, "unit": "samples/s", "n_gpus": world, "steps": 0, "warmup": 0, "dry_run": True,
+                          "comm": "gloo" if world > 1 else "none", "gradient_buckets": len(buckets), "exchange_ok": ok,
+                          "exchange_s_per_rank": [round(v, 4) for v in per_rank], "plan_ops": len(plan.prep + plan.fwd + plan.bwd)}), flush=True)
+    if not ok:
+        raise SystemExit("dry run: the bucketed exchange did not produce the all-rank sum over the whole arena")
 
 
 def main():
@@ -179,10 +277,14 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--batch", type=int, default=16, help="per-GPU batch (weak scaling)")
-    ap.add_argument("--height", type=int, default=450)
-    ap.add_argument("--width", type=int, default=800)
-    ap.add_argument("--arch", default="resnet18_latefusion",
+    ap.add_argument("--config", type=int, default=None, choices=sorted(CONFIGS),
+                    help="BASELINE.json configs index: 2 = latefusion b=16 450x800 fp32 (the metric's configuration, the default), "
+                         "3 = the same with bf16 storage, 4 = multistage_uncertainty_fixs b=8 450x800 fp32, 5 = multistage b=8/GPU "
+                         "900x1600 bf16 storage; sets --arch/--batch/--height/--width/--storage")
+    ap.add_argument("--batch", type=int, default=None, help="per-GPU batch (weak scaling); default 16, or the --config's")
+    ap.add_argument("--height", type=int, default=None)
+    ap.add_argument("--width", type=int, default=None)
+    ap.add_argument("--arch", default=None,
                     choices=["resnet18_latefusion", "resnet18_multistage_uncertainty_fixs"],
                     help="headline = resnet18_latefusion (BASELINE configs[1]); the multistage arch is configs[3] (use --batch 8)")
     ap.add_argument("--graph", action="store_true", help="replay the step as hipGraphs (slower than plain stream launches here)")
@@ -191,27 +293,44 @@ def main():
                     help="conv operand precision.  fp32 (default) is the BASELINE.json configs[1] measurement; bf16 (configs 2/4) runs the "
                          "forward / input-gradient / weight-gradient convolutions on bf16 MFMA with fp32 tensors + accumulation and is reported with "
                          "dtype \"bf16\" and its own metric name -- never as the fp32 headline")
-    ap.add_argument("--storage", default="fp32", choices=["fp32", "bf16"],
+    ap.add_argument("--storage", default=None, choices=["fp32", "bf16"],
                     help="element type of the NHWC activation / gradient tensors in HBM.  bf16 (BASELINE.json configs 3 / 5) implies "
                          "--operands bf16; statistics, parameters, their gradients and the optimizer stay fp32")
     ap.add_argument("--autotune", action="store_true",
                     help="time the candidate plans of every fp32 convolution descriptor once while the plan is built, before "
                          "the warm-up steps, and pin the fastest (radar_depth_amd/autotune.py; cudnn.benchmark's role).  Off by "
                          "default: at the headline geometry the gain is inside the run-to-run spread (+0..1.3 percent), and heuristic plans "
-                         "keep the bench line, the kernel trace and the counter passes on identical launches")
+                         "keep the bench line, the kernel trace and the counter passes on identical launches -- and identical on "
+                         "every data-parallel rank (timing-dependent plans would give ranks different summation orders)")
     ap.add_argument("--no-autotune", action="store_true", help="(default; kept for older command lines)")
     ap.add_argument("--comm", default="rccl", choices=["rccl", "torch"],
                     help="gradient exchange for --gpus > 1: rccl = the C ABI's own communicator (rd_allreduce_bucket on a communication "
                          "stream, event-chained per backward segment); torch = torch.distributed.all_reduce (cross-check)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--dry-run", action="store_true",
+                    help="no GPU: exercise the multi-rank plumbing (self-launch, rendezvous, bucketed exchange, JSON line) over gloo")
     args = ap.parse_args()
+    cfg = CONFIGS[args.config if args.config is not None else 2]
+    args.arch = args.arch or cfg[0]
+    args.batch = args.batch or (cfg[1] if args.config is not None or args.arch == cfg[0] else 8)
+    args.height = args.height or cfg[2]
+    args.width = args.width or cfg[3]
+    args.storage = args.storage or (cfg[4] if args.config is not None else "fp32")
     if args.storage == "bf16":
         args.operands = "bf16"
 
+    # `python bench.py --gpus N` with no launcher around it: start the N ranks ourselves
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        self_launch(args.gpus)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit("bench.py --gpus %d was started inside a %d-rank job (WORLD_SIZE): launch with torch.distributed.run "
+                         "--nproc-per-node %d, or run it bare and it launches its ranks itself" % (args.gpus, world, args.gpus))
+    if args.dry_run:
+        return dry_run(args, world, rank)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback for the HIP path)")
     torch.cuda.set_device(local_rank)
@@ -221,7 +340,6 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
         torch.distributed.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
-    assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node %d (WORLD_SIZE=%d)" % (args.gpus, world)
     comm_used = "none"
     if torch.distributed.is_initialized():
         comm_used = "torch"
@@ -264,105 +382,107 @@ def main():
     # per-step events on the caller's stream (step() fences it behind the step's own streams): median / min without any
     # synchronisation inside the timed region
     marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
+    host_issue = 0.0
     t0 = time.perf_counter()
     marks[0].record()
     for k in range(args.steps):
+        h0 = time.perf_counter()
         loss, _ = ts.step(x, t)
+        host_issue += time.perf_counter() - h0
         marks[k + 1].record()
     sync()
     dt = time.perf_counter() - t0
     per_step = sorted(marks[k].elapsed_time(marks[k + 1]) for k in range(args.steps))
+    per_rank_ms = [1e3 * dt / args.steps]
     if world > 1:
-        tt = torch.tensor([dt], device="cuda", dtype=torch.float64)
-        torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
-        dt = tt.item()
+        box = [torch.zeros(1, device="cuda", dtype=torch.float64) for _ in range(world)]
+        torch.distributed.all_gather(box, torch.tensor([dt], device="cuda", dtype=torch.float64))
+        per_rank_ms = [1e3 * b.item() / args.steps for b in box]
+        dt = max(b.item() for b in box)
     final_loss = float(loss.item())
 
+    multistage = args.arch != "resnet18_latefusion"
+    bf16 = args.operands == "bf16"
+    bnd = bound_for(args.arch, args.height, args.width)
+    env_knobs = {k: v for k, v in sorted(os.environ.items()) if k.startswith("RD_")}
     out = {
         "metric": METRIC, "value": round(world * args.batch * args.steps / dt, 2), "unit": "samples/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 3),
         "ms_per_step_median": round(per_step[len(per_step) // 2], 3), "ms_per_step_min": round(per_step[0], 3),
+        "ms_per_step_rank_min": round(min(per_rank_ms), 3), "ms_per_step_rank_max": round(max(per_rank_ms), 3),
+        "host_issue_ms_per_step": round(1e3 * host_issue / args.steps, 3),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": "%s --decoder upproj --modality rgbd, b=%d/GPU %dx%d fp32, full step "
                                "(fwd + loss + bwd + SGD momentum .9 wd 1e-4), random init" % (args.arch, args.batch, args.height, args.width),
+                   "baseline_config": args.config if args.config is not None else (2 if (args.arch, args.batch, args.height, args.width, args.storage, args.operands) == CONFIGS[2] + ("fp32",) else None),
                    "global_batch": world * args.batch, "parallelism": "dp%d" % world if world > 1 else ("dp1 (forced data-parallel code path)" if os.environ.get("RD_FORCE_DP") == "1" else "single"),
-                   "hipgraph": args.graph, "comm": comm_used, "autotuned_plans": bool(args.autotune), "final_loss": round(final_loss, 5)},
+                   "hipgraph": args.graph, "comm": comm_used, "autotuned_plans": bool(args.autotune), "final_loss": round(final_loss, 5),
+                   "step_issue": "one rd_optable_run call per step (%d ops)" % len(ts._ops),
+                   "rd_env": env_knobs},
     }
-    multistage = args.arch != "resnet18_latefusion"
-    bf16 = args.operands == "bf16"
+    if multistage or args.batch != 16 or (args.height, args.width) != (450, 800):
+        out["metric"] = "training samples/sec, %s b=%d %dx%d rgbd" % (args.arch, args.batch, args.height, args.width)
     if bf16:
         out["dtype"] = "bf16"
-        out["metric"] = METRIC + " [bf16 conv operands on v_mfma_f32_32x32x16_bf16: forward, input gradients, weight gradients of the >=32-channel layers; stems/head/16-channel weight gradients fp32; fp32 tensors/accumulation]"
+        out["metric"] += " [bf16 conv operands on v_mfma_f32_32x32x16_bf16: forward, input gradients, weight gradients of the >=32-channel layers; stems/head/16-channel weight gradients fp32; fp32 tensors/accumulation]"
         out["config"]["workload"] = out["config"]["workload"].replace(" fp32,", " bf16-operand convs,")
         if args.storage == "bf16":
-            out["metric"] = METRIC + " [bf16 storage: NHWC activations and gradients bf16 in HBM, bf16 MFMA convolutions incl. every weight gradient, fp32 accumulation / BatchNorm statistics / loss / parameters / SGD]"
+            out["metric"] = out["metric"].split(" [")[0] + " [bf16 storage: NHWC activations and gradients bf16 in HBM, bf16 MFMA convolutions incl. every weight gradient, fp32 accumulation / BatchNorm statistics / loss / parameters / SGD]"
             out["config"]["workload"] = out["config"]["workload"].replace(" bf16-operand convs,", " bf16 storage + bf16 convs,")
-            # HBM-bound configuration: fraction of SURVEY 8(d)'s bf16 bound (0.329 GB/sample at 6.29 TB/s measured copy rate and 8 TB/s spec)
-            out["roofline_note"] = "bf16 bound (SURVEY 8d): 15181 samples/s @6.29 TB/s, 17527 @8 TB/s per GPU at 450x800; this run: %.1f%% / %.1f%%" % (
-                100 * out["value"] / world / (15181 * 360000.0 / (args.height * args.width)), 100 * out["value"] / world / (17527 * 360000.0 / (args.height * args.width)))
-    if rank == 0 and not args.no_roofline and not multistage and not bf16:
-        agg, fam = instrumented_pass(ts)
-        name, (ms, n, flops, _) = max(agg.items(), key=lambda kv: kv[1][0])
-        achieved = flops / (ms * 1e-3) / 1e12
-        # algorithmic work of one training sample (UpProj zero-skipped, stem dgrads omitted): 104.57 GFLOP at 450x800
-        alg_gflop = 104.57 * (args.height * args.width) / (450.0 * 800.0)
-        step_flops = alg_gflop * 1e9 * args.batch
-        # HBM bytes per launch of that kernel from the committed rocprofv3 --pmc passes (FETCH_SIZE x2 + WRITE_SIZE,
-        # profiles/r01_pmc_traffic.json; collected with tools described in DESIGN.md, not re-measured on every run)
-        traffic = None
-        try:
-            pmc = "r02_pmc_traffic.json" if os.path.exists(os.path.join(REPO, "profiles", "r02_pmc_traffic.json")) else "r01_pmc_traffic.json"
-            tj = json.load(open(os.path.join(REPO, "profiles", pmc)))["kernels"]
-            key = name.replace(" ", "")
-            if key in tj:
-                traffic = tj[key]["hbm_read_bytes_per_launch"] + tj[key]["hbm_write_bytes_per_launch"]
-        except (OSError, KeyError, ValueError):
-            pass
-        out["roofline"] = {"bound": "mfma", "kernel": name, "launches_per_step": n, "avg_launch_us": round(1e3 * ms / n, 2),
-                           "achieved": round(achieved, 2), "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
-                           "frac": round(achieved / PEAK_FP32_TFLOPS, 4), "traffic": traffic,
-                           "algorithmic_gflop_per_sample": round(alg_gflop, 2),
-                           "step_conv_tflops": round(step_flops * args.steps / dt / 1e12, 2),
-                           "step_frac_of_peak": round(step_flops * args.steps / dt / 1e12 / PEAK_FP32_TFLOPS, 4),
-                           "eager_ms_by_family": {k: round(v, 3) for k, v in sorted(fam.items(), key=lambda kv: -kv[1])},
-                           "eager_ms_by_kernel": {k: [round(v[0], 3), v[1], round(v[2] / (v[0] * 1e-3) / 1e12, 1)]
-                                                  for k, v in sorted(agg.items(), key=lambda kv: -kv[1][0])}}
-    if rank == 0 and not args.no_roofline and not multistage and bf16:
-        # bf16 configurations are HBM-bound (arithmetic intensity ~ the ridge): the roofline of the dominant kernel is
-        # algorithmic bytes per launch (operand tensors once in, result once out) / its average duration against 8 TB/s
+    per_gpu = out["value"] / world
+    if rank == 0 and not args.no_roofline:
         agg, fam = instrumented_pass(ts)
         name, (ms, n, flops, nbytes) = max(agg.items(), key=lambda kv: kv[1][0])
-        achieved = nbytes / (ms * 1e-3) / 1e9
-        traffic = None
-        try:
-            tj = json.load(open(os.path.join(REPO, "profiles", "r02_pmc_traffic_bf16_storage.json" if args.storage == "bf16"
-                                             else "r02_pmc_traffic_bf16_operands.json")))["kernels"]
-            if name in tj:
-                traffic = tj[name]["hbm_read_bytes_per_launch"] + tj[name]["hbm_write_bytes_per_launch"]
-        except (OSError, KeyError, ValueError):
-            pass
-        out["roofline"] = {"bound": "hbm", "kernel": name, "launches_per_step": n, "avg_launch_us": round(1e3 * ms / n, 2),
-                           "achieved": round(achieved, 1), "peak": 8000.0, "unit": "GB/s", "frac": round(achieved / 8000.0, 4),
-                           "traffic": traffic, "algorithmic_bytes_per_launch": int(nbytes / n),
-                           "kernel_tflops": round(flops / (ms * 1e-3) / 1e12, 1),
-                           "eager_ms_by_family": {k: round(v, 3) for k, v in sorted(fam.items(), key=lambda kv: -kv[1])},
-                           "eager_ms_by_kernel": {k: [round(v[0], 3), v[1], round(v[3] / (v[0] * 1e-3) / 1e9, 0)]
-                                                  for k, v in sorted(agg.items(), key=lambda kv: -kv[1][0])}}
+        tfile = {("fp32", "fp32"): "r03_pmc_traffic.json", ("bf16", "bf16"): "r03_pmc_traffic_bf16_storage.json"}.get((args.operands, args.storage))
+        traffic, traffic_source = None, None
+        if tfile and not multistage and (args.batch, args.height, args.width) == (16, 450, 800) and os.path.exists(os.path.join(REPO, "profiles", tfile)):
+            # HBM bytes per launch of that kernel from the committed rocprofv3 --pmc passes of THIS command line (FETCH_SIZE x2 +
+            # WRITE_SIZE, tools/pmc_traffic.py); counters cannot be read from inside the run, so the figure is labelled with its source
+            try:
+                tj = json.load(open(os.path.join(REPO, "profiles", tfile)))
+                key = name.replace(" ", "")
+                if key in tj["kernels"]:
+                    traffic = tj["kernels"][key]["hbm_read_bytes_per_launch"] + tj["kernels"][key]["hbm_write_bytes_per_launch"]
+                    traffic_source = "profiles/%s@%s" % (tfile, tj.get("collected_at", "unknown"))
+            except (OSError, KeyError, ValueError):
+                pass
+        common = {"kernel": name, "launches_per_step": n, "avg_launch_us": round(1e3 * ms / n, 2), "traffic": traffic,
+                  "traffic_source": traffic_source}
+        if not bf16:
+            achieved = flops / (ms * 1e-3) / 1e12
+            step_flops = bnd["gflop"] * 1e9 * args.batch
+            out["roofline"] = dict(common, bound="mfma", achieved=round(achieved, 2), peak=PEAK_FP32_TFLOPS, unit="TFLOP/s",
+                                   frac=round(achieved / PEAK_FP32_TFLOPS, 4),
+                                   algorithmic_gflop_per_sample=round(bnd["gflop"], 2),
+                                   step_conv_tflops=round(step_flops * args.steps / dt / 1e12, 2),
+                                   step_frac_of_peak=round(step_flops * args.steps / dt / 1e12 / PEAK_FP32_TFLOPS, 4),
+                                   bound_samples_per_s_per_gpu=round(bnd["fp32"], 1), step_frac_of_bound=round(per_gpu / bnd["fp32"], 4))
+            by_kernel = {k: [round(v[0], 3), v[1], round(v[2] / (v[0] * 1e-3) / 1e12, 1)] for k, v in sorted(agg.items(), key=lambda kv: -kv[1][0])}
+        else:
+            # bf16 configurations are HBM-bound (arithmetic intensity ~ the ridge): the roofline of the dominant kernel is
+            # algorithmic bytes per launch (operand tensors once in, result once out) / its average duration against 8 TB/s
+            achieved = nbytes / (ms * 1e-3) / 1e9
+            out["roofline"] = dict(common, bound="hbm", achieved=round(achieved, 1), peak=8000.0, unit="GB/s", frac=round(achieved / 8000.0, 4),
+                                   algorithmic_bytes_per_launch=int(nbytes / n), kernel_tflops=round(flops / (ms * 1e-3) / 1e12, 1),
+                                   algorithmic_gb_per_sample=bnd["gb"][1 if args.storage == "bf16" else 0],
+                                   bound_samples_per_s_per_gpu=[round(bnd["bf16"][0], 1), round(bnd["bf16"][1], 1)],
+                                   bound_note="SURVEY 8(d) bf16 bound at 6.29 TB/s measured copy rate / 8 TB/s spec",
+                                   step_frac_of_bound=round(per_gpu / bnd["bf16"][0], 4), step_frac_of_bound_8tbs=round(per_gpu / bnd["bf16"][1], 4))
+            by_kernel = {k: [round(v[0], 3), v[1], round(v[3] / (v[0] * 1e-3) / 1e9, 0)] for k, v in sorted(agg.items(), key=lambda kv: -kv[1][0])}
+        out["roofline"]["eager_ms_by_family"] = {k: round(v, 3) for k, v in sorted(fam.items(), key=lambda kv: -kv[1])}
+        out["roofline"]["eager_ms_by_kernel"] = by_kernel
     if world > 1:
         torch.distributed.barrier()
     # communicator teardown BEFORE the result line, and C stdio flushed around it: RCCL writes its version banner through C
     # stdio, which would otherwise land after the JSON line when the buffers drain at exit
     if comm_used == "rccl":
         from radar_depth_amd import comm as rd_comm
+        ts.synchronize_comm()
         rd_comm.destroy()
     C.CDLL(None).fflush(None)
     if rank == 0:
-        if multistage:
-            out["metric"] = "training samples/sec, %s b=%d %dx%d rgbd" % (args.arch, args.batch, args.height, args.width)
-            out["roofline_note"] = "algorithmic work 209.57 GFLOP/sample at 450x800 (SURVEY 8d): %.1f%% of the fp32 peak" % (
-                100 * 209.57e9 * (args.height * args.width / 360000.0) * out["value"] / 157.3e12)
-        if world == 1 and not args.no_cpu_baseline and not multistage and not bf16:
-            out["cpu_baseline"] = cpu_baseline(args.height, args.width)
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args.arch, args.batch, args.height, args.width)
         print(json.dumps(out), flush=True)
     if torch.distributed.is_available() and torch.distributed.is_initialized():
         torch.distributed.destroy_process_group()

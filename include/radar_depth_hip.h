@@ -436,6 +436,28 @@ int rd_graph_end(void* stream, void** graph_exec);
 int rd_graph_launch(void* graph_exec, void* stream);
 int rd_graph_destroy(void* graph_exec);
 
+/* ---------------------------------------------------------------------------------------
+ * Op-table replay: the step body of main.py:416-445 (forward, loss, zero_grad, backward, [gradient exchange], SGD) is a STATIC
+ * list of the entry points above over fixed buffers.  A table holds that list pre-marshalled -- per op the entry point's name
+ * and its arguments as 64-bit words (pointers / integers by value, a float as its IEEE bit pattern in the low 32 bits) -- and
+ * rd_optable_run issues ops [begin, end) with ONE call from the host language: no per-launch FFI marshalling, nothing for
+ * eight per-GPU ranks to contend for on the host.  Arguments that are streams are marked with a slot index
+ * (stream_slots[i] >= 0, else -1) and take streams[slot] of each run, so a table survives stream rebinding and can be
+ * replayed under rd_graph_begin / rd_graph_end.  Descriptor / table arguments are pointers into caller-owned memory that must
+ * outlive the table.  There is no second implementation of any op: a run calls exactly the functions named.
+ *   rd_optable_add      -> index of the new op (>= 0) or a negative error (unknown entry point, wrong argument count)
+ *   rd_optable_entry_args(name) -> that entry point's argument count, RD_EINVAL if it is not replayable
+ *   rd_optable_run      -> 0, or the failing op's return code with *failed_op set (ops behind it are not issued)
+ * A table is not thread-safe: one table, one issuing thread.
+ * ------------------------------------------------------------------------------------- */
+int rd_optable_create(void** table);
+int rd_optable_destroy(void* table);
+int rd_optable_entry_args(const char* entry);
+int rd_optable_add(void* table, const char* entry, int32_t nargs, const uint64_t* words, const int32_t* stream_slots);
+int rd_optable_size(const void* table);
+int rd_optable_set_word(void* table, int32_t op, int32_t arg, uint64_t word);
+int rd_optable_run(void* table, int32_t begin, int32_t end, void* const* streams, int32_t n_streams, int32_t* failed_op);
+
 #ifdef __cplusplus
 }
 #endif

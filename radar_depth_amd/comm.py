@@ -52,24 +52,43 @@ def init_from_torch_distributed():
     _join(box[0], r, w)
 
 
-def init_from_file(path, rank_, world_, timeout_s=120.0):
-    """Rendezvous through a file on a shared filesystem: rank 0 writes the token atomically, the others poll for it."""
+def init_from_file(path, rank_, world_, timeout_s=120.0, job_id=None):
+    """Rendezvous through a file on a shared filesystem: rank 0 writes the token atomically, the others poll for it.
+    job_id (any string every rank of THIS run agrees on -- e.g. the launcher's job / run id) is written next to the token and
+    compared on read, so a stale file of an earlier run at the same path is never accepted -- pass one whenever a path can be
+    reused.  Without it the only protection is that rank 0 removes an existing file before writing and removes its own once every
+    rank has joined (ncclCommInitRank returns when all ranks did), so a CLEANLY finished run leaves nothing behind; use a fresh
+    path per run then."""
     if initialised():
         return
+    tag = ("" if job_id is None else str(job_id)).encode()
     if rank_ == 0:
+        if os.path.exists(path):
+            os.unlink(path)
         token = _new_token()
         with open(path + ".tmp", "wb") as f:
-            f.write(token)
+            f.write(token + tag)
         os.replace(path + ".tmp", path)
     else:
         t0 = time.time()
-        while not (os.path.exists(path) and os.path.getsize(path) == TOKEN_BYTES):
+        while True:
+            try:
+                with open(path, "rb") as f:
+                    blob = f.read()
+                if len(blob) >= TOKEN_BYTES and blob[TOKEN_BYTES:] == tag:
+                    token = blob[:TOKEN_BYTES]
+                    break
+            except OSError:
+                pass
             if time.time() - t0 > timeout_s:
-                raise TimeoutError("no RCCL token at %s after %.0f s" % (path, timeout_s))
+                raise TimeoutError("no RCCL token for this run at %s after %.0f s" % (path, timeout_s))
             time.sleep(0.01)
-        with open(path, "rb") as f:
-            token = f.read()
     _join(token, rank_, world_)
+    if rank_ == 0:
+        try:
+            os.unlink(path)
+        except OSError:
+            pass
 
 
 def allreduce_(tensor, stream, lo=0, hi=None):

@@ -126,10 +126,15 @@ class LateFusionPlan:
         self.dense_grad_dst = dense_grad_dst
         self.Ho, self.Wo = getattr(module, "output_size", (height, width))
         self.generation = 0    # bumped by every forward: autograd nodes of an earlier forward must not read this plan's buffers
+        self._optable = None   # prep + fwd + bwd marshalled once for rd_optable_run (see run_list)
         self._build()
 
     def close(self):
-        """Destroy the plan's hipEvents (its buffers are torch tensors and go with the object)."""
+        """Destroy the plan's hipEvents (its buffers are torch tensors and go with the object).  Called when the LAST holder lets go
+        (__del__): the plan cache only drops its reference, because a HipTrainStep / HipInference / autograd node may still hold the plan."""
+        tb, self._optable = getattr(self, "_optable", None), None
+        if tb is not None:
+            tb.close()
         evs, self.events = getattr(self, "events", []), []
         if not getattr(self, "dry_run", True):
             for ev in evs:
@@ -777,6 +782,32 @@ class LateFusionPlan:
         end_segment(("conv1", "bn1", "layer1", "layer2", "conv1_depth", "bn1_depth", "layer1_depth", "layer2_depth"), last=True)
 
     # ------------------------------------------------------------------ execution
+    def _diagnostic_loop(self):
+        """RD_POISON_LDS / RD_TRACE_OPS need a host hook between ops: they keep the Python loop (RD_PY_LOOP=1 forces it, to
+        measure what the op table saves: tools/host_time.py)."""
+        return ((os.environ.get("RD_POISON_LDS") == "1" and not self.multi_stream) or os.environ.get("RD_TRACE_OPS") == "1"
+                or os.environ.get("RD_PY_LOOP") == "1")
+
+    def run_list(self, key, begin=0, end=None):
+        """Issue ops [begin, end) of self.prep / self.fwd / self.bwd (key = "prep" | "fwd" | "bwd") with ONE C-ABI call: the three
+        lists are marshalled once into an op table (optable.py, rd_optable_run)."""
+        lst = getattr(self, key)
+        end = len(lst) if end is None else end
+        if self.dry_run:
+            raise RuntimeError("dry-run plans cannot execute: the HIP path has no CPU fallback")
+        if self._diagnostic_loop():
+            return self._run(lst[begin:end])
+        if self._optable is None:
+            from .optable import OpTable
+            self._table_base, ops = {}, []
+            for k in ("prep", "fwd", "bwd"):
+                self._table_base[k] = (len(ops), len(getattr(self, k)))
+                ops += getattr(self, k)
+            self._optable = OpTable(self.L, ops, self.streams)
+        base, n = self._table_base[key]
+        assert n == len(lst), "the plan's op lists changed after its op table was built"
+        self._optable.run(base + begin, base + end)
+
     def _run(self, ops):
         if self.dry_run:
             raise RuntimeError("dry-run plans cannot execute: the HIP path has no CPU fallback")
@@ -816,15 +847,15 @@ class LateFusionPlan:
             if tuple(x.shape[:1]) + tuple(x.shape[2:]) != (self.N, self.H, self.W):
                 raise ValueError("plan built for [%d,*,%d,%d], got %s" % (self.N, self.H, self.W, tuple(x.shape)))
             self.x_in.copy_(x[:, :self.x_in.shape[1]])
-        self._run(self.prep)
-        self._run(self.fwd)
+        self.run_list("prep")
+        self.run_list("fwd")
         return self.pred
 
     def run_backward(self, dpred=None):
         self.set_stream()
         if dpred is not None:
             self.dpred.copy_(dpred)
-        self._run(self.bwd)
+        self.run_list("bwd")
 
 
 class ModulePlan(LateFusionPlan):
@@ -853,9 +884,9 @@ class ModulePlan(LateFusionPlan):
         """x [N,C,H,W], dy [N,C',H',W'] CUDA fp32 -> (y, dx) as NCHW tensors; parameter gradients land in the owner's arena."""
         self.set_stream()
         self.x.t.copy_(x_nchw.permute(0, 2, 3, 1))
-        self._run(self.prep)
-        self._run(self.fwd)
+        self.run_list("prep")
+        self.run_list("fwd")
         self.dy.t.copy_(dy_nchw.permute(0, 2, 3, 1))
-        self._run(self.bwd)
+        self.run_list("bwd")
         torch.cuda.synchronize()
         return self.y.view().permute(0, 3, 1, 2).contiguous(), self.dx.view().permute(0, 3, 1, 2).contiguous()

@@ -188,7 +188,9 @@ class HipTrainStep:
             self.loss = self.loss4[3:4]
         self.use_graph = use_graph
         self.graphs = None
-        self.steps = 0
+        self.steps = 0                 # optimizer steps (state_dict: a momentum state exists once > 0)
+        self._warm = 0                 # plain launches issued by THIS object: hipGraph capture only after one warm, un-captured step
+        self._table, self._ops, self._ranges, self._bucket_events, self._cs = None, None, None, None, None
         # hipGraph capture is illegal on the legacy default stream: the step owns a stream and fences it against the caller's
         self.side = torch.cuda.Stream(device=dev)   # default priority: raising any stream's priority measured 17-29 % slower
         offs = _param_offsets(model)
@@ -210,17 +212,24 @@ class HipTrainStep:
         """Data-parallel replicas must start from one state (DDP broadcasts at construction): parameters, momentum and the
         BatchNorm buffers of rank 0 replace every other rank's, so a checkpoint loaded on rank 0 only -- or different seeds --
         cannot silently train divergent replicas whose gradients are still averaged."""
+        # three collectives in all (parameter arena, momentum arena, every BatchNorm buffer packed into one flat word array): the
+        # ~160 per-buffer broadcasts this used to issue were 160 chances for a rank-order mismatch
+        bufs = [b for b in self.model.buffers()]
+        flat = torch.cat([b.detach().contiguous().view(-1).view(torch.float32) for b in bufs]) if bufs else None
         if self.comm == "rccl":
             from . import comm as _comm
             cur = C.c_void_p(torch.cuda.current_stream().cuda_stream)
-            for tns in [self.st["arena"], self.st["mom"]] + list(self.model.buffers()):
+            for tns in [self.st["arena"], self.st["mom"]] + ([flat] if flat is not None else []):
                 _comm.broadcast_(tns, cur, 0)
-            return
-        dist = torch.distributed
-        dist.broadcast(self.st["arena"], 0)
-        dist.broadcast(self.st["mom"], 0)
-        for b in self.model.buffers():
-            dist.broadcast(b, 0)
+        else:
+            dist = torch.distributed
+            for tns in [self.st["arena"], self.st["mom"]] + ([flat] if flat is not None else []):
+                dist.broadcast(tns, 0)
+        off = 0
+        for b in bufs:
+            n = b.numel() * b.element_size() // 4
+            b.view(-1).view(torch.float32).copy_(flat[off:off + n])
+            off += n
 
     # ---- optimizer state in torch.optim.SGD's layout (the reference checkpoints `optimizer.state_dict()`, main.py:358-374)
     def state_dict(self):
@@ -246,6 +255,7 @@ class HipTrainStep:
         params = self.st["params"]
         off = 0
         loaded = 0
+        self.st["mom"].zero_()          # parameters missing from sd["state"] start from an empty buffer, as in torch.optim.SGD
         for i, p in enumerate(params):
             ent = sd["state"].get(i)
             if ent is not None and ent.get("momentum_buffer") is not None:
@@ -255,7 +265,7 @@ class HipTrainStep:
         # torch.optim.SGD starts a missing buffer as buf = grad; rd_sgd_step's first step does the same on a zero buffer
         # (0.9 * 0 + g), so only a restored state switches the "first step" behaviour off
         if loaded:
-            self.steps = max(self.steps, 1)
+            self.steps = max(self.steps, 1)     # (graph capture is gated by self._warm, not by this counter)
 
     def set_lr(self, lr):
         if lr != self.lr:
@@ -263,86 +273,149 @@ class HipTrainStep:
             self._drop_graphs()
 
     def _drop_graphs(self):
-        if self.graphs:
-            for g in self.graphs:
-                self.L.rd_graph_destroy(g)
+        """Hyper-parameters are baked into the marshalled step (and its graphs): drop both, the next step rebuilds them."""
+        for g in (self.graphs or {}).values():
+            self.L.rd_graph_destroy(g)
         self.graphs = None
+        tb, self._table = getattr(self, "_table", None), None
+        if tb is not None:
+            tb.close()
 
-    # ---- pieces of one step: each is a sequence of C-ABI launches on the step's stream, separately graph-capturable;
-    # ---- after piece i (i < len(buckets)) the gradient bucket i is final
-    def _l1(self, pred, sums):
-        check(self._f_sums(ptr(pred), ptr(self.target), C.c_int64(self.n_out), ptr(self.l1_ws), ptr(sums), self.plan.stream), "masked_sums")
+    # ---- pieces of one step: each is a list of (name, C-ABI function, arguments) on the step's streams, separately
+    # ---- graph-capturable; after piece i (i < len(buckets)) the gradient bucket i is final
+    def _l1_ops(self, tag, pred, sums, s):
+        return [(tag + ".sums", self._f_sums, (ptr(pred), ptr(self.target), C.c_int64(self.n_out), ptr(self.l1_ws), ptr(sums), s))]
 
-    def _l1_bwd(self, pred, sums, coef, dpred, accumulate):
-        check(self._f_bwd(ptr(pred), ptr(self.target), C.c_int64(self.n_out), ptr(sums), coef, ptr(dpred), accumulate,
-                          self.plan.stream), "masked_bwd")
+    def _l1_bwd_ops(self, tag, pred, sums, coef, dpred, accumulate, s):
+        return [(tag + ".bwd", self._f_bwd, (ptr(pred), ptr(self.target), C.c_int64(self.n_out), ptr(sums), coef, ptr(dpred), accumulate, s))]
 
     def _latefusion_pieces(self):
         p = self.plan
-
-        def head():
-            p._run(p.prep)
-            p._run(p.fwd)
-            self._l1(p.pred, self.sums)
-            check(self.L.rd_l1_total(ptr(self.sums), ptr(self.loss), ptr(self.coef), p.stream), "l1_total")
-            self._l1_bwd(p.pred, self.sums, ptr(self.coef), p.dpred, 0)
+        s = p.streams[0]
         segs = self._segments
-        pieces = [lambda: (head(), p._run(p.bwd[segs[0][0]:segs[0][1]]))]
-        pieces += [(lambda k=k: p._run(p.bwd[segs[k][0]:segs[k][1]])) for k in range(1, len(segs))]
+        head = list(p.prep) + list(p.fwd) + self._l1_ops("loss", p.pred, self.sums, s)
+        head.append(("loss.total", self.L.rd_l1_total, (ptr(self.sums), ptr(self.loss), ptr(self.coef), s)))
+        head += self._l1_bwd_ops("loss", p.pred, self.sums, ptr(self.coef), p.dpred, 0, s)
+        pieces = [head + p.bwd[segs[0][0]:segs[0][1]]]
+        pieces += [p.bwd[segs[k][0]:segs[k][1]] for k in range(1, len(segs))]
         return pieces
 
     def _multistage_pieces(self):
-        mp, p1, p2, s = self.mp, self.mp.p1, self.mp.p2, self.plan.stream
+        mp, p1, p2 = self.mp, self.mp.p1, self.mp.p2
+        s = p1.streams[0]
         fptr = lambda t, i: C.c_void_p(t.data_ptr() + 4 * i)
-
         seg2, seg1 = self._seg2, self._seg1
-
-        def stage2_head():
-            p1._run(p1.prep)
-            p1._run(p1.fwd)
-            mp.filter_op()
-            p2._run(p2.prep)
-            p2._run(p2.fwd)
-            self._l1(p1.pred, self.sums)
-            self._l1(p2.pred, self.sums2)
-            if self.uncertainty:
-                check(self.L.rd_smooth_fwd(ptr(p1.pred), ptr(p1.x_in), p1.N, p1.x_in.shape[1], p1.H, p1.W, ptr(self.smooth_ws),
-                                           ptr(self.smooth_out), s), "smooth_fwd")
-            check(self.L.rd_uncertainty_total(ptr(self.sums), ptr(self.sums2), ptr(self.smooth_out), ptr(self.w1), ptr(self.w2),
-                                              C.c_float(self.w_smooth), ptr(self.loss4), ptr(self.coefs3), ptr(self.dw1), ptr(self.dw2), s),
-                  "uncertainty_total")
-            self._l1_bwd(p2.pred, self.sums2, fptr(self.coefs3, 2), p2.dpred, 0)
-            p2._run(p2.bwd[seg2[0][0]:seg2[0][1]])
-
-        def stage1_head():
-            # the last segment of stage 2 has written d(loss)/d(stage-1 prediction) into p1.dpred (multistage_model.py:75)
-            self._l1_bwd(p1.pred, self.sums, fptr(self.coefs3, 0), p1.dpred, 1)
-            if self.uncertainty:
-                check(self.L.rd_smooth_bwd(p1.N, p1.H, p1.W, ptr(self.smooth_ws), fptr(self.coefs3, 1), ptr(p1.dpred), 1, s), "smooth_bwd")
-            p1._run(p1.bwd[seg1[0][0]:seg1[0][1]])
-        pieces = [stage2_head] + [(lambda k=k: p2._run(p2.bwd[seg2[k][0]:seg2[k][1]])) for k in range(1, len(seg2))]
-        pieces += [stage1_head] + [(lambda k=k: p1._run(p1.bwd[seg1[k][0]:seg1[k][1]])) for k in range(1, len(seg1))]
+        head2 = list(p1.prep) + list(p1.fwd) + [mp.filter_args()] + list(p2.prep) + list(p2.fwd)
+        head2 += self._l1_ops("loss1", p1.pred, self.sums, s) + self._l1_ops("loss2", p2.pred, self.sums2, s)
+        if self.uncertainty:
+            head2.append(("smooth.fwd", self.L.rd_smooth_fwd, (ptr(p1.pred), ptr(p1.x_in), p1.N, p1.x_in.shape[1], p1.H, p1.W,
+                                                               ptr(self.smooth_ws), ptr(self.smooth_out), s)))
+        head2.append(("uncertainty_total", self.L.rd_uncertainty_total,
+                      (ptr(self.sums), ptr(self.sums2), ptr(self.smooth_out), ptr(self.w1), ptr(self.w2), C.c_float(self.w_smooth),
+                       ptr(self.loss4), ptr(self.coefs3), ptr(self.dw1), ptr(self.dw2), s)))
+        head2 += self._l1_bwd_ops("loss2", p2.pred, self.sums2, fptr(self.coefs3, 2), p2.dpred, 0, s)
+        # the last segment of stage 2 writes d(loss)/d(stage-1 prediction) into p1.dpred (multistage_model.py:75)
+        head1 = self._l1_bwd_ops("loss1", p1.pred, self.sums, fptr(self.coefs3, 0), p1.dpred, 1, s)
+        if self.uncertainty:
+            head1.append(("smooth.bwd", self.L.rd_smooth_bwd, (p1.N, p1.H, p1.W, ptr(self.smooth_ws), fptr(self.coefs3, 1), ptr(p1.dpred), 1, s)))
+        pieces = [head2 + p2.bwd[seg2[0][0]:seg2[0][1]]] + [p2.bwd[seg2[k][0]:seg2[k][1]] for k in range(1, len(seg2))]
+        pieces += [head1 + p1.bwd[seg1[0][0]:seg1[0][1]]] + [p1.bwd[seg1[k][0]:seg1[k][1]] for k in range(1, len(seg1))]
         return pieces
 
-    def _sgd(self):
+    def _sgd_ops(self):
         st = self.st
-        check(self.L.rd_sgd_step(ptr(st["arena"]), ptr(st["grads"]), ptr(st["mom"]), C.c_int64(st["total"]), C.c_float(self.lr),
-                                 C.c_float(self.momentum), C.c_float(self.wd), C.c_float(1.0 / self.world), 0, self.plan.stream), "sgd_step")
+        return [("sgd_step", self.L.rd_sgd_step, (ptr(st["arena"]), ptr(st["grads"]), ptr(st["mom"]), C.c_int64(st["total"]), C.c_float(self.lr),
+                                                   C.c_float(self.momentum), C.c_float(self.wd), C.c_float(1.0 / self.world), 0,
+                                                   self.plan.streams[0]))]
 
-    def _pieces(self):
-        parts = self._multistage_pieces() if self.multistage else self._latefusion_pieces()
-        if not self.dp:                                       # single GPU: the whole step is one graph
-            return [lambda: ([f() for f in parts], self._sgd())]
-        return parts + [self._sgd]
+    def _comm_ops(self, i):
+        """Native exchange behind piece i: an event behind the piece on the step's stream (plus the segment's tails on the depth /
+        weight-gradient streams) releases bucket i's in-place sums on the communication stream; they run under pieces i+1.."""
+        s, cs = self.plan.streams[0], self._cs
+        ops = [("bucket%d.record" % i, self.L.rd_event_record, (self._bucket_events[i], s)),
+               ("bucket%d.wait" % i, self.L.rd_stream_wait_event, (cs, self._bucket_events[i]))]
+        ops += [("bucket%d.wait_side" % i, self.L.rd_stream_wait_event, (cs, ev)) for ev in self._bucket_side_events[i]]
+        g = self.st["grads"]
+        ops += [("bucket%d.allreduce" % i, self.L.rd_allreduce_bucket, (C.c_void_p(g.data_ptr() + 4 * lo), C.c_int64(hi - lo), 0, cs))
+                for lo, hi in self._buckets[i]]
+        return ops
+
+    def _build_table(self):
+        """Marshal the whole step once (optable.py).  self._ranges: [(kind, begin, end)], kind "piece" (graph-capturable compute),
+        "comm" (native exchange between pieces) -- issued in order; the torch.distributed cross-check path interleaves its
+        all_reduce calls from Python after every "piece" but the last (SGD)."""
+        from .optable import OpTable
+        pieces = self._multistage_pieces() if self.multistage else self._latefusion_pieces()
+        streams = [q for pl in self.plans for q in pl.streams]
+        ops, ranges = [], []
+
+        def add(kind, lst):
+            ranges.append((kind, len(ops), len(ops) + len(lst)))
+            ops.extend(lst)
+        if not self.dp:                                       # single GPU: the whole step is one piece (one graph)
+            add("piece", [op for pc in pieces for op in pc] + self._sgd_ops())
+        elif self.comm == "rccl":
+            if self._bucket_events is None:
+                self._bucket_events = []
+                for _ in range(len(self._buckets) + 1):
+                    ev = C.c_void_p(0)
+                    check(self.L.rd_event_create(C.byref(ev)), "rd_event_create")
+                    self._bucket_events.append(ev)
+            self._cs = C.c_void_p(self.comm_stream.cuda_stream)
+            streams.append(self._cs)
+            for i, pc in enumerate(pieces):
+                add("piece", pc)
+                add("comm", self._comm_ops(i))
+            s = self.plan.streams[0]
+            add("comm", [("exchange.done", self.L.rd_event_record, (self._bucket_events[-1], self._cs)),
+                         ("exchange.join", self.L.rd_stream_wait_event, (s, self._bucket_events[-1]))])
+            add("piece", self._sgd_ops())
+        else:
+            for pc in pieces:
+                add("piece", pc)
+            add("piece", self._sgd_ops())
+        self._ops, self._ranges = ops, ranges
+        self._table = OpTable(self.L, ops, streams)
+
+    def synchronize_comm(self):
+        """Block the host until this step's own communicator (comm="rccl": a second RCCL communicator on a private stream next to
+        torch.distributed's) has drained.  Call it -- or torch.cuda.synchronize() -- BEFORE issuing a torch.distributed collective
+        (metric averaging, barrier) after step(): collectives of two communicators enqueued without a device sync in between can
+        interleave in a different order on different ranks, which deadlocks RCCL/NCCL."""
+        if self.comm_stream is not None:
+            self.comm_stream.synchronize()
+        self.side.synchronize()
+
+    def close(self):
+        self._drop_graphs()
+        tb, self._table = getattr(self, "_table", None), None
+        if tb is not None:
+            tb.close()
+        evs, self._bucket_events = getattr(self, "_bucket_events", None), None
+        for ev in evs or []:
+            if ev.value:
+                self.L.rd_event_destroy(ev)
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
     def step(self, inputs, target):
-        """inputs [B,4,H,W], target [B,1,Ho,Wo] CUDA fp32.  Returns (loss[1], pred) device tensors (no sync)."""
+        """inputs [B,4,H,W], target [B,1,Ho,Wo] CUDA fp32.  Returns (loss[1], pred) device tensors (no sync).
+        With comm="rccl" see synchronize_comm() before mixing in torch.distributed collectives."""
         caller = torch.cuda.current_stream()
         self.side.wait_stream(caller)
         with torch.cuda.stream(self.side):
             self._step_on_side(inputs, target)
         caller.wait_stream(self.side)
         return self.loss, self.plans[-1].pred
+
+    def _issue(self, begin, end):
+        if self.plan._diagnostic_loop():                       # RD_POISON_LDS / RD_TRACE_OPS: host hook between ops
+            return self.plan._run(self._ops[begin:end])
+        self._table.run(begin, end)
 
     def _step_on_side(self, inputs, target):
         p = self.plan
@@ -360,49 +433,42 @@ class HipTrainStep:
                                "reassigned parameter .data): build a new HipTrainStep")
         for pl in self.plans:
             pl.set_stream()
+            pl.generation += 1          # the step overwrites the plan's saved activations: autograd nodes of an earlier eager forward go stale
         p.x_in.copy_(inputs[:, :p.x_in.shape[1]])
         self.target.copy_(target)
-        pieces = self._pieces()
-        if self.use_graph and self.steps >= 1 and self.graphs is None:
-            self.graphs = []
-            for piece in pieces:
-                check(self.L.rd_graph_begin(p.stream), "graph_begin")
-                piece()
+        if self._table is None:
+            self._build_table()
+        ranges = self._ranges
+        if self.use_graph and self._warm >= 1 and self.graphs is None:
+            self.graphs = {}
+            for k, (kind, b, e) in enumerate(ranges):
+                if kind != "piece":
+                    continue
+                check(self.L.rd_graph_begin(p.streams[0]), "graph_begin")
+                self._issue(b, e)
                 g = C.c_void_p(0)
-                check(self.L.rd_graph_end(p.stream, C.byref(g)), "graph_end")
-                self.graphs.append(g)
-        def launch(i):
-            if self.graphs is not None:
-                check(self.L.rd_graph_launch(self.graphs[i], p.stream), "graph_launch")
-            else:
-                pieces[i]()
-        if not self.dp:
-            launch(0)
-        elif self.comm == "rccl":
-            # piece i completes gradient bucket i: an event behind it on the step's stream releases the bucket's all-reduce on
-            # the communication stream, which runs under pieces i+1..; the SGD kernel waits for the last bucket's event
-            from . import comm as _comm
-            cs = C.c_void_p(self.comm_stream.cuda_stream)
-            grads = self.st["grads"]
-            if not hasattr(self, "_bucket_events"):
-                self._bucket_events = [torch.cuda.Event() for _ in range(len(self._buckets) + 1)]
-            for i, slices in enumerate(self._buckets):
-                launch(i)
-                self._bucket_events[i].record(self.side)
-                self.comm_stream.wait_event(self._bucket_events[i])
-                for ev in self._bucket_side_events[i]:          # the segment's tails on the depth / weight-gradient streams
-                    check(self.L.rd_stream_wait_event(cs, ev), "stream_wait_event")
-                for lo, hi in slices:
-                    _comm.allreduce_(grads, cs, lo, hi)
-            self._bucket_events[-1].record(self.comm_stream)
-            self.side.wait_event(self._bucket_events[-1])
-            launch(len(self._buckets))
+                check(self.L.rd_graph_end(p.streams[0], C.byref(g)), "graph_end")
+                self.graphs[k] = g
+        if self.graphs is None and (not self.dp or self.comm == "rccl"):
+            self._issue(0, len(self._ops))                     # ONE C-ABI call: every launch, event and collective of the step
         else:
-            # piece i completes gradient bucket i; its all-reduce is enqueued right behind it and overlaps pieces i+1..
-            for i, _ in enumerate(reduce_gradient_buckets(self.st["grads"], self._buckets)):
-                launch(i)
-            launch(len(self._buckets))                        # SGD, after every bucket has been waited for
+            works, n_piece = [], sum(1 for kind, _, _ in ranges if kind == "piece")
+            seen = 0
+            for k, (kind, b, e) in enumerate(ranges):
+                if kind == "piece" and self.dp and self.comm == "torch" and seen == n_piece - 1:
+                    for wk in works:                           # SGD, after every bucket has been waited for
+                        wk.wait()
+                if kind == "piece" and self.graphs is not None:
+                    check(self.L.rd_graph_launch(self.graphs[k], p.streams[0]), "graph_launch")
+                else:
+                    self._issue(b, e)
+                if kind == "piece":
+                    if self.dp and self.comm == "torch" and seen < len(self._buckets):
+                        # piece i completes gradient bucket i; its all-reduce is enqueued right behind it and overlaps pieces i+1..
+                        works += [torch.distributed.all_reduce(self.st["grads"][lo:hi], async_op=True) for lo, hi in self._buckets[seen]]
+                    seen += 1
         self.steps += 1
+        self._warm += 1
 
 
 class HipInference:
@@ -427,17 +493,21 @@ class HipInference:
         self.use_graph = use_graph
         self.graph = None
         self.calls = 0
+        self._table = self._ops = None
         self.side = torch.cuda.Stream(device=self.plans[0].dev)
 
     def _run(self):
         p1 = self.plans[0]
-        p1._run(p1.prep)
-        p1._run(p1.fwd)
-        if self.multistage:
-            self.mp.filter_op()
-            p2 = self.plans[1]
-            p2._run(p2.prep)
-            p2._run(p2.fwd)
+        if self._table is None:
+            from .optable import OpTable
+            self._ops = list(p1.prep) + list(p1.fwd)
+            if self.multistage:
+                p2 = self.plans[1]
+                self._ops += [self.mp.filter_args()] + list(p2.prep) + list(p2.fwd)
+            self._table = OpTable(self.L, self._ops, [q for pl in self.plans for q in pl.streams])
+        if p1._diagnostic_loop():
+            return p1._run(self._ops)
+        self._table.run()
 
     def __call__(self, x):
         """x [B,>=4,H,W] CUDA fp32 -> prediction(s) (plan-owned tensors, valid until the next call)."""

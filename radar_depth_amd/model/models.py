@@ -150,12 +150,12 @@ PLAN_CACHE_SIZE = int(os.environ.get("RD_PLAN_CACHE", "3"))
 def _evict_plans(cache, version, room_for=1):
     """A plan owns every activation / gradient / workspace buffer of one (batch, size, mode) key -- about 11 GB at b=16
     450x800 training.  The cache is a small LRU (the steady batch, a ragged last batch, validate()'s batch 1): plans of a
-    rebuilt parameter arena go first, then the least recently used; a dropped plan frees its HBM and its hipEvents."""
+    rebuilt parameter arena go first, then the least recently used.  Eviction only drops the CACHE's reference: a HipTrainStep /
+    HipInference / autograd node fetched its plan once and keeps using it, so the plan's HBM and hipEvents go when its last holder
+    does (LateFusionPlan.__del__), never under a live step."""
     stale = [k for k in cache if k[4] != version]
     for k in stale + [k for k in cache if k not in stale][:max(0, len(cache) - len(stale) + room_for - PLAN_CACHE_SIZE)]:
-        plan = cache.pop(k)
-        for pl in (getattr(plan, "p1", None), getattr(plan, "p2", None)) if hasattr(plan, "p1") else (plan,):
-            pl.close()
+        cache.pop(k)
 
 
 # ------------------------------------------------------------------------------------------------

@@ -125,11 +125,16 @@ class MultistagePlan:
         self.p1, self.p2, self.kept, self.mask = p1, p2, kept, mask
         self.L = lib()
 
-    def filter_op(self):
+    def filter_args(self):
+        """The radar filter between the stages as a plan op (name, C-ABI function, arguments) on stage 1's main stream."""
         p1 = self.p1
         hw = p1.H * p1.W
-        check(self.L.rd_radar_filter(ptr(p1.x_in), p1.N, p1.x_in.shape[1], 3, C.c_int64(hw), ptr(p1.pred), ptr(self.kept),
-                                     ptr(self.mask), p1.stream), "rd_radar_filter")
+        return ("radar_filter", self.L.rd_radar_filter, (ptr(p1.x_in), p1.N, p1.x_in.shape[1], 3, C.c_int64(hw), ptr(p1.pred), ptr(self.kept),
+                                                         ptr(self.mask), p1.streams[0]))
+
+    def filter_op(self):
+        name, fn, args = self.filter_args()
+        check(fn(*args), name)
 
     def run_forward(self, x=None):
         self.p1.run_forward(x)
@@ -146,10 +151,10 @@ class MultistagePlan:
             p2.dpred.copy_(g2)
         else:
             p2.dpred.zero_()
-        p2._run(p2.bwd)                      # writes d(loss)/d(stage-1 prediction as stage-2 input) into p1.dpred
+        p2.run_list("bwd")                   # writes d(loss)/d(stage-1 prediction as stage-2 input) into p1.dpred
         if g1 is not None:
             p1.dpred.add_(g1.view_as(p1.dpred))
-        p1._run(p1.bwd)
+        p1.run_list("bwd")
 
 
 class _MultistageFunction(torch.autograd.Function):

@@ -482,7 +482,7 @@ def _two_rank_worker(rank, world, token_path, out_path):
     from radar_depth_amd.model.models import ResNet_latefusion
     from radar_depth_amd.synthetic import make_batch, procedural_fill_
     torch.cuda.set_device(rank)
-    comm.init_from_file(token_path, rank, world)
+    comm.init_from_file(token_path, rank, world, job_id="two-rank-test")
     b, h, w = 2, 97, 161
     torch.manual_seed(100 + rank)                      # deliberately different seeds: rank 0's state must win
     m = ResNet_latefusion(18, "upproj", [h, w], 4, False)

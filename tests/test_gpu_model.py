@@ -285,7 +285,9 @@ def test_data_parallel_path_single_rank(monkeypatch):
         m, m2 = build(h, w), build(h, w)
         ts = HipTrainStep(m, b, h, w, use_graph=True)         # data-parallel path as segment graphs
         ts2 = HipTrainStep(m2, b, h, w)                       # ... and as plain stream launches (the default)
-        assert ts.dp and ts2.dp and len(ts._pieces()) == len(ts._buckets) + 1
+        assert ts.dp and ts2.dp
+        ts._build_table()
+        assert sum(1 for kind, _, _ in ts._ranges if kind == "piece") == len(ts._buckets) + 1
         for it in range(3):
             x, t = make_batch(b, h, w, 300 + it, ref_pixels=h * w)
             l0, _ = ts_ref.step(x.cuda(), t.cuda())

@@ -123,28 +123,42 @@ def test_multistage_buckets_partition_the_arena():
 
 
 def test_plan_cache_is_a_small_lru():
-    """A plan owns ~11 GB of buffers at b=16 450x800: the per-module cache keeps the PLAN_CACHE_SIZE most recently used keys,
-    drops plans of a rebuilt parameter arena first, and closes what it drops (frees HBM, destroys the hipEvents)."""
+    """A plan owns ~11 GB of buffers at b=16 450x800: the per-module cache keeps the PLAN_CACHE_SIZE most recently used keys and
+    drops plans of a rebuilt parameter arena first.  Eviction only drops the cache's REFERENCE: a HipTrainStep / HipInference /
+    autograd node that still holds an evicted plan keeps a usable plan (events alive); it is closed when its last holder goes."""
+    import gc
+
     from radar_depth_amd.model import models
 
+    closed = []
+
     class FakePlan:
-        def __init__(self):
-            self.closed = False
+        def __init__(self, i):
+            self.i = i
 
         def close(self):
-            self.closed = True
+            closed.append(self.i)
+
+        def __del__(self):
+            self.close()
     cap = models.PLAN_CACHE_SIZE
-    cache, plans = {}, []
-    for i in range(cap + 2):
+    cache = {}
+    held = FakePlan(0)                                   # what a HipTrainStep does: fetch once, keep using
+    cache[(0, 450, 800, True, 1, None, False, "fp32", True)] = held
+    for i in range(1, cap + 2):
         models._evict_plans(cache, version=1)
-        p = FakePlan()
-        plans.append(p)
-        cache[(i, 450, 800, True, 1, None, False, "fp32", True)] = p
+        cache[(i, 450, 800, True, 1, None, False, "fp32", True)] = FakePlan(i)
         assert len(cache) <= cap
-    assert [p.closed for p in plans] == [True, True] + [False] * cap            # oldest first
-    # a rebuilt arena (new version): every plan of the old version goes, whatever its age
+    gc.collect()
+    assert sorted(k[0] for k in cache) == list(range(2, cap + 2))                # oldest keys went first
+    assert closed == [1]                                  # the un-held evicted plan is gone; the held one was NOT closed under its holder
+    # a rebuilt arena (new version): every plan of the old version leaves the cache, whatever its age
     models._evict_plans(cache, version=2)
-    assert not cache and all(p.closed for p in plans)
+    gc.collect()
+    assert not cache and sorted(closed) == list(range(1, cap + 2))
+    del held
+    gc.collect()
+    assert 0 in closed
 
 
 def test_segment_events_replace_joins():
@@ -164,3 +178,60 @@ def test_segment_events_replace_joins():
     assert strip(names(pj)) == strip(names(pe))
     assert names(pj).count("join1.record") == 4 and names(pe).count("join1.record") == 1
     assert [s[2] for s in pj.bwd_segments] == [s[2] for s in pe.bwd_segments]
+
+
+def test_op_table_marshals_every_plan_op():
+    """rd_optable_* (the one-call replay of a step, include/radar_depth_hip.h): every op of the training and inference plans of
+    both storage types names a replayable entry point and carries exactly the argument count of its C prototype; stream
+    arguments are recognised by identity.  Marshalling needs no GPU (nothing is launched)."""
+    import ctypes as C
+
+    import pytest
+
+    from radar_depth_amd._lib import RadarDepthHipError, lib
+    from radar_depth_amd.engine import LateFusionPlan
+    from radar_depth_amd.model.models import ResNet_latefusion
+    from radar_depth_amd.optable import OpTable, _word
+    L = lib()
+    m = ResNet_latefusion(18, "upproj", [64, 96], 4, False)
+    for kw in (dict(train=True), dict(train=True, storage="bf16"), dict(train=False), dict(train=True, bf16=True)):
+        plan = LateFusionPlan(m, 1, 64, 96, dry_run=True, **kw)
+        ops = plan.prep + plan.fwd + plan.bwd
+        tb = OpTable(L, ops, plan.streams)
+        assert len(tb) == len(ops) == L.rd_optable_size(tb.h)
+        for name, fn, args in ops:
+            assert L.rd_optable_entry_args(fn.__name__.encode()) == len(args), (name, fn.__name__)
+            assert sum(1 for a in args if any(a is s for s in plan.streams)) >= 1, name      # every op is bound to a plan stream
+        tb.close()
+    # floats travel as their bit pattern, negative ints as two's complement, byref as the address
+    assert _word(C.c_float(1.0)) == 0x3F800000 and _word(-1) == 2 ** 64 - 1
+    d = C.c_int32(5)
+    assert _word(C.byref(d)) == C.addressof(d)
+    with pytest.raises(RadarDepthHipError):
+        OpTable(L, [("bad", L.rd_last_error, ())], [])                     # not a replayable entry point
+    with pytest.raises(RadarDepthHipError):
+        OpTable(L, [("short", L.rd_fill, (C.c_void_p(0), C.c_int64(1)))], [])     # wrong argument count
+
+
+def test_bench_launches_its_own_ranks():
+    """`python bench.py --gpus 2` with no launcher around it (the way the driver starts the N=1 run) must start its two ranks
+    itself -- torch.distributed.run on 127.0.0.1 -- and rank 0 prints ONE JSON line.  --dry-run swaps the GPU step for the
+    plan's bucketed gradient exchange over gloo, so the whole multi-rank plumbing of the script runs here on CPU."""
+    import json
+    import os
+    import subprocess
+    import sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(repo, "bench.py"), "--gpus", "2", "--dry-run"], capture_output=True, text=True,
+                       env=env, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["dry_run"] is True and out["comm"] == "gloo"
+    assert out["exchange_ok"] is True and out["gradient_buckets"] == 4 and len(out["exchange_s_per_rank"]) == 2
+    # a rank count that contradicts the surrounding job is refused, not silently run
+    r = subprocess.run([sys.executable, os.path.join(repo, "bench.py"), "--gpus", "2", "--dry-run"], capture_output=True, text=True,
+                       env=dict(env, WORLD_SIZE="3", RANK="0"), timeout=120)
+    assert r.returncode != 0 and "3-rank job" in (r.stderr + r.stdout)
