@@ -143,6 +143,28 @@ int rd_wgrad_plan_info(const RdConvDesc* d, int32_t* out);
 int rd_pack_weights(const float* w_oihw, float* packed, int32_t O, int32_t I, int32_t KH, int32_t KW,
                     int32_t ldc, int32_t co_off, int32_t rows_total, int32_t transpose, void* stream);
 
+/* Batched form of rd_wgrad_reduce / rd_wgrad_bf16_reduce: the slab reductions of MANY weight-gradient launches (all of one
+ * backward segment on one stream: the gradients are not needed before the segment's bucket boundary) in two launches instead
+ * of one or two per weight tensor (98 launches of ~10 us per step at b=16 450x800).  rd_wgrad_reduce_job fills the HOST
+ * record of one reduction (same arguments as rd_wgrad_reduce; bf16_kernel != 0: the slabs came from rd_wgrad_bf16); the caller
+ * assigns consecutive block ranges (first_block1 / first_block2; n_blocks1 may be 0: no first stage), uploads the job array
+ * and the two block -> job tables, and issues rd_wgrad_reduce_batched.  Column ranges of one slab set (the two 5x5
+ * convolutions of an UpProj module) must appear in increasing co_off order, as with rd_wgrad_reduce.  Same summation order
+ * as the per-tensor entry points: bit-identical results. */
+typedef struct {
+    const float* slabs;
+    float* tmp;
+    float* grad;
+    int64_t E;                      /* floats per slab */
+    int32_t n_splits, J, S, Cin, Cout, O, I, co_off, accumulate;
+    int32_t first_block1, n_blocks1, first_block2, n_blocks2;
+    int32_t pad_;
+} RdReduceJob;
+int rd_wgrad_reduce_job(const RdConvDesc* d, int32_t bf16_kernel, const float* slabs, float* grad_oihw, int32_t O, int32_t I,
+                        int32_t KH, int32_t KW, int32_t co_off, int32_t accumulate, RdReduceJob* job);
+int rd_wgrad_reduce_batched(const RdReduceJob* jobs_dev, const int32_t* block_job1_dev, int32_t n_blocks1,
+                            const int32_t* block_job2_dev, int32_t n_blocks2, void* stream);
+
 /* bf16-operand form of rd_wgrad / rd_wgrad_reduce for descriptors that decompose into at most four stride-1 3x3-shaped
  * passes over decimated tensors (3x3 / 1x1 at stride 1 or 2, the UpProj phases; channel counts multiples of 16;
  * rd_wgrad_bf16_supported says whether a descriptor qualifies -- everything else stays on rd_wgrad): in / dout are the fp32 tensors of rd_wgrad, rounded to bf16 (nearest even) while they are staged, accumulated

@@ -28,6 +28,14 @@ class RdConvDesc(C.Structure):
                 ("phase", RdPhase * RD_MAX_PHASES)]
 
 
+class RdReduceJob(C.Structure):
+    _fields_ = [("slabs", C.c_void_p), ("tmp", C.c_void_p), ("grad", C.c_void_p), ("E", C.c_int64),
+                ("n_splits", C.c_int32), ("J", C.c_int32), ("S", C.c_int32), ("Cin", C.c_int32), ("Cout", C.c_int32),
+                ("O", C.c_int32), ("I", C.c_int32), ("co_off", C.c_int32), ("accumulate", C.c_int32),
+                ("first_block1", C.c_int32), ("n_blocks1", C.c_int32), ("first_block2", C.c_int32), ("n_blocks2", C.c_int32),
+                ("pad_", C.c_int32)]
+
+
 class RadarDepthHipError(RuntimeError):
     pass
 

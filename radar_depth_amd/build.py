@@ -17,6 +17,9 @@ LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libradardepth_hip.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
+# every object keeps hipcc's per-kernel register / spill / scratch report next to it (<source>.resource.txt): the ISA audit
+# (tools/audit_resources.py, tests/test_abi_host.py) reads those instead of recompiling
+RES_FLAG = "-Rpass-analysis=kernel-resource-usage"
 
 
 def _sources():
@@ -39,14 +42,30 @@ def build(force=False, verbose=True):
     for f in _sources():
         src, obj = os.path.join(CSRC, f), os.path.join(OBJ, f + ".o")
         objs.append(obj)
-        if force or _stale(src, obj, headers):
+        if force or _stale(src, obj, headers) or not os.path.exists(os.path.join(OBJ, f + ".resource.txt")):
             lang = ["-x", "hip"] if f.endswith(".cpp") else []
-            jobs.append((f, [HIPCC] + FLAGS + lang + ["-c", src, "-o", obj]))
+            jobs.append((f, [HIPCC] + FLAGS + [RES_FLAG] + lang + ["-c", src, "-o", obj]))
 
     def run(job):
         name, cmd = job
         r = subprocess.run(cmd, capture_output=True, text=True)
-        return name, r.returncode, r.stdout + r.stderr
+        text = r.stdout + r.stderr
+        if r.returncode == 0:
+            with open(os.path.join(OBJ, name + ".resource.txt"), "w") as fh:
+                fh.write("".join(ln + "\n" for ln in text.splitlines() if RES_FLAG in ln))
+        # the resource remarks are not diagnostics: only real warnings / errors are shown
+        shown, after_remark = [], False
+        for ln in text.splitlines():
+            if RES_FLAG in ln or "remarks generated" in ln:
+                after_remark = True
+                continue
+            if after_remark and ln.lstrip()[:1].isdigit() is False and "|" in ln[:12]:
+                continue                                   # the "      | ^" caret line under a remark
+            if after_remark and ln.split("|")[0].strip().isdigit():
+                continue                                   # the quoted source line under a remark
+            after_remark = False
+            shown.append(ln + "\n")
+        return name, r.returncode, "".join(shown)
 
     failed = False
     with ThreadPoolExecutor(max_workers=min(8, max(1, len(jobs)))) as ex:

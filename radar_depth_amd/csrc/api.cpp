@@ -48,7 +48,7 @@ extern "C" int rd_graph_end(void* stream, void** graph_exec) {
     RD_CHECK_HIP(hipStreamEndCapture(static_cast<hipStream_t>(stream), &g));
     hipGraphExec_t ge = nullptr;
     hipError_t e = hipGraphInstantiate(&ge, g, nullptr, nullptr, 0);
-    hipGraphDestroy(g);
+    (void)hipGraphDestroy(g);
     if (e != hipSuccess) {
         rd::set_error("hipGraphInstantiate: %s", hipGetErrorString(e));
         return RD_ELAUNCH;

@@ -260,15 +260,21 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MT * NT <= 
         // registers, no LDS-write pass); the next chunk's patch is loaded into registers while the last slab of the current
         // chunk is in the matrix cores.  Per-element addresses are computed once per workgroup, so a chunk issues ~50 VALU
         // instructions for its staging instead of ~900 (they would queue behind the co-resident workgroup's MFMAs).
-        constexpr int UPP = MT * NT >= 4 ? 8 : 4, UWP = 7;
+        constexpr int UPP = MT * NT >= 4 ? 8 : 4, UWP = 7;      // (a six-load form that pipelines the 2x1 tile's 256-pixel patch measured 4-7 % slower than its plain loop: round 3)
         const int welems = ntaps * W4 * BN;
         const int slab_bytes = a.taps_max * WSD * BN * 4;
         unsigned pgo[UPP];      // byte offset of the element inside the image at channel 0; ~0u: outside -> zero
         int pdst[UPP];          // LDS float offset, -1: no such element
+        // Input-parity groups: the element maps are rebuilt per group from an opaque copy of the thread id.  Without it the compiler
+        // hoists every element's group-invariant (row, column, quad, tap) out of the group loop and keeps ~45 VGPRs live across
+        // the whole kernel -- the 3x2 / 2x2 register tiles then spilled 40-65 VGPRs into scratch (round 2).
+        int tidg = tid;
+        if constexpr (GRP) asm volatile("" : "+v"(tidg));
+        const int lq4 = 31 - __clz(q4), lW4 = 31 - __clz(W4);          // q4 and W4 are powers of two
 #pragma unroll
         for (int u = 0; u < UPP; ++u) {
-            const int e = tid + u * 256;
-            const int pix = e / q4, qq = e - pix * q4;
+            const int e = tidg + u * 256;
+            const int pix = e >> lq4, qq = e & (q4 - 1);
             const int py = pix / PW, px = pix - py * PW;
             const int ih = gih0 + gst * py, iw = giw0 + gst * px;
             pdst[u] = e < patch_elems ? paddr(pix, qq * 4) : -1;
@@ -277,9 +283,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MT * NT <= 
         unsigned woff[UWP];     // byte offset of the element inside the packed weights at input-channel quad 0; ~0u: zero
 #pragma unroll
         for (int u = 0; u < UWP; ++u) {
-            const int e = tid + u * 256;
+            const int e = tidg + u * 256;
             const int j = e % BN, tk = e / BN;
-            const int k4 = tk % W4, t = min(tk / W4, ntaps - 1);
+            const int k4 = tk & (W4 - 1), t = min(tk >> lW4, ntaps - 1);
             woff[u] = (e < welems && co0 + j < D.Cout) ? (unsigned)((((unsigned)s_widx[tb + t] * (D.Cin >> 2) + k4) * a.ldw + co0 + j) * 16) : ~0u;
         }
         auto issue_slab = [&](int buf, int cq0) {          // cq0: first input-channel quad of the slab
@@ -287,9 +293,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MT * NT <= 
             float* dst = s_w + buf * (slab_bytes >> 2);
 #pragma unroll
             for (int u = 0; u < UWP; ++u) {
-                const int e = tid + u * 256;
+                const int e = tidg + u * 256;
                 if (e < welems) {
-                    if (woff[u] != ~0u) glds16(reinterpret_cast<const float*>(src + woff[u]), dst + (e - lane) * 4);
+                    if (woff[u] != ~0u) glds16(reinterpret_cast<const float*>(src + woff[u]), dst + (e - (tidg & 63)) * 4);
                     else *reinterpret_cast<float4*>(dst + e * 4) = make_float4(0.f, 0.f, 0.f, 0.f);
                 }
             }

@@ -516,6 +516,65 @@ int launch_slab_reduce(const float* slabs, int n_splits, int64_t E, float* tmp, 
     return RD_OK;
 }
 
+// ---- batched form: the reductions of MANY weight-gradient launches (one backward segment) in two launches.  A job is one
+// rd_wgrad_reduce call; blocks are dealt to jobs through a block -> job table.  Same summation order as the single-job kernels
+// above, hence the same bits (tests/test_gpu_wgrad.py).
+__global__ __launch_bounds__(256) void wgrad_reduce1_batched_kernel(const RdReduceJob* __restrict__ jobs, const int32_t* __restrict__ block_job) {
+    const RdReduceJob jb = jobs[block_job[blockIdx.x]];
+    const int lb = (int)blockIdx.x - jb.first_block1;
+    const int J = jb.J, j = lb % J, bx = lb / J, nbx = jb.n_blocks1 / J;
+    const int64_t E4 = jb.E / 4;
+    const float4* src = reinterpret_cast<const float4*>(jb.slabs);
+    float4* dst = reinterpret_cast<float4*>(jb.tmp);
+    for (int64_t e = (int64_t)bx * 256 + threadIdx.x; e < E4; e += (int64_t)nbx * 256) {
+        float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll 4
+        for (int k = j; k < jb.n_splits; k += J) {
+            const float4 v = src[(int64_t)k * E4 + e];
+            s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+        }
+        dst[(int64_t)j * E4 + e] = s;
+    }
+}
+
+__global__ __launch_bounds__(256) void wgrad_reduce2_batched_kernel(const RdReduceJob* __restrict__ jobs, const int32_t* __restrict__ block_job) {
+    const RdReduceJob jb = jobs[block_job[blockIdx.x]];
+    const int lb = (int)blockIdx.x - jb.first_block2;
+    const unsigned total = (unsigned)jb.S * (unsigned)jb.I * (unsigned)jb.O;       // < 2^31 (checked when the job is made)
+    const float* tmp = jb.n_splits <= 16 ? jb.slabs : jb.tmp;
+    for (unsigned u = (unsigned)lb * 256u + threadIdx.x; u < total; u += (unsigned)jb.n_blocks2 * 256u) {
+        const unsigned r = u / (unsigned)jb.O;
+        const int o = (int)(u - r * (unsigned)jb.O);
+        const int t = (int)(r / (unsigned)jb.I);
+        const int i = (int)(r - (unsigned)t * (unsigned)jb.I);
+        const float* src = tmp + ((int64_t)t * jb.Cin + i) * jb.Cout + jb.co_off + o;
+        float s = 0.f;
+        for (int k = 0; k < jb.J; ++k) s += src[k * jb.E];
+        float* dst = jb.grad + ((int64_t)o * jb.I + i) * jb.S + t;
+        *dst = jb.accumulate ? *dst + s : s;
+    }
+}
+
+// Fills a job from the reduction's shape (block ranges are the caller's: rd_wgrad_reduce_job)
+int make_reduce_job(const float* slabs, int n_splits, int64_t E, float* grad_oihw, int S, int Cin, int Cout, int O, int I, int co_off,
+                    int accumulate, RdReduceJob* jb) {
+    RD_CHECK_ARG(E % 4 == 0, "slab_reduce: slab size must be a multiple of 4");
+    RD_CHECK_ARG((int64_t)S * I * O < (1ll << 31), "wgrad_reduce_job: one weight tensor must stay below 2^31 elements");
+    const int J = n_splits < 16 ? n_splits : 16;
+    jb->slabs = slabs; jb->tmp = const_cast<float*>(slabs) + (int64_t)n_splits * E; jb->grad = grad_oihw;
+    jb->E = E; jb->n_splits = n_splits; jb->J = J; jb->S = S; jb->Cin = Cin; jb->Cout = Cout; jb->O = O; jb->I = I;
+    jb->co_off = co_off; jb->accumulate = accumulate;
+    int64_t g1 = cdiv64(E / 4, 256);
+    if (g1 > 2048) g1 = 2048;
+    jb->n_blocks1 = (n_splits > 16 && co_off == 0) ? (int)g1 * J : 0;      // stage 1 once per slab set (column ranges in increasing co_off order)
+    int64_t g2 = cdiv64((int64_t)S * I * O, 256);
+    if (g2 > 4096) g2 = 4096;
+    jb->n_blocks2 = (int)g2;
+    jb->first_block1 = jb->first_block2 = 0;
+    jb->pad_ = 0;
+    return RD_OK;
+}
+
 struct WgradPlan {
     int TG, MF, layoutA;
     int TH, TW, tiles_h, tiles_w, total_tiles, tiles_per_split, n_splits, slab_splits;
@@ -897,4 +956,38 @@ extern "C" int rd_wgrad_reduce(const RdConvDesc* d, const float* slabs, float* g
     float* tmp = const_cast<float*>(slabs) + (int64_t)pl.slab_splits * E;
     return launch_slab_reduce(slabs, pl.slab_splits, E, tmp, grad_oihw, pl.S, d->Cin, d->Cout, O, I, co_off, accumulate,
                               static_cast<hipStream_t>(stream));
+}
+
+// ---- batched reductions (one backward segment's rd_wgrad_reduce / rd_wgrad_bf16_reduce calls as two launches)
+namespace rd { bool wgrad_bf16_reduce_shape(const RdConvDesc* d, int* slab_splits, int* S); }
+
+extern "C" int rd_wgrad_reduce_job(const RdConvDesc* d, int32_t bf16_kernel, const float* slabs, float* grad_oihw, int32_t O, int32_t I,
+                                   int32_t KH, int32_t KW, int32_t co_off, int32_t accumulate, RdReduceJob* job) {
+    RD_CHECK_ARG(d && slabs && grad_oihw && job, "wgrad_reduce_job: null argument");
+    int slab_splits = 0, S = 0;
+    if (bf16_kernel) {
+        if (!wgrad_bf16_reduce_shape(d, &slab_splits, &S)) { set_error("wgrad_reduce_job: unsupported descriptor"); return RD_EINVAL; }
+    } else {
+        WgradPlan pl;
+        int rc = plan_any(*d, pl);
+        if (rc != RD_OK) return rc;
+        slab_splits = pl.slab_splits; S = pl.S;
+    }
+    RD_CHECK_ARG(KH * KW == S && I == d->Cin && co_off + O <= d->Cout, "wgrad_reduce_job: shape mismatch");
+    return make_reduce_job(slabs, slab_splits, (int64_t)S * d->Cin * d->Cout, grad_oihw, S, d->Cin, d->Cout, O, I, co_off, accumulate, job);
+}
+
+extern "C" int rd_wgrad_reduce_batched(const RdReduceJob* jobs_dev, const int32_t* block_job1_dev, int32_t n_blocks1,
+                                       const int32_t* block_job2_dev, int32_t n_blocks2, void* stream) {
+    RD_CHECK_ARG(jobs_dev && (n_blocks1 == 0 || block_job1_dev) && (n_blocks2 == 0 || block_job2_dev), "wgrad_reduce_batched: null argument");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (n_blocks1 > 0) {
+        hipLaunchKernelGGL(wgrad_reduce1_batched_kernel, dim3(n_blocks1), dim3(256), 0, s, jobs_dev, block_job1_dev);
+        RD_CHECK_LAUNCH("wgrad_reduce1_batched_kernel");
+    }
+    if (n_blocks2 > 0) {
+        hipLaunchKernelGGL(wgrad_reduce2_batched_kernel, dim3(n_blocks2), dim3(256), 0, s, jobs_dev, block_job2_dev);
+        RD_CHECK_LAUNCH("wgrad_reduce2_batched_kernel");
+    }
+    return RD_OK;
 }

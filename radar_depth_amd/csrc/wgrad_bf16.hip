@@ -495,3 +495,14 @@ extern "C" int rd_wgrad_bf16_reduce(const RdConvDesc* d, const float* slabs, flo
     return launch_slab_reduce(slabs, pl.slab_splits, E, tmp, grad_oihw, pl.S, d->Cin, d->Cout, O, I, co_off, accumulate,
                               static_cast<hipStream_t>(stream));
 }
+
+// shape of this descriptor's slab reduction (rd_wgrad_reduce_job, wgrad.hip)
+namespace rd {
+bool wgrad_bf16_reduce_shape(const RdConvDesc* d, int* slab_splits, int* S) {
+    WgradBfPlan pl;
+    if (!wgrad_bf16_plan(d, pl)) return false;
+    *slab_splits = pl.slab_splits;
+    *S = pl.S;
+    return true;
+}
+}  // namespace rd

@@ -127,6 +127,15 @@ class LateFusionPlan:
         self.Ho, self.Wo = getattr(module, "output_size", (height, width))
         self.generation = 0    # bumped by every forward: autograd nodes of an earlier forward must not read this plan's buffers
         self._optable = None   # prep + fwd + bwd marshalled once for rd_optable_run (see run_list)
+        # RD_WGRAD_REDUCE_BATCH=n: at most n slab reductions per rd_wgrad_reduce_batched launch pair (flushed earlier at every bucket
+        # boundary); 0: one rd_wgrad_reduce per weight tensor right behind its rd_wgrad, as in round 2
+        # Default: unbatched for fp32 storage -- measured at b=16 450x800 (profiles/r03_reduce_batch.txt): 759.6 samples/s unbatched,
+        # 757.1 / 753.6 / 753.7 with batches of 4 / 8 / a whole segment: the per-tensor reductions run hidden beside the MFMA-bound
+        # kernels of the other streams, a batch at the end of a segment is a serial tail
+        self.reduce_batch_max = int(os.environ.get("RD_WGRAD_REDUCE_BATCH", "0"))
+        self.batch_reduces = self.reduce_batch_max > 0
+        self._pending_reduces, self.reduce_batches = {}, []
+        self.table_pins = 0    # descriptors whose plan came from the offline-tuned table
         self._build()
 
     def close(self):
@@ -201,9 +210,14 @@ class LateFusionPlan:
     def _tune(self, d):
         """fp32 gconv descriptors only (the bf16 kernels have their own planner); must run before the descriptor's statistics
         tiles / workspace are sized, because both depend on the plan."""
-        if self.autotune and not self.dry_run and not self.bf16:
-            from . import autotune as _at
+        if self.dry_run or self.bf16:
+            return
+        from . import autotune as _at
+        if self.autotune:
             _at.tune_gconv(self.L, d, self.dev)
+        else:
+            # offline-tuned plan table (radar_depth_amd/tuned_plans.json): a deterministic lookup, identical on every rank
+            self.table_pins += 1 if _at.pin_from_table(self.L, d) else 0
 
     def _gconv_ws(self, d, name):
         """Split-K workspace of a descriptor (None when the library's plan does not split)."""
@@ -294,8 +308,16 @@ class LateFusionPlan:
                 self.meta[name + ".wgrad"] = (fam, dwd)
                 for w, off in sorted(ctx["weights"], key=lambda t: t[1]):
                     o, i, kh, kw = w.shape
-                    self.op(self.bwd, name + ".wreduce", f_reduce, C.byref(dwd), _p(ws), _p(self.grad_of(w)), o, i, kh, kw,
-                            off, 0, self.stream)
+                    if self.batch_reduces:
+                        # the slab reductions are not needed before the segment's bucket boundary: they are collected per
+                        # stream and issued as ONE batched launch pair at the end of the segment (_flush_reduces)
+                        self._pending_reduces.setdefault(self.streams.index(self._s), []).append(
+                            (name, dwd, 1 if wg_bf16 else 0, ws, self.grad_of(w), o, i, kh, kw, off))
+                    else:
+                        self.op(self.bwd, name + ".wreduce", f_reduce, C.byref(dwd), _p(ws), _p(self.grad_of(w)), o, i, kh, kw,
+                                off, 0, self.stream)
+                if self.batch_reduces and len(self._pending_reduces.get(self.streams.index(self._s), [])) >= self.reduce_batch_max:
+                    self._flush_reduces(only=self.streams.index(self._s))
 
         # the weight-gradient chain is forked BEHIND the dgrad launch rather than beside it: both are MFMA-bound and gain nothing
         # from running together, whereas behind the dgrad the wgrad overlaps the memory-bound BatchNorm kernels that follow
@@ -330,6 +352,34 @@ class LateFusionPlan:
         if late:
             launch_wgrad()
         return dx
+
+    def _flush_reduces(self, only=None):
+        """Emit the pending weight-gradient slab reductions of every stream as one rd_wgrad_reduce_batched op each (two launches:
+        the first stage of the many-split layers, then every OIHW gradient).  Called at bucket boundaries, before the streams'
+        segment-end events / joins."""
+        import numpy as np
+        from ._lib import RdReduceJob
+        for k in sorted(self._pending_reduces):
+            jobs = self._pending_reduces[k]
+            if not jobs or (only is not None and k != only):
+                continue
+            self._pending_reduces[k] = []
+            arr = (RdReduceJob * len(jobs))()
+            bj1, bj2 = [], []
+            for q, (name, dwd, is_bf16, ws, grad, o, i, kh, kw, off) in enumerate(jobs):
+                check(self.L.rd_wgrad_reduce_job(C.byref(dwd), is_bf16, _p(ws), _p(grad), o, i, kh, kw, off, 0, C.byref(arr[q])),
+                      "rd_wgrad_reduce_job(%s)" % name)
+                arr[q].first_block1, arr[q].first_block2 = len(bj1), len(bj2)
+                bj1 += [q] * arr[q].n_blocks1
+                bj2 += [q] * arr[q].n_blocks2
+            table = torch.from_numpy(np.frombuffer(bytes(arr), dtype=np.uint8).copy()).to(self.dev)
+            t1 = torch.tensor(bj1 or [0], dtype=torch.int32, device=self.dev)
+            t2 = torch.tensor(bj2, dtype=torch.int32, device=self.dev)
+            self.keep += [table, t1, t2]
+            with self.on(k):
+                self.op(self.bwd, "segment%d.s%d.b%d.wreduce_all" % (len(self.bwd_segments) if hasattr(self, "bwd_segments") else 0, k, len(self.reduce_batches)),
+                        self.L.rd_wgrad_reduce_batched, _p(table), _p(t1), len(bj1), _p(t2), len(bj2), self.stream)
+            self.reduce_batches.append((len(self.bwd_segments) if hasattr(self, "bwd_segments") else 0, k, [j[0] for j in jobs]))
 
     # ------------------------------------------------------------------ inference: conv + folded BatchNorm (+ReLU, +residual)
     def conv_bn_eval(self, name, x, parts, k, stride, pad, act, act_cols=None, addend=None, out=None, upproj=False):
@@ -727,6 +777,7 @@ class LateFusionPlan:
 
         def end_segment(prefixes, last=False):
             evs = []
+            self._flush_reduces()
             if last or self.segment_joins:
                 self.edge(self.bwd, "join1", 1, 0)
                 self.edge(self.bwd, "join2", 2, 0)
@@ -877,6 +928,7 @@ class ModulePlan(LateFusionPlan):
         self._finish_pack_jobs()
         self.dy = self.act(self.y.N, self.y.H, self.y.W, self.y.C)
         self.dx = back(ctx, self.dy)
+        self._flush_reduces()
         self.edge(self.bwd, "join1", 1, 0)
         self.edge(self.bwd, "join2", 2, 0)
 

@@ -125,6 +125,27 @@ def wgrad_reduce(desc, slabs, grad_oihw, co_off=0, accumulate=False):
     return grad_oihw
 
 
+def wgrad_reduce_batched(jobs):
+    """jobs: [(desc, slabs, grad_oihw, co_off)] (fp32 rd_wgrad slabs) reduced by ONE rd_wgrad_reduce_batched call (two launches)."""
+    import numpy as np
+    from ._lib import RdReduceJob
+    arr = (RdReduceJob * len(jobs))()
+    bj1, bj2 = [], []
+    for q, (desc, slabs, grad, co_off) in enumerate(jobs):
+        o, i, kh, kw = grad.shape
+        check(lib().rd_wgrad_reduce_job(C.byref(desc), 0, ptr(slabs), ptr(_f32(grad)), o, i, kh, kw, co_off, 0, C.byref(arr[q])), "rd_wgrad_reduce_job")
+        arr[q].first_block1, arr[q].first_block2 = len(bj1), len(bj2)
+        bj1 += [q] * arr[q].n_blocks1
+        bj2 += [q] * arr[q].n_blocks2
+    dev = jobs[0][1].device
+    table = torch.from_numpy(np.frombuffer(bytes(arr), dtype=np.uint8).copy()).to(dev)
+    t1 = torch.tensor(bj1 or [0], dtype=torch.int32, device=dev)
+    t2 = torch.tensor(bj2, dtype=torch.int32, device=dev)
+    check(lib().rd_wgrad_reduce_batched(ptr(table), ptr(t1), len(bj1), ptr(t2), len(bj2), current_stream()), "rd_wgrad_reduce_batched")
+    torch.cuda.current_stream().synchronize()          # the tables are temporaries
+    return len(bj1), len(bj2)
+
+
 # ---- BatchNorm / activation helpers (used by the unit tests; the engine calls the C ABI directly)
 def bn_stats(x2d, C_):
     """x2d: [M, ld] view (ld >= C_).  Returns (partial [tiles,2,C], tiles)."""

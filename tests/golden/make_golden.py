@@ -305,6 +305,24 @@ def block_case(models):
     return out
 
 
+def block16_case(models):
+    """The depth encoder's layer1 block (models.py:567: BasicBlock(16, 16), identity residual) on a map that is not a multiple of the
+    16x16-pixel tiles the 16-channel kernels use: pins conv16 / wgrad16 behind the reference WITH their BatchNorm joins."""
+    out = {}
+    g = torch.Generator().manual_seed(29)
+    m = models.BasicBlock(16, 16, 1, None)
+    procedural_fill_(m)
+    m.train()
+    x = torch.randn(2, 16, 19, 37, generator=g).requires_grad_(True)
+    y = m(x)
+    gy = torch.randn(y.shape, generator=g)
+    y.backward(gy)
+    out.update({"id16/x": _np(x), "id16/y": _np(y), "id16/gy": _np(gy), "id16/gx": _np(x.grad)})
+    for n, p in m.named_parameters():
+        out["id16/grad/" + n] = _np(p.grad)
+    return out
+
+
 def main():
     _install_shims()
     from model import models, multistage_model as mm
@@ -332,6 +350,7 @@ def main():
     np.savez_compressed(os.path.join(HERE, "units.npz"), **unit_cases(mm, crit_mod))
     np.savez_compressed(os.path.join(HERE, "upproj_module.npz"), **upproj_case(models))
     np.savez_compressed(os.path.join(HERE, "basic_block.npz"), **block_case(models))
+    np.savez_compressed(os.path.join(HERE, "basic_block16.npz"), **block16_case(models))
     for f in sorted(os.listdir(HERE)):
         if f.endswith(".npz"):
             print(f, os.path.getsize(os.path.join(HERE, f)))

@@ -181,3 +181,25 @@ def test_every_kernel_barrier_goes_through_rd_sync():
     common = open(os.path.join(root, "common.h")).read()
     assert re.search(r"void rd_sync\(\)\s*\{\s*asm volatile\(\"s_waitcnt lgkmcnt\(0\)\"[^;]*;\s*__syncthreads\(\);", common)
     assert 'asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)"' in common          # glds_wait
+
+
+def test_no_kernel_spills_vector_registers():
+    """ISA audit: no kernel of the library spills VGPRs to scratch (round 2: the input-parity-group instantiations of
+    gconv_kernel spilled 40-65 VGPRs -- 264 B of scratch per lane inside the stride-2 convolutions).  Reads hipcc's
+    -Rpass-analysis=kernel-resource-usage report that radar_depth_amd/build.py keeps next to every object."""
+    import importlib.util
+    from radar_depth_amd.build import OBJ, build
+    build(verbose=False)
+    spec = importlib.util.spec_from_file_location("audit_resources", os.path.join(REPO, "tools", "audit_resources.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    n, bad = 0, []
+    for f in sorted(os.listdir(OBJ)):
+        if not f.endswith(".resource.txt"):
+            continue
+        for name, r in mod.parse(os.path.join(OBJ, f)):
+            n += 1
+            if r.get("VGPRs Spill", 0) > 0 or r.get("ScratchSize [bytes/lane]", 0) > 0:
+                bad.append((f, name, r.get("VGPRs Spill", 0), r.get("ScratchSize [bytes/lane]", 0)))
+    assert n > 150, "resource reports missing (%d kernels seen): rebuild with python -m radar_depth_amd.build --force" % n
+    assert not bad, bad

@@ -329,15 +329,15 @@ def test_config3_per_gpu_workload_b16_450x800_bf16_storage():
     assert all(torch.isfinite(p).all() for p in hm.parameters())
 
 
-def test_config5_geometry_multistage_900x1600_bf16_storage():
-    """BASELINE configs[4]'s network and geometry (multistage_uncertainty_fixs, 900x1600) under bf16 storage, b=2: the four loss
-    terms of the fused step against the oracle with the plan's rounding points (2e-3); stage-1 map to the chaos floor; finite
-    parameters after the update.  (The per-GPU batch of 8 is what `bench.py --arch ... --batch 8 --height 900 --width 1600
-    --storage bf16` runs: 244 samples/s.)"""
+@pytest.mark.parametrize("b", [2, 8])
+def test_config5_geometry_multistage_900x1600_bf16_storage(b):
+    """BASELINE configs[4]'s network and geometry (multistage_uncertainty_fixs, 900x1600) under bf16 storage, at b=2 and at the
+    configuration's own per-GPU batch b=8 (what `bench.py --config 5` runs): the four loss terms of the fused step against the
+    oracle with the plan's rounding points (2e-3); stage-1 map to the chaos floor; finite parameters after the update."""
     from oracle import train as otrain
     from radar_depth_amd.main import HipTrainStep
     from radar_depth_amd.synthetic import make_batch
-    b, h, w = 2, 900, 1600
+    h, w = 900, 1600
     args, hm, hw_, om, ow = _pair("resnet18_multistage_uncertainty_fixs", h, w)
     assert _emulate_bf16_storage(om) == 104
     x, t = make_batch(b, h, w, 4321)
@@ -354,3 +354,33 @@ def test_config5_geometry_multistage_900x1600_bf16_storage():
     print("config 5 geometry, bf16 storage: losses %.3e  stage-1 map max %.3e" % (e_loss, e1))
     assert e_loss < 2e-3 and e1 < 0.15
     assert all(torch.isfinite(p).all() for p in hm.parameters())
+
+
+def test_bf16_storage_loss_trajectory_vs_fp32_oracle_450x800():
+    """A bf16 check whose expectation does NOT pass through tests/bf16_emulation.py: three SGD steps of resnet18_latefusion at
+    450x800 (b=2) under bf16 storage against the plain fp32 CPU oracle (pinned to the reference by the golden vectors) taking
+    the same three steps with torch.optim.SGD.  Stated band: every step's loss within 1e-2 relative of the fp32 oracle's --
+    the pixel-averaged quantity is well conditioned (bf16 storage rounds each stored tensor to 2^-9 relative; the masked-L1
+    mean over ~6000 valid pixels averages that down), whereas individual pixels of the quantised network are chaotic
+    (tests/test_conditioning.py).  A rounding point misplaced in BOTH the kernels and the emulation would pass the emulated
+    tests and fail here."""
+    from oracle import train as otrain
+    from radar_depth_amd.main import HipTrainStep
+    from radar_depth_amd.synthetic import make_batch
+    b, h, w = 2, 450, 800
+    args, hm, hw_, om, ow = _pair("resnet18_latefusion", h, w)
+    crit = otrain.make_criterion(args.arch)
+    opt = torch.optim.SGD(om.parameters(), 0.01, momentum=0.9, weight_decay=1e-4)
+    ts = HipTrainStep(hm, b, h, w, lr=0.01, momentum=0.9, weight_decay=1e-4, storage="bf16")
+    got, want = [], []
+    for it in range(3):
+        x, t = make_batch(b, h, w, 5150 + it)
+        lo, _, _ = otrain.train_step(args.arch, om, crit, opt, x, t, ow)
+        loss, _ = ts.step(x.cuda(), t.cuda())
+        torch.cuda.synchronize()
+        got.append(loss.item())
+        want.append(lo.item())
+    errs = [abs(g - w_) / abs(w_) for g, w_ in zip(got, want)]
+    print("bf16 storage vs fp32 oracle, 3 steps at 450x800: losses", got, want, "rel", errs)
+    assert max(errs) < 1e-2, (got, want)
+    assert got != want                      # it is the bf16 path that ran

@@ -430,3 +430,25 @@ def test_eager_multistage_forward_backward_is_bitwise_reproducible():
             assert all(torch.equal(a_, b_) for a_, b_ in zip(ref, cur)), "repetition %d differs" % it
         junk = [torch.empty(int(1e6 * (1 + (it * 7 + k) % 5)), device="cuda") for k in range(3)]      # shuffle the allocator
         del junk
+
+
+@pytest.mark.parametrize("storage", ["fp32", "bf16"])
+def test_batched_slab_reductions_step_is_bit_identical(monkeypatch, storage):
+    """RD_WGRAD_REDUCE_BATCH=4 (rd_wgrad_reduce_batched: the slab reductions of several weight tensors in two launches) against the
+    default one-reduction-per-tensor plan: same summation order, so three training steps end in bit-identical parameters."""
+    from radar_depth_amd.main import HipTrainStep
+    from radar_depth_amd.synthetic import make_batch
+    b, h, w = 2, 97, 161
+    runs = []
+    for batch in ("0", "4"):
+        monkeypatch.setenv("RD_WGRAD_REDUCE_BATCH", batch)
+        m = build(h, w)
+        ts = HipTrainStep(m, b, h, w, storage=storage)
+        assert bool(ts.plan.reduce_batches) == (batch != "0")
+        for it in range(3):
+            x, t = make_batch(b, h, w, 700 + it, ref_pixels=h * w)
+            ts.step(x.cuda(), t.cuda())
+        torch.cuda.synchronize()
+        runs.append([p.detach().clone() for p in m.parameters()])
+    for p, q in zip(*runs):
+        assert torch.equal(p, q)

@@ -82,3 +82,39 @@ def test_wgrad_upproj(c, h, w):
     torch.cuda.synchronize()
     assert _rel(g_up.cpu(), wcat.grad[:c // 2]) < 5e-5
     assert _rel(g_bt.cpu(), wcat.grad[c // 2:]) < 5e-5
+
+
+def test_wgrad_reduce_batched_is_bit_identical():
+    """rd_wgrad_reduce_batched (all slab reductions of a backward segment in two launches) against one rd_wgrad_reduce per weight
+    tensor: same summation order, hence the same bits -- a many-split layer (two-stage reduction), a few-split layer (stage 2
+    reads the slabs), the 16-channel kernel's slabs, and an UpProj pair (two column ranges of one slab set)."""
+    from radar_depth_amd import convdesc as cd, ops
+    g = torch.Generator().manual_seed(5)
+    jobs, want = [], []
+    for n, ci, co, k, s, p, h, w in [(4, 64, 64, 3, 1, 1, 113, 200), (2, 512, 512, 3, 1, 1, 15, 25), (4, 16, 16, 3, 1, 1, 113, 200),
+                                     (2, 64, 128, 1, 2, 0, 113, 200)]:
+        d = cd.conv_fwd(n, h, w, ci, co, k, s, p)
+        x = torch.randn(n, h, w, ci, generator=g).cuda()
+        gy = torch.randn(n, d.Ho, d.Wo, co, generator=g).cuda()
+        slabs = torch.empty(ops.wgrad_workspace_floats(d), device="cuda")
+        ops.wgrad(d, x, gy, slabs)
+        ref = torch.empty(co, ci, k, k, device="cuda")
+        ops.wgrad_reduce(d, slabs, ref)
+        jobs.append((d, slabs, torch.full((co, ci, k, k), float("nan"), device="cuda"), 0))
+        want.append(ref)
+    c, h, w = 64, 60, 100
+    d = cd.upproj_fwd(2, h, w, c, c)
+    x = torch.randn(2, h, w, c, generator=g).cuda()
+    gy = torch.randn(2, 2 * h, 2 * w, c, generator=g).cuda()
+    slabs = torch.empty(ops.wgrad_workspace_floats(d), device="cuda")
+    ops.wgrad(d, x, gy, slabs)
+    for off in (0, c // 2):
+        ref = torch.empty(c // 2, c, 5, 5, device="cuda")
+        ops.wgrad_reduce(d, slabs, ref, co_off=off)
+        jobs.append((d, slabs, torch.full((c // 2, c, 5, 5), float("nan"), device="cuda"), off))
+        want.append(ref)
+    nb1, nb2 = ops.wgrad_reduce_batched(jobs)
+    torch.cuda.synchronize()
+    assert nb1 > 0 and nb2 > 0
+    for (_, _, got, _), ref in zip(jobs, want):
+        assert torch.equal(got, ref)

@@ -56,6 +56,25 @@ def test_dry_run_plan_structure():
 
 
 
+def test_batched_slab_reductions(monkeypatch):
+    """RD_WGRAD_REDUCE_BATCH=n: the slab reductions become rd_wgrad_reduce_batched ops of at most n jobs per stream, each issued
+    inside the backward segment whose gradient bucket its tensors belong to (never behind the bucket boundary)."""
+    from radar_depth_amd.engine import LateFusionPlan
+    monkeypatch.setenv("RD_WGRAD_REDUCE_BATCH", "4")
+    m = _model()
+    plan = LateFusionPlan(m, 2, 97, 161, train=True, dry_run=True)
+    names = [n for n, _, _ in plan.bwd]
+    n_w = sum(1 for n, p in m.named_parameters() if p.dim() == 4)
+    assert not any(n.endswith(".wreduce") for n in names)
+    assert sum(len(jobs) for _, _, jobs in plan.reduce_batches) + 2 + 1 == n_w      # + two stems + conv3 (own kernels)
+    assert sum(1 for n in names if n.endswith(".wreduce_all")) == len(plan.reduce_batches) < n_w // 2
+    for b, (seg, stream, jobs) in enumerate(plan.reduce_batches):
+        prefixes = plan.bwd_segments[seg][2]
+        assert all(j.split(".")[0] in prefixes for j in jobs) and 1 <= len(jobs) <= plan.reduce_batch_max + 1, (seg, jobs)      # (an UpProj pair adds two jobs at once)
+        op = "segment%d.s%d.b%d.wreduce_all" % (seg, stream, b)
+        assert plan.bwd_segments[seg][0] <= names.index(op) < plan.bwd_segments[seg][1]
+
+
 def _dp_worker(rank, world, port, q):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     torch.distributed.init_process_group("gloo", rank=rank, world_size=world)
