@@ -91,6 +91,17 @@ int64_t rd_gconv_workspace_floats(const RdConvDesc* d);
 int rd_gconv_stat_tiles_ws(const RdConvDesc* d);
 int rd_gconv_ws(const RdConvDesc* d, const float* in, const float* w_packed, float* out,
                 const float* addend, int32_t ld_add, float* stat_partial, float* ws, void* stream);
+/* Input gradient with the BatchNorm-backward sums in its epilogue.  For the chains conv -> BatchNorm -> ReLU -> conv
+ * (models.py:96-112 BasicBlock conv1/bn1/relu/conv2; :203-206 UpProj conv1/batchnorm1/relu/conv2) the gradient dy that the second
+ * convolution's dgrad produces is exactly what the first BatchNorm's backward reduces: g = dy * act'(scale*x + shift),
+ * red_partial[tile][0][c] = sum g, red_partial[tile][1][c] = sum g * (x - mean) over the launch's pixel tiles
+ * (rd_gconv_stat_tiles_ws(d) tiles, layout [tiles][3][Cout], slot 2 untouched) -- the layout rd_bn_bwd_apply_x_t reads.  Saves the
+ * rd_bn_bwd_reduce_x_t pass over (dy, x) and its launch.  rd_gconv_bnbwd_supported: 1 when the descriptor's plan can do it
+ * (single phase, unit output stride, no split-K, not the 16-channel kernel). */
+int rd_gconv_bnbwd_supported(const RdConvDesc* d);
+int rd_gconv_bnbwd(const RdConvDesc* d, const float* dout, const float* w_packed, float* dx, const float* bn_x, int32_t ld_x,
+                   const float* bn_mean, const float* bn_scale, const float* bn_shift, int32_t act, float* red_partial, float* ws,
+                   void* stream);
 /* Inference form (validate() body main.py:564-595):
  *   out = act_{co < act_cols}( conv(in, w) + bias[co] + addend )
  * with the eval-mode BatchNorm folded in: scale into the packed weights, shift = bias.  bias / addend / ws may be NULL. */
@@ -441,7 +452,8 @@ int rd_head_conv_bwd_t(int32_t dtype, const void* x, int32_t ldx, const float* w
                        int32_t W, int32_t C, void* dx, int32_t lddx, float* dw_oihw, float* ws, void* stream);
 
 /* Plan tuner for rd_gconv / rd_gconv_ws (the role cudnn.benchmark plays for the reference's convolutions): list the candidate
- * execution plans of a descriptor (9 ints each: MT, NT, WM, WN, CKP, TH, TW, ksplit, pipelined; best heuristic score first; returns
+ * execution plans of a descriptor (9 ints each: MT, NT, WM, WN, CKP, TH, TW, ksplit, loop form -- 0 plain, 1 software-pipelined,
+ * 2 pipelined with half-depth weight slabs (more resident workgroups, more barriers); best heuristic score first; returns
  * the count), pin one -- every later call with that descriptor, workspace / statistics-tile queries included, uses it -- or pin
  * NULL to return to the heuristic.  The caller times rd_gconv_ws under each pinned candidate (radar_depth_amd/autotune.py).
  * allow_split: 1 for the rd_gconv_ws form (with workspace), 0 for rd_gconv. */

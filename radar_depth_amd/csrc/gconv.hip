@@ -22,6 +22,7 @@
 #include <algorithm>
 #include <mutex>
 #include <string>
+#include <type_traits>
 #include <unordered_map>
 #include <vector>
 
@@ -61,6 +62,15 @@ struct GconvArgs {
     int g_ntaps[4], g_oh[4], g_ow[4], g_tbase[4];
     int g_sh_max, g_sw_max;      // largest sub-patch tap offset over all groups (sub-patch = (TH + sh_max) x (TW + sw_max))
     short g_widx[32];            // weight slab index of every tap, groups concatenated (g_tbase)
+    // BatchNorm-backward sums from the epilogue (rd_gconv_bnbwd): this launch is the input gradient dy of act(s*x + t) -- the
+    // BatchNorm that PRODUCED this convolution's forward input.  The epilogue then reads x at its output pixels and emits, per
+    // pixel tile, sum g and sum g*(x - mean) with g = dy * act'(s*x + t) into `stat` (layout [tiles][3][Cout], slots 0 and 1): the
+    // separate reduce pass over (dy, x) and its launch go away (bn_bwd_reduce_kernel, csrc/norm_act.hip).
+    const float* bnb_x;
+    const float* bnb_mean;
+    const float* bnb_scale;
+    const float* bnb_shift;
+    int bnb_ld, bnb_act;
     int lds_floats;              // floats of LDS in use before the trace stamps
     unsigned long long* trace;   // diagnostics (RD_GCONV_TRACE=1): per-workgroup cycle-counter stamps, 64 per workgroup
     int debug;         // ablation bits (RD_GCONV_DEBUG env): 1 skip patch staging, 2 skip weight staging, 4 skip MFMA loop
@@ -68,7 +78,8 @@ struct GconvArgs {
 
 // GRP: the descriptor runs as input-parity groups (GconvArgs::ngroups).  A template parameter, not a run-time flag: the large
 // register tiles sit exactly at 256 registers and the group bookkeeping as run-time state made the ordinary kernels spill (67 VGPRs).
-template <int MT, int NT, int WM, int WN, int CKW, bool SWZ, bool PIPE, bool GRP = false>
+// BNB: the epilogue also emits BatchNorm-backward sums (GconvArgs::bnb_x; rd_gconv_bnbwd).  A template parameter for the same reason.
+template <int MT, int NT, int WM, int WN, int CKW, bool SWZ, bool PIPE, bool GRP = false, bool BNB = false>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MT * NT <= 6 ? 2 : 1))) void gconv_kernel(const GconvArgs a) {
     static_assert(!(GRP && SWZ), "input-parity groups use the padded patch layout");
     constexpr int BM = WM * MT * 32;
@@ -86,6 +97,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MT * NT <= 
     if (a.trace && tid == 0 && n_stamp < 63) s_stamp[n_stamp++] = __builtin_readcyclecounter();
     RD_STAMP()
     const unsigned long long rt0 = a.trace ? __builtin_amdgcn_s_memrealtime() : 0;   // 100 MHz constant clock
+    // diagnostics (RD_GCONV_DEBUG bit 8, delay in units of 6.4k cycles in bits 8..15): hold back the workgroups that sit in odd
+    // thread-group slots of their CU, so that the two resident workgroups do not run their chunk loops in lockstep
+    if (a.debug & 8) {
+        const unsigned hw = __builtin_amdgcn_s_getreg((31 << 11) | 4);       // HW_REG_HW_ID: tg_id in bits 19:16
+        if ((hw >> 16) & 1)
+            for (int i = 0; i < ((a.debug >> 8) & 255); ++i) __builtin_amdgcn_s_sleep(100);
+    }
     const int vid0 = xcd_remap(blockIdx.x, gridDim.x);
     const int ksl = vid0 % a.ksplit;              // split-K slice (slices of one tile are neighbours: same XCD, shared patch)
     const int vid = vid0 / a.ksplit;
@@ -260,6 +278,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MT * NT <= 
         // registers, no LDS-write pass); the next chunk's patch is loaded into registers while the last slab of the current
         // chunk is in the matrix cores.  Per-element addresses are computed once per workgroup, so a chunk issues ~50 VALU
         // instructions for its staging instead of ~900 (they would queue behind the co-resident workgroup's MFMAs).
+        // (Round 3 also ran the input-parity groups through this pipeline as ONE flat (group, chunk, slab) sequence -- next group's
+        //  first slab and patch fetched under the last slab of the current one.  Parity-green, no gain: the exposed restart moved
+        //  from the staging stamps into the MFMA stamps, stride-2 forward 140 -> 138.5 us, UpProj input gradients 3-6 % slower:
+        //  the co-resident workgroups run in lockstep, so it is the barrier / LDS-write phases that are exposed, not the fetch.)
         constexpr int UPP = MT * NT >= 4 ? 8 : 4, UWP = 7;      // (a six-load form that pipelines the 2x1 tile's 256-pixel patch measured 4-7 % slower than its plain loop: round 3)
         const int welems = ntaps * W4 * BN;
         const int slab_bytes = a.taps_max * WSD * BN * 4;
@@ -464,8 +486,20 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MT * NT <= 
     bool cok[NT];
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) cok[nt] = cob + nt * 32 < D.Cout;
+    // BatchNorm-backward sums (see GconvArgs::bnb_x): a lane owns one channel per N-tile, so the coefficients are lane constants
+    constexpr bool bnb = BNB;
+    float bnS[NT], bnT[NT], bnM[NT];
 #pragma unroll
-    for (int mt = 0; mt < MT; ++mt) {
+    for (int nt = 0; nt < NT; ++nt) {
+        const bool on = bnb && cok[nt];
+        bnS[nt] = on ? a.bnb_scale[cob + nt * 32] : 0.f;
+        bnT[nt] = on ? a.bnb_shift[cob + nt * 32] : 0.f;
+        bnM[nt] = on ? a.bnb_mean[cob + nt * 32] : 0.f;
+    }
+    // (one M-tile per call of a generic lambda with a compile-time index: with the BatchNorm-backward sums in the body the
+    //  `#pragma unroll` form of this loop was no longer unrolled for the 3x2 tile -- the accumulators must stay statically indexed)
+    auto epilogue_tile = [&](auto MTC) {
+        constexpr int mt = decltype(MTC)::value;
         __builtin_amdgcn_sched_barrier(0);   // keep one M-tile's row offsets / addends live at a time
         int ro[16];
         bool rows_ok = true;
@@ -479,11 +513,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MT * NT <= 
             // kernel past 256 registers (arch + accumulation), which would halve the waves per SIMD
 #pragma unroll
             for (int h8 = 0; h8 < 16; h8 += 8) {
-                float addv[NT][8];
-                if (has_add) {
+                float addv[NT][8];       // the residual-gradient addend, or (bnb) the BatchNorm input x at the output pixels
+                if (has_add || bnb) {
+                    const float* const src = bnb ? a.bnb_x : a.addend;
+                    const int lds_ = bnb ? a.bnb_ld : a.ld_add;
 #pragma unroll
                     for (int i = 0; i < 8; ++i) {
-                        const float* ap = a.addend + (size_t)ro[h8 + i] * a.ld_add + cob;
+                        const float* ap = src + (size_t)ro[h8 + i] * lds_ + cob;
 #pragma unroll
                         for (int nt = 0; nt < NT; ++nt) addv[nt][i] = cok[nt] ? ap[nt * 32] : 0.f;
                     }
@@ -494,10 +530,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MT * NT <= 
 #pragma unroll
                     for (int nt = 0; nt < NT; ++nt) {
                         float v = acc[mt][nt][h8 + i];
-                        if (has_add) v += addv[nt][i];
+                        if (has_add && !bnb) v += addv[nt][i];
                         if (cok[nt]) rp[nt * 32] = v;
-                        ssum[nt] += v;
-                        ssq[nt] += v * v;
+                        if (bnb) {
+                            const float xv = addv[nt][i];
+                            const float g = v * act_grad_from_out(fmaf(bnS[nt], xv, bnT[nt]), a.bnb_act);
+                            ssum[nt] += g;
+                            ssq[nt] += g * (xv - bnM[nt]);
+                        } else {
+                            ssum[nt] += v;
+                            ssq[nt] += v * v;
+                        }
                     }
                 }
                 __builtin_amdgcn_sched_barrier(0);
@@ -515,13 +558,24 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MT * NT <= 
                         if (has_add) v += a.addend[(size_t)ro[i] * a.ld_add + co];
                         if (co < a.act_cols) v = act_fwd(v, a.act);
                         outp[(size_t)ro[i] * D.ldo + co] = v;
-                        ssum[nt] += v;
-                        ssq[nt] += v * v;
+                        if (bnb) {
+                            const float xv = a.bnb_x[(size_t)ro[i] * a.bnb_ld + co];
+                            const float g = v * act_grad_from_out(fmaf(bnS[nt], xv, bnT[nt]), a.bnb_act);
+                            ssum[nt] += g;
+                            ssq[nt] += g * (xv - bnM[nt]);
+                        } else {
+                            ssum[nt] += v;
+                            ssq[nt] += v * v;
+                        }
                     }
                 }
             }
         }
-    }
+    };
+    epilogue_tile(std::integral_constant<int, 0>{});
+    if constexpr (MT > 1) epilogue_tile(std::integral_constant<int, 1>{});
+    if constexpr (MT > 2) epilogue_tile(std::integral_constant<int, 2>{});
+    static_assert(MT <= 3, "epilogue covers up to three M-tiles");
     if (a.stat) {
         rd_sync();
         float* red = s_w;  // [WM][2][BN]
@@ -541,7 +595,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MT * NT <= 
 #pragma unroll
             for (int w = 0; w < WM; ++w) s += red[(w * 2 + which) * BN + j];
             const int co = co0 + j;
-            if (co < D.Cout) a.stat[((size_t)pt * 2 + which) * D.Cout + co] = s;
+            if (co < D.Cout) a.stat[((size_t)pt * (bnb ? 3 : 2) + which) * D.Cout + co] = s;
         }
     }
     RD_STAMP()
@@ -622,6 +676,8 @@ struct GconvPlan {
     int pipe;      // software-pipelined chunk loop (double-buffered weight slabs via global_load_lds)
     int grouped;   // input-parity groups (in_stride == 2, one phase): see GconvArgs::ngroups
     int c16;       // served by conv16.hip (16 -> 16 channels, 3x3, unit strides): 16 x 16 pixel tiles, no split, no workspace
+    int wsd_half;  // pipelined loop with half-depth weight slabs (tuner-only point: less LDS -> a third / fourth resident workgroup,
+                   // twice the barriers; layer4 3x3 270 -> 253 us, UpProj 128 207 -> 192 us, UpProj 256 211 -> 216 us)
 };
 
 // Input-parity decomposition of a single-phase in_stride == 2 descriptor.
@@ -670,9 +726,10 @@ static int pick_wsd(int taps_max, int BN, int CKW, int CKP, bool pipe = false) {
     while (w > CKW && (size_t)taps_max * w * BN * 4 > budget) w >>= 1;
     return w < CKW ? CKW : w;
 }
-static size_t lds_need(int BM, int BN, int CKW, int CKP, int PP, int taps_max, bool swz, bool pipe = false) {
+static size_t lds_need(int BM, int BN, int CKW, int CKP, int PP, int taps_max, bool swz, bool pipe = false, int wsd = 0) {
     // + one CKW quantum of slab rows and one patch pixel row of slack: the pipelined loop prefetches one step past the end
-    return (size_t)(2 * BM + 64) * 4 + ((size_t)taps_max * pick_wsd(taps_max, BN, CKW, CKP, pipe) * (pipe ? 2 : 1) + CKW) * BN * 4 +
+    if (wsd == 0) wsd = pick_wsd(taps_max, BN, CKW, CKP, pipe);
+    return (size_t)(2 * BM + 64) * 4 + ((size_t)taps_max * wsd * (pipe ? 2 : 1) + CKW) * BN * 4 +
             (size_t)(PP + 2) * (swz ? CKP : CKP + 4) * 4 + 64;
 }
 
@@ -731,9 +788,15 @@ static bool plan_gconv(const RdConvDesc& d, GconvPlan& best, bool allow_split = 
                 const bool pipe_ok = !nopipe && !(grouped && gnopipe) && PP * (ckp / 4) <= upp * 256 && taps_max * (wsd_p / 4) * BN <= 7 * 256;
                 // (a collecting search also lists the plain-loop form of a pipelinable point: the tuner found it faster for some
                 //  small launches)
-                for (int pv = pipe_ok ? 1 : 0; pv >= ((all && pipe_ok) ? 0 : (pipe_ok ? 1 : 0)); --pv) {
+                // (pv == 2: the pipelined loop with half-depth weight slabs -- listed for the tuner only)
+                for (int pv = pipe_ok ? (all ? 2 : 1) : 0; pv >= ((all && pipe_ok) ? 0 : (pipe_ok ? 1 : 0)); --pv) {
                 const bool pipe = pv != 0;
-                const size_t lds = lds_need(BM, BN, CKW, ckp, PP, taps_max, d.in_stride == 2 && !grouped, pipe);
+                int wsd_pt = pick_wsd(taps_max, BN, CKW, ckp, pipe);
+                if (pv == 2) {
+                    if (wsd_pt <= CKW) continue;
+                    wsd_pt >>= 1;
+                }
+                const size_t lds = lds_need(BM, BN, CKW, ckp, PP, taps_max, d.in_stride == 2 && !grouped, pipe, wsd_pt);
                 if (lds > 160 * 1024 - 512) continue;
                 const double m_util = (double)P.lh * P.lw / ((double)cdiv(P.lh, TH) * cdiv(P.lw, TW) * BM);
                 const double halo = grouped ? (double)PP / (TH * TW) : (double)PP / (TH * TW * d.in_stride * d.in_stride);
@@ -791,8 +854,8 @@ static bool plan_gconv(const RdConvDesc& d, GconvPlan& best, bool allow_split = 
                     score = base * (wgs / (ncu * ceil(wgs / ncu))) * (ksp == 1 ? 1.0 : (ksp == 2 ? p2 : p4)) *
                             (wgs < 2 * ncu && lds <= 80 * 1024 ? 0.9 : 1.0) *   // (a > 80 KB tile already paid for single residency)
                             phase_balance;
-                    const GconvPlan cand{c.MT, c.NT, c.WM, c.WN, CKW, ckp, TH, TW, PP, 0, n_cot, taps_max, pick_wsd(taps_max, BN, CKW, ckp, pipe), ksp, lds,
-                                         pipe ? 1 : 0, grouped ? 1 : 0};
+                    const GconvPlan cand{c.MT, c.NT, c.WM, c.WN, CKW, ckp, TH, TW, PP, 0, n_cot, taps_max, wsd_pt, ksp, lds,
+                                         pipe ? 1 : 0, grouped ? 1 : 0, 0, pv == 2 ? 1 : 0};
                     if (all) all->emplace_back(score, cand);
                     if (score > best_score) {
                         best_score = score;
@@ -806,10 +869,10 @@ static bool plan_gconv(const RdConvDesc& d, GconvPlan& best, bool allow_split = 
     return best_score > 0;
 }
 
-template <int MT, int NT, int WM, int WN, int CKW, bool SWZ, bool PIPE, bool GRP = false>
+template <int MT, int NT, int WM, int WN, int CKW, bool SWZ, bool PIPE, bool GRP = false, bool BNB = false>
 static int launch_cfg(const GconvArgs& a, int grid, size_t lds, hipStream_t s) {
     static bool attr_set = false;
-    auto k = gconv_kernel<MT, NT, WM, WN, CKW, SWZ, PIPE, GRP>;
+    auto k = gconv_kernel<MT, NT, WM, WN, CKW, SWZ, PIPE, GRP, BNB>;
     if (!attr_set) {
         RD_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr_set = true;
@@ -935,7 +998,7 @@ static int plan_query(const RdConvDesc* d, bool allow_split, GconvPlan& pl, RdCo
 // MT, NT, WM, WN, CKP, TH, TW, ksplit, pipelined.
 static bool same_point(const GconvPlan& p, const int32_t* c) {
     return p.MT == c[0] && p.NT == c[1] && p.WM == c[2] && p.WN == c[3] && p.CKP == c[4] && p.TH == c[5] && p.TW == c[6] && p.ksplit == c[7] &&
-           p.pipe == c[8];
+           p.pipe + p.wsd_half == c[8];
 }
 extern "C" int rd_gconv_tune_candidates(const RdConvDesc* d, int32_t allow_split, int32_t* out, int32_t max_candidates) {
     if (validate_desc(d) != RD_OK) return RD_EINVAL;
@@ -959,13 +1022,13 @@ extern "C" int rd_gconv_tune_candidates(const RdConvDesc* d, int32_t allow_split
         const GconvPlan& p = sp.second;
         bool dup = false;
         for (const GconvPlan& q : pick)
-            dup = dup || (q.MT == p.MT && q.NT == p.NT && q.CKP == p.CKP && q.ksplit == p.ksplit && q.pipe == p.pipe);
+            dup = dup || (q.MT == p.MT && q.NT == p.NT && q.CKP == p.CKP && q.ksplit == p.ksplit && q.pipe == p.pipe && q.wsd_half == p.wsd_half);
         if (!dup) pick.push_back(p);
     }
     int n = 0;
     for (const GconvPlan& p : pick) {
         if (n == max_candidates) break;
-        const int v[9] = {p.MT, p.NT, p.WM, p.WN, p.CKP, p.TH, p.TW, p.ksplit, p.pipe};
+        const int v[9] = {p.MT, p.NT, p.WM, p.WN, p.CKP, p.TH, p.TW, p.ksplit, p.pipe + p.wsd_half};
         for (int i = 0; i < 9; ++i) out[n * 9 + i] = v[i];
         ++n;
     }
@@ -1036,14 +1099,23 @@ extern "C" int rd_gconv_trace_read(unsigned long long* host, int n_wg) {
     return RD_OK;
 }
 
+struct BnBwdArgs { const float* x; int ld; const float* mean; const float* scale; const float* shift; int act; };
+
 static int gconv_impl(const RdConvDesc* d, const float* in, const float* w_packed, float* out, const float* addend,
                       int32_t ld_add, float* stat_partial, float* ws, void* stream, const float* bias = nullptr,
-                      int act = RD_ACT_NONE, int act_cols = 0) {
+                      int act = RD_ACT_NONE, int act_cols = 0, const BnBwdArgs* bnb = nullptr) {
     RD_CHECK_ARG(in && w_packed && out, "gconv: null tensor");
     GconvArgs a;
     GconvPlan pl;
     int rc = plan_lookup(d, ws != nullptr, pl, a.d);
     if (rc != RD_OK) return rc;
+    a.bnb_x = nullptr; a.bnb_mean = a.bnb_scale = a.bnb_shift = nullptr; a.bnb_ld = 0; a.bnb_act = RD_ACT_NONE;
+    if (bnb) {
+        RD_CHECK_ARG(!pl.c16 && pl.ksplit == 1 && d->in_stride == 1 && d->out_stride == 1 && d->n_phases == 1 && pl.CKW == 8,
+                     "gconv_bnbwd: needs a single-phase unit-stride descriptor of at most nine taps whose plan neither splits nor runs on the "
+                     "16-channel kernel (rd_gconv_bnbwd_supported)");
+        a.bnb_x = bnb->x; a.bnb_ld = bnb->ld; a.bnb_mean = bnb->mean; a.bnb_scale = bnb->scale; a.bnb_shift = bnb->shift; a.bnb_act = bnb->act;
+    }
     if (pl.c16) {
         if (!bias && act == RD_ACT_NONE) return launch_conv16(*d, in, w_packed, out, addend, ld_add, stat_partial, static_cast<hipStream_t>(stream));
         rc = plan_query(d, false, pl, a.d, true);      // inference form: bias / activation live in the 32x32 kernels' epilogue
@@ -1117,7 +1189,11 @@ static int gconv_impl(const RdConvDesc* d, const float* in, const float* w_packe
 #define RD_TRY(MT_, NT_, WM_, WN_)                                                                  \
     if (!launched && pl.MT == MT_ && pl.NT == NT_ && pl.WM == WM_ && pl.WN == WN_) {                \
         launched = true;                                                                            \
-        rc = pl.pipe ? RD_LAUNCH2(MT_, NT_, WM_, WN_, true) : RD_LAUNCH2(MT_, NT_, WM_, WN_, false);              \
+        if (a.bnb_x)                                                                                \
+            rc = pl.pipe ? launch_cfg<MT_, NT_, WM_, WN_, 8, false, true, false, true>(a, grid, lds_launch, s)    \
+                         : launch_cfg<MT_, NT_, WM_, WN_, 8, false, false, false, true>(a, grid, lds_launch, s);  \
+        else                                                                                        \
+            rc = pl.pipe ? RD_LAUNCH2(MT_, NT_, WM_, WN_, true) : RD_LAUNCH2(MT_, NT_, WM_, WN_, false);              \
     }
     const bool swz = d->in_stride == 2 && !pl.grouped;
     const size_t lds_launch = (size_t)a.lds_floats * 4 + (a.trace ? 512 : 0);
@@ -1156,4 +1232,21 @@ extern "C" int rd_gconv_ws(const RdConvDesc* d, const float* in, const float* w_
 extern "C" int rd_gconv_fused(const RdConvDesc* d, const float* in, const float* w_packed, float* out, const float* bias,
                               int32_t act, int32_t act_cols, const float* addend, int32_t ld_add, float* ws, void* stream) {
     return gconv_impl(d, in, w_packed, out, addend, ld_add, nullptr, ws, stream, bias, act, act_cols);
+}
+
+// Input gradient of a convolution whose forward input was act(BatchNorm(x)) (models.py:96-112: conv2 of a BasicBlock behind
+// bn1 + relu; :203-206: an UpProj module's 3x3 behind batchnorm1 + relu), with the BatchNorm-backward sums of THAT BatchNorm
+// taken in the epilogue: red_partial[tiles][3][Cout] receives sum g (slot 0) and sum g*(x - mean) (slot 1), g = dy * act'(scale*x
+// + shift), over each pixel tile (tiles = rd_gconv_stat_tiles_ws(d)); rd_bn_bwd_apply_x_t consumes it unchanged.
+extern "C" int rd_gconv_bnbwd_supported(const RdConvDesc* d) {
+    GconvPlan pl; RdConvDesc dd;
+    if (plan_query(d, true, pl, dd) != RD_OK) return 0;
+    return (!pl.c16 && pl.ksplit == 1 && d->n_phases == 1 && d->out_stride == 1 && d->in_stride == 1 && pl.CKW == 8) ? 1 : 0;
+}
+extern "C" int rd_gconv_bnbwd(const RdConvDesc* d, const float* dout, const float* w_packed, float* dx, const float* bn_x, int32_t ld_x,
+                              const float* bn_mean, const float* bn_scale, const float* bn_shift, int32_t act, float* red_partial,
+                              float* ws, void* stream) {
+    RD_CHECK_ARG(bn_x && bn_mean && bn_scale && bn_shift && red_partial, "gconv_bnbwd: null argument");
+    const BnBwdArgs b{bn_x, ld_x, bn_mean, bn_scale, bn_shift, act};
+    return gconv_impl(d, dout, w_packed, dx, nullptr, 0, red_partial, ws, stream, nullptr, RD_ACT_NONE, 0, &b);
 }

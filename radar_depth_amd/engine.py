@@ -136,6 +136,9 @@ class LateFusionPlan:
         self.batch_reduces = self.reduce_batch_max > 0
         self._pending_reduces, self.reduce_batches = {}, []
         self.table_pins = 0    # descriptors whose plan came from the offline-tuned table
+        # RD_FUSE_BN_BWD=0 (diagnostics): every BatchNorm backward runs its own reduce pass, as in round 2
+        self.fuse_bn_bwd = os.environ.get("RD_FUSE_BN_BWD", "1") == "1"
+        self.bnb_out = None
         self._build()
 
     def close(self):
@@ -267,8 +270,12 @@ class LateFusionPlan:
                    stat=stat, tiles=tiles, cin=cin, cout=cout)
         return out, ctx
 
-    def conv_bwd(self, ctx, dout, need_dx=True, addend=None, dx=None):
-        """Appends wgrad (+ reduce into the parameters' gradient views) and, optionally, dgrad.  Returns dx Act."""
+    def conv_bwd(self, ctx, dout, need_dx=True, addend=None, dx=None, bnb=None):
+        """Appends wgrad (+ reduce into the parameters' gradient views) and, optionally, dgrad.  Returns dx Act.
+        bnb = dict(x=raw BatchNorm input Act, co=its coefficient dict, act=activation): this convolution's forward input was
+        act(BatchNorm(x)); when the library can (fp32, unsplit plan) the dgrad launch also emits that BatchNorm's backward sums
+        (rd_gconv_bnbwd) and self.bnb_out = (red, tiles) tells the caller to skip its reduce pass; else self.bnb_out = None."""
+        self.bnb_out = None
         name, d, x = ctx["name"], ctx["d"], ctx["x"]
         N, H, W, cin, cout, k = x.N, x.H, x.W, ctx["cin"], ctx["cout"], ctx["k"]
         # wgrad uses the forward descriptor with dout's stride
@@ -341,14 +348,31 @@ class LateFusionPlan:
             if addend is not None:
                 raise NotImplementedError("addend with a zero-filled stride-2 dgrad")
         self.meta[name + ".dgrad"] = ("gconv_bf16" if self.bf16 else "gconv", dd)
+        # (bf16 plans keep the separate BatchNorm-backward reduce pass: the same fusion in gconv_bf16's epilogue -- parity-green in
+        #  round 3 -- made the bf16-storage step 5 % SLOWER, 1790 -> 1697 samples/s: that kernel's epilogue is already its longest
+        #  phase, and the extra x loads sit on it)
         if self.bf16:
             self.op(self.bwd, name + ".dgrad", self.L.rd_gconv_bf16_t, self.dt, C.byref(dd), dout.ptr, _p(ctx["wd"]), dx.ptr, C.c_void_p(0), 0, 0,
                     addend.ptr if addend is not None else C.c_void_p(0), addend.ld if addend is not None else 0,
                     C.c_void_p(0), self.stream)
         else:
-            self.op(self.bwd, name + ".dgrad", self.L.rd_gconv_ws, C.byref(dd), dout.ptr, _p(ctx["wd"]), dx.ptr,
-                    addend.ptr if addend is not None else C.c_void_p(0), addend.ld if addend is not None else 0,
-                    C.c_void_p(0), _p(self._gconv_ws(dd, name + ".dgrad")), self.stream)
+            ws_d = self._gconv_ws(dd, name + ".dgrad")      # (plans the descriptor: table pin / tuner first)
+            fuse = (bnb is not None and addend is None and not zero_fill and self.fuse_bn_bwd
+                    and self.L.rd_gconv_bnbwd_supported(C.byref(dd)) == 1)
+            if fuse:
+                # the BatchNorm behind this convolution's forward input takes its backward sums from this launch's epilogue:
+                # one pass over (dy, x) and one launch less per conv -> BN -> ReLU -> conv chain
+                tiles = self.L.rd_gconv_stat_tiles_ws(C.byref(dd))
+                red = self.buf(tiles, 3, dx.C)
+                xb, co = bnb["x"], bnb["co"]
+                assert xb.M == dx.M and xb.C == dx.C
+                self.op(self.bwd, name + ".dgrad", self.L.rd_gconv_bnbwd, C.byref(dd), dout.ptr, _p(ctx["wd"]), dx.ptr, xb.ptr, xb.ld,
+                        _p(co["mean"]), _p(co["scale"]), _p(co["shift"]), bnb["act"], _p(red), _p(ws_d), self.stream)
+                self.bnb_out = (red, tiles)
+            else:
+                self.op(self.bwd, name + ".dgrad", self.L.rd_gconv_ws, C.byref(dd), dout.ptr, _p(ctx["wd"]), dx.ptr,
+                        addend.ptr if addend is not None else C.c_void_p(0), addend.ld if addend is not None else 0,
+                        C.c_void_p(0), _p(ws_d), self.stream)
         if late:
             launch_wgrad()
         return dx
@@ -440,10 +464,16 @@ class LateFusionPlan:
         self.taps[name] = out
         return out
 
-    def bn_join_bwd(self, name, dy, y, act, x1, co1, x2=None, co2=None, dx2=None, lone=False):
+    def bn_join_bwd(self, name, dy, y, act, x1, co1, x2=None, co2=None, dx2=None, lone=False, pre=None):
         """Backward of out = act(bn1(x1) [+ bn2(x2) | + x2]).  Returns (dx1, dx2 or g-if-identity-residual).
         lone: out is act(bn1(x1)) with nothing added (callers with an identity residual pass x2=None too, hence the flag)."""
         M, Cc = x1.M, x1.C
+        if lone and x2 is None and act != ACT_NONE and pre is not None:
+            # the sums came out of the dgrad launch that produced dy (conv_bwd(..., bnb=...)): no reduce pass
+            red, tiles = pre
+            dx1 = self.act(x1.N, x1.H, x1.W, Cc)
+            self._bn_apply_x(name + ".bn1", dy, x1, red, tiles, co1, act, dx1)
+            return dx1, None
         tiles = self.L.rd_bn_bwd_tiles(C.c_int64(M))
         red = self.buf(tiles, 3, Cc)
         if lone and x2 is None and act != ACT_NONE:
@@ -590,8 +620,8 @@ class LateFusionPlan:
             dr2, drd = self.bn_join_bwd(name, dy, ctx["y"], ACT_RELU, ctx["r2"], ctx["co2"], x2=ds["rd"], co2=ds["co"])
         else:
             dr2, g = self.bn_join_bwd(name, dy, ctx["y"], ACT_RELU, ctx["r2"], ctx["co2"])
-        dy1 = self.conv_bwd(ctx["c2"], dr2)
-        dr1, _ = self.bn_join_bwd(name + ".relu1", dy1, ctx["y1"], ACT_RELU, ctx["r1"], ctx["co1"], lone=True)
+        dy1 = self.conv_bwd(ctx["c2"], dr2, bnb=dict(x=ctx["r1"], co=ctx["co1"], act=ACT_RELU))
+        dr1, _ = self.bn_join_bwd(name + ".relu1", dy1, ctx["y1"], ACT_RELU, ctx["r1"], ctx["co1"], lone=True, pre=self.bnb_out)
         self.taps["grad_out:" + name] = dy
         if ctx["ds"] is not None:
             dx_part = self.conv_bwd(ctx["ds"]["c"], drd)          # 1x1 stride-2 dgrad (zero-filled odd pixels)
@@ -628,12 +658,15 @@ class LateFusionPlan:
         dR = self.act(R.N, R.H, R.W, R.C)
         dr2, _ = self.bn_join_bwd(name, dy, ctx["y"], ACT_RELU, ctx["r2"], ctx["co_u2"], x2=R.chan(half, half), co2=ctx["co_b"],
                                   dx2=dR.chan(half, half))
-        dy1 = self.conv_bwd(ctx["c2"], dr2)
-        M, tiles = R.M, self.L.rd_bn_bwd_tiles(C.c_int64(R.M))
-        red = self.buf(tiles, 3, half)
         x1, co = R.chan(0, half), ctx["co_u1"]
-        self.op(self.bwd, name + ".bn1.bwd_reduce", self.L.rd_bn_bwd_reduce_x_t, self.dt, dy1.ptr, dy1.ld, x1.ptr, x1.ld, _p(co["mean"]),
-                _p(co["scale"]), _p(co["shift"]), C.c_void_p(0), 0, C.c_int64(M), half, ACT_RELU, _p(red), self.stream)
+        dy1 = self.conv_bwd(ctx["c2"], dr2, bnb=dict(x=x1, co=co, act=ACT_RELU))
+        if self.bnb_out is not None:
+            red, tiles = self.bnb_out
+        else:
+            M, tiles = R.M, self.L.rd_bn_bwd_tiles(C.c_int64(R.M))
+            red = self.buf(tiles, 3, half)
+            self.op(self.bwd, name + ".bn1.bwd_reduce", self.L.rd_bn_bwd_reduce_x_t, self.dt, dy1.ptr, dy1.ld, x1.ptr, x1.ld, _p(co["mean"]),
+                    _p(co["scale"]), _p(co["shift"]), C.c_void_p(0), 0, C.c_int64(M), half, ACT_RELU, _p(red), self.stream)
         self._bn_apply_x(name + ".bn1", dy1, x1, red, tiles, co, ACT_RELU, dR.chan(0, half))
         dx = self.conv_bwd(ctx["cR"], dR)
         self.taps["grad_out:" + name] = dy

@@ -86,6 +86,14 @@ def gconv(desc, x, w_packed, out, addend=None, ld_add=0, stat=None):
     return out
 
 
+def gconv_bnbwd(desc, dout, w_packed, dx, bn_x, ld_x, mean, scale, shift, act, red):
+    """Input gradient + the BatchNorm-backward sums of the BatchNorm behind the convolution's forward input (rd_gconv_bnbwd)."""
+    _poison()
+    check(lib().rd_gconv_bnbwd(C.byref(desc), ptr(dout), ptr(w_packed), ptr(dx), ptr(bn_x), ld_x, ptr(mean), ptr(scale), ptr(shift),
+                               act, ptr(red), None, current_stream()), "rd_gconv_bnbwd")
+    return dx
+
+
 def fill(t, v):
     check(lib().rd_fill(ptr(t), C.c_int64(t.numel()), C.c_float(v), current_stream()), "rd_fill")
     return t

@@ -179,3 +179,53 @@ def test_gconv_launches_are_bitwise_reproducible():
                 ref = cur
             else:
                 assert torch.equal(ref[0], cur[0]) and torch.equal(ref[1], cur[1]), (n, h, w, ci, co, it)
+
+
+@pytest.mark.parametrize("cfg", [
+    (2, 64, 64, 113, 200, 1),      # layer1 conv2 (ReLU)
+    (2, 128, 128, 57, 100, 1),
+    (4, 32, 32, 57, 100, 1),       # depth layer2
+    (2, 48, 80, 31, 17, 2),        # ragged channels / tiles, LeakyReLU(0.2)
+    (3, 64, 32, 9, 7, 1),
+    (2, 256, 256, 29, 50, 1),
+])
+def test_gconv_bnbwd_epilogue(cfg):
+    """rd_gconv_bnbwd: the input gradient dy of conv(act(s*x + t)) with the BatchNorm-backward sums of that BatchNorm taken in the
+    epilogue -- sum g and sum g*(x - mean), g = dy * act'(s*x + t) -- against the plain dgrad and float64 sums (5e-5 of each
+    vector's largest magnitude: summation order only).  x lives in a WIDER buffer (channel slice), as in the UpProj modules."""
+    from radar_depth_amd import convdesc as cd, ops
+    from radar_depth_amd._lib import lib
+    import ctypes as C
+    n, ci, co, h, w, act = cfg
+    g = torch.Generator().manual_seed(11)
+    wt = torch.randn(co, ci, 3, 3, generator=g) * (2.0 / (9 * co)) ** 0.5
+    gy = torch.randn(n, co, h, w, generator=g)
+    d, zero_fill = cd.conv_dgrad(n, h, w, ci, co, 3, 1, 1)
+    assert not zero_fill
+    if lib().rd_gconv_bnbwd_supported(C.byref(d)) != 1:
+        pytest.skip("this descriptor's plan splits the reduction")
+    wp = ops.pack_weights(wt.cuda(), transpose=True)
+    dy_in = ops.nchw_to_nhwc(gy.cuda())
+    dx_ref = torch.empty(n, h, w, ci, device="cuda")
+    ops.gconv(d, dy_in, wp, dx_ref)
+    ld = ci + 8
+    xbuf = torch.randn(n, h, w, ld, generator=g).cuda()
+    x = xbuf[..., 4:4 + ci]
+    scale = (torch.rand(ci, generator=g) + 0.5).cuda() * (torch.randint(0, 2, (ci,), generator=g).cuda() * 2 - 1)
+    shift = torch.randn(ci, generator=g).cuda() * 0.3
+    mean = torch.randn(ci, generator=g).cuda() * 0.2
+    tiles = ops.gconv_stat_tiles(d)
+    red = torch.full((tiles, 3, ci), float("nan"), device="cuda")
+    dx = torch.full((n, h, w, ci), float("nan"), device="cuda")
+    xs = xbuf.view(-1)[4:]
+    ops.gconv_bnbwd(d, dy_in, wp, dx, xs, ld, mean, scale, shift, act, red)
+    torch.cuda.synchronize()
+    assert torch.equal(dx, dx_ref)                       # the convolution itself is untouched
+    z = (scale * x + shift).double()
+    slope = torch.where(z > 0, torch.ones_like(z), torch.full_like(z, 0.0 if act == 1 else 0.2))
+    gg = dx_ref.double() * slope
+    want0 = gg.sum((0, 1, 2))
+    want1 = (gg * (x.double() - mean.double())).sum((0, 1, 2))
+    got = red[:, :2].double().sum(0)
+    assert ((got[0] - want0).abs().max() / want0.abs().max()).item() < 5e-5
+    assert ((got[1] - want1).abs().max() / want1.abs().max()).item() < 5e-5

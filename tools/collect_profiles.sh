@@ -1,5 +1,5 @@
 set -x
-R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/r02n; mkdir -p $O
+R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/${RD_ROUND:-r03}; mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
 B="python $R/bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-roofline"   # (heuristic plans: the default)
 rocprofv3 --kernel-trace -d $O/kt -o tr -- $B > /dev/null 2>&1
@@ -23,8 +23,8 @@ python tools/pmc_traffic.py --steady $O/fetch16 $O/write16 > $O/pmc_traffic_bf16
 rm -rf $O/kt16 $O/kt161 $O/kt $O/kt1 $O/fetch $O/write $O/fetch16 $O/write16
 head -20 $O/kernel_stats_single_stream.txt
 python - <<'P'
-import json
+import json, os
 for f in ("pmc_traffic.json","pmc_traffic_bf16_storage.json"):
-    d=json.load(open("gpurun_out/r02n/"+f))["kernels"]
+    d=json.load(open("gpurun_out/"+os.environ.get("RD_ROUND","r03")+"/"+f))["kernels"]
     print(f, len(d), list(d.items())[:2])
 P

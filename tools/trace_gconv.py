@@ -9,14 +9,26 @@ from radar_depth_amd import convdesc as cd, ops
 from radar_depth_amd._lib import lib
 B, dev = 16, "cuda"
 SH = {"layer1": (64, 64, 3, 113, 200), "layer2": (128, 128, 3, 57, 100), "layer3": (256, 256, 3, 29, 50), "layer4": (512, 512, 3, 15, 25)}
+SH.update({"d2": (32, 32, 3, 57, 100), "d3": (64, 64, 3, 29, 50), "dec1c2": (128, 128, 3, 30, 50), "dec3c2": (32, 32, 3, 120, 200),
+           "fusion": (640, 512, 1, 15, 25)})
+UP = {"up256": (256, 15, 25), "up128": (128, 30, 50), "up64": (64, 60, 100), "up32": (32, 120, 200)}
 name = sys.argv[1] if len(sys.argv) > 1 else "layer2"
-ci, co, k, h, w = SH[name]
-d = cd.conv_fwd(B, h, w, ci, co, k, 1, k // 2)
+if name in UP:
+    ci, h, w = UP[name]
+    co, k = ci, 5
+    d = cd.upproj_fwd(B, h, w, ci, co)
+elif name.startswith("s2"):            # stride-2 3x3 forward: s2_64 (layer2.0.conv1), s2_128, s2_256
+    ci = int(name.split("_")[1]); co, k = 2 * ci, 3
+    h, w = {64: (113, 200), 128: (57, 100), 256: (29, 50)}[ci]
+    d = cd.conv_fwd(B, h, w, ci, co, 3, 2, 1)
+else:
+    ci, co, k, h, w = SH[name]
+    d = cd.conv_fwd(B, h, w, ci, co, k, 1, k // 2)
 L = lib()
 info = (C.c_int32 * 10)()
 L.rd_gconv_plan_info(C.byref(d), info)
 nwg = info[9]
-x = torch.randn(B, h, w, ci, device=dev); wp = torch.randn(k * k, ci, co, device=dev); y = torch.empty(B, d.Ho, d.Wo, co, device=dev)
+x = torch.randn(B, h, w, ci, device=dev); wp = torch.randn(k * k, ci, co, device=dev); y = torch.empty(B, d.Ho, d.Wo, d.Cout, device=dev)
 import time
 w0 = time.perf_counter()
 while time.perf_counter() - w0 < 0.08:      # ramp the device clock first (cold launches run at ~2.06 GHz)
