@@ -435,6 +435,14 @@ int rd_bn_bwd_apply_x_t(int32_t dtype, const void* dy, int32_t lddy, const void*
 int rd_bnact_maxpool_fwd_t(int32_t dtype, const void* x, const float* scale, const float* shift, int32_t act, int32_t N, int32_t H, int32_t W, int32_t C, void* y, int32_t ldy, uint8_t* idx, void* stream);
 int rd_bnact_maxpool_bwd_t(int32_t dtype, const void* dy, int32_t lddy, const uint8_t* idx, const void* x, const float* scale, const float* shift, int32_t act, int32_t N, int32_t H, int32_t W, int32_t C, void* g, void* stream);
 int rd_bnact_maxpool_bwd_stats_t(int32_t dtype, const void* dy, int32_t lddy, const uint8_t* idx, const void* x, const float* scale, const float* shift, int32_t act, int32_t N, int32_t H, int32_t W, int32_t C, void* g, const float* mean, float* red_partial, void* stream);
+/* Two-pass form of the stem's pool + BatchNorm backward that never materialises the full-resolution gradient g (the largest tensor
+ * of the network; models.py:633-650 backward): pass 1 = rd_bnact_maxpool_bwd_stats_t with g == NULL (sums only), pass 2 = this call:
+ * finishes the sums into dgamma / dbeta / the dx coefficients and repeats the pool gather, storing dx = A*g + B*(x - mean) + K.
+ * Saves one write and one read of [N,H,W,C] against one more read of the quarter-size pooled gradient and its argmax bytes. */
+int rd_bnact_maxpool_bwd_apply_t(int32_t dtype, const void* dy, int32_t lddy, const uint8_t* idx, const void* x, const float* scale,
+                                 const float* shift, int32_t act, int32_t N, int32_t H, int32_t W, int32_t C, const float* red_partial,
+                                 int32_t n_tiles, const float* gamma, const float* mean, const float* invstd, float* dgamma, float* dbeta,
+                                 float* coef_ws, void* dx, void* stream);
 int rd_gconv_bf16_t(int32_t dtype, const RdConvDesc* d, const void* in, const void* w_packed_bf16, void* out, const float* bias,
                     int32_t act, int32_t act_cols, const void* addend, int32_t ld_add, float* stat_partial, void* stream);
 int rd_wgrad_bf16_t(int32_t dtype, const RdConvDesc* d, const void* in, const void* dout, float* slabs, void* stream);

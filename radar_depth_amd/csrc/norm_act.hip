@@ -382,6 +382,10 @@ __global__ __launch_bounds__(256) void bnact_maxpool_fwd_kernel(const T* __restr
 }
 
 // g[n,h,w,c] = act'(scale*x+shift) * sum over windows whose argmax is (h,w) of dy.
+template <typename T> __device__ __forceinline__ float round_store(float v);
+template <> __device__ __forceinline__ float round_store<float>(float v) { return v; }
+template <> __device__ __forceinline__ float round_store<bf16s>(float v) { return __uint_as_float((unsigned)__builtin_bit_cast(unsigned short, (__bf16)v) << 16); }
+
 // part != nullptr: also the BatchNorm-backward sums of the stem (sum g, sum g*(x - mean)) per block, [block][3][C] like
 // bn_bwd_reduce_kernel -- g and x are in registers here, so the separate reduce pass over both (the largest tensors of the
 // network) disappears.  Needs 256 % (C/4) == 0 so that a thread keeps its channel quad across the grid-stride loop.
@@ -391,13 +395,24 @@ __global__ __launch_bounds__(256) void bnact_maxpool_bwd_kernel(const T* __restr
                                                                 const float* __restrict__ scale, const float* __restrict__ shift,
                                                                 int act, int N, int H, int W, int C, int Ho, int Wo,
                                                                 T* __restrict__ g, const float* __restrict__ mean,
-                                                                float* __restrict__ part) {
+                                                                float* __restrict__ part, const float* __restrict__ coef) {
+    // g == nullptr (with part): sums only -- the gradient is not materialised.  coef != nullptr: the second pass of that form --
+    // the gather is repeated and the BatchNorm input gradient dx = A*g + B*(x - mean) + K (coef = [3][C], bn_bwd_coeffs_kernel)
+    // is what gets stored (to g).  Saves a write and a read of the largest tensor of the network against one more read of the
+    // quarter-size pooled gradient and its argmax bytes.
     extern __shared__ float sm[];
     const int Q = C >> 2;
     const int lq = quad_log2(Q);
     const int64_t total = (int64_t)N * H * W * Q;
     float4 acc[3] = {make_float4(0, 0, 0, 0), make_float4(0, 0, 0, 0), make_float4(0, 0, 0, 0)};
-    const float4 mu = part ? *reinterpret_cast<const float4*>(mean + (threadIdx.x % Q) * 4) : make_float4(0, 0, 0, 0);
+    const float4 mu = (part || coef) ? *reinterpret_cast<const float4*>(mean + (threadIdx.x % Q) * 4) : make_float4(0, 0, 0, 0);
+    float4 cA = make_float4(0, 0, 0, 0), cB = cA, cK = cA;
+    if (coef) {
+        const int c_ = (threadIdx.x % Q) * 4;
+        cA = *reinterpret_cast<const float4*>(coef + c_);
+        cB = *reinterpret_cast<const float4*>(coef + C + c_);
+        cK = *reinterpret_cast<const float4*>(coef + 2 * C + c_);
+    }
     for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
         int64_t r;
         int c;
@@ -441,7 +456,18 @@ __global__ __launch_bounds__(256) void bnact_maxpool_bwd_kernel(const T* __restr
         o4.y = s[1] * act_grad_from_out(fmaf(a.y, v.y, b.y), act);
         o4.z = s[2] * act_grad_from_out(fmaf(a.z, v.z, b.z), act);
         o4.w = s[3] * act_grad_from_out(fmaf(a.w, v.w, b.w), act);
-        st4(g + i, o4);
+        if (coef) {
+            // g as the one-pass form would have stored it (bf16 storage: rounded), then bn_bwd_dx_kernel's expression
+            const float4 gr = make_float4(round_store<T>(o4.x), round_store<T>(o4.y), round_store<T>(o4.z), round_store<T>(o4.w));
+            float4 d4;
+            d4.x = fmaf(cA.x, gr.x, fmaf(cB.x, v.x - mu.x, cK.x));
+            d4.y = fmaf(cA.y, gr.y, fmaf(cB.y, v.y - mu.y, cK.y));
+            d4.z = fmaf(cA.z, gr.z, fmaf(cB.z, v.z - mu.z, cK.z));
+            d4.w = fmaf(cA.w, gr.w, fmaf(cB.w, v.w - mu.w, cK.w));
+            st4(g + i, d4);
+        } else if (g) {
+            st4(g + i, o4);
+        }
         if (part) {
             acc[0].x += o4.x; acc[0].y += o4.y; acc[0].z += o4.z; acc[0].w += o4.w;
             acc[1].x += o4.x * (v.x - mu.x); acc[1].y += o4.y * (v.y - mu.y);
@@ -701,7 +727,7 @@ static int rd_bnact_maxpool_bwd_T(const T* dy, int32_t lddy, const uint8_t* idx,
     const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
     hipLaunchKernelGGL((bnact_maxpool_bwd_kernel<T>), dim3(ew_grid((int64_t)N * H * W * (C / 4))), dim3(256), 0,
                        static_cast<hipStream_t>(stream), dy, lddy, idx, x, scale, shift, act, N, H, W, C, Ho, Wo, g,
-                       (const float*)nullptr, (float*)nullptr);
+                       (const float*)nullptr, (float*)nullptr, (const float*)nullptr);
     RD_CHECK_LAUNCH("bnact_maxpool_bwd_kernel");
     return RD_OK;
 }
@@ -723,14 +749,14 @@ extern "C" int rd_bnact_maxpool_bwd_tiles(int32_t N, int32_t H, int32_t W, int32
 }
 template <typename T>
 static int rd_bnact_maxpool_bwd_stats_T(const T* dy, int32_t lddy, const uint8_t* idx, const T* x, const float* scale, const float* shift, int32_t act, int32_t N, int32_t H, int32_t W, int32_t C, T* g, const float* mean, float* red_partial, void* stream) {
-    RD_CHECK_ARG(dy && idx && x && scale && shift && g && mean && red_partial && C % 4 == 0 && lddy % 4 == 0,
-                 "bnact_maxpool_bwd_stats: bad arguments");
+    RD_CHECK_ARG(dy && idx && x && scale && shift && mean && red_partial && C % 4 == 0 && lddy % 4 == 0,
+                 "bnact_maxpool_bwd_stats: bad arguments");      // (g may be NULL: sums only, see rd_bnact_maxpool_bwd_apply_t)
     RD_CHECK_ARG(C >= 4 && 256 % (C / 4) == 0, "bnact_maxpool_bwd_stats: C/4 = %d must divide 256", C / 4);
     const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
     const int Q = C / 4, RL = 256 / Q;
     hipLaunchKernelGGL((bnact_maxpool_bwd_kernel<T>), dim3(ew_grid((int64_t)N * H * W * (C / 4))), dim3(256),
                        (size_t)RL * 3 * C * sizeof(float), static_cast<hipStream_t>(stream), dy, lddy, idx, x, scale, shift, act, N, H,
-                       W, C, Ho, Wo, g, mean, red_partial);
+                       W, C, Ho, Wo, g, mean, red_partial, (const float*)nullptr);
     RD_CHECK_LAUNCH("bnact_maxpool_bwd_kernel");
     return RD_OK;
 }
@@ -742,5 +768,40 @@ extern "C" int rd_bnact_maxpool_bwd_stats_t(int32_t dtype, const void* dy, int32
     if (dtype == RD_DTYPE_F32) return rd_bnact_maxpool_bwd_stats_T<float>(static_cast<const float*>(dy), lddy, idx, static_cast<const float*>(x), scale, shift, act, N, H, W, C, static_cast<float*>(g), mean, red_partial, stream);
     if (dtype == RD_DTYPE_BF16) return rd_bnact_maxpool_bwd_stats_T<bf16s>(static_cast<const bf16s*>(dy), lddy, idx, static_cast<const bf16s*>(x), scale, shift, act, N, H, W, C, static_cast<bf16s*>(g), mean, red_partial, stream);
     rd::set_error("rd_bnact_maxpool_bwd_stats_t: bad dtype %d", dtype);
+    return RD_EINVAL;
+}
+
+// Second pass of the stem's BatchNorm + pool backward when the first pass (rd_bnact_maxpool_bwd_stats_t with g == NULL) only took
+// the sums: finishes them into dgamma / dbeta / the dx coefficients (bn_bwd_coeffs_kernel) and repeats the pool gather, storing
+// dx = A*g + B*(x - mean) + K directly.  x / dx are the full-resolution [N,H,W,C] stem tensors, dy / idx the pooled ones.
+template <typename T>
+static int rd_bnact_maxpool_bwd_apply_T(const T* dy, int32_t lddy, const uint8_t* idx, const T* x, const float* scale, const float* shift,
+                                        int32_t act, int32_t N, int32_t H, int32_t W, int32_t C, const float* red_partial, int32_t n_tiles,
+                                        const float* gamma, const float* mean, const float* invstd, float* dgamma, float* dbeta,
+                                        float* coef_ws, T* dx, void* stream) {
+    RD_CHECK_ARG(dy && idx && x && scale && shift && red_partial && gamma && mean && invstd && coef_ws && dx && C % 4 == 0 && lddy % 4 == 0 &&
+                     n_tiles > 0, "bnact_maxpool_bwd_apply: bad arguments");
+    RD_CHECK_ARG(C >= 4 && 256 % (C / 4) == 0, "bnact_maxpool_bwd_apply: C/4 = %d must divide 256", C / 4);
+    const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    hipLaunchKernelGGL(bn_bwd_coeffs_kernel, dim3(C), dim3(256), 0, s, red_partial, n_tiles, C, 1, (double)((int64_t)N * H * W), gamma, invstd,
+                       dgamma, dbeta, coef_ws);
+    RD_CHECK_LAUNCH("bn_bwd_coeffs_kernel");
+    hipLaunchKernelGGL((bnact_maxpool_bwd_kernel<T>), dim3(ew_grid((int64_t)N * H * W * (C / 4))), dim3(256), 0, s, dy, lddy, idx, x, scale,
+                       shift, act, N, H, W, C, Ho, Wo, dx, mean, (float*)nullptr, (const float*)coef_ws);
+    RD_CHECK_LAUNCH("bnact_maxpool_bwd_kernel");
+    return RD_OK;
+}
+extern "C" int rd_bnact_maxpool_bwd_apply_t(int32_t dtype, const void* dy, int32_t lddy, const uint8_t* idx, const void* x, const float* scale,
+                                            const float* shift, int32_t act, int32_t N, int32_t H, int32_t W, int32_t C,
+                                            const float* red_partial, int32_t n_tiles, const float* gamma, const float* mean,
+                                            const float* invstd, float* dgamma, float* dbeta, float* coef_ws, void* dx, void* stream) {
+    if (dtype == RD_DTYPE_F32)
+        return rd_bnact_maxpool_bwd_apply_T<float>(static_cast<const float*>(dy), lddy, idx, static_cast<const float*>(x), scale, shift, act, N, H, W, C,
+                                                   red_partial, n_tiles, gamma, mean, invstd, dgamma, dbeta, coef_ws, static_cast<float*>(dx), stream);
+    if (dtype == RD_DTYPE_BF16)
+        return rd_bnact_maxpool_bwd_apply_T<bf16s>(static_cast<const bf16s*>(dy), lddy, idx, static_cast<const bf16s*>(x), scale, shift, act, N, H, W, C,
+                                                   red_partial, n_tiles, gamma, mean, invstd, dgamma, dbeta, coef_ws, static_cast<bf16s*>(dx), stream);
+    rd::set_error("rd_bnact_maxpool_bwd_apply_t: bad dtype %d", dtype);
     return RD_EINVAL;
 }

@@ -470,7 +470,8 @@ static int stem_fill(StemArgs& a, const float* const* planes, const int64_t* str
 }
 
 static int stem_wgrad_splits(int total_tiles) {
-    int want = 2 * num_cus();
+    static const char* spc = getenv("RD_STEM_WGRAD_SPLITS_PER_CU");      // diagnostics
+    int want = (spc ? atoi(spc) : 2) * num_cus();
     return want < total_tiles ? want : total_tiles;
 }
 
@@ -493,7 +494,11 @@ static int stem_fwd_impl(int io16, const float* const* planes, const int64_t* st
     { static const char* dbg = getenv("RD_STEM_DEBUG"); a.debug = dbg ? atoi(dbg) : 0; }
     a.tiles_h = cdiv(a.Ho, 8); a.tiles_w = cdiv(a.Wo, ST_TW);
     const int total = N * a.tiles_h * a.tiles_w;
-    const int grid = total < 2 * num_cus() ? total : 2 * num_cus();     // persistent: two workgroups per CU walk the tiles
+    // persistent: two workgroups per CU walk the tiles.  (More resident workgroups do not help the latency-bound one-plane depth stem:
+    // at 164 VGPRs only two fit a SIMD -- RD_STEM_WG_PER_CU = 3 / 4 / 6 / 8 measured 85 / 79 / 80 / 81 us against 77 us, round 3.)
+    static const char* wpc_env = getenv("RD_STEM_WG_PER_CU");
+    const int wpc = wpc_env ? atoi(wpc_env) : 2;
+    const int grid = total < wpc * num_cus() ? total : wpc * num_cus();
     const int NT = Cout > 32 ? 2 : 1, BN = NT * 32;
     const int Kp = (49 * Cin + 1) & ~1;
     const int Kq = Kp + 4;

@@ -562,15 +562,27 @@ class LateFusionPlan:
     def _stem_bwd(self, ctx, dpooled, dgrad_channel=None):
         N, H, W = self.N, self.H, self.W
         raw, co, cout, cin = ctx["raw"], ctx["co"], ctx["cout"], ctx["cin"]
-        g = self.act(N, ctx["Hc"], ctx["Wc"], cout)
         # the pooling gather applies the activation derivative and, in the same pass, produces the BatchNorm-backward sums
         # (g and x are in registers there): no separate reduce pass over the two largest tensors of the network
         tiles = self.L.rd_bnact_maxpool_bwd_tiles(N, ctx["Hc"], ctx["Wc"], cout)
         red = self.buf(tiles, 3, cout)
-        self.op(self.bwd, ctx["name"] + ".pool_bwd", self.L.rd_bnact_maxpool_bwd_stats_t, self.dt, dpooled.ptr, dpooled.ld, _p(ctx["idx"]), raw.ptr,
-                _p(co["scale"]), _p(co["shift"]), ctx["act"], N, ctx["Hc"], ctx["Wc"], cout, g.ptr, _p(co["mean"]), _p(red), self.stream)
         dx = self.act(raw.N, raw.H, raw.W, cout)
-        self._bn_apply(ctx["name"] + ".bn.bn1", g, raw, red, tiles, 1, co, dx)
+        if os.environ.get("RD_STEM_BWD_TWO_PASS", "0") == "1":
+            # opt-in: the full-resolution gradient g is never materialised -- the first pass takes the sums only, the second repeats
+            # the (quarter-size) gather and stores the BatchNorm input gradient directly.  0.6 GB/step less HBM traffic, bit-identical
+            # results, but no faster: fp32 760.2 / 759.5 vs 762.6 / 758.0 samples/s, bf16 storage 1 % slower (1798 vs 1818), round 3
+            self.op(self.bwd, ctx["name"] + ".pool_bwd", self.L.rd_bnact_maxpool_bwd_stats_t, self.dt, dpooled.ptr, dpooled.ld, _p(ctx["idx"]), raw.ptr,
+                    _p(co["scale"]), _p(co["shift"]), ctx["act"], N, ctx["Hc"], ctx["Wc"], cout, C.c_void_p(0), _p(co["mean"]), _p(red), self.stream)
+            bn = co["bn"]
+            coef = self.buf(3 * cout)
+            self.op(self.bwd, ctx["name"] + ".bn.bn1.bwd_apply", self.L.rd_bnact_maxpool_bwd_apply_t, self.dt, dpooled.ptr, dpooled.ld, _p(ctx["idx"]),
+                    raw.ptr, _p(co["scale"]), _p(co["shift"]), ctx["act"], N, ctx["Hc"], ctx["Wc"], cout, _p(red), tiles, _p(bn.weight),
+                    _p(co["mean"]), _p(co["invstd"]), _p(self.grad_of(bn.weight)), _p(self.grad_of(bn.bias)), _p(coef), dx.ptr, self.stream)
+        else:
+            g = self.act(N, ctx["Hc"], ctx["Wc"], cout)
+            self.op(self.bwd, ctx["name"] + ".pool_bwd", self.L.rd_bnact_maxpool_bwd_stats_t, self.dt, dpooled.ptr, dpooled.ld, _p(ctx["idx"]), raw.ptr,
+                    _p(co["scale"]), _p(co["shift"]), ctx["act"], N, ctx["Hc"], ctx["Wc"], cout, g.ptr, _p(co["mean"]), _p(red), self.stream)
+            self._bn_apply(ctx["name"] + ".bn.bn1", g, raw, red, tiles, 1, co, dx)
         nws = self.L.rd_stem_wgrad_workspace_floats(N, H, W, cin, cout)
         ws = self.buf(int(nws))
         cur = self.streams.index(self._s) if self._s in self.streams else 0

@@ -452,3 +452,27 @@ def test_batched_slab_reductions_step_is_bit_identical(monkeypatch, storage):
         runs.append([p.detach().clone() for p in m.parameters()])
     for p, q in zip(*runs):
         assert torch.equal(p, q)
+
+
+@pytest.mark.parametrize("storage", ["fp32", "bf16"])
+def test_stem_backward_two_pass_is_bit_identical(monkeypatch, storage):
+    """The stem's pool + BatchNorm backward without the materialised full-resolution gradient (rd_bnact_maxpool_bwd_stats_t with
+    g == NULL, then rd_bnact_maxpool_bwd_apply_t repeating the gather) against the one-pass form that stores g: same expressions,
+    same rounding of g under bf16 storage -> bit-identical parameters after three steps."""
+    from radar_depth_amd.main import HipTrainStep
+    from radar_depth_amd.synthetic import make_batch
+    b, h, w = 2, 97, 161
+    runs = []
+    for mode in ("0", "1"):
+        monkeypatch.setenv("RD_STEM_BWD_TWO_PASS", mode)
+        m = build(h, w)
+        ts = HipTrainStep(m, b, h, w, storage=storage)
+        names = [n for n, _, _ in ts.plan.bwd]
+        assert ("conv1.bn.bn1.bwd_apply" in names) and (mode == "0" or names.count("conv1.pool_bwd") == 1)
+        for it in range(3):
+            x, t = make_batch(b, h, w, 800 + it, ref_pixels=h * w)
+            ts.step(x.cuda(), t.cuda())
+        torch.cuda.synchronize()
+        runs.append([p.detach().clone() for p in m.parameters()])
+    for p, q in zip(*runs):
+        assert torch.equal(p, q)
