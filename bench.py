@@ -57,15 +57,17 @@ def kernel_identity(L, kind, d, io16=False):
         L.rd_wgrad_bf16_plan_info(C.byref(d), info)           # cpi, cpo, ...
         full = d.n_phases == 1 and d.in_stride == 1 and d.phase[0].n_taps == 9
         return "wgrad_bf16_kernel<%s,%d,%s>" % (tb_(full), 4 // (info[0] * info[1]), tb_(io16))
-    if kind == "gconv":
+    if kind in ("gconv", "gconv_bnb"):
         info = (C.c_int32 * 10)()
         L.rd_gconv_plan_info(C.byref(d), info)                 # info[4] = grouped*1000000 + pipelined*10000 + ksplit*100 + CKW
         grouped = info[4] >= 1000000                          # in_stride == 2 run as input-parity groups: SWZ = false instantiation
         if info[0] == 0:                                      # 16 -> 16 channel 3x3 layers: csrc/conv16.hip (16x16x4 MFMA)
             return "conv16_kernel<stat|add>"
-        return "gconv_kernel<%d,%d,%d,%d,%d,%s,%s,%s>" % (info[0], info[1], info[2], info[3], info[4] % 100,
-                                                          "true" if (d.in_stride == 2 and not grouped) else "false",
-                                                          "true" if info[4] % 1000000 >= 10000 else "false", "true" if grouped else "false")
+        # template parameters: MT, NT, WM, WN, CKW, SWZ, PIPE, GRP, BNB (BNB: the dgrad launches that also emit BatchNorm-backward sums)
+        return "gconv_kernel<%d,%d,%d,%d,%d,%s,%s,%s,%s>" % (info[0], info[1], info[2], info[3], info[4] % 100,
+                                                             "true" if (d.in_stride == 2 and not grouped) else "false",
+                                                             "true" if info[4] % 1000000 >= 10000 else "false", "true" if grouped else "false",
+                                                             "true" if kind == "gconv_bnb" else "false")
     w = (C.c_int32 * 9)()
     L.rd_wgrad_plan_info(C.byref(d), w)
     if w[0] == 0:      # 16 -> 16 channel 3x3 layers: csrc/wgrad16.hip (16x16x4 MFMA)

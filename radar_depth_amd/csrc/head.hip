@@ -1,6 +1,8 @@
 // Network head: conv3 (3x3, C -> 1, pad 1, no bias; model/models.py:587,661) and the bilinear
 // align_corners=True resize to output_size (models.py:588,662), forward and backward.
 // All HBM-streaming kernels (one channel out); no matrix cores.
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace rd {
@@ -25,40 +27,52 @@ __device__ __forceinline__ void split_pixel(int64_t e, bool small, int H, int W,
 }
 
 // d[n,h,w] = sum_{kh,kw,c} x[n,h+kh-1,w+kw-1,c] * w[c][kh][kw]      (w: OIHW with O == 1)
+// thread = (output pixel, channel quad): the C/4 lanes of a pixel read the 16-byte quads of each neighbour pixel side by side
+// (one coalesced 4C-byte access per tap), multiply by their quad of the tap's weights and are summed with two DPP exchanges.
+// All nine loads of a thread are issued unconditionally from clamped coordinates (a `continue` per tap made the compiler wait for
+// each load before issuing the next; out-of-image taps get a zero weight instead).  Round 2's form -- one thread per pixel walking
+// 9 x C/4 sixteen-byte loads behind per-tap branches -- streamed the 98 MB decoder output at 1.5 TB/s (65 us).
 template <int C, typename T>
 __global__ __launch_bounds__(256) void head_conv_fwd_kernel(const T* __restrict__ x, int ldx, const float* __restrict__ w,
                                                             int N, int H, int W, float* __restrict__ d) {
-    __shared__ float s_w[9 * C];
-    for (int e = threadIdx.x; e < 9 * C; e += blockDim.x) {
-        const int t = e / C, c = e - t * C;
-        s_w[e] = w[c * 9 + t];
+    static_assert(C == 16, "four lanes per pixel");
+    constexpr int Q = C / 4;
+    __shared__ float4 s_w[9 * Q];
+    for (int e = threadIdx.x; e < 9 * Q; e += blockDim.x) {
+        const int t = e / Q, c = (e - t * Q) * 4;
+        s_w[e] = make_float4(w[c * 9 + t], w[(c + 1) * 9 + t], w[(c + 2) * 9 + t], w[(c + 3) * 9 + t]);
     }
     rd_sync();
     const int64_t total = (int64_t)N * H * W;
     const bool small = total < (1ll << 31);
-    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+    const int q = threadIdx.x & (Q - 1);
+    for (int64_t p = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / Q; p < total; p += (int64_t)gridDim.x * blockDim.x / Q) {
         int wx, h, n;
-        split_pixel(e, small, H, W, n, h, wx);
-        float s = 0.f;
+        split_pixel(p, small, H, W, n, h, wx);
+        const T* img = x + (size_t)n * H * W * ldx + q * 4;
+        float4 v[9];
+        float ok[9];
 #pragma unroll
         for (int kh = 0; kh < 3; ++kh) {
-            const int ih = h + kh - 1;
-            if (ih < 0 || ih >= H) continue;
+            const int ih = h + kh - 1, ihc = min(max(ih, 0), H - 1);
 #pragma unroll
             for (int kw = 0; kw < 3; ++kw) {
-                const int iw = wx + kw - 1;
-                if (iw < 0 || iw >= W) continue;
-                const T* px = x + (((size_t)n * H + ih) * W + iw) * ldx;
-                const float* wt = s_w + (kh * 3 + kw) * C;
-#pragma unroll
-                for (int c = 0; c < C; c += 4) {
-                    const float4 v = ld4(px + c);
-                    s = fmaf(v.x, wt[c], s); s = fmaf(v.y, wt[c + 1], s);
-                    s = fmaf(v.z, wt[c + 2], s); s = fmaf(v.w, wt[c + 3], s);
-                }
+                const int iw = wx + kw - 1, iwc = min(max(iw, 0), W - 1);
+                ok[kh * 3 + kw] = (ih == ihc && iw == iwc) ? 1.f : 0.f;
+                v[kh * 3 + kw] = ld4(img + ((size_t)ihc * W + iwc) * ldx);
             }
         }
-        d[e] = s;
+        float s = 0.f;
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            const float4 wt = s_w[t * Q + q];
+            float a = v[t].x * wt.x;
+            a = fmaf(v[t].y, wt.y, a); a = fmaf(v[t].z, wt.z, a); a = fmaf(v[t].w, wt.w, a);
+            s = fmaf(ok[t], a, s);
+        }
+        s += dpp_xor1(s);
+        s += dpp_xor2(s);
+        if (q == 0) d[p] = s;
     }
 }
 
@@ -226,7 +240,9 @@ static int ew_grid64(int64_t elems) {
 }
 static int head_wgrad_blocks(int64_t pixels) {
     int64_t b = cdiv64(pixels, 512);
-    const int64_t cap = (int64_t)num_cus() * 4;
+    // (four blocks per CU: RD_HEAD_WGRAD_BLOCKS_PER_CU = 2 / 4 / 8 / 16 measured 134 / 120 / 133 / 146 us for the whole head backward, round 3)
+    static const char* bpc = getenv("RD_HEAD_WGRAD_BLOCKS_PER_CU");      // diagnostics
+    const int64_t cap = (int64_t)num_cus() * (bpc ? atoi(bpc) : 4);
     return (int)(b > cap ? cap : (b < 1 ? 1 : b));
 }
 
@@ -236,7 +252,7 @@ using namespace rd;
 template <typename T>
 static int head_conv_fwd_T(const T* x, int32_t ldx, const float* w_oihw, int32_t N, int32_t H, int32_t W, int32_t C, float* d, void* stream) {
     RD_CHECK_ARG(x && w_oihw && d && C == 16 && ldx % 4 == 0, "head_conv_fwd: bad arguments (C must be 16)");
-    hipLaunchKernelGGL((head_conv_fwd_kernel<16, T>), dim3(ew_grid64((int64_t)N * H * W)), dim3(256), 0,
+    hipLaunchKernelGGL((head_conv_fwd_kernel<16, T>), dim3(ew_grid64((int64_t)N * H * W * 4)), dim3(256), 0,
                        static_cast<hipStream_t>(stream), x, ldx, w_oihw, N, H, W, d);
     RD_CHECK_LAUNCH("head_conv_fwd_kernel");
     return RD_OK;

@@ -369,6 +369,7 @@ class LateFusionPlan:
                 self.op(self.bwd, name + ".dgrad", self.L.rd_gconv_bnbwd, C.byref(dd), dout.ptr, _p(ctx["wd"]), dx.ptr, xb.ptr, xb.ld,
                         _p(co["mean"]), _p(co["scale"]), _p(co["shift"]), bnb["act"], _p(red), _p(ws_d), self.stream)
                 self.bnb_out = (red, tiles)
+                self.meta[name + ".dgrad"] = ("gconv_bnb", dd)      # (the BNB instantiation of the kernel: its own name in a trace)
             else:
                 self.op(self.bwd, name + ".dgrad", self.L.rd_gconv_ws, C.byref(dd), dout.ptr, _p(ctx["wd"]), dx.ptr,
                         addend.ptr if addend is not None else C.c_void_p(0), addend.ld if addend is not None else 0,

@@ -34,7 +34,7 @@ def _descriptors_here(arch, b, h, w):
         dp = [torch.empty(b, h, w), torch.empty(b, h, w)] if k == 1 else None
         plan = LateFusionPlan(m, b, h, w, train=True, dry_run=True, depth_planes=dp)
         for name, (kind, d) in plan.meta.items():
-            if kind == "gconv":
+            if kind in ("gconv", "gconv_bnb"):
                 out.append((name, d))
     return out
 

@@ -21,7 +21,7 @@ def descriptors():
     plan = LateFusionPlan(m, 16, 450, 800, train=True, dry_run=True)
     seen, out = set(), []
     for name, (kind, d) in plan.meta.items():
-        if kind != "gconv":
+        if kind not in ("gconv", "gconv_bnb"):
             continue
         key = bytes(d)
         if key in seen:

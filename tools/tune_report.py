@@ -20,7 +20,7 @@ plans = [ts.mp.p1, ts.mp.p2] if getattr(ts, "mp", None) is not None else [ts.pla
 seen, rows = set(), []
 for pl in plans:
     for name, (kind, d) in pl.meta.items():
-        if kind != "gconv":
+        if kind not in ("gconv", "gconv_bnb"):
             continue
         key = bytes(d) + b"\x01"
         if key in seen or not autotune._TUNED.get(key):
