@@ -272,7 +272,8 @@ int rd_bn_bwd_reduce(const float* dy, int32_t lddy, const float* y, int32_t ldy,
 int rd_bn_bwd_reduce_x(const float* dy, int32_t lddy, const float* x1, int32_t ldx1, const float* mean1,
                        const float* scale1, const float* shift1, float* g, int32_t ldg, int64_t M, int32_t C,
                        int32_t act, float* red_partial, void* stream);
-int rd_bn_bwd_tiles(int64_t M);
+/* row blocks (= rows of red_partial) the backward reductions of an [M, C] tensor produce */
+int rd_bn_bwd_tiles(int64_t M, int32_t C);
 /* backward pass 2 (per BN): finishes the reduction, writes dgamma/dbeta (overwrite) and
  * dx = gamma*invstd*(g - mean(g) - xhat*mean(g*xhat)).  which = 1 or 2 selects the x1 / x2 sums. */
 int rd_bn_bwd_apply(const float* g, int32_t ldg, const float* x, int32_t ldx, const float* red_partial,

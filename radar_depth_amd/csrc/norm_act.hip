@@ -89,6 +89,15 @@ static inline int rows_per_block(int64_t M) {
     int64_t r = cdiv64(M, 2048);
     return (int)(r < 64 ? 64 : r);
 }
+// Backward reductions: a block reduces RPB rows 256 / (C/4) at a time, so with many channels 64 rows are a long serial walk of
+// single 16-byte loads (C = 512: 32 round trips; the layer4 / bn_fusion reductions ran at 1.1 TB/s, 21 us for 25 MB).  Four row
+// groups per block keep the loop short and the grid wide: C = 64 -> 64 rows as before, 128 -> 32, 256 -> 16, 512 -> 8.
+static inline int bwd_rows_per_block(int64_t M, int C) {
+    const int RL = 256 / (C / 4) > 0 ? 256 / (C / 4) : 1;
+    int64_t r = cdiv64(M, 2048);
+    const int64_t lo = 4 * RL < 64 ? 4 * RL : 64;
+    return (int)(r < lo ? lo : r);
+}
 
 template <int NS>  // number of per-channel sums
 __device__ __forceinline__ void block_reduce_store(float4 (&acc)[NS], int Q, int RL, int q, int rl, bool active, float* out,
@@ -516,7 +525,7 @@ extern "C" int rd_bn_eval_coeffs_batched(const void* jobs_dev, int32_t n_jobs, f
 }
 
 extern "C" int rd_bn_stats_tiles(int64_t M) { return (int)cdiv64(M, rows_per_block(M)); }
-extern "C" int rd_bn_bwd_tiles(int64_t M) { return (int)cdiv64(M, rows_per_block(M)); }
+extern "C" int rd_bn_bwd_tiles(int64_t M, int32_t C) { return (C >= 4 && C % 4 == 0 && M > 0) ? (int)cdiv64(M, bwd_rows_per_block(M, C)) : RD_EINVAL; }
 
 template <typename T>
 static int rd_bn_stats_T(const T* x, int64_t M, int32_t C, int32_t ldx, float* stat_partial, int32_t* n_tiles, void* stream) {
@@ -569,7 +578,7 @@ static int bn_bwd_reduce_impl(const T* dy, int32_t lddy, const T* y, int32_t ldy
     RD_CHECK_ARG(act == RD_ACT_NONE || y || (scale1 && shift1 && x1 && (!x2 || (scale2 && shift2))),
                  "bn_bwd_reduce: activation needs y (or the scale/shift of every operand)");
     RD_CHECK_ARG((!x1 || mean1) && (!x2 || mean2), "bn_bwd_reduce: x without mean");
-    const int RPB = rows_per_block(M), grid = (int)cdiv64(M, RPB);
+    const int RPB = bwd_rows_per_block(M, C), grid = (int)cdiv64(M, RPB);
     const int Q = C / 4, RL = 256 / Q;
     hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(grid), dim3(256), (size_t)RL * 3 * C * sizeof(float),
                        static_cast<hipStream_t>(stream), dy, lddy, y, ldy, x1, ldx1, mean1, x2, ldx2, mean2, g, ldg, M, C, act, RPB,

@@ -475,7 +475,7 @@ class LateFusionPlan:
             dx1 = self.act(x1.N, x1.H, x1.W, Cc)
             self._bn_apply_x(name + ".bn1", dy, x1, red, tiles, co1, act, dx1)
             return dx1, None
-        tiles = self.L.rd_bn_bwd_tiles(C.c_int64(M))
+        tiles = self.L.rd_bn_bwd_tiles(C.c_int64(M), Cc)
         red = self.buf(tiles, 3, Cc)
         if lone and x2 is None and act != ACT_NONE:
             # lone act(bn(x1)): the activation's sign is recomputed from x1 in both passes -- y is not read and the masked
@@ -676,7 +676,7 @@ class LateFusionPlan:
         if self.bnb_out is not None:
             red, tiles = self.bnb_out
         else:
-            M, tiles = R.M, self.L.rd_bn_bwd_tiles(C.c_int64(R.M))
+            M, tiles = R.M, self.L.rd_bn_bwd_tiles(C.c_int64(R.M), half)
             red = self.buf(tiles, 3, half)
             self.op(self.bwd, name + ".bn1.bwd_reduce", self.L.rd_bn_bwd_reduce_x_t, self.dt, dy1.ptr, dy1.ld, x1.ptr, x1.ld, _p(co["mean"]),
                     _p(co["scale"]), _p(co["shift"]), C.c_void_p(0), 0, C.c_int64(M), half, ACT_RELU, _p(red), self.stream)

@@ -150,7 +150,7 @@ def test_norm_kernels_bf16_storage():
     gamma = torch.rand(Cc, generator=g) + 0.5
     sc = gamma * invstd
     sh = -mean * sc + 0.1
-    tiles = L.rd_bn_bwd_tiles(C.c_int64(M))
+    tiles = L.rd_bn_bwd_tiles(C.c_int64(M), Cc)
     red = torch.zeros(tiles, 3, Cc, device="cuda")
     MEAN, INV, GAM, SC, SH = dev(mean), dev(invstd), dev(gamma), dev(sc), dev(sh)
     check(L.rd_bn_bwd_reduce_x_t(BF16, ptr(DY), Cc, ptr(X1), Cc, ptr(MEAN), ptr(SC), ptr(SH), None, 0, C.c_int64(M), Cc, 1, ptr(red), current_stream()),

@@ -68,7 +68,7 @@ def test_bn_forward_backward(M, Cc, act, res):
     assert _rel(RM.cpu(), rm) < 1e-5 and _rel(RV.cpu(), rv) < 1e-5 and int(nbt) == 1
     # backward
     DY = dy.to(dev)
-    tiles = L.rd_bn_bwd_tiles(C.c_int64(M))
+    tiles = L.rd_bn_bwd_tiles(C.c_int64(M), Cc)
     red = torch.zeros(tiles, 3, Cc, device=dev)
     Gt = torch.empty(M, Cc, device=dev)
     check(L.rd_bn_bwd_reduce(ptr(DY), Cc, ptr(Y), Cc, ptr(X1), Cc, ptr(mean1), ptr(X2) if res == "bn" else None, Cc if res == "bn" else 0,
