@@ -85,6 +85,22 @@ def reduce_gradient_buckets(grads, buckets):
         wk.wait()
 
 
+def pack_buffers(bufs):
+    """Every module buffer (BatchNorm running_mean / running_var fp32, num_batches_tracked int64 scalars) as ONE flat array of
+    32-bit words, bit-preserving: what the data-parallel state broadcast ships instead of one collective per buffer."""
+    return torch.cat([b.detach().contiguous().view(-1).view(torch.float32) for b in bufs]) if bufs else None
+
+
+def unpack_buffers(bufs, flat):
+    """Inverse of pack_buffers: writes the words back INTO the buffers (in place, whatever their dtype / rank)."""
+    off = 0
+    for b in bufs:
+        n = b.numel() * b.element_size() // 4
+        b.view(-1).view(torch.float32).copy_(flat[off:off + n])
+        off += n
+    assert flat is None or off == flat.numel()
+
+
 class HipTrainStep:
     """One reference training step entirely on the device (no host synchronisation inside):
 
@@ -158,10 +174,10 @@ class HipTrainStep:
         self.comm = comm
         self.world = _comm.world() if comm == "rccl" else (torch.distributed.get_world_size() if tdist else 1)
         self.comm_stream = torch.cuda.Stream(device=dev) if comm == "rccl" else None
-        if self.world > 1:
-            self.sync_state_from_rank0()
-        # RD_FORCE_DP=1 runs the data-parallel code path (segmented graphs + bucketed all-reduce) even with one rank (tests)
+        # RD_FORCE_DP=1 runs the data-parallel code path (state broadcast, segmented graphs, bucketed all-reduce) even with one rank (tests)
         self.dp = self.world > 1 or (os.environ.get("RD_FORCE_DP") == "1" and (comm == "rccl" or tdist))
+        if self.dp:
+            self.sync_state_from_rank0()
         p = self.plan
         self.n_out = batch * p.Ho * p.Wo
         self.target = torch.zeros(batch, 1, p.Ho, p.Wo, device=dev)
@@ -215,7 +231,7 @@ class HipTrainStep:
         # three collectives in all (parameter arena, momentum arena, every BatchNorm buffer packed into one flat word array): the
         # ~160 per-buffer broadcasts this used to issue were 160 chances for a rank-order mismatch
         bufs = [b for b in self.model.buffers()]
-        flat = torch.cat([b.detach().contiguous().view(-1).view(torch.float32) for b in bufs]) if bufs else None
+        flat = pack_buffers(bufs)
         if self.comm == "rccl":
             from . import comm as _comm
             cur = C.c_void_p(torch.cuda.current_stream().cuda_stream)
@@ -225,11 +241,7 @@ class HipTrainStep:
             dist = torch.distributed
             for tns in [self.st["arena"], self.st["mom"]] + ([flat] if flat is not None else []):
                 dist.broadcast(tns, 0)
-        off = 0
-        for b in bufs:
-            n = b.numel() * b.element_size() // 4
-            b.view(-1).view(torch.float32).copy_(flat[off:off + n])
-            off += n
+        unpack_buffers(bufs, flat)
 
     # ---- optimizer state in torch.optim.SGD's layout (the reference checkpoints `optimizer.state_dict()`, main.py:358-374)
     def state_dict(self):

@@ -254,3 +254,29 @@ def test_bench_launches_its_own_ranks():
     r = subprocess.run([sys.executable, os.path.join(repo, "bench.py"), "--gpus", "2", "--dry-run"], capture_output=True, text=True,
                        env=dict(env, WORLD_SIZE="3", RANK="0"), timeout=120)
     assert r.returncode != 0 and "3-rank job" in (r.stderr + r.stdout)
+
+
+def test_state_broadcast_packing_round_trip():
+    """pack_buffers / unpack_buffers (the flat word array the data-parallel state broadcast ships): bit-preserving for the fp32
+    running statistics AND the int64 0-dim num_batches_tracked counters, written back in place."""
+    import torch
+
+    from radar_depth_amd.main import pack_buffers, unpack_buffers
+    from radar_depth_amd.model.models import ResNet_latefusion
+    m = ResNet_latefusion(18, "upproj", [64, 96], 4, False)
+    bufs = list(m.buffers())
+    assert any(b.dtype == torch.int64 and b.dim() == 0 for b in bufs) and any(b.dtype == torch.float32 for b in bufs)
+    g = torch.Generator().manual_seed(3)
+    for b in bufs:                                  # "rank 0" state
+        if b.dtype == torch.int64:
+            b.fill_(int(torch.randint(1, 2 ** 40, (1,), generator=g)))
+        else:
+            b.copy_(torch.randn(b.shape, generator=g))
+    want = [b.clone() for b in bufs]
+    flat = pack_buffers(bufs)
+    assert flat.dtype == torch.float32 and flat.numel() == sum(b.numel() * b.element_size() // 4 for b in bufs)
+    ptrs = [b.data_ptr() for b in bufs]
+    for b in bufs:                                  # "rank 1" state before the broadcast
+        b.zero_()
+    unpack_buffers(bufs, flat)
+    assert all(torch.equal(a, b) for a, b in zip(bufs, want)) and ptrs == [b.data_ptr() for b in bufs]
