@@ -476,3 +476,30 @@ def test_stem_backward_two_pass_is_bit_identical(monkeypatch, storage):
         runs.append([p.detach().clone() for p in m.parameters()])
     for p, q in zip(*runs):
         assert torch.equal(p, q)
+
+
+def test_op_table_replay_ranges_streams_and_errors():
+    """rd_optable_run on the GPU: a sub-range issues exactly its ops, stream arguments are taken from the slots of THAT run, float
+    arguments arrive bit-exact, and a failing op stops the run and reports its index (the ops behind it are not issued)."""
+    import ctypes as C
+    from radar_depth_amd._lib import RadarDepthHipError, lib, ptr
+    from radar_depth_amd.optable import OpTable
+    L = lib()
+    t = torch.zeros(4, 1024, device="cuda")
+    s_main = C.c_void_p(0)
+    row = lambda i: C.c_void_p(t.data_ptr() + 4 * 1024 * i)
+    ops = [("fill0", L.rd_fill, (row(0), C.c_int64(1024), C.c_float(1.5), s_main)),
+           ("fill1", L.rd_fill, (row(1), C.c_int64(1024), C.c_float(-2.25), s_main)),
+           ("bad", L.rd_fill, (C.c_void_p(0), C.c_int64(1024), C.c_float(9.0), s_main)),          # null pointer -> RD_EINVAL
+           ("fill3", L.rd_fill, (row(3), C.c_int64(1024), C.c_float(7.0), s_main))]
+    tb = OpTable(L, ops, [s_main])
+    side = torch.cuda.Stream()
+    s_main.value = side.cuda_stream                     # the slot's value at RUN time is what counts
+    tb.run(1, 2)
+    side.synchronize()
+    assert t[0].abs().max().item() == 0.0 and bool((t[1] == -2.25).all()) and t[3].abs().max().item() == 0.0
+    with pytest.raises(RadarDepthHipError, match="bad"):
+        tb.run(0, 4)
+    side.synchronize()
+    assert bool((t[0] == 1.5).all()) and t[3].abs().max().item() == 0.0          # ops behind the failing one were not issued
+    tb.close()
