@@ -72,6 +72,8 @@ def kernel_identity(L, kind, d, io16=False):
     L.rd_wgrad_plan_info(C.byref(d), w)
     if w[0] == 0:      # 16 -> 16 channel 3x3 layers: csrc/wgrad16.hip (16x16x4 MFMA)
         return "wgrad16_kernel"
+    if w[2] == -1:     # 1x1 layers with >= 64 channels each side: csrc/wgrad1x1.hip (pixel-reduction GEMM, 64x64 tiles per wave)
+        return "wgrad1x1_kernel<%d,%d>" % (2 if d.Cin >= 128 else 1, 2 if d.Cout >= 128 else 1)
     tb = lambda v: "true" if v else "false"
     if w[8]:       # column-strip kernel (one per UpProj phase when w[6])
         return "wgrad_strip_kernel<%s>%s" % ("3,3|2,3|3,2|2,2" if w[6] else "%d,%d" % (w[0] // w[5], w[5]), " (4 UpProj phase launches)" if w[6] else "")

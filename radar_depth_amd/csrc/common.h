@@ -48,6 +48,10 @@ int conv16_tiles_per_image(const RdConvDesc& d);
 bool wgrad16_eligible(const RdConvDesc& d);
 void wgrad16_splits(const RdConvDesc& d, int& total_tiles, int& n_splits);
 int launch_wgrad16(const RdConvDesc& d, const float* x, const float* dout, float* slabs, hipStream_t s);
+// wgrad1x1.hip: the weight gradient of the 1x1 convolutions (>= 64 channels each side) as a pixel-reduction GEMM
+bool wgrad1x1_eligible(const RdConvDesc& d);
+void wgrad1x1_splits(const RdConvDesc& d, int& n_splits, long long& pix_per_split);
+int launch_wgrad1x1(const RdConvDesc& d, const float* x, const float* dout, float* slabs, hipStream_t s);
 int launch_conv16(const RdConvDesc& d, const float* in, const float* w_packed, float* out, const float* addend, int ld_add,
                   float* stat, hipStream_t s);
 

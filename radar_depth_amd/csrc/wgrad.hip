@@ -584,6 +584,7 @@ struct WgradPlan {
     int per_phase;  // UpProj: one launch per output phase (each a rectangular sub-stencil with a shared dout pixel)
     int strip;      // column-strip kernel with LDS row rings (rectangular stencil, unit input stride, 64-channel blocks)
     int w16;        // served by wgrad16.hip (16 -> 16 channels, 3x3, unit strides, 16x16x4 MFMA): only S, n_splits, slab_splits, J are used
+    int w1x1;       // served by wgrad1x1.hip (one tap, >= 64 channels each side): only S, n_splits, slab_splits, J are used
     WgradStripArgs sa;
     size_t lds;
 };
@@ -623,6 +624,7 @@ static int plan_wgrad(const RdConvDesc& d_in, WgradPlan& pl, WgradArgs* out, int
     pl.rw = rw;
     pl.per_phase = 0;
     pl.w16 = 0;
+    pl.w1x1 = 0;
     RD_CHECK_ARG(d.Cin % 4 == 0 && d.Cout % 4 == 0 && d.ldi % 4 == 0 && d.ldo % 4 == 0, "wgrad: channels must be multiples of 4");
     pl.shb = d.n_phases == 1;   // single phase: every tap pairs with the same dout pixel
     pl.TG = ntaps == 25 ? 5 : ntaps;
@@ -819,6 +821,14 @@ static int plan_any_uncached(const RdConvDesc& d, WgradPlan& pl) {
         pl.total_tiles = total_tiles; pl.MF = 16;
         return RD_OK;
     }
+    if (wgrad1x1_eligible(d)) {
+        pl = WgradPlan{};
+        long long pps = 0;
+        wgrad1x1_splits(d, pl.n_splits, pps);
+        pl.w1x1 = 1; pl.S = 1; pl.slab_splits = pl.n_splits; pl.J = pl.n_splits < 16 ? pl.n_splits : 16;
+        pl.MF = 32; pl.TG = 1;
+        return RD_OK;
+    }
     if (upproj_split(d)) {
         bool ok = plan_wgrad(d, pl, nullptr, 0) == RD_OK && pl.pitch > 0;
         for (int ph = 1; ok && ph < 4; ++ph) {
@@ -856,11 +866,12 @@ static int launch_pitch(const WgradPlan& pl, const WgradArgs& a, int grid, hipSt
 using namespace rd;
 
 // diagnostics: out[0..8] = TG, MF, layoutA, shb, pitch, taps per row, per_phase (4 launches), n_splits, strip kernel
+// (TG == 0: wgrad16.hip; layoutA == -1: wgrad1x1.hip)
 extern "C" int rd_wgrad_plan_info(const RdConvDesc* d, int32_t* out) {
     if (!d || !out) return RD_EINVAL;
     WgradPlan pl;
     if (plan_any(*d, pl) != RD_OK) return RD_EINVAL;
-    const int v[9] = {pl.TG, pl.MF, pl.layoutA, pl.shb, pl.pitch, pl.rw, pl.per_phase, pl.n_splits, pl.strip};
+    const int v[9] = {pl.TG, pl.MF, pl.w1x1 ? -1 : pl.layoutA, pl.shb, pl.pitch, pl.rw, pl.per_phase, pl.n_splits, pl.strip};
     for (int i = 0; i < 9; ++i) out[i] = v[i];
     return RD_OK;
 }
@@ -881,6 +892,7 @@ extern "C" int rd_wgrad(const RdConvDesc* d, const float* in, const float* dout,
     int rc = plan_any(*d, pl);
     if (rc != RD_OK) return rc;
     if (pl.w16) return launch_wgrad16(*d, in, dout, slabs, s);
+    if (pl.w1x1) return launch_wgrad1x1(*d, in, dout, slabs, s);
     // the launch records (plan + kernel arguments minus the tensor pointers) are cached per descriptor like the plans
     struct Launch { WgradPlan pl; WgradArgs a; };
     static std::mutex mu;

@@ -38,6 +38,15 @@ def _rel(a, b):
     (5, 16, 16, 3, 1, 1, 1, 1),
     (2, 16, 16, 3, 1, 1, 3, 50),
     (16, 16, 16, 3, 1, 1, 113, 200),
+    # csrc/wgrad1x1.hip (one tap, >= 64 channels each side): every tile shape, partial channel blocks, pixel counts that are not a
+    # multiple of the 32-pixel chunk, stride-2 gathers over odd image sizes, fewer pixels than one chunk
+    (2, 128, 256, 1, 2, 0, 57, 100),
+    (4, 256, 512, 1, 2, 0, 29, 50),
+    (3, 512, 256, 1, 1, 0, 15, 25),
+    (1, 64, 64, 1, 1, 0, 3, 5),
+    (2, 96, 160, 1, 2, 0, 9, 7),
+    (5, 192, 64, 1, 1, 0, 7, 9),
+    (16, 640, 512, 1, 1, 0, 15, 25),
 ])
 def test_wgrad_conv(cfg):
     from radar_depth_amd import convdesc as cd, ops
