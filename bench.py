@@ -52,6 +52,10 @@ def kernel_identity(L, kind, d, io16=False):
         info = (C.c_int32 * 8)()
         L.rd_gconv_bf16_plan_info(C.byref(d), info)           # MT, NT, pipe*1000 + CKP, ...
         return "gconv_bf16_kernel<%d,%d,%s,%s>" % (info[0], info[1], tb_(info[2] >= 1000), tb_(io16))
+    if kind == "gconv_split":
+        info = (C.c_int32 * 8)()
+        L.rd_gconv_split_plan_info(C.byref(d), info)          # MT, NT, TH, TW, PP, lds, workgroups, tap groups + 100 * double-buffered patch
+        return "gconv_split_kernel<%d,%d,%s>" % (info[0], info[1], tb_(info[7] >= 100))
     if kind == "wgrad_bf16":
         info = (C.c_int32 * 8)()
         L.rd_wgrad_bf16_plan_info(C.byref(d), info)           # cpi, cpo, ...
@@ -293,10 +297,12 @@ def main():
                     help="headline = resnet18_latefusion (BASELINE configs[1]); the multistage arch is configs[3] (use --batch 8)")
     ap.add_argument("--graph", action="store_true", help="replay the step as hipGraphs (slower than plain stream launches here)")
     ap.add_argument("--no-graph", action="store_true", help="(default; kept for older command lines)")
-    ap.add_argument("--operands", default="fp32", choices=["fp32", "bf16"],
+    ap.add_argument("--operands", default="fp32", choices=["fp32", "bf16", "split"],
                     help="conv operand precision.  fp32 (default) is the BASELINE.json configs[1] measurement; bf16 (configs 2/4) runs the "
                          "forward / input-gradient / weight-gradient convolutions on bf16 MFMA with fp32 tensors + accumulation and is reported with "
-                         "dtype \"bf16\" and its own metric name -- never as the fp32 headline")
+                         "dtype \"bf16\" and its own metric name -- never as the fp32 headline; split = fp32 arithmetic on the bf16 matrix cores "
+                         "(csrc/gconv_split.hip: three bf16 pieces per fp32 operand, six MFMAs per product, fp32 accumulation; fp32 tensors, fp32 "
+                         "tolerances) for the forward / input-gradient convolutions the library plans that way, reported under its own metric name")
     ap.add_argument("--storage", default=None, choices=["fp32", "bf16"],
                     help="element type of the NHWC activation / gradient tensors in HBM.  bf16 (BASELINE.json configs 3 / 5) implies "
                          "--operands bf16; statistics, parameters, their gradients and the optimizer stay fp32")
@@ -433,6 +439,14 @@ def main():
         if args.storage == "bf16":
             out["metric"] = out["metric"].split(" [")[0] + " [bf16 storage: NHWC activations and gradients bf16 in HBM, bf16 MFMA convolutions incl. every weight gradient, fp32 accumulation / BatchNorm statistics / loss / parameters / SGD]"
             out["config"]["workload"] = out["config"]["workload"].replace(" bf16-operand convs,", " bf16 storage + bf16 convs,")
+    split = args.operands == "split"
+    if split:
+        out["metric"] += (" [fp32 arithmetic on the bf16 matrix cores: forward / input-gradient convolutions with >= 32 channels split each fp32 "
+                          "operand into three bf16 pieces and rebuild the product from six v_mfma_f32_32x32x16_bf16 terms, fp32 accumulation "
+                          "(error vs fp64 <= the fp32 MFMA's, tests/test_gpu_gconv_split.py); weight gradients, stems, head, 1x1 and 16-channel "
+                          "layers on the fp32 MFMA; fp32 tensors]")
+        out["config"]["workload"] = out["config"]["workload"].replace(" fp32,", " fp32 (split-bf16 MFMA convolutions),")
+        out["config"]["arith"] = "fp32 operands as 3 bf16 pieces, 6 of 9 piece products kept (dropped terms < 2^-24 of the product), fp32 accumulate"
     per_gpu = out["value"] / world
     if rank == 0 and not args.no_roofline:
         agg, fam = instrumented_pass(ts)
@@ -452,7 +466,20 @@ def main():
                 pass
         common = {"kernel": name, "launches_per_step": n, "avg_launch_us": round(1e3 * ms / n, 2), "traffic": traffic,
                   "traffic_source": traffic_source}
-        if not bf16:
+        if not bf16 and name.startswith("gconv_split_kernel"):
+            # the dominant kernel runs six bf16 MFMAs per fp32 multiply-add: priced against the dense bf16 peak on the MFMA FLOPs it
+            # actually issues (6 x algorithmic); `fp32_equivalent_tflops` is the algorithmic rate next to the fp32 MFMA peak
+            achieved = 6.0 * flops / (ms * 1e-3) / 1e12
+            step_flops = bnd["gflop"] * 1e9 * args.batch
+            out["roofline"] = dict(common, bound="mfma", achieved=round(achieved, 1), peak=2500.0, unit="TFLOP/s", frac=round(achieved / 2500.0, 4),
+                                   note="bf16 MFMA FLOPs issued (6 per algorithmic fp32 FLOP) against the dense bf16 peak; random-data "
+                                        "sustained rate of this device is ~1850 TFLOP/s (tools/micro/mfma_agpr.hip: the clock drops to 1.85 GHz)",
+                                   fp32_equivalent_tflops=round(flops / (ms * 1e-3) / 1e12, 1), fp32_mfma_peak=PEAK_FP32_TFLOPS,
+                                   algorithmic_gflop_per_sample=round(bnd["gflop"], 2),
+                                   step_conv_tflops=round(step_flops * args.steps / dt / 1e12, 2),
+                                   bound_samples_per_s_per_gpu=round(bnd["fp32"], 1), step_frac_of_fp32_mfma_bound=round(per_gpu / bnd["fp32"], 4))
+            by_kernel = {k: [round(v[0], 3), v[1], round(v[2] / (v[0] * 1e-3) / 1e12, 1)] for k, v in sorted(agg.items(), key=lambda kv: -kv[1][0])}
+        elif not bf16:
             achieved = flops / (ms * 1e-3) / 1e12
             step_flops = bnd["gflop"] * 1e9 * args.batch
             out["roofline"] = dict(common, bound="mfma", achieved=round(achieved, 2), peak=PEAK_FP32_TFLOPS, unit="TFLOP/s",

@@ -121,6 +121,20 @@ int rd_gconv_bf16_plan_info(const RdConvDesc* d, int32_t* out);
 /* diagnostics: with RD_GCONV_BF16_TRACE=1 every workgroup records cycle-counter stamps at its phase boundaries (32 slots per
  * workgroup: count, stamps); copies the last traced launch to the host (tools/trace_gconv_bf16.py) */
 int rd_gconv_bf16_trace_read(unsigned long long* host, int n_wg);
+/* fp32 convolution on the bf16 matrix cores (csrc/gconv_split.hip; opt-in, rd_gconv stays the default and the parity reference):
+ * same tensors, descriptor and epilogue as rd_gconv_fused, but every fp32 operand is split into three bf16 pieces
+ * (x = x0 + x1 + x2 exactly) and the product is rebuilt from the six bf16 MFMAs whose terms are not below 2^-24 of it, with fp32
+ * accumulation: results as close to an fp64 convolution as rd_gconv's, at 2.67x the fp32 MFMA rate.  w_split: operand written by
+ * rd_pack_weights_batched with quad == 3 -- three planes of the bf16 layout of rd_gconv_bf16, piece_elems elements apart.
+ * rd_gconv_split_supported: 1 when the library has a plan for d (>= 32 channels on both sides, Cin a multiple of 16, a tile whose
+ * three-piece patch fits the LDS), else 0 -- callers keep rd_gconv for those.  Replaces the F.conv2d / conv_transpose2d call sites
+ * of models.py:27,203-206 and their autograd input gradients, like rd_gconv. */
+int rd_gconv_split_supported(const RdConvDesc* d);
+int rd_gconv_split(const RdConvDesc* d, const float* in, const void* w_split, int64_t piece_elems, float* out, const float* bias,
+                   int32_t act, int32_t act_cols, const float* addend, int32_t ld_add, float* stat_partial, void* stream);
+int rd_gconv_split_stat_tiles(const RdConvDesc* d);
+/* diagnostics: out[0..7] = MT, NT, TH, TW, patch pixels, lds_bytes, workgroups, tap groups of the largest phase */
+int rd_gconv_split_plan_info(const RdConvDesc* d, int32_t* out);
 /* diagnostics: out[0..9] = MT, NT, WM, WN, pipelined*10000+ksplit*100+CKW, CKP, TH, TW, lds_bytes, workgroups chosen for d
  * (workspace plan) */
 int rd_gconv_plan_info(const RdConvDesc* d, int32_t* out);

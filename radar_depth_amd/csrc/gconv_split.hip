@@ -1,0 +1,710 @@
+// fp32 convolution on the bf16 matrix cores: every fp32 operand is split into three bf16 pieces and the product is rebuilt
+// from six bf16 MFMAs with fp32 accumulation.
+//
+//   x = x0 + x1 + x2,  x0 = bf16(x), x1 = bf16(x - x0), x2 = bf16(x - x0 - x1)          (exact: 3 x 8 significant bits = fp32's 24)
+//   x * w = x0 w0 + (x0 w1 + x1 w0) + (x0 w2 + x1 w1 + x2 w0) + [x1 w2 + x2 w1 + x2 w2]
+// The bracketed terms are below 2^-24 |x w| -- the size of the rounding of ONE fp32 product -- and are dropped; each kept product
+// of two 8-bit significands is exact in fp32, a v_mfma_f32_32x32x16_bf16 sums sixteen of them and rounds once into the fp32
+// accumulator (six roundings per 16 reduction elements; the fp32 MFMA of gconv.hip rounds eight times for the same sixteen).
+// Measured against an fp64 convolution the results are as close as gconv.hip's (tests/test_gpu_gconv_split.py).  Cost: six
+// 32-cycle instructions per 16 reduction elements instead of eight 64-cycle ones: 2.67x the fp32 MFMA rate.
+//
+// Same descriptor (phases x taps over an NHWC halo patch), same fp32 tensors in HBM, same epilogue as gconv.hip / gconv_bf16.hip;
+// opt-in per plan (engine operands = "split"), gconv.hip stays the default and the parity reference.
+//
+//   workgroup : 8 waves, ONE per CU.  Waves 0-3 own the accumulators (MT x NT tiles of 32 x 32 each) and do nothing but LDS
+//               fragment reads and MFMAs; waves 4-7 stage: weight pieces by global_load_lds, the next 16-channel chunk of the
+//               patch through registers, where they split it into pieces (11 VALU instructions per pair of values: hidden
+//               beside the other waves' MFMAs; inside one wave they would sit between MFMA bursts).
+//   LDS       : patch [piece][pixel][16 + 8] bf16 (pixel pitch 48 B: the 16 lanes of a b128 read pass fall into 16 bank groups);
+//               weights [buffer][piece][tap of the group][2][BN] x 16 B, staged in groups of <= 3 taps, double-buffered: three
+//               pieces of everything do not fit otherwise (9 taps x 64 channels x 3 pieces x 2 buffers = 110 KB).
+//   loop      : per (16-channel chunk, tap group): barrier; the loaders start the next group's weights (and, in a chunk's first
+//               group, fetch and split the next chunk's patch); the compute waves walk the group; after a chunk's last group a
+//               second barrier lets the loaders overwrite the patch.
+//   operand   : packed weights [piece][slab][Cin/8][ldw][8] bf16 (rd_pack_weights_batched, quad == 3).
+#include <math.h>
+#include <stdlib.h>
+
+#include <mutex>
+#include <string>
+#include <type_traits>
+#include <unordered_map>
+
+#include "common.h"
+
+namespace rd {
+
+typedef __bf16 sbf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned int su32x4 __attribute__((ext_vector_type(4)));
+
+constexpr unsigned GS_OOB = 0x80000000u;
+constexpr int GS_CKP = 16;                    // input channels per chunk = one MFMA step per tap
+constexpr int GS_PSB = (GS_CKP + 8) * 2;      // patch pixel pitch in bytes
+constexpr int GS_UPP = 6;                     // patch units (8 channels of one pixel) per loader thread
+constexpr int GS_UW = 2;                      // weight units per loader thread, piece and tap group
+constexpr int GS_TPS = 3;                     // taps per weight group
+
+struct GsArgs {
+    RdConvDesc d;
+    const float* in;
+    const unsigned short* w;      // packed operand, three piece planes
+    float* out;
+    const float* addend;
+    const float* bias;
+    float* stat;
+    int act, act_cols, ld_add, ldw;
+    int TH, TW, PP, tiles_total, n_cotiles, taps_max;
+    int vec4;
+    int debug;                    // diagnostics (RD_GCONV_SPLIT_DEBUG): timing experiments that break the results
+    int pplane;                   // bytes per piece plane of the LDS patch
+    long long wplane;             // bytes per piece plane of the packed operand
+    int tapoff[RD_MAX_PHASES][RD_MAX_TAPS];   // byte offset of tap t inside a patch plane
+};
+
+// the three bf16 pieces of eight fp32 values (round to nearest even at every level; the remainders are exact)
+__device__ __forceinline__ void split8(const float4 v0, const float4 v1, sbf16x8& p0, sbf16x8& p1, sbf16x8& p2) {
+    const float x[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const __bf16 h = (__bf16)x[i];
+        float r = x[i] - (float)h;
+        const __bf16 m = (__bf16)r;
+        r -= (float)m;
+        p0[i] = h;
+        p1[i] = m;
+        p2[i] = (__bf16)r;
+    }
+}
+
+template <int MT, int NT, bool PDB>
+__global__ __launch_bounds__(512) void gconv_split_kernel(const GsArgs a) {
+    constexpr int BM = 4 * MT * 32;
+    constexpr int BN = NT * 32;
+    constexpr int LBN = NT == 2 ? 6 : 5;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const bool loader = wave >= 4;
+    const int wm = wave & 3;
+    const int l31 = lane & 31, hh = lane >> 5;
+    const RdConvDesc& D = a.d;
+
+    const int vid = xcd_remap(blockIdx.x, gridDim.x);
+    const int cot = vid % a.n_cotiles;
+    const int pt = vid / a.n_cotiles;
+    const int n = pt / a.tiles_total;
+    const int tt = pt - n * a.tiles_total;
+    int ph_ = 0;
+    for (int i = 1; i < D.n_phases; ++i)
+        if (tt >= D.phase[i].tile_begin) ph_ = i;
+    const int ph = __builtin_amdgcn_readfirstlane(ph_);
+    const RdPhase& P = D.phase[ph];
+    const int tloc = tt - P.tile_begin;
+    const int tiles_w = (P.lw + a.TW - 1) / a.TW;
+    const int r0 = (tloc / tiles_w) * a.TH, c0 = (tloc % tiles_w) * a.TW;
+    const int th_n = min(a.TH, P.lh - r0), tw_n = min(a.TW, P.lw - c0);
+    const int IS = D.in_stride, OS = D.out_stride;
+    const int PW = (a.TW - 1) * IS + (P.dw_max - P.dw_min) + 1;
+    const int PH = (th_n - 1) * IS + (P.dh_max - P.dh_min) + 1;
+    const int ih0 = r0 * IS + P.dh_min, iw0 = c0 * IS + P.dw_min;
+    const int ntaps = __builtin_amdgcn_readfirstlane(P.n_taps);
+    const int ngroups = (ntaps + GS_TPS - 1) / GS_TPS;      // the last group is padded with zero-weight taps: every group is 3 steps
+    const int co0 = cot * BN;
+
+    // LDS carve-up
+    int* s_opix = reinterpret_cast<int*>(smem);          // [BM] output pixel index or -1
+    int* s_apix = s_opix + BM;                           // [BM] patch pixel index of tap (0,0)
+    int* s_widx = s_apix + BM;                           // [32] weight slab index of each tap
+    char* s_w = reinterpret_cast<char*>(s_widx + 32);    // [3][3][GS_TPS][2][BN] x 16 B: ring of three tap groups
+    constexpr int WPP = GS_TPS * 2 * BN * 16;            // bytes per piece of one weight buffer
+    constexpr int SLAB = 3 * WPP;
+    char* s_patch = s_w + 3 * SLAB;                      // [PDB ? 2 : 1][3][pplane]
+    const int pplane = a.pplane;
+
+    for (int m = tid; m < BM; m += 512) {
+        const int r = m / a.TW, c = m - r * a.TW;
+        const bool ok = (r < th_n) && (c < tw_n);
+        s_opix[m] = ok ? ((n * D.Ho + (r0 + r) * OS + P.out_off_h) * D.Wo + (c0 + c) * OS + P.out_off_w) : -1;
+        s_apix[m] = ok ? ((r * IS) * PW + c * IS) : 0;
+    }
+    if (tid < ntaps) s_widx[tid] = P.widx[tid];
+    rd_sync();
+
+    f32x16 acc[MT][NT];      // (zeroed in the compute branch only: live registers of the staging waves otherwise)
+
+    const int nchunks = D.Cin / GS_CKP;
+    const int total_groups = nchunks * ngroups;
+
+    // Barrier protocol (B1 once per tap group g of chunk c, iteration `it`; every wave of the workgroup takes part):
+    //   B1(it) publishes weight group it + 1 (issued behind B1(it - 1), awaited by the loaders before they arrive) and frees the
+    //          ring buffer of group it - 1, into which the loaders then issue group it + 2;
+    //   patch : the loaders fetch chunk c + 1 in the chunk's first group, split it in the second, and write it in the last one --
+    //           PDB: into the other patch buffer, published by the next B1; else behind a second barrier B2 (the compute waves
+    //           are then done with the patch) into the only one.
+    // The compute waves read the first fragments of group it + 1 BEFORE B1(it + 1) (they are published), so the MFMAs continue
+    // straight behind the barrier; only at a chunk boundary do they have to wait for the new patch first.
+    if (loader) {
+        // ------------------------------------------------------------------------------------------ staging waves
+        const int ltid = tid - 256;
+        const int lw = wave - 4;
+        const int cin8 = D.Cin >> 3;
+        const char* in_n = reinterpret_cast<const char*>(a.in) + (size_t)n * D.Hi * D.Wi * D.ldi * 4;
+        const unsigned img_bytes = (unsigned)(D.Hi * D.Wi * D.ldi) * 4u;
+        // patch units of this thread: wave lw copies the 64-unit row segments lw, lw + 4, ... (two 8-channel units per pixel)
+        const int rowu = PW * 2;
+        const int nseg = (rowu + 63) >> 6;
+        const int nsegs = PH * nseg;
+        unsigned pgo[GS_UPP];     // byte offset of the unit inside the image at channel 0; GS_OOB: outside -> zeros
+        int pdst[GS_UPP];         // LDS byte offset inside a patch plane, -1: no such unit
+#pragma unroll
+        for (int u = 0; u < GS_UPP; ++u) {
+            const int seg = lw + 4 * u;
+            const int row = nseg == 1 ? seg : seg / nseg;
+            const int cu = ((seg - row * nseg) << 6) + lane;
+            const int px = cu >> 1, qq = cu & 1;
+            const int ih = ih0 + row, iw = iw0 + px;
+            const bool ok = seg < nsegs && cu < rowu;
+            pdst[u] = ok ? (row * PW + px) * GS_PSB + qq * 16 : -1;
+            pgo[u] = (ok && ih >= 0 && ih < D.Hi && iw >= 0 && iw < D.Wi) ? (unsigned)(((ih * D.Wi + iw) * D.ldi + qq * 8) * 4) : GS_OOB;
+        }
+        auto issue_slab = [&](int buf, int cb, int g) {
+            const int tap0 = g * GS_TPS;
+            constexpr int welems = (GS_TPS * 2) << LBN;  // 16-byte units of one piece: [tap][2][BN]
+            const char* src = reinterpret_cast<const char*>(a.w) + (size_t)(cb >> 3) * a.ldw * 16;
+            char* dst = s_w + buf * SLAB;
+#pragma unroll
+            for (int u = 0; u < GS_UW; ++u) {
+                const int e = ltid + u * 256;
+                if (e < welems) {
+                    const int j = e & (BN - 1), tk = e >> LBN;
+                    const int k8 = tk & 1, t = tap0 + (tk >> 1);
+                    if (t < ntaps && co0 + j < D.Cout) {
+                        const size_t go = (((size_t)s_widx[t] * cin8 + k8) * a.ldw + co0 + j) * 16;
+#pragma unroll
+                        for (int p = 0; p < 3; ++p)
+                            glds16(reinterpret_cast<const float*>(src + p * a.wplane + go), reinterpret_cast<float*>(dst + p * WPP + (e - lane) * 16));
+                    } else {                             // padding taps of the last group, output channels beyond Cout
+#pragma unroll
+                        for (int p = 0; p < 3; ++p) *reinterpret_cast<uint4*>(dst + p * WPP + e * 16) = make_uint4(0u, 0u, 0u, 0u);
+                    }
+                }
+            }
+        };
+        sbf16x8 pc[GS_UPP][3];
+        float4 v0[GS_UPP], v1[GS_UPP];
+        auto fetch = [&](int cb) {
+            const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(in_n + cb * 4), 0, img_bytes - cb * 4, 0x00020000);
+#pragma unroll
+            for (int u = 0; u < GS_UPP; ++u) {
+                v0[u] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)pgo[u], 0, 0));
+                v1[u] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)pgo[u] + 16, 0, 0));
+            }
+        };
+        auto split = [&]() {
+#pragma unroll
+            for (int u = 0; u < GS_UPP; ++u) {
+                split8(v0[u], v1[u], pc[u][0], pc[u][1], pc[u][2]);
+                __builtin_amdgcn_sched_barrier(0);      // one unit at a time: interleaved, the units' temporaries cost ~100 registers
+            }
+        };
+        auto put_patch = [&](int pbuf) {
+            char* base = s_patch + pbuf * 3 * pplane;
+#pragma unroll
+            for (int u = 0; u < GS_UPP; ++u)
+                if (pdst[u] >= 0) {
+#pragma unroll
+                    for (int p = 0; p < 3; ++p) *reinterpret_cast<sbf16x8*>(base + p * pplane + pdst[u]) = pc[u][p];
+                }
+        };
+        issue_slab(0, 0, 0);
+        if (total_groups > 1) issue_slab(1, ngroups > 1 ? 0 : GS_CKP, ngroups > 1 ? 1 : 0);
+        fetch(0);
+        split();
+        put_patch(0);
+        glds_wait();
+        int it = 0, wi = 2;                       // wi: ring buffer of group it + 2
+        int c2 = 0, g2 = 2;                       // (chunk, group) of group it + 2
+        while (g2 >= ngroups) { g2 -= ngroups; ++c2; }
+        const int gmid = ngroups > 1 ? 1 : 0;
+        for (int c = 0; c < nchunks; ++c) {
+            const bool more = c + 1 < nchunks;
+            for (int g = 0; g < ngroups; ++g, ++it) {
+                rd_sync();                        // B1(it)
+                if (it + 2 < total_groups) issue_slab(wi, c2 * GS_CKP, g2);
+                wi = wi == 2 ? 0 : wi + 1;
+                if (++g2 == ngroups) { g2 = 0; ++c2; }
+                if (g == 0 && more) fetch((c + 1) * GS_CKP);
+                if (g == gmid && more) split();
+                if (g == ngroups - 1 && more) {
+                    if constexpr (!PDB) rd_sync();        // B2: the compute waves are done with this chunk's patch
+                    put_patch(PDB ? ((c + 1) & 1) : 0);
+                }
+                glds_wait();
+            }
+        }
+    } else {
+        // ------------------------------------------------------------------------------------------ compute waves
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) acc[mt][nt][i] = 0.f;
+        int aoffB[MT];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) aoffB[mt] = s_apix[(wm * MT + mt) * 32 + l31] * GS_PSB + hh * 16;
+        const int boffB = (hh * BN + l31) * 16;
+        // tap offsets in the lanes of one VGPR, fetched with v_readlane (an s_load in the walk would force lgkmcnt(0) waits);
+        // the padding taps of the last group read tap 0's pixels against zero weights
+        const int tapv = a.tapoff[ph][lane < ntaps ? lane : 0];
+        // fragment addresses: A = patch plane p, this lane's pixel of M-tile mt (+ the tap's offset, wave-uniform, added per
+        // step); B = one base per ring buffer, everything else (piece, tap of the group, N-tile) is an immediate
+        int abase[3][MT];
+#pragma unroll
+        for (int p = 0; p < 3; ++p)
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) abase[p][mt] = p * pplane + aoffB[mt];
+        auto load = [&](const char* pbase, const char* wbuf, int tap, int t, sbf16x8 (&A)[3][MT], sbf16x8 (&B)[3][NT]) {
+            const int ao = __builtin_amdgcn_readlane(tapv, tap);
+            const char* pa = pbase + ao;
+            const char* wbl = wbuf + boffB;
+#pragma unroll
+            for (int p = 0; p < 3; ++p) {
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) A[p][mt] = *reinterpret_cast<const sbf16x8*>(pa + abase[p][mt]);
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) B[p][nt] = *reinterpret_cast<const sbf16x8*>(wbl + p * WPP + t * 2 * BN * 16 + nt * 512);
+            }
+        };
+        // issue order of one step: the 3 (MT + NT) fragment reads of the NEXT step go out between this step's first MFMAs, one
+        // read (and its address add) per two MFMAs: a burst of reads in front of the MFMAs costs ~250 clocks per step in which
+        // the matrix pipe is idle (an in-order wave issues nothing else while it issues them)
+        auto interleave = [&]() {
+#pragma unroll
+            for (int i = 0; i < 3 * (MT + NT); ++i) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);      // 2 MFMA
+                __builtin_amdgcn_sched_group_barrier(0x002, 1, 0);      // 1 VALU (address)
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);      // 1 LDS read
+            }
+            __builtin_amdgcn_sched_group_barrier(0x008, 6 * MT * NT - 6 * (MT + NT), 0);
+        };
+        // the six kept terms of one accumulator back to back, smallest first (a chain on one accumulator is FASTER than rotating
+        // over the MT x NT accumulators between terms: layer3 3x3 133 vs 156 us)
+        auto mma = [&](const sbf16x8 (&A)[3][MT], const sbf16x8 (&B)[3][NT]) {
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) {
+                    f32x16 c = acc[mt][nt];
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[0][mt], B[2][nt], c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[1][mt], B[1][nt], c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[2][mt], B[0][nt], c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[0][mt], B[1][nt], c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[1][mt], B[0][nt], c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[0][mt], B[0][nt], c, 0, 0, 0);
+                    acc[mt][nt] = c;
+                }
+        };
+        // two fragment sets; a group is three steps, so the set holding a group's first step alternates from group to group.  The
+        // loop body is a PAIR of groups: set 0 is then the only one alive across the back edge (carrying both made the compiler
+        // keep 120 fragment registers next to the 96 accumulators and spill).
+        sbf16x8 fa[2][3][MT], fb[2][3][NT];
+        int it = 0, wi = 0, c = 0, g = 0;
+        bool have = false;
+        auto group = [&](auto parity) {
+            constexpr int P0 = decltype(parity)::value, P1 = 1 - P0;
+            rd_sync();                            // B1(it)
+            const char* pbase = s_patch + (PDB ? (c & 1) * 3 * pplane : 0);
+            const int wn = wi == 2 ? 0 : wi + 1;
+            const char* wb = s_w + wi * SLAB;
+            const char* wbn = s_w + wn * SLAB;
+            const int tap0 = g * GS_TPS;
+            const bool pref = g + 1 < ngroups;
+            if (!have) load(pbase, wb, min(tap0, ntaps - 1), 0, fa[P0], fb[P0]);
+            __builtin_amdgcn_sched_barrier(0);
+            if constexpr (MT * NT < 4 || (MT * NT == 4 && PDB)) {
+                load(pbase, wb, min(tap0 + 1, ntaps - 1), 1, fa[P1], fb[P1]);
+                mma(fa[P0], fb[P0]);
+                interleave();
+                __builtin_amdgcn_sched_barrier(0);
+                load(pbase, wb, min(tap0 + 2, ntaps - 1), 2, fa[P0], fb[P0]);
+                mma(fa[P1], fb[P1]);
+                interleave();
+                __builtin_amdgcn_sched_barrier(0);
+                if (pref) {
+                    load(pbase, wbn, min(tap0 + 3, ntaps - 1), 0, fa[P1], fb[P1]);      // first step of the next group (same chunk)
+                    mma(fa[P0], fb[P0]);
+                    interleave();
+                } else {
+                    mma(fa[P0], fb[P0]);
+                }
+            } else {
+                // the 3 x 2 tile (and the single-buffered 2 x 2) has no registers for interleaved reads (96 accumulators + two
+                // fragment sets of 60 + the read addresses spill): its reads go out in front of each step's MFMAs
+                load(pbase, wb, min(tap0 + 1, ntaps - 1), 1, fa[P1], fb[P1]);
+                __builtin_amdgcn_sched_barrier(0);
+                mma(fa[P0], fb[P0]);
+                __builtin_amdgcn_sched_barrier(0);
+                load(pbase, wb, min(tap0 + 2, ntaps - 1), 2, fa[P0], fb[P0]);
+                __builtin_amdgcn_sched_barrier(0);
+                mma(fa[P1], fb[P1]);
+                __builtin_amdgcn_sched_barrier(0);
+                if (pref) load(pbase, wbn, min(tap0 + 3, ntaps - 1), 0, fa[P1], fb[P1]);
+                __builtin_amdgcn_sched_barrier(0);
+                mma(fa[P0], fb[P0]);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            have = pref;
+            wi = wn;
+            if constexpr (!PDB) {
+                if (!pref && c + 1 < nchunks) rd_sync();      // B2
+            }
+            ++it;
+            if (++g == ngroups) { g = 0; ++c; }
+        };
+        while (it + 2 <= total_groups) {
+            group(std::integral_constant<int, 0>{});
+            group(std::integral_constant<int, 1>{});
+        }
+        if (it < total_groups) group(std::integral_constant<int, 0>{});
+    }
+
+    // ---- epilogue (gconv_bf16.hip's, fp32 tensors): the compute waves store, every wave takes part in the barriers
+    float ssum[NT], ssq[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) ssum[nt] = ssq[nt] = 0.f;
+    if (!loader) {
+        const bool has_add = a.addend != nullptr;
+        const bool has_bias = a.bias != nullptr;
+        const int cob = co0 + l31;
+        float biasv[NT];
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) biasv[nt] = (has_bias && cob + nt * 32 < D.Cout) ? a.bias[cob + nt * 32] : 0.f;
+        const bool want_stat = a.stat != nullptr;
+        // 4x4 blocks (4 accumulator registers x the 4 lanes of a quad) are transposed in registers so that a lane holds four
+        // consecutive channels of one pixel: 16-byte accesses (needs 4-channel alignment of every pointer and stride: a.vec4)
+        const int q4l = l31 & 3, k4l = l31 >> 2;
+        const bool odd1 = q4l & 1, odd2 = q4l & 2;
+        float4 ssum4[NT], ssq4[NT];
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) ssum4[nt] = ssq4[nt] = make_float4(0.f, 0.f, 0.f, 0.f);
+        bool any4 = false;
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            int ro4[4];
+            bool rows_ok = true;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                ro4[g] = s_opix[(wm * MT + mt) * 32 + q4l + 8 * g + 4 * hh];
+                rows_ok = rows_ok && ro4[g] >= 0;
+            }
+            if (a.vec4 && __all(rows_ok)) {
+                any4 = true;
+                const int cq = co0 + 4 * k4l;
+                float4 addv[NT][4];
+                if (has_add) {
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const float* ap = a.addend + (size_t)ro4[g] * a.ld_add + cq;
+#pragma unroll
+                        for (int nt = 0; nt < NT; ++nt) addv[nt][g] = (cq + nt * 32 < D.Cout) ? ld4(ap + nt * 32) : make_float4(0.f, 0.f, 0.f, 0.f);
+                    }
+                }
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) {
+                    const bool cok4 = cq + nt * 32 < D.Cout;
+                    float4 b4 = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (has_bias && cok4) b4 = *reinterpret_cast<const float4*>(a.bias + cq + nt * 32);
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        float e0 = acc[mt][nt][4 * g], e1 = acc[mt][nt][4 * g + 1], e2 = acc[mt][nt][4 * g + 2], e3 = acc[mt][nt][4 * g + 3];
+                        quad_transpose(e0, e1, e2, e3, odd1, odd2);
+                        float4 v = make_float4(e0 + b4.x, e1 + b4.y, e2 + b4.z, e3 + b4.w);
+                        if (has_add) { v.x += addv[nt][g].x; v.y += addv[nt][g].y; v.z += addv[nt][g].z; v.w += addv[nt][g].w; }
+                        const int cc = cq + nt * 32;
+                        if (cc < a.act_cols) {
+                            v.x = act_fwd(v.x, a.act); v.y = act_fwd(v.y, a.act); v.z = act_fwd(v.z, a.act); v.w = act_fwd(v.w, a.act);
+                        }
+                        if (cok4) st4(a.out + (size_t)ro4[g] * D.ldo + cc, v);
+                        if (want_stat) {
+                            ssum4[nt].x += v.x; ssum4[nt].y += v.y; ssum4[nt].z += v.z; ssum4[nt].w += v.w;
+                            ssq4[nt].x += v.x * v.x; ssq4[nt].y += v.y * v.y; ssq4[nt].z += v.z * v.z; ssq4[nt].w += v.w * v.w;
+                        }
+                    }
+                }
+            } else {
+                int ro[16];
+#pragma unroll
+                for (int i = 0; i < 16; ++i) ro[i] = s_opix[(wm * MT + mt) * 32 + (i & 3) + 8 * (i >> 2) + 4 * hh];
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) {
+                    const int co = cob + nt * 32;
+                    const bool cok = co < D.Cout;
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) {
+                        if (cok && ro[i] >= 0) {
+                            float v = acc[mt][nt][i] + biasv[nt];
+                            if (has_add) v += a.addend[(size_t)ro[i] * a.ld_add + co];
+                            if (co < a.act_cols) v = act_fwd(v, a.act);
+                            a.out[(size_t)ro[i] * D.ldo + co] = v;
+                            ssum[nt] += v;
+                            ssq[nt] += v * v;
+                        }
+                    }
+                }
+            }
+        }
+        if (want_stat && __any(any4)) {
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                float4 s4 = ssum4[nt], q4 = ssq4[nt];
+                s4.x += dpp_xor1(s4.x); s4.y += dpp_xor1(s4.y); s4.z += dpp_xor1(s4.z); s4.w += dpp_xor1(s4.w);
+                q4.x += dpp_xor1(q4.x); q4.y += dpp_xor1(q4.y); q4.z += dpp_xor1(q4.z); q4.w += dpp_xor1(q4.w);
+                s4.x += dpp_xor2(s4.x); s4.y += dpp_xor2(s4.y); s4.z += dpp_xor2(s4.z); s4.w += dpp_xor2(s4.w);
+                q4.x += dpp_xor2(q4.x); q4.y += dpp_xor2(q4.y); q4.z += dpp_xor2(q4.z); q4.w += dpp_xor2(q4.w);
+                ssum[nt] += odd2 ? (odd1 ? s4.w : s4.z) : (odd1 ? s4.y : s4.x);
+                ssq[nt] += odd2 ? (odd1 ? q4.w : q4.z) : (odd1 ? q4.y : q4.x);
+            }
+        }
+    }
+    if (a.stat) {
+        rd_sync();
+        float* red = reinterpret_cast<float*>(s_w);  // [4][2][BN]
+        if (!loader) {
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                const float s = ssum[nt] + __shfl_xor(ssum[nt], 32, 64);
+                const float q = ssq[nt] + __shfl_xor(ssq[nt], 32, 64);
+                if (hh == 0) {
+                    red[(wm * 2 + 0) * BN + nt * 32 + l31] = s;
+                    red[(wm * 2 + 1) * BN + nt * 32 + l31] = q;
+                }
+            }
+        }
+        rd_sync();
+        if (tid < 2 * BN) {
+            const int which = tid / BN, j = tid - which * BN;
+            float s = 0.f;
+#pragma unroll
+            for (int w = 0; w < 4; ++w) s += red[(w * 2 + which) * BN + j];
+            const int co = co0 + j;
+            if (co < D.Cout) a.stat[((size_t)pt * 2 + which) * D.Cout + co] = s;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------ host
+struct GsPlan {
+    int MT, NT, TH, TW, PP, tiles_total, n_cotiles, taps_max, pplane;
+    size_t lds_bytes;
+    int pdb;        // two patch buffers: the next chunk's patch is written while the current one is read (no second barrier)
+};
+
+static int gs_patch_pixels(const RdConvDesc& d, const RdPhase& p, int TH, int TW, int* rows, int* cols) {
+    const int th = TH < p.lh ? TH : p.lh;
+    const int PH = (th - 1) * d.in_stride + (p.dh_max - p.dh_min) + 1;
+    const int PW = (TW - 1) * d.in_stride + (p.dw_max - p.dw_min) + 1;
+    if (rows) *rows = PH;
+    if (cols) *cols = PW;
+    return PH * PW;
+}
+
+static bool plan_gconv_split(const RdConvDesc& d, GsPlan& best) {
+    struct Cfg { int MT, NT; };
+    static const Cfg cfgs[] = {{3, 2}, {2, 2}, {1, 2}, {2, 1}, {1, 1}};
+    int taps_max = 0;
+    for (int i = 0; i < d.n_phases; ++i) {
+        taps_max = taps_max > d.phase[i].n_taps ? taps_max : d.phase[i].n_taps;
+    }
+    int pr = 0;
+    for (int i = 1; i < d.n_phases; ++i)
+        if ((int64_t)d.phase[i].lh * d.phase[i].lw > (int64_t)d.phase[pr].lh * d.phase[pr].lw) pr = i;
+    const RdPhase& P = d.phase[pr];
+    double best_cost = -1;
+    static const char* force = getenv("RD_GCONV_SPLIT_FORCE");   // diagnostics: index into cfgs
+    int cfg_i = -1;
+    for (const Cfg& c : cfgs) {
+        ++cfg_i;
+        if (force && atoi(force) != cfg_i) continue;
+        const int BM = 4 * c.MT * 32, BN = c.NT * 32;
+        if (BN > 32 && d.Cout <= 32) continue;
+        const int n_cot = cdiv(d.Cout, BN);
+        for (int twt = 1; twt <= cdiv(P.lw, 4); ++twt) {
+            const int TW = cdiv(P.lw, twt);
+            if (TW > BM) continue;
+            int TH = BM / TW;
+            if (TH > P.lh) TH = P.lh;
+            TH = cdiv(P.lh, cdiv(P.lh, TH));
+            int PP = 0, segs = 0;
+            for (int i = 0; i < d.n_phases; ++i) {
+                int rows, cols;
+                const int pp = gs_patch_pixels(d, d.phase[i], TH, TW, &rows, &cols);
+                PP = PP > pp ? PP : pp;
+                const int sg = rows * cdiv(cols * 2, 64);
+                segs = segs > sg ? segs : sg;
+            }
+            if (segs > 4 * GS_UPP) continue;                 // the next chunk's patch is one register batch of the staging waves
+            const int pplane = (((PP + 1) * GS_PSB) + 15) & ~15;
+            static const char* nopdb = getenv("RD_GCONV_SPLIT_NOPDB");       // diagnostics
+            for (int pdb = nopdb ? 0 : 1; pdb >= 0; --pdb) {
+                const size_t lds = (size_t)(2 * BM + 32) * 4 + (size_t)3 * 3 * GS_TPS * 2 * BN * 16 + (size_t)(pdb ? 2 : 1) * 3 * pplane + 64;
+                if (lds > 160 * 1024 - 512) continue;
+                // matrix-core bound, one workgroup per CU: rounds of workgroups x (clocks of one: three-step tap groups of
+                // MT x NT x 6 MFMAs of ~36 clocks, a barrier per group, an exposed patch write per chunk unless double-buffered,
+                // a fixed prologue / epilogue)
+                double groups = 0, wgs = 0;
+                for (int i = 0; i < d.n_phases; ++i) {
+                    const double t = (double)cdiv(d.phase[i].lh, TH) * cdiv(d.phase[i].lw, TW);
+                    groups += t * cdiv(d.phase[i].n_taps, GS_TPS);
+                    wgs += t;
+                }
+                const double groups_per_wg = groups / wgs;
+                wgs *= (double)d.N * n_cot;
+                const double mfma_clk = 3.0 * c.MT * c.NT * 6 * 36;
+                const double lds_clk = 3.0 * 3 * (c.MT + c.NT) * 4 * 4 / 0.7;         // four compute waves x 4 LDS clocks per b128 read
+                const double per_group = (mfma_clk > lds_clk ? mfma_clk : lds_clk) + 250.0;
+                const double per_chunk = groups_per_wg * per_group + (pdb ? 300.0 : 1800.0);
+                const double per_wg = (double)(d.Cin / GS_CKP) * per_chunk + 7000.0 + 16.0 * c.MT * c.NT * 60;
+                const double rounds = ceil(wgs / (double)num_cus());
+                const double cost = rounds * per_wg;
+                if (best_cost < 0 || cost < best_cost) {
+                    best_cost = cost;
+                    best = GsPlan{c.MT, c.NT, TH, TW, PP, 0, n_cot, taps_max, pplane, lds, pdb};
+                }
+                break;      // the double-buffered form of a tile is never worse than its single-buffered one
+            }
+        }
+    }
+    return best_cost > 0;
+}
+
+template <int MT, int NT, bool PDB>
+static int launch_gs(const GsArgs& a, int grid, size_t lds, hipStream_t s) {
+    static bool attr_set = false;
+    auto k = gconv_split_kernel<MT, NT, PDB>;
+    if (!attr_set) {
+        RD_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(k, dim3(grid), dim3(512), lds, s, a);
+    RD_CHECK_LAUNCH("gconv_split_kernel");
+    return RD_OK;
+}
+
+static bool gs_shape_ok(const RdConvDesc* d) {
+    if (!d || d->n_phases < 1 || d->n_phases > RD_MAX_PHASES) return false;
+    if (d->Cin % 16 != 0 || d->ldi % 4 != 0 || d->Cin < 32 || d->Cout < 32) return false;      // (the 16-channel layers stay on conv16.hip)
+    if (d->in_stride < 1 || d->in_stride > 2 || d->out_stride < 1 || d->out_stride > 2) return false;
+    static const char* all = getenv("RD_GCONV_SPLIT_ALL");      // diagnostics: plan every shape the kernel can run
+    if (!all) {
+        // measured slower than gconv.hip (tools/bench_split.py): one-tap layers (a chunk is 36 MFMAs: nothing to hide the staging
+        // behind), and the wide patches of a stride-2 input over few channels
+        int taps_max = 0;
+        for (int i = 0; i < d->n_phases; ++i) taps_max = taps_max > d->phase[i].n_taps ? taps_max : d->phase[i].n_taps;
+        if (taps_max < 4) return false;
+        if (d->in_stride == 2 && d->Cin < 256) return false;
+    }
+    if ((int64_t)d->Hi * d->Wi * d->ldi * 4 >= (int64_t)GS_OOB) return false;
+    for (int i = 0; i < d->n_phases; ++i) {
+        const RdPhase& p = d->phase[i];
+        if (p.n_taps < 1 || p.n_taps > RD_MAX_TAPS || p.lh < 1 || p.lw < 1) return false;
+        for (int t = 0; t < p.n_taps; ++t)
+            if (p.dh[t] < p.dh_min || p.dh[t] > p.dh_max || p.dw[t] < p.dw_min || p.dw[t] > p.dw_max) return false;
+    }
+    return true;
+}
+
+// 1: planned, 0: no plan (shape outside the kernel's domain or no tiling fits the LDS)
+static int gs_plan_query(const RdConvDesc* d, GsPlan& pl, RdConvDesc& dd) {
+    struct Entry { int ok; GsPlan pl; RdConvDesc dd; };
+    static std::mutex mu;
+    static std::unordered_map<std::string, Entry> cache;
+    if (!d) return 0;
+    std::string key(reinterpret_cast<const char*>(d), sizeof(RdConvDesc));
+    {
+        std::lock_guard<std::mutex> lk(mu);
+        auto it = cache.find(key);
+        if (it != cache.end()) { pl = it->second.pl; dd = it->second.dd; return it->second.ok; }
+    }
+    Entry e{};
+    e.dd = *d;
+    e.ok = gs_shape_ok(d) && plan_gconv_split(e.dd, e.pl) ? 1 : 0;
+    if (e.ok) {
+        int tb = 0;
+        for (int i = 0; i < e.dd.n_phases; ++i) {
+            e.dd.phase[i].tile_begin = tb;
+            tb += cdiv(e.dd.phase[i].lh, e.pl.TH) * cdiv(e.dd.phase[i].lw, e.pl.TW);
+        }
+        e.pl.tiles_total = tb;
+    }
+    pl = e.pl; dd = e.dd;
+    std::lock_guard<std::mutex> lk(mu);
+    cache.emplace(std::move(key), e);
+    return e.ok;
+}
+
+}  // namespace rd
+
+using namespace rd;
+
+extern "C" int rd_gconv_split_supported(const RdConvDesc* d) {
+    GsPlan pl; RdConvDesc dd;
+    return gs_plan_query(d, pl, dd);
+}
+
+// diagnostics: out[0..7] = MT, NT, TH, TW, PP, LDS bytes, workgroups, tap groups of the largest phase
+extern "C" int rd_gconv_split_plan_info(const RdConvDesc* d, int32_t* out) {
+    GsPlan pl; RdConvDesc dd;
+    if (!out || gs_plan_query(d, pl, dd) != 1) return RD_EINVAL;
+    const int v[8] = {pl.MT, pl.NT, pl.TH, pl.TW, pl.PP, (int)pl.lds_bytes, d->N * pl.tiles_total * pl.n_cotiles, (pl.taps_max + GS_TPS - 1) / GS_TPS + 100 * pl.pdb};
+    for (int i = 0; i < 8; ++i) out[i] = v[i];
+    return RD_OK;
+}
+
+extern "C" int rd_gconv_split_stat_tiles(const RdConvDesc* d) {
+    GsPlan pl; RdConvDesc dd;
+    if (gs_plan_query(d, pl, dd) != 1) return RD_EINVAL;
+    return d->N * pl.tiles_total;
+}
+
+extern "C" int rd_gconv_split(const RdConvDesc* d, const float* in, const void* w_split, int64_t piece_elems, float* out, const float* bias,
+                              int32_t act, int32_t act_cols, const float* addend, int32_t ld_add, float* stat_partial, void* stream) {
+    RD_CHECK_ARG(d && in && w_split && out, "gconv_split: null argument");
+    GsArgs a;
+    GsPlan pl;
+    if (gs_plan_query(d, pl, a.d) != 1) { set_error("gconv_split: descriptor not supported (rd_gconv_split_supported)"); return RD_EINVAL; }
+    RD_CHECK_ARG(reinterpret_cast<uintptr_t>(in) % 16 == 0 && reinterpret_cast<uintptr_t>(w_split) % 16 == 0, "gconv_split: unaligned tensor");
+    a.in = in; a.w = static_cast<const unsigned short*>(w_split); a.out = out;
+    a.addend = addend; a.bias = bias; a.stat = stat_partial;
+    a.act = act; a.act_cols = act_cols; a.ld_add = ld_add; a.ldw = d->Cout;
+    a.TH = pl.TH; a.TW = pl.TW; a.PP = pl.PP;
+    a.tiles_total = pl.tiles_total; a.n_cotiles = pl.n_cotiles; a.taps_max = pl.taps_max;
+    a.pplane = pl.pplane;
+    {
+        static const char* dbg = getenv("RD_GCONV_SPLIT_DEBUG");
+        a.debug = dbg ? atoi(dbg) : 0;
+    }
+    int S = 0;
+    for (int i = 0; i < d->n_phases; ++i)
+        for (int t = 0; t < d->phase[i].n_taps; ++t) S = S > d->phase[i].widx[t] + 1 ? S : d->phase[i].widx[t] + 1;
+    RD_CHECK_ARG(piece_elems >= (int64_t)S * d->Cin * d->Cout && piece_elems % 8 == 0, "gconv_split: piece stride %lld too small for %d slabs of %d x %d",
+                 (long long)piece_elems, S, d->Cin, d->Cout);
+    a.wplane = (long long)piece_elems * 2;
+    a.vec4 = d->Cout % 4 == 0 && d->ldo % 4 == 0 && reinterpret_cast<uintptr_t>(out) % 16 == 0 && act_cols % 4 == 0 &&
+             (!addend || (ld_add % 4 == 0 && reinterpret_cast<uintptr_t>(addend) % 16 == 0)) &&
+             (!bias || reinterpret_cast<uintptr_t>(bias) % 16 == 0);
+    for (int i = 0; i < d->n_phases; ++i) {
+        const RdPhase& p = d->phase[i];
+        const int PW_ = (pl.TW - 1) * d->in_stride + (p.dw_max - p.dw_min) + 1;
+        for (int t = 0; t < p.n_taps; ++t) a.tapoff[i][t] = ((p.dh[t] - p.dh_min) * PW_ + (p.dw[t] - p.dw_min)) * GS_PSB;
+    }
+    const int grid = d->N * pl.tiles_total * pl.n_cotiles;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+#define RD_GS(MT_, NT_) \
+    if (pl.MT == MT_ && pl.NT == NT_) return pl.pdb ? launch_gs<MT_, NT_, true>(a, grid, pl.lds_bytes, s) : launch_gs<MT_, NT_, false>(a, grid, pl.lds_bytes, s);
+    RD_GS(3, 2) RD_GS(2, 2) RD_GS(1, 2) RD_GS(2, 1) RD_GS(1, 1)
+#undef RD_GS
+    set_error("gconv_split: no kernel for tile %dx%d", pl.MT, pl.NT);
+    return RD_EINVAL;
+}

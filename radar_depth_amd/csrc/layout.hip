@@ -57,7 +57,18 @@ struct PackJob {
     const float* scale;   // optional per-output-channel factor (eval mode: folded BatchNorm scale), may be null
     int O, I, T, ldc, off, rows_total, transpose, first_block;
     int quad, pad_;       // 1: gconv operand layout (rows interleaved by four); 2: bf16 operand (by eight); 0: plain [slab][row][col] (stem kernels)
+                          // 3: three bf16 piece planes of the bf16 layout (gconv_split.hip), plane stride T * rows * ldc elements
 };
+// the three bf16 pieces of an fp32 value (gconv_split.hip): v = p0 + p1 + p2 exactly
+__device__ __forceinline__ void store_split3(__bf16* dst, int64_t idx, int64_t plane, float v) {
+    const __bf16 h = (__bf16)v;
+    float r = v - (float)h;
+    const __bf16 m = (__bf16)r;
+    r -= (float)m;
+    dst[idx] = h;
+    dst[idx + plane] = m;
+    dst[idx + 2 * plane] = (__bf16)r;
+}
 constexpr int PACK_CHUNK = 2048;
 __global__ __launch_bounds__(256) void pack_weights_batched_kernel(const PackJob* __restrict__ jobs, const int* __restrict__ block_job) {
     const PackJob j = jobs[block_job[blockIdx.x]];
@@ -74,7 +85,8 @@ __global__ __launch_bounds__(256) void pack_weights_batched_kernel(const PackJob
             const int t = (int)(r / (unsigned)j.I), i = (int)(r - (r / (unsigned)j.I) * (unsigned)j.I);
             float v = j.src[((int64_t)o * j.I + i) * j.T + t];
             if (j.scale) v *= j.scale[o];
-            if (j.quad == 2) reinterpret_cast<__bf16*>(j.dst)[packed_index_bf16(t, j.I, i, j.ldc, j.off + o)] = (__bf16)v;
+            if (j.quad == 3) store_split3(reinterpret_cast<__bf16*>(j.dst), packed_index_bf16(t, j.I, i, j.ldc, j.off + o), (int64_t)j.T * j.I * j.ldc, v);
+            else if (j.quad == 2) reinterpret_cast<__bf16*>(j.dst)[packed_index_bf16(t, j.I, i, j.ldc, j.off + o)] = (__bf16)v;
             else j.dst[packed_index(j.quad, t, j.I, i, j.ldc, j.off + o)] = v;
         } else {
             const unsigned r = e / (unsigned)j.I;
@@ -82,7 +94,8 @@ __global__ __launch_bounds__(256) void pack_weights_batched_kernel(const PackJob
             const int t = (int)(r / (unsigned)j.O), o = (int)(r - (r / (unsigned)j.O) * (unsigned)j.O);
             float v = j.src[((int64_t)o * j.I + i) * j.T + t];
             if (j.scale) v *= j.scale[o];
-            if (j.quad == 2) reinterpret_cast<__bf16*>(j.dst)[packed_index_bf16(t, j.rows_total, j.off + o, j.ldc, i)] = (__bf16)v;
+            if (j.quad == 3) store_split3(reinterpret_cast<__bf16*>(j.dst), packed_index_bf16(t, j.rows_total, j.off + o, j.ldc, i), (int64_t)j.T * j.rows_total * j.ldc, v);
+            else if (j.quad == 2) reinterpret_cast<__bf16*>(j.dst)[packed_index_bf16(t, j.rows_total, j.off + o, j.ldc, i)] = (__bf16)v;
             else j.dst[packed_index(j.quad, t, j.rows_total, j.off + o, j.ldc, i)] = v;
         }
     }

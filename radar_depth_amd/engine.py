@@ -74,7 +74,7 @@ def _p(t):
 
 class LateFusionPlan:
     def __init__(self, module, batch, height, width, train=True, depth_planes=None, x_source=None, dense_grad_dst=None,
-                 dry_run=False, bf16=False, storage="fp32", segment_joins=True, autotune=None):
+                 dry_run=False, bf16=False, storage="fp32", segment_joins=True, autotune=None, split=False):
         """module: a radar_depth_amd ResNet_latefusion(2); bf16: run the gconv-lowered convolutions with bf16 operands on
         v_mfma_f32_32x32x16_bf16 (fp32 tensors, fp32 accumulation -- BASELINE.json configs 3/5, opt-in; in train plans the
         forward and input-gradient convolutions and the weight gradients of the >= 32-channel layers -- wgrad_bf16.hip; the
@@ -100,6 +100,9 @@ class LateFusionPlan:
         self.adt = torch.bfloat16 if storage == "bf16" else torch.float32
         self.dt = 1 if storage == "bf16" else 0            # RD_DTYPE_BF16 / RD_DTYPE_F32
         self.bf16 = bool(bf16) or storage == "bf16"
+        # split: fp32 arithmetic on the bf16 matrix cores for the forward / input-gradient convolutions the library plans that way
+        # (csrc/gconv_split.hip: three bf16 pieces per operand, six MFMAs per product, fp32 accumulation); the rest is the fp32 plan
+        self.split = bool(split) and not self.bf16
         self.dev = next(module.parameters()).device
         # dry_run: record the op lists against host buffers without ever launching (CPU tests of the host logic)
         assert dry_run or self.dev.type == "cuda", "the HIP path needs the module on a GPU"
@@ -246,28 +249,39 @@ class LateFusionPlan:
         S = k * k
         wdt = torch.bfloat16 if self.bf16 else torch.float32
         quad = 2 if self.bf16 else 1
-        wp = self.buf(S, cin, cout, dtype=wdt)
-        wd = self.buf(S, cout, cin, dtype=wdt)
+        # split plans: each of the two operands (forward, input gradient) is packed as three bf16 piece planes when the library has a
+        # split plan for that descriptor, and stays the fp32 operand of rd_gconv otherwise
+        sp_f = sp_d = False
+        if self.split:
+            sp_f = self.L.rd_gconv_split_supported(C.byref(d)) == 1
+            dd0 = (cd.upproj_dgrad(N, H, W, cin, cout) if upproj else cd.conv_dgrad(N, H, W, cin, cout, k, stride, pad)[0])
+            sp_d = self.L.rd_gconv_split_supported(C.byref(dd0)) == 1
+        wp = self.buf(3, S, cin, cout, dtype=torch.bfloat16) if sp_f else self.buf(S, cin, cout, dtype=wdt)
+        wd = self.buf(3, S, cout, cin, dtype=torch.bfloat16) if sp_d else self.buf(S, cout, cin, dtype=wdt)
         for w, off in weights:
             o, i, kh, kw = w.shape
-            self.pack_jobs.append((w, wp, o, i, kh * kw, cout, off, i, 0, None, quad))
-            self.pack_jobs.append((w, wd, o, i, kh * kw, cin, off, cout, 1, None, quad))
-        self._tune(d)
-        tiles = (self.L.rd_gconv_bf16_stat_tiles if self.bf16 else self.L.rd_gconv_stat_tiles_ws)(C.byref(d))
+            self.pack_jobs.append((w, wp, o, i, kh * kw, cout, off, i, 0, None, 3 if sp_f else quad))
+            self.pack_jobs.append((w, wd, o, i, kh * kw, cin, off, cout, 1, None, 3 if sp_d else quad))
+        if not sp_f:
+            self._tune(d)
+        tiles = (self.L.rd_gconv_split_stat_tiles if sp_f else self.L.rd_gconv_bf16_stat_tiles if self.bf16 else self.L.rd_gconv_stat_tiles_ws)(C.byref(d))
         if tiles < 0:
             check(tiles, "rd_gconv_stat_tiles(%s)" % name)
         stat = self.buf(tiles, 2, cout) if self.train else None
         self.keep.append(d)
-        if self.bf16:
+        if sp_f:
+            self.op(lst, name, self.L.rd_gconv_split, C.byref(d), x.ptr, _p(wp), C.c_int64(S * cin * cout), out.ptr, C.c_void_p(0), 0, 0,
+                    C.c_void_p(0), 0, _p(stat), self.stream)
+        elif self.bf16:
             self.op(lst, name, self.L.rd_gconv_bf16_t, self.dt, C.byref(d), x.ptr, _p(wp), out.ptr, C.c_void_p(0), 0, 0, C.c_void_p(0), 0,
                     _p(stat), self.stream)
         else:
             ws = self._gconv_ws(d, name)
             self.op(lst, name, self.L.rd_gconv_ws, C.byref(d), x.ptr, _p(wp), out.ptr, C.c_void_p(0), 0, _p(stat), _p(ws), self.stream)
         self.taps[name] = out
-        self.meta[name] = ("gconv_bf16" if self.bf16 else "gconv", d)
+        self.meta[name] = ("gconv_split" if sp_f else "gconv_bf16" if self.bf16 else "gconv", d)
         ctx = dict(name=name, d=d, x=x, out=out, weights=weights, wd=wd, k=k, stride=stride, pad=pad, upproj=upproj,
-                   stat=stat, tiles=tiles, cin=cin, cout=cout)
+                   stat=stat, tiles=tiles, cin=cin, cout=cout, split_dgrad=sp_d)
         return out, ctx
 
     def conv_bwd(self, ctx, dout, need_dx=True, addend=None, dx=None, bnb=None):
@@ -347,11 +361,19 @@ class LateFusionPlan:
                     self.stream)
             if addend is not None:
                 raise NotImplementedError("addend with a zero-filled stride-2 dgrad")
-        self.meta[name + ".dgrad"] = ("gconv_bf16" if self.bf16 else "gconv", dd)
+        sp_d = bool(ctx.get("split_dgrad"))
+        if sp_d and self.L.rd_gconv_split_supported(C.byref(dd)) != 1:
+            raise RuntimeError("%s: the input-gradient operand was packed for rd_gconv_split, but the library has no split plan for the final descriptor" % name)
+        self.meta[name + ".dgrad"] = ("gconv_split" if sp_d else "gconv_bf16" if self.bf16 else "gconv", dd)
         # (bf16 plans keep the separate BatchNorm-backward reduce pass: the same fusion in gconv_bf16's epilogue -- parity-green in
         #  round 3 -- made the bf16-storage step 5 % SLOWER, 1790 -> 1697 samples/s: that kernel's epilogue is already its longest
         #  phase, and the extra x loads sit on it)
-        if self.bf16:
+        if sp_d:
+            # (no BatchNorm-backward sums from this epilogue: the caller keeps its reduce pass, as in the bf16 plans)
+            self.op(self.bwd, name + ".dgrad", self.L.rd_gconv_split, C.byref(dd), dout.ptr, _p(ctx["wd"]), C.c_int64(k * k * cin * cout), dx.ptr,
+                    C.c_void_p(0), 0, 0, addend.ptr if addend is not None else C.c_void_p(0), addend.ld if addend is not None else 0,
+                    C.c_void_p(0), self.stream)
+        elif self.bf16:
             self.op(self.bwd, name + ".dgrad", self.L.rd_gconv_bf16_t, self.dt, C.byref(dd), dout.ptr, _p(ctx["wd"]), dx.ptr, C.c_void_p(0), 0, 0,
                     addend.ptr if addend is not None else C.c_void_p(0), addend.ld if addend is not None else 0,
                     C.c_void_p(0), self.stream)

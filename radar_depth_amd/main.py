@@ -120,7 +120,11 @@ class HipTrainStep:
     operands: "fp32" (default, the parity path) or "bf16": forward, input-gradient and stride-1 3x3 weight-gradient convolutions
     with bf16 operands on the bf16 matrix cores (csrc/gconv_bf16.hip, csrc/wgrad_bf16.hip; fp32 tensors, fp32 accumulation, fp32
     BatchNorm / loss / SGD and the remaining weight gradients) -- the
-    torch.autocast(bfloat16) analogue for BASELINE.json configs 2/4; tolerances in tests/test_gpu_bf16.py."""
+    torch.autocast(bfloat16) analogue for BASELINE.json configs 2/4; tolerances in tests/test_gpu_bf16.py.
+    "split": fp32 arithmetic on the bf16 matrix cores -- the forward and input-gradient convolutions the library has a plan for
+    (csrc/gconv_split.hip: >= 32 channels, 3x3 / 5x5 shapes) split every fp32 operand into three bf16 pieces and rebuild the
+    product from six bf16 MFMAs with fp32 accumulation; results as close to fp64 as the fp32 MFMA path's (tests/test_gpu_gconv_split.py),
+    fp32 tolerances unchanged; everything else is the fp32 path."""
 
     def __init__(self, model, batch, height, width, lr=0.01, momentum=0.9, weight_decay=1e-4, loss_weights=None, use_graph=False,
                  operands="fp32", criterion="l1", comm="auto", storage="fp32", autotune=None):
@@ -133,6 +137,7 @@ class HipTrainStep:
         # storage="bf16": NHWC activations and their gradients live in HBM as bf16 (implies bf16 conv operands); BatchNorm
         # statistics, losses, parameters, their gradients and the optimizer stay fp32 -- BASELINE.json configs 3 / 5
         assert storage in ("fp32", "bf16"), storage
+        assert operands in ("fp32", "bf16", "split"), operands
         if storage == "bf16":
             operands = "bf16"
         self.operands, self.storage = operands, storage
@@ -151,13 +156,14 @@ class HipTrainStep:
         model.train()
         self.multistage = isinstance(model, ResNet_multistage)
         if self.multistage:
-            self.mp = model._plans(batch, height, width, True, bf16=operands == "bf16", storage=storage, segment_joins=joins, autotune=autotune)
+            self.mp = model._plans(batch, height, width, True, bf16=operands == "bf16", storage=storage, segment_joins=joins, autotune=autotune,
+                                   split=operands == "split")
             self.plans = [self.mp.p1, self.mp.p2]
         else:
             assert isinstance(model, ResNet_latefusion)
             self.mp = None
             self.plans = [model._plan(batch, height, width, True, bf16=operands == "bf16", storage=storage, segment_joins=joins,
-                                      autotune=autotune)]
+                                      autotune=autotune, split=operands == "split")]
         self.plan = self.plans[0]
         self.st = model._ensure_arenas()
         self._arena_version = self.st["version"]

@@ -265,16 +265,16 @@ class ResNet_latefusion(ArenaOwner, nn.Module):
         return 1
 
     # ------------------------------------------------------------------ HIP execution
-    def _plan(self, batch, height, width, train, depth_planes=None, bf16=False, storage="fp32", segment_joins=True, autotune=None):
+    def _plan(self, batch, height, width, train, depth_planes=None, bf16=False, storage="fp32", segment_joins=True, autotune=None, split=False):
         from ..engine import LateFusionPlan
         st = self._ensure_arenas()
         key = (batch, height, width, bool(train), st["version"], None if depth_planes is None else tuple(t.data_ptr() for t in depth_planes),
-               bool(bf16), storage, bool(segment_joins))
+               bool(bf16), storage, bool(segment_joins), bool(split))
         plans = self.__dict__.setdefault("_plans", {})
         if key not in plans:
             _evict_plans(plans, st["version"])
             plans[key] = LateFusionPlan(self, batch, height, width, train=train, depth_planes=depth_planes, bf16=bf16, storage=storage,
-                                        segment_joins=segment_joins, autotune=autotune)
+                                        segment_joins=segment_joins, autotune=autotune, split=split)
         else:
             plans[key] = plans.pop(key)          # most recently used last
         return plans[key]

@@ -54,6 +54,36 @@ def gconv_bf16(desc, x, w_packed_bf16, out, bias=None, act=0, act_cols=0, addend
     return out
 
 
+def pack_weights_split(w_oihw, transpose=False, ldc=None, off=0, rows_total=None):
+    """Three-piece bf16 operand of gconv_split: [piece][slab][rows][ldc], w = p0 + p1 + p2 exactly (each piece packed like
+    pack_weights_bf16; the pieces are bf16-representable, so packing them is exact)."""
+    h = w_oihw.to(torch.bfloat16).float()
+    r = w_oihw - h
+    m = r.to(torch.bfloat16).float()
+    lo = (r - m).to(torch.bfloat16).float()
+    return torch.stack([pack_weights_bf16(p.contiguous(), transpose, ldc, off, rows_total) for p in (h, m, lo)]).contiguous()
+
+
+def gconv_split_supported(desc):
+    return lib().rd_gconv_split_supported(C.byref(desc)) == 1
+
+
+def gconv_split(desc, x, w_split, out, bias=None, act=0, act_cols=0, addend=None, ld_add=0, stat=None):
+    """fp32 convolution rebuilt from six bf16 MFMAs per product (three-piece operands): rd_gconv_split."""
+    _poison()
+    assert w_split.dtype == torch.bfloat16 and w_split.shape[0] == 3
+    check(lib().rd_gconv_split(C.byref(desc), ptr(_f32(x)), ptr(w_split), C.c_int64(w_split[0].numel()), ptr(_f32(out)), ptr(bias), act,
+                               act_cols, ptr(addend), ld_add, ptr(stat), current_stream()), "rd_gconv_split")
+    return out
+
+
+def gconv_split_stat_tiles(desc):
+    n = lib().rd_gconv_split_stat_tiles(C.byref(desc))
+    if n < 0:
+        check(n, "rd_gconv_split_stat_tiles")
+    return n
+
+
 def gconv_stat_tiles(desc):
     n = lib().rd_gconv_stat_tiles_ws(C.byref(desc))
     if n < 0:

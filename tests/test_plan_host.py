@@ -2,6 +2,7 @@
  * a dry-run LateFusionPlan records the op lists on host buffers: every parameter gets exactly one gradient writer, the
    backward ops are ordered so that the gradient buckets complete in arena-contiguous slices;
  * world_size-2 gloo run of reduce_gradient_buckets == gradient averaging over the flat arena."""
+import collections
 import os
 
 import pytest
@@ -280,3 +281,30 @@ def test_state_broadcast_packing_round_trip():
         b.zero_()
     unpack_buffers(bufs, flat)
     assert all(torch.equal(a, b) for a, b in zip(bufs, want)) and ptrs == [b.data_ptr() for b in bufs]
+
+
+def test_split_plan_routes_supported_convolutions():
+    """operands="split": every forward / input-gradient convolution the library has a split plan for goes to rd_gconv_split with a
+    three-piece bf16 operand (pack quad 3); the rest keeps rd_gconv with the fp32 operand; weight gradients stay fp32; the BatchNorm
+    reduce passes are all present (no rd_gconv_bnbwd fusion on split input gradients)."""
+    import ctypes as C
+    from radar_depth_amd.engine import LateFusionPlan
+    m = _model(450, 800)
+    plan = LateFusionPlan(m, 16, 450, 800, train=True, dry_run=True, split=True)
+    ref = LateFusionPlan(m, 16, 450, 800, train=True, dry_run=True)
+    kinds = collections.Counter(k for k, _ in plan.meta.values())
+    assert kinds["gconv_split"] > 40 and kinds["gconv"] > 0 and kinds["wgrad"] == collections.Counter(k for k, _ in ref.meta.values())["wgrad"]
+    L = plan.L
+    for name, (kind, d) in plan.meta.items():
+        if kind == "gconv_split":
+            assert L.rd_gconv_split_supported(C.byref(d)) == 1, name
+            assert min(d.Cin, d.Cout) >= 32
+    quads = collections.Counter(j[-1] for j in plan.pack_jobs)
+    assert quads[3] > 0 and quads[1] > 0 and quads[2] == 0
+    for j in plan.pack_jobs:
+        if j[-1] == 3:
+            assert j[1].dtype == torch.bfloat16 and j[1].shape[0] == 3
+    names = [n for n, _, _ in plan.fwd + plan.bwd]
+    assert any(n.endswith(".dgrad") for n in names)
+    fns = collections.Counter(f.__name__ if hasattr(f, "__name__") else str(f) for _, f, _ in plan.fwd + plan.bwd)
+    assert fns["rd_gconv_split"] == kinds["gconv_split"]
