@@ -135,6 +135,9 @@ int rd_gconv_split(const RdConvDesc* d, const float* in, const void* w_split, in
 int rd_gconv_split_stat_tiles(const RdConvDesc* d);
 /* diagnostics: out[0..7] = MT, NT, TH, TW, patch pixels, lds_bytes, workgroups, tap groups of the largest phase */
 int rd_gconv_split_plan_info(const RdConvDesc* d, int32_t* out);
+/* diagnostics: with RD_GCONV_SPLIT_TRACE=1 (an MFMA wave) / =2 (a staging wave) every workgroup records cycle-counter stamps around
+ * the barrier of its first 30 tap groups (64 slots per workgroup); copies the last traced launch to the host (tools/trace_gconv_split.py) */
+int rd_gconv_split_trace_read(unsigned long long* host, int n_wg);
 /* diagnostics: out[0..9] = MT, NT, WM, WN, pipelined*10000+ksplit*100+CKW, CKP, TH, TW, lds_bytes, workgroups chosen for d
  * (workspace plan) */
 int rd_gconv_plan_info(const RdConvDesc* d, int32_t* out);

@@ -56,25 +56,42 @@ struct GsArgs {
     int act, act_cols, ld_add, ldw;
     int TH, TW, PP, tiles_total, n_cotiles, taps_max;
     int vec4;
-    int debug;                    // diagnostics (RD_GCONV_SPLIT_DEBUG): timing experiments that break the results
     int pplane;                   // bytes per piece plane of the LDS patch
     long long wplane;             // bytes per piece plane of the packed operand
     int tapoff[RD_MAX_PHASES][RD_MAX_TAPS];   // byte offset of tap t inside a patch plane
+    unsigned long long* trace;    // diagnostics (RD_GCONV_SPLIT_TRACE=1 compute wave 0, =2 staging wave 4): 64 stamps per workgroup
+    int trace_role;
 };
 
-// the three bf16 pieces of eight fp32 values (round to nearest even at every level; the remainders are exact)
+// the three bf16 pieces of eight fp32 values (round to nearest even at every level; the remainders are exact), two values at a
+// time so that every conversion is one v_cvt_pk_bf16_f32 and the packed result IS the piece operand: 11 VALU instructions per pair
+// (element by element the compiler spends one conversion per value and packs afterwards: 17)
+typedef float sf32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 sbf16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned cvt_pk(float a, float b) {
+    sf32x2 v;
+    v[0] = a; v[1] = b;
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, sbf16x2));
+}
 __device__ __forceinline__ void split8(const float4 v0, const float4 v1, sbf16x8& p0, sbf16x8& p1, sbf16x8& p2) {
     const float x[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+    su32x4 w0, w1, w2;
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        const __bf16 h = (__bf16)x[i];
-        float r = x[i] - (float)h;
-        const __bf16 m = (__bf16)r;
-        r -= (float)m;
-        p0[i] = h;
-        p1[i] = m;
-        p2[i] = (__bf16)r;
+    for (int i = 0; i < 4; ++i) {
+        float a = x[2 * i], b = x[2 * i + 1];
+        const unsigned u0 = cvt_pk(a, b);
+        a -= __uint_as_float(u0 << 16);
+        b -= __uint_as_float(u0 & 0xffff0000u);
+        const unsigned u1 = cvt_pk(a, b);
+        a -= __uint_as_float(u1 << 16);
+        b -= __uint_as_float(u1 & 0xffff0000u);
+        w0[i] = u0;
+        w1[i] = u1;
+        w2[i] = cvt_pk(a, b);
     }
+    p0 = __builtin_bit_cast(sbf16x8, w0);
+    p1 = __builtin_bit_cast(sbf16x8, w1);
+    p2 = __builtin_bit_cast(sbf16x8, w2);
 }
 
 template <int MT, int NT, bool PDB>
@@ -90,6 +107,7 @@ __global__ __launch_bounds__(512) void gconv_split_kernel(const GsArgs a) {
     const int l31 = lane & 31, hh = lane >> 5;
     const RdConvDesc& D = a.d;
 
+    if (a.trace && tid == 0) a.trace[(size_t)blockIdx.x * 64 + 62] = __builtin_readcyclecounter();
     const int vid = xcd_remap(blockIdx.x, gridDim.x);
     const int cot = vid % a.n_cotiles;
     const int pt = vid / a.n_cotiles;
@@ -201,50 +219,76 @@ __global__ __launch_bounds__(512) void gconv_split_kernel(const GsArgs a) {
                 v1[u] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)pgo[u] + 16, 0, 0));
             }
         };
-        auto split = [&]() {
+        auto split_units = [&](auto u0_, auto u1_) {
 #pragma unroll
-            for (int u = 0; u < GS_UPP; ++u) {
+            for (int u = decltype(u0_)::value; u < decltype(u1_)::value; ++u) {
                 split8(v0[u], v1[u], pc[u][0], pc[u][1], pc[u][2]);
                 __builtin_amdgcn_sched_barrier(0);      // one unit at a time: interleaved, the units' temporaries cost ~100 registers
             }
         };
-        auto put_patch = [&](int pbuf) {
-            char* base = s_patch + pbuf * 3 * pplane;
+        // (ds_write_b128 as inline assembly: behind outstanding global_load_lds copies the compiler makes a plain LDS store wait for
+        //  the copies -- they could alias for all it knows; these stores go to the patch, the copies to the weight ring.  Completion
+        //  is covered by the explicit lgkmcnt(0) in front of every barrier.)
+        auto put_units = [&](int pbuf, auto u0_, auto u1_) {
+            const unsigned base = (unsigned)(size_t)(s_patch + pbuf * 3 * pplane);
 #pragma unroll
-            for (int u = 0; u < GS_UPP; ++u)
+            for (int u = decltype(u0_)::value; u < decltype(u1_)::value; ++u)
                 if (pdst[u] >= 0) {
 #pragma unroll
-                    for (int p = 0; p < 3; ++p) *reinterpret_cast<sbf16x8*>(base + p * pplane + pdst[u]) = pc[u][p];
+                    for (int p = 0; p < 3; ++p) {
+                        const unsigned addr = base + p * pplane + pdst[u];
+                        const su32x4 dv = __builtin_bit_cast(su32x4, pc[u][p]);
+                        asm volatile("ds_write_b128 %0, %1" ::"v"(addr), "v"(dv) : "memory");
+                    }
                 }
         };
+        constexpr std::integral_constant<int, 0> U0{};
+        constexpr std::integral_constant<int, GS_UPP> UN{};
         issue_slab(0, 0, 0);
         if (total_groups > 1) issue_slab(1, ngroups > 1 ? 0 : GS_CKP, ngroups > 1 ? 1 : 0);
         fetch(0);
-        split();
-        put_patch(0);
+        split_units(U0, UN);
+        put_units(0, U0, UN);
+        if (nchunks > 1) fetch(GS_CKP);
         glds_wait();
         int it = 0, wi = 2;                       // wi: ring buffer of group it + 2
         int c2 = 0, g2 = 2;                       // (chunk, group) of group it + 2
         while (g2 >= ngroups) { g2 -= ngroups; ++c2; }
-        const int gmid = ngroups > 1 ? 1 : 0;
+        // the patch of chunk c + 1 is fetched one chunk ahead (in the last group of chunk c - 1: HBM latency under load is more than a
+        // tap group), split into pieces in the second group of chunk c and written in its last group
+        const int gsplit = ngroups > 2 ? 1 : 0;
+        unsigned long long* ltr = (a.trace && a.trace_role == 2 && tid == 256) ? a.trace + (size_t)blockIdx.x * 64 : nullptr;
         for (int c = 0; c < nchunks; ++c) {
             const bool more = c + 1 < nchunks;
             for (int g = 0; g < ngroups; ++g, ++it) {
+                if (ltr && it < 30) ltr[2 * it] = __builtin_readcyclecounter();
                 rd_sync();                        // B1(it)
+                if (ltr && it < 30) ltr[2 * it + 1] = __builtin_readcyclecounter();
+                // this group's weight copies first: the split arithmetic / the patch stores below run while they are in flight
                 if (it + 2 < total_groups) issue_slab(wi, c2 * GS_CKP, g2);
                 wi = wi == 2 ? 0 : wi + 1;
                 if (++g2 == ngroups) { g2 = 0; ++c2; }
-                if (g == 0 && more) fetch((c + 1) * GS_CKP);
-                if (g == gmid && more) split();
-                if (g == ngroups - 1 && more) {
-                    if constexpr (!PDB) rd_sync();        // B2: the compute waves are done with this chunk's patch
-                    put_patch(PDB ? ((c + 1) & 1) : 0);
+                const bool refetch = g == ngroups - 1 && c + 2 < nchunks;
+                if (more) {
+                    // (spreading the split arithmetic and the stores over two groups was slower: 3x2 tile 139 -> 150 us on layer3)
+                    if (g == gsplit) split_units(U0, UN);
+                    if (g == ngroups - 1) {
+                        if constexpr (!PDB) rd_sync();    // B2: the compute waves are done with this chunk's patch
+                        put_units(PDB ? ((c + 1) & 1) : 0, U0, UN);
+                    }
                 }
-                glds_wait();
+                if (refetch) fetch((c + 2) * GS_CKP);
+                // the weights issued above must have landed before the next barrier; the patch loads issued BEHIND them in this
+                // group (2 * GS_UPP buffer loads per wave, unconditionally) need not: a plain vmcnt(0) would hold the next barrier
+                // back by the HBM latency (~1400 clocks of the MFMA waves per chunk, tools/trace_gconv_split.py)
+                if (refetch) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(2 * GS_UPP) : "memory");
+                else glds_wait();
             }
         }
     } else {
         // ------------------------------------------------------------------------------------------ compute waves
+        // (s_setprio(3) for these waves starves the staging waves' split arithmetic: 1880 -> 4760 clocks per chunk, the MFMA waves then
+        //  wait for the patch: 2x2 tile 182 -> 195 us on layer1)
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
@@ -310,11 +354,14 @@ __global__ __launch_bounds__(512) void gconv_split_kernel(const GsArgs a) {
         // loop body is a PAIR of groups: set 0 is then the only one alive across the back edge (carrying both made the compiler
         // keep 120 fragment registers next to the 96 accumulators and spill).
         sbf16x8 fa[2][3][MT], fb[2][3][NT];
+        unsigned long long* trc = (a.trace && a.trace_role == 1 && tid == 0) ? a.trace + (size_t)blockIdx.x * 64 : nullptr;
         int it = 0, wi = 0, c = 0, g = 0;
         bool have = false;
         auto group = [&](auto parity) {
             constexpr int P0 = decltype(parity)::value, P1 = 1 - P0;
+            if (trc && it < 30) trc[2 * it] = __builtin_readcyclecounter();
             rd_sync();                            // B1(it)
+            if (trc && it < 30) trc[2 * it + 1] = __builtin_readcyclecounter();
             const char* pbase = s_patch + (PDB ? (c & 1) * 3 * pplane : 0);
             const int wn = wi == 2 ? 0 : wi + 1;
             const char* wb = s_w + wi * SLAB;
@@ -368,6 +415,7 @@ __global__ __launch_bounds__(512) void gconv_split_kernel(const GsArgs a) {
             group(std::integral_constant<int, 1>{});
         }
         if (it < total_groups) group(std::integral_constant<int, 0>{});
+        if (trc) { trc[60] = __builtin_readcyclecounter(); trc[63] = (unsigned long long)total_groups; }
     }
 
     // ---- epilogue (gconv_bf16.hip's, fp32 tensors): the compute waves store, every wave takes part in the barriers
@@ -492,6 +540,7 @@ __global__ __launch_bounds__(512) void gconv_split_kernel(const GsArgs a) {
             if (co < D.Cout) a.stat[((size_t)pt * 2 + which) * D.Cout + co] = s;
         }
     }
+    if (a.trace && a.trace_role == 1 && tid == 0) a.trace[(size_t)blockIdx.x * 64 + 61] = __builtin_readcyclecounter();
 }
 
 // ------------------------------------------------------------------------------------------ host
@@ -561,10 +610,13 @@ static bool plan_gconv_split(const RdConvDesc& d, GsPlan& best) {
                 }
                 const double groups_per_wg = groups / wgs;
                 wgs *= (double)d.N * n_cot;
-                const double mfma_clk = 3.0 * c.MT * c.NT * 6 * 36;
+                // calibrated on layer1..4 at b = 16 (tools/bench_split_one.py, tools/trace_gconv_split.py), all in: a tap group costs
+                // ~42 clocks per MFMA (the MFMA waves' own stream runs at ~40) + ~1300 (barrier, the wait for the staging waves,
+                // which share the SIMDs' issue slots): 3x2 tile 5870 measured, 2x2 4000, 1x1 2060
+                const double mfma_clk = 3.0 * c.MT * c.NT * 6 * 42;
                 const double lds_clk = 3.0 * 3 * (c.MT + c.NT) * 4 * 4 / 0.7;         // four compute waves x 4 LDS clocks per b128 read
-                const double per_group = (mfma_clk > lds_clk ? mfma_clk : lds_clk) + 250.0;
-                const double per_chunk = groups_per_wg * per_group + (pdb ? 300.0 : 1800.0);
+                const double per_group = (mfma_clk > lds_clk ? mfma_clk : lds_clk) + 1300.0;
+                const double per_chunk = groups_per_wg * per_group;
                 const double per_wg = (double)(d.Cin / GS_CKP) * per_chunk + 7000.0 + 16.0 * c.MT * c.NT * 60;
                 const double rounds = ceil(wgs / (double)num_cus());
                 const double cost = rounds * per_wg;
@@ -598,12 +650,18 @@ static bool gs_shape_ok(const RdConvDesc* d) {
     if (d->in_stride < 1 || d->in_stride > 2 || d->out_stride < 1 || d->out_stride > 2) return false;
     static const char* all = getenv("RD_GCONV_SPLIT_ALL");      // diagnostics: plan every shape the kernel can run
     if (!all) {
-        // measured slower than gconv.hip (tools/bench_split.py): one-tap layers (a chunk is 36 MFMAs: nothing to hide the staging
-        // behind), and the wide patches of a stride-2 input over few channels
+        // measured slower than (or level with) gconv.hip at the bench geometry (tools/bench_split.py, profiles/r03_bench_split.txt):
+        //   * one-tap layers (0.4-0.8x: a chunk is 36 MFMAs, nothing to hide the staging behind);
+        //   * fewer than 64 channels on a side (0.8-1.0x on the 32-channel decoder layers: the 32-wide output tile halves the reuse
+        //     of every staged patch);
+        //   * stride-2 convolutions in either direction (0.75-0.95x forward: the patch holds four times the pixels a tap touches;
+        //     0.9x for their zero-filled input gradients); the UpProj input gradient (stride-2 input, four phases) gains 1.1-1.4x
         int taps_max = 0;
         for (int i = 0; i < d->n_phases; ++i) taps_max = taps_max > d->phase[i].n_taps ? taps_max : d->phase[i].n_taps;
         if (taps_max < 4) return false;
-        if (d->in_stride == 2 && d->Cin < 256) return false;
+        if (d->Cin < 64 || d->Cout < 64) return false;
+        if (d->in_stride == 2 && taps_max <= 9) return false;       // stride-2 forward (the UpProj input gradient has 25 taps)
+        if (d->out_stride == 2 && taps_max <= 4) return false;      // stride-2 input gradient (phases of 1 / 2 / 2 / 4 taps)
     }
     if ((int64_t)d->Hi * d->Wi * d->ldi * 4 >= (int64_t)GS_OOB) return false;
     for (int i = 0; i < d->n_phases; ++i) {
@@ -648,6 +706,15 @@ static int gs_plan_query(const RdConvDesc* d, GsPlan& pl, RdConvDesc& dd) {
 
 using namespace rd;
 
+static unsigned long long* g_gs_trace = nullptr;
+// diagnostics: copy the stamps of the last traced launch (64 slots per workgroup: before / after barrier B1 of the first 30 tap
+// groups; [60] end of the MFMA loop, [61] end of the epilogue, [62] kernel entry, [63] tap groups)
+extern "C" int rd_gconv_split_trace_read(unsigned long long* host, int n_wg) {
+    if (!g_gs_trace) return RD_EINVAL;
+    RD_CHECK_HIP(hipMemcpy(host, g_gs_trace, (size_t)n_wg * 64 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    return RD_OK;
+}
+
 extern "C" int rd_gconv_split_supported(const RdConvDesc* d) {
     GsPlan pl; RdConvDesc dd;
     return gs_plan_query(d, pl, dd);
@@ -681,10 +748,6 @@ extern "C" int rd_gconv_split(const RdConvDesc* d, const float* in, const void* 
     a.TH = pl.TH; a.TW = pl.TW; a.PP = pl.PP;
     a.tiles_total = pl.tiles_total; a.n_cotiles = pl.n_cotiles; a.taps_max = pl.taps_max;
     a.pplane = pl.pplane;
-    {
-        static const char* dbg = getenv("RD_GCONV_SPLIT_DEBUG");
-        a.debug = dbg ? atoi(dbg) : 0;
-    }
     int S = 0;
     for (int i = 0; i < d->n_phases; ++i)
         for (int t = 0; t < d->phase[i].n_taps; ++t) S = S > d->phase[i].widx[t] + 1 ? S : d->phase[i].widx[t] + 1;
@@ -701,6 +764,16 @@ extern "C" int rd_gconv_split(const RdConvDesc* d, const float* in, const void* 
     }
     const int grid = d->N * pl.tiles_total * pl.n_cotiles;
     hipStream_t s = static_cast<hipStream_t>(stream);
+    a.trace = nullptr;
+    a.trace_role = 0;
+    {
+        static const char* tr = getenv("RD_GCONV_SPLIT_TRACE");
+        if (tr && atoi(tr)) {
+            if (!g_gs_trace) RD_CHECK_HIP(hipMalloc(&g_gs_trace, (size_t)65536 * 64 * sizeof(unsigned long long)));
+            a.trace = g_gs_trace;
+            a.trace_role = atoi(tr);
+        }
+    }
 #define RD_GS(MT_, NT_) \
     if (pl.MT == MT_ && pl.NT == NT_) return pl.pdb ? launch_gs<MT_, NT_, true>(a, grid, pl.lds_bytes, s) : launch_gs<MT_, NT_, false>(a, grid, pl.lds_bytes, s);
     RD_GS(3, 2) RD_GS(2, 2) RD_GS(1, 2) RD_GS(2, 1) RD_GS(1, 1)
