@@ -56,6 +56,8 @@ def kernel_identity(L, kind, d, io16=False):
         info = (C.c_int32 * 8)()
         L.rd_gconv_split_plan_info(C.byref(d), info)          # MT, NT, TH, TW, PP, lds, workgroups, tap groups + 100 * double-buffered patch
         return "gconv_split_kernel<%d,%d,%s>" % (info[0], info[1], tb_(info[7] >= 100))
+    if kind == "wgrad_split":
+        return "wgrad_split_kernel"
     if kind == "wgrad_bf16":
         info = (C.c_int32 * 8)()
         L.rd_wgrad_bf16_plan_info(C.byref(d), info)           # cpi, cpo, ...

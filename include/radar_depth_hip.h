@@ -138,6 +138,18 @@ int rd_gconv_split_plan_info(const RdConvDesc* d, int32_t* out);
 /* diagnostics: with RD_GCONV_SPLIT_TRACE=1 (an MFMA wave) / =2 (a staging wave) every workgroup records cycle-counter stamps around
  * the barrier of its first 30 tap groups (64 slots per workgroup); copies the last traced launch to the host (tools/trace_gconv_split.py) */
 int rd_gconv_split_trace_read(unsigned long long* host, int n_wg);
+/* fp32 weight gradient on the bf16 matrix cores (csrc/wgrad_split.hip; opt-in like rd_gconv_split, rd_wgrad stays the default and the
+ * parity reference): same tensors, slab layout and deterministic reduction as rd_wgrad / rd_wgrad_reduce; both operands are split
+ * into three bf16 pieces while they are staged and every product is rebuilt from six bf16 MFMAs with fp32 accumulation.
+ * rd_wgrad_split_supported: 1 for the full 3x3 / stride-1 descriptors with >= 64 channels on both sides (multiples of 8), else 0.
+ * slabs: rd_wgrad_split_workspace_floats(d) floats.  Replaces the autograd weight gradients of the same F.conv2d call sites. */
+int rd_wgrad_split_supported(const RdConvDesc* d);
+int64_t rd_wgrad_split_workspace_floats(const RdConvDesc* d);
+int rd_wgrad_split(const RdConvDesc* d, const float* in, const float* dout, float* slabs, void* stream);
+int rd_wgrad_split_reduce(const RdConvDesc* d, const float* slabs, float* grad_oihw, int32_t O, int32_t I, int32_t KH, int32_t KW,
+                          int32_t co_off, int32_t accumulate, void* stream);
+/* diagnostics: out[0..3] = splits, tiles per split, workgroups, pixel tiles */
+int rd_wgrad_split_plan_info(const RdConvDesc* d, int32_t* out);
 /* diagnostics: out[0..9] = MT, NT, WM, WN, pipelined*10000+ksplit*100+CKW, CKP, TH, TW, lds_bytes, workgroups chosen for d
  * (workspace plan) */
 int rd_gconv_plan_info(const RdConvDesc* d, int32_t* out);

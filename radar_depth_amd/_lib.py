@@ -54,7 +54,8 @@ def lib():
         _lib = C.CDLL(LIB_PATH)
         _lib.rd_last_error.restype = C.c_char_p
         for name in ("rd_wgrad_workspace_floats", "rd_stem_wgrad_workspace_floats", "rd_smooth_workspace_floats",
-                     "rd_head_conv_bwd_workspace_floats", "rd_gconv_workspace_floats", "rd_wgrad_bf16_workspace_floats"):
+                     "rd_head_conv_bwd_workspace_floats", "rd_gconv_workspace_floats", "rd_wgrad_bf16_workspace_floats",
+                     "rd_wgrad_split_workspace_floats"):
             if hasattr(_lib, name):
                 getattr(_lib, name).restype = C.c_int64
     return _lib

@@ -60,7 +60,7 @@ const std::unordered_map<std::string, Entry>& registry() {
     static const std::unordered_map<std::string, Entry> r = {
         RD_ENTRY(rd_gconv), RD_ENTRY(rd_gconv_ws), RD_ENTRY(rd_gconv_fused), RD_ENTRY(rd_gconv_bnbwd), RD_ENTRY(rd_gconv_bf16_t), RD_ENTRY(rd_gconv_split),
         RD_ENTRY(rd_wgrad), RD_ENTRY(rd_wgrad_reduce), RD_ENTRY(rd_wgrad_reduce_batched),
-        RD_ENTRY(rd_wgrad_bf16_t), RD_ENTRY(rd_wgrad_bf16), RD_ENTRY(rd_wgrad_bf16_reduce),
+        RD_ENTRY(rd_wgrad_bf16_t), RD_ENTRY(rd_wgrad_bf16), RD_ENTRY(rd_wgrad_bf16_reduce), RD_ENTRY(rd_wgrad_split), RD_ENTRY(rd_wgrad_split_reduce),
         RD_ENTRY(rd_pack_weights_batched), RD_ENTRY(rd_fill),
         RD_ENTRY(rd_stem_fwd_t), RD_ENTRY(rd_stem_fwd_bf16_t), RD_ENTRY(rd_stem_wgrad_t), RD_ENTRY(rd_stem_dgrad_channel_t),
         RD_ENTRY(rd_bn_finalize), RD_ENTRY(rd_bn_eval_coeffs), RD_ENTRY(rd_bn_eval_coeffs_batched), RD_ENTRY(rd_bn_act_t),

@@ -1,0 +1,359 @@
+// fp32 weight gradient of the 3x3 / stride-1 convolutions on the bf16 matrix cores: both operands of
+//     dW[tap][ci][co] = sum over output pixels p of  x[p + tap][ci] * dy[p][co]
+// are activations, so both are split into three bf16 pieces while they are staged (x = x0 + x1 + x2 exactly) and every product is
+// rebuilt from the six bf16 MFMAs whose terms are not below 2^-24 of it, with fp32 accumulation -- gconv_split.hip's arithmetic
+// (error analysis there), applied to the GEMM whose reduction index is the PIXEL.
+//
+// The bf16 MFMA wants eight consecutive reduction elements (pixels) per lane for a fixed row (channel), i.e. channel-major
+// operands, while the tensors are NHWC.  wgrad_bf16.hip transposes in its staging waves (pixel pairs packed per dword, v_alignbyte
+// for the horizontal taps).  Here the LDS images stay PIXEL-major -- [piece][32-channel tile][pixel][32 channels], 64 bytes per
+// pixel -- and the fragments are read with ds_read_b64_tr_b16: the 16 lanes of a group pass the addresses of four pixel rows x
+// four 8-byte chunks and each lane receives ONE channel of those four pixels (tools/micro/tr_b16.hip prints the mapping).  A
+// tap is then nothing but an immediate offset of (dh * 34 + dw) pixels: no alignbyte, no address arithmetic in the walk.  A
+// 32-lane read pass covers 4 consecutive pixels x 64 bytes = 256 contiguous bytes: all 64 banks once.
+//
+//   workgroup : 8 waves, one per CU.  Waves 0-3: one 32 x 32 (ci, co) pair each of a 64 x 64 block of dW, all nine taps: nine
+//               accumulators = 144 registers, and nothing but fragment reads and MFMAs.  Waves 4-7 stage: 8-channel units of the
+//               next pixel tile through registers (split into pieces there), two LDS buffers, ONE barrier per tile.
+//   pixel tile: 2 rows x 32 columns of one image (x patch 4 x 34 with the halo); four 16-pixel reduction steps.
+//   split-K   : contiguous ranges of pixel tiles per workgroup, per-split slabs [split][tap][Cin][Cout] like rd_wgrad, reduced in
+//               a fixed order by the same slab reduction.
+#include <math.h>
+#include <stdlib.h>
+
+#include <mutex>
+#include <string>
+#include <unordered_map>
+
+#include "common.h"
+
+namespace rd {
+
+int launch_slab_reduce(const float* slabs, int n_splits, int64_t E, float* tmp, float* grad_oihw, int S, int Cin, int Cout,
+                       int O, int I, int co_off, int accumulate, hipStream_t s);   // wgrad.hip
+
+typedef __bf16 wsbf16x8 __attribute__((ext_vector_type(8)));
+typedef short wss16x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int wsu32x4 __attribute__((ext_vector_type(4)));
+typedef float wsf32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 wsbf16x2 __attribute__((ext_vector_type(2)));
+
+constexpr unsigned WS_OOB = 0x80000000u;
+constexpr int WS_R = 2, WS_TW = 32;                 // output rows / columns of a pixel tile
+constexpr int WS_XW = WS_TW + 2, WS_XH = WS_R + 2;   // x patch with the 3x3 halo
+constexpr int WS_XPIX = WS_XW * WS_XH;              // 136
+constexpr int WS_YPIX = WS_R * WS_TW;               // 64
+constexpr int WS_XPLANE = WS_XPIX * 64;             // bytes of one [pixel][32 channels] bf16 plane of the patch: 8704 (a multiple of 256)
+constexpr int WS_YPLANE = WS_YPIX * 64;             // 4096
+constexpr int WS_XBYTES = 3 * 2 * WS_XPLANE;        // [piece][channel tile][plane]
+constexpr int WS_YBYTES = 3 * 2 * WS_YPLANE;
+constexpr int WS_BUF = WS_XBYTES + WS_YBYTES;       // 76800 bytes per buffer, two of them
+constexpr int WS_XUNITS = WS_XPIX * 8;              // 8-channel units of a 64-channel patch: 1088 = 17 waves' worth
+constexpr int WS_UNITS = WS_XUNITS + WS_YPIX * 8;   // 1600
+constexpr int WS_UPT = (WS_UNITS + 255) / 256;      // units per staging thread: 7
+
+struct WsArgs {
+    const float* x;
+    const float* dy;
+    float* slabs;
+    int N, Hi, Wi, Cin, ldi, Ho, Wo, Cout, ldo;
+    int tiles_h, tiles_w, total_tiles, tiles_per_split, n_splits, n_cib, n_cob;
+    int dh0, dw0;               // offset of tap (0, 0): x pixel = output pixel + (dh0 + i, dw0 + j), slab index 3 i + j
+};
+
+__device__ __forceinline__ unsigned ws_cvt_pk(float a, float b) {
+    wsf32x2 v;
+    v[0] = a; v[1] = b;
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, wsbf16x2));
+}
+// three bf16 pieces of eight fp32 values, a pair at a time (see gconv_split.hip)
+__device__ __forceinline__ void ws_split8(const float4 v0, const float4 v1, wsu32x4& w0, wsu32x4& w1, wsu32x4& w2) {
+    const float x[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        float a = x[2 * i], b = x[2 * i + 1];
+        const unsigned u0 = ws_cvt_pk(a, b);
+        a -= __uint_as_float(u0 << 16);
+        b -= __uint_as_float(u0 & 0xffff0000u);
+        const unsigned u1 = ws_cvt_pk(a, b);
+        a -= __uint_as_float(u1 << 16);
+        b -= __uint_as_float(u1 & 0xffff0000u);
+        w0[i] = u0;
+        w1[i] = u1;
+        w2[i] = ws_cvt_pk(a, b);
+    }
+}
+
+// eight consecutive pixels of one channel: two transposing reads of four pixels each
+__device__ __forceinline__ wsbf16x8 ws_frag(unsigned base, int off) {
+    typedef __attribute__((address_space(3))) wss16x4* lp;
+    const wss16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(reinterpret_cast<lp>(base + off));
+    const wss16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(reinterpret_cast<lp>(base + off + 4 * 64));
+    typedef short s16x8 __attribute__((ext_vector_type(8)));
+    s16x8 r;
+    r[0] = lo[0]; r[1] = lo[1]; r[2] = lo[2]; r[3] = lo[3];
+    r[4] = hi[0]; r[5] = hi[1]; r[6] = hi[2]; r[7] = hi[3];
+    return __builtin_bit_cast(wsbf16x8, r);
+}
+
+__global__ __launch_bounds__(512) void wgrad_split_kernel(const WsArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const bool loader = wave >= 4;
+    const unsigned lds0 = (unsigned)(size_t)smem;
+
+    const int vid = xcd_remap(blockIdx.x, gridDim.x);
+    const int nblk = a.n_cib * a.n_cob;
+    const int blk = vid % nblk, split = vid / nblk;
+    const int cib0 = (blk / a.n_cob) * 64, cob0 = (blk % a.n_cob) * 64;
+    const int tile_begin = split * a.tiles_per_split;
+    const int tile_end = min(tile_begin + a.tiles_per_split, a.total_tiles);
+    const int ntiles = tile_end - tile_begin;
+
+    f32x16 acc[9];       // (zeroed in the compute branch only: live registers of the staging waves otherwise)
+
+    if (loader) {
+        // ------------------------------------------------------------------------------------------ staging waves
+        const int ltid = tid - 256;
+        // this thread's units: e = ltid + 256 u; e < 1088: x patch unit (tile t, pixel, quad q), else dy unit.  1088 = 17 * 64, so a
+        // wave's unit u is entirely x or entirely dy (wave-uniform buffer resource)
+        int upr[WS_UPT], upc[WS_UPT], uch[WS_UPT], udst[WS_UPT];
+#pragma unroll
+        for (int u = 0; u < WS_UPT; ++u) {
+            const int e = ltid + 256 * u;
+            if (e < WS_XUNITS) {
+                const int t = e / (WS_XPIX * 4), rem = e - t * (WS_XPIX * 4);
+                const int px = rem >> 2, q = rem & 3;
+                upr[u] = px / WS_XW; upc[u] = px - upr[u] * WS_XW;
+                uch[u] = t * 32 + q * 8;
+                udst[u] = t * WS_XPLANE + rem * 16;
+            } else if (e < WS_UNITS) {
+                const int e2 = e - WS_XUNITS;
+                const int t = e2 >> 8, rem = e2 & 255;
+                const int px = rem >> 2, q = rem & 3;
+                upr[u] = px / WS_TW; upc[u] = px - upr[u] * WS_TW;
+                uch[u] = t * 32 + q * 8;
+                udst[u] = WS_XBYTES + t * WS_YPLANE + rem * 16;
+            } else {
+                upr[u] = upc[u] = uch[u] = 0;
+                udst[u] = -1;
+            }
+        }
+        const unsigned ximg = (unsigned)(a.Hi * a.Wi * a.ldi) * 4u, yimg = (unsigned)(a.Ho * a.Wo * a.ldo) * 4u;
+        float4 v0[WS_UPT], v1[WS_UPT];
+        auto fetch = [&](int tile) {
+            const int n = tile / (a.tiles_h * a.tiles_w), tr = tile - n * (a.tiles_h * a.tiles_w);
+            const int r0 = (tr / a.tiles_w) * WS_R, c0 = (tr % a.tiles_w) * WS_TW;
+            const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.x) + (size_t)n * a.Hi * a.Wi * a.ldi, 0, ximg, 0x00020000);
+            const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.dy) + (size_t)n * a.Ho * a.Wo * a.ldo, 0, yimg, 0x00020000);
+#pragma unroll
+            for (int u = 0; u < WS_UPT; ++u) {
+                const bool is_x = __builtin_amdgcn_readfirstlane(ltid + 256 * u) < WS_XUNITS;      // wave-uniform
+                unsigned off;
+                if (is_x) {
+                    const int ih = r0 + a.dh0 + upr[u], iw = c0 + a.dw0 + upc[u], ch = cib0 + uch[u];
+                    off = (ih >= 0 && ih < a.Hi && iw >= 0 && iw < a.Wi && ch < a.Cin && udst[u] >= 0) ? (unsigned)(((ih * a.Wi + iw) * a.ldi + ch) * 4) : WS_OOB;
+                    v0[u] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rx, (int)off, 0, 0));
+                    v1[u] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rx, (int)off + 16, 0, 0));
+                } else {
+                    const int oh = r0 + upr[u], ow = c0 + upc[u], ch = cob0 + uch[u];
+                    off = (oh < a.Ho && ow < a.Wo && ch < a.Cout && udst[u] >= 0) ? (unsigned)(((oh * a.Wo + ow) * a.ldo + ch) * 4) : WS_OOB;
+                    v0[u] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(ry, (int)off, 0, 0));
+                    v1[u] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(ry, (int)off + 16, 0, 0));
+                }
+            }
+        };
+        auto split_put = [&](int buf) {
+            const unsigned base = lds0 + buf * WS_BUF;
+#pragma unroll
+            for (int u = 0; u < WS_UPT; ++u) {
+                wsu32x4 w0, w1, w2;
+                ws_split8(v0[u], v1[u], w0, w1, w2);
+                if (udst[u] >= 0) {
+                    const bool is_x = udst[u] < WS_XBYTES;
+                    const unsigned pstride = is_x ? 2 * WS_XPLANE : 2 * WS_YPLANE;
+                    const unsigned ad = base + udst[u];
+                    asm volatile("ds_write_b128 %0, %1" ::"v"(ad), "v"(w0) : "memory");
+                    asm volatile("ds_write_b128 %0, %1" ::"v"(ad + pstride), "v"(w1) : "memory");
+                    asm volatile("ds_write_b128 %0, %1" ::"v"(ad + 2 * pstride), "v"(w2) : "memory");
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        };
+        // tile i of this workgroup lives in buffer i & 1.  Iteration i: barrier B(i) (tile i published, buffer (i + 1) & 1 free);
+        // split and store tile i + 1 (fetched during iteration i - 1); fetch tile i + 2.
+        if (ntiles > 0) {
+            fetch(tile_begin);
+            split_put(0);
+            if (ntiles > 1) fetch(tile_begin + 1);
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        for (int i = 0; i < ntiles; ++i) {
+            rd_sync();                            // B(i)
+            if (i + 1 < ntiles) {
+                split_put((i + 1) & 1);
+                if (i + 2 < ntiles) fetch(tile_begin + i + 2);
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        }
+        rd_sync();                                // matches the compute waves' final barrier
+    } else {
+        // ------------------------------------------------------------------------------------------ compute waves
+#pragma unroll
+        for (int t = 0; t < 9; ++t)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
+        const int ti = wave >> 1, to = wave & 1;          // 32-channel tile of the block on the ci / co side
+        // lane part of every fragment address: pixel row (lane & 15) / 4 of the group's four, 8-byte chunk lane & 3, second 16
+        // channels for lanes 16..31 of each half, pixels 8.. for the upper half wave
+        const unsigned lpart = (unsigned)((((lane & 15) >> 2) + (lane >> 5) * 8) * 64 + ((lane >> 4) & 1) * 32 + (lane & 3) * 8);
+        const unsigned xb = lds0 + ti * WS_XPLANE + lpart;
+        const unsigned yb = lds0 + WS_XBYTES + to * WS_YPLANE + lpart;
+        for (int i = 0; i < ntiles; ++i) {
+            rd_sync();                            // B(i)
+            const unsigned xa = xb + (i & 1) * WS_BUF, ya = yb + (i & 1) * WS_BUF;
+            // 36 steps per tile = (row, 16-pixel reduction step, tap); the fragments of step s + 1 are read in front of the MFMAs of
+            // step s and the order is pinned (left alone the compiler hoists a whole reduction step's reads and spills them)
+            constexpr int NSTEP = WS_R * (WS_TW / 16) * 9;
+            wsbf16x8 A[2][3], B[2][3];
+            auto loadA = [&](int s_, wsbf16x8 (&F)[3]) {
+                const int rk = s_ / 9, t = s_ % 9, r = rk / (WS_TW / 16), ks = rk % (WS_TW / 16);
+#pragma unroll
+                for (int p = 0; p < 3; ++p) F[p] = ws_frag(xa, p * 2 * WS_XPLANE + ((r + t / 3) * WS_XW + ks * 16 + t % 3) * 64);
+            };
+            auto loadB = [&](int rk, wsbf16x8 (&F)[3]) {
+                const int r = rk / (WS_TW / 16), ks = rk % (WS_TW / 16);
+#pragma unroll
+                for (int p = 0; p < 3; ++p) F[p] = ws_frag(ya, p * 2 * WS_YPLANE + (r * WS_TW + ks * 16) * 64);
+            };
+            loadB(0, B[0]);
+            loadA(0, A[0]);
+#pragma unroll
+            for (int s_ = 0; s_ < NSTEP; ++s_) {
+                const int rk = s_ / 9, t = s_ % 9;
+                if (s_ + 1 < NSTEP) {
+                    loadA(s_ + 1, A[(s_ + 1) & 1]);
+                    if (t == 8) loadB(rk + 1, B[(rk + 1) & 1]);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                f32x16 c = acc[t];
+                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[s_ & 1][0], B[rk & 1][2], c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[s_ & 1][1], B[rk & 1][1], c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[s_ & 1][2], B[rk & 1][0], c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[s_ & 1][0], B[rk & 1][1], c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[s_ & 1][1], B[rk & 1][0], c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[s_ & 1][0], B[rk & 1][0], c, 0, 0, 0);
+                acc[t] = c;
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        rd_sync();
+        // slab [tap][Cin][Cout] of this split (zeros when the split has no tiles: every element of the block is written)
+        const int l31 = lane & 31, hh = lane >> 5;
+        float* slab = a.slabs + (size_t)split * 9 * a.Cin * a.Cout;
+        const int co = cob0 + to * 32 + l31;
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            float* dst = slab + (size_t)t * a.Cin * a.Cout;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int ci = cib0 + ti * 32 + (i & 3) + 8 * (i >> 2) + 4 * hh;
+                if (ci < a.Cin && co < a.Cout) dst[(size_t)ci * a.Cout + co] = acc[t][i];
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------ host
+struct WsPlan {
+    int ok, tiles_h, tiles_w, total_tiles, tiles_per_split, n_splits, n_cib, n_cob, J;
+};
+
+static bool ws_shape_ok(const RdConvDesc& d) {
+    static const char* off = getenv("RD_WGRAD_NO_SPLIT");       // diagnostics: keep every weight gradient on the fp32 kernels
+    if (off) return false;
+    if (d.n_phases != 1 || d.in_stride != 1 || d.out_stride != 1) return false;
+    const RdPhase& p = d.phase[0];
+    if (p.n_taps != 9 || p.out_off_h != 0 || p.out_off_w != 0 || p.lh != d.Ho || p.lw != d.Wo) return false;
+    for (int t = 0; t < 9; ++t)
+        if (p.dh[t] != p.dh[0] + t / 3 || p.dw[t] != p.dw[0] + t % 3 || p.widx[t] != t) return false;      // full 3x3, row-major taps and slabs
+    if (d.Cin < 64 || d.Cout < 64 || d.Cin % 8 != 0 || d.Cout % 8 != 0 || d.ldi % 4 != 0 || d.ldo % 4 != 0) return false;
+    if ((int64_t)d.Hi * d.Wi * d.ldi * 4 >= (int64_t)WS_OOB || (int64_t)d.Ho * d.Wo * d.ldo * 4 >= (int64_t)WS_OOB) return false;
+    return true;
+}
+
+static WsPlan ws_plan(const RdConvDesc& d) {
+    WsPlan pl{};
+    pl.ok = ws_shape_ok(d) ? 1 : 0;
+    if (!pl.ok) return pl;
+    pl.tiles_h = cdiv(d.Ho, WS_R);
+    pl.tiles_w = cdiv(d.Wo, WS_TW);
+    pl.total_tiles = d.N * pl.tiles_h * pl.tiles_w;
+    pl.n_cib = cdiv(d.Cin, 64);
+    pl.n_cob = cdiv(d.Cout, 64);
+    // one workgroup per CU: about num_cus workgroups in all, at least four tiles per split (the first tile's staging is exposed)
+    static const char* wpc = getenv("RD_WGRAD_SPLIT_WG_PER_CU");      // diagnostics
+    int ns = (wpc ? atoi(wpc) : 1) * num_cus() / (pl.n_cib * pl.n_cob);
+    if (ns < 1) ns = 1;
+    const int max_ns = cdiv(pl.total_tiles, 4);
+    if (ns > max_ns) ns = max_ns < 1 ? 1 : max_ns;
+    pl.tiles_per_split = cdiv(pl.total_tiles, ns);
+    pl.n_splits = cdiv(pl.total_tiles, pl.tiles_per_split);
+    pl.J = pl.n_splits < 16 ? pl.n_splits : 16;
+    return pl;
+}
+
+}  // namespace rd
+
+using namespace rd;
+
+extern "C" int rd_wgrad_split_supported(const RdConvDesc* d) { return d && ws_shape_ok(*d) ? 1 : 0; }
+
+extern "C" int64_t rd_wgrad_split_workspace_floats(const RdConvDesc* d) {
+    if (!d) return RD_EINVAL;
+    const WsPlan pl = ws_plan(*d);
+    if (!pl.ok) return RD_EINVAL;
+    return (int64_t)(pl.n_splits + pl.J) * 9 * d->Cin * d->Cout;
+}
+
+// diagnostics: out[0..3] = splits, tiles per split, workgroups, tiles
+extern "C" int rd_wgrad_split_plan_info(const RdConvDesc* d, int32_t* out) {
+    if (!d || !out) return RD_EINVAL;
+    const WsPlan pl = ws_plan(*d);
+    if (!pl.ok) return RD_EINVAL;
+    out[0] = pl.n_splits; out[1] = pl.tiles_per_split; out[2] = pl.n_splits * pl.n_cib * pl.n_cob; out[3] = pl.total_tiles;
+    return RD_OK;
+}
+
+extern "C" int rd_wgrad_split(const RdConvDesc* d, const float* in, const float* dout, float* slabs, void* stream) {
+    RD_CHECK_ARG(d && in && dout && slabs, "wgrad_split: null argument");
+    const WsPlan pl = ws_plan(*d);
+    if (!pl.ok) { set_error("wgrad_split: descriptor not supported (rd_wgrad_split_supported)"); return RD_EINVAL; }
+    RD_CHECK_ARG(reinterpret_cast<uintptr_t>(in) % 16 == 0 && reinterpret_cast<uintptr_t>(dout) % 16 == 0, "wgrad_split: unaligned tensor");
+    WsArgs a;
+    a.x = in; a.dy = dout; a.slabs = slabs;
+    a.N = d->N; a.Hi = d->Hi; a.Wi = d->Wi; a.Cin = d->Cin; a.ldi = d->ldi; a.Ho = d->Ho; a.Wo = d->Wo; a.Cout = d->Cout; a.ldo = d->ldo;
+    a.tiles_h = pl.tiles_h; a.tiles_w = pl.tiles_w; a.total_tiles = pl.total_tiles; a.tiles_per_split = pl.tiles_per_split;
+    a.n_splits = pl.n_splits; a.n_cib = pl.n_cib; a.n_cob = pl.n_cob;
+    a.dh0 = d->phase[0].dh[0]; a.dw0 = d->phase[0].dw[0];
+    static bool attr_set = false;
+    if (!attr_set) {
+        RD_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_split_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(wgrad_split_kernel, dim3(pl.n_splits * pl.n_cib * pl.n_cob), dim3(512), 2 * WS_BUF, static_cast<hipStream_t>(stream), a);
+    RD_CHECK_LAUNCH("wgrad_split_kernel");
+    return RD_OK;
+}
+
+extern "C" int rd_wgrad_split_reduce(const RdConvDesc* d, const float* slabs, float* grad_oihw, int32_t O, int32_t I, int32_t KH, int32_t KW,
+                                     int32_t co_off, int32_t accumulate, void* stream) {
+    RD_CHECK_ARG(d && slabs && grad_oihw, "wgrad_split_reduce: null argument");
+    const WsPlan pl = ws_plan(*d);
+    if (!pl.ok) { set_error("wgrad_split_reduce: descriptor not supported"); return RD_EINVAL; }
+    RD_CHECK_ARG(KH * KW == 9 && I == d->Cin && co_off >= 0 && co_off + O <= d->Cout, "wgrad_split_reduce: gradient shape does not match the descriptor");
+    const int64_t E = (int64_t)9 * d->Cin * d->Cout;
+    float* tmp = const_cast<float*>(slabs) + (int64_t)pl.n_splits * E;
+    return launch_slab_reduce(slabs, pl.n_splits, E, tmp, grad_oihw, 9, d->Cin, d->Cout, O, I, co_off, accumulate, static_cast<hipStream_t>(stream));
+}

@@ -308,8 +308,14 @@ class LateFusionPlan:
             wg_bf16 = True
             if self.L.rd_wgrad_bf16_supported(C.byref(dwd)) != 1:
                 raise NotImplementedError("bf16 storage: no bf16 weight-gradient decomposition for %s" % name)
+        # split plans: the 3x3 / stride-1 weight gradients with >= 64 channels run on the bf16 matrix cores as well (csrc/wgrad_split.hip:
+        # both operands split into three bf16 pieces while they are staged); same slabs, same deterministic reduction
+        wg_split = (self.split and not self.batch_reduces and os.environ.get("RD_WGRAD_SPLIT", "1") == "1"
+                    and self.L.rd_wgrad_split_supported(C.byref(dwd)) == 1)
         f_ws, f_wgrad, f_reduce, fam = ((self.L.rd_wgrad_bf16_workspace_floats, self.L.rd_wgrad_bf16, self.L.rd_wgrad_bf16_reduce, "wgrad_bf16")
-                                        if wg_bf16 else (self.L.rd_wgrad_workspace_floats, self.L.rd_wgrad, self.L.rd_wgrad_reduce, "wgrad"))
+                                        if wg_bf16 else
+                                        (self.L.rd_wgrad_split_workspace_floats, self.L.rd_wgrad_split, self.L.rd_wgrad_split_reduce, "wgrad_split")
+                                        if wg_split else (self.L.rd_wgrad_workspace_floats, self.L.rd_wgrad, self.L.rd_wgrad_reduce, "wgrad"))
         nws = f_ws(C.byref(dwd))
         if nws < 0:
             check(int(nws), "rd_wgrad_workspace_floats(%s)" % name)

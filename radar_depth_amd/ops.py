@@ -208,3 +208,26 @@ def wgrad_bf16(desc, x, dout, grad_oihw):
     check(lib().rd_wgrad_bf16_reduce(C.byref(desc), ptr(slabs), ptr(_f32(grad_oihw)), o, i, kh, kw, 0, 0, current_stream()),
           "rd_wgrad_bf16_reduce")
     return grad_oihw
+
+
+def wgrad_split_supported(desc):
+    return lib().rd_wgrad_split_supported(C.byref(desc)) == 1
+
+
+def wgrad_split_workspace_floats(desc):
+    n = int(lib().rd_wgrad_split_workspace_floats(C.byref(desc)))
+    if n < 0:
+        check(n, "rd_wgrad_split_workspace_floats")
+    return n
+
+
+def wgrad_split(desc, x, dout, slabs):
+    """fp32 weight gradient rebuilt from six bf16 MFMAs per product (three-piece operands): rd_wgrad_split."""
+    _poison()
+    check(lib().rd_wgrad_split(C.byref(desc), ptr(_f32(x)), ptr(_f32(dout)), ptr(slabs), current_stream()), "rd_wgrad_split")
+
+
+def wgrad_split_reduce(desc, slabs, grad, co_off=0, accumulate=False):
+    o, i, kh, kw = grad.shape
+    check(lib().rd_wgrad_split_reduce(C.byref(desc), ptr(slabs), ptr(grad), o, i, kh, kw, co_off, int(accumulate), current_stream()),
+          "rd_wgrad_split_reduce")

@@ -1,0 +1,93 @@
+"""GPU parity of rd_wgrad_split (csrc/wgrad_split.hip: the fp32 weight gradient rebuilt from six bf16 MFMAs per product over three-piece
+operands, fragments by ds_read_b64_tr_b16 from pixel-major LDS images) against torch CPU autograd at the fp32 kernel's tolerance
+(tests/test_gpu_wgrad.py: 5e-5 of the gradient's max magnitude), and against an fp64 gradient side by side with rd_wgrad."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+def _rel(a, b):
+    return ((a - b).abs().max() / b.abs().max().clamp_min(1e-30)).item()
+
+
+@pytest.mark.parametrize("cfg", [
+    (2, 64, 64, 113, 200),      # layer1
+    (2, 128, 128, 57, 100),
+    (2, 256, 256, 29, 50),
+    (2, 512, 512, 15, 25),      # layer4
+    (16, 64, 64, 60, 100),      # many tiles per split
+    (3, 96, 160, 31, 51),       # partial 64-channel blocks on both sides, odd rows, ragged last column tile
+    (1, 64, 64, 1, 1),          # a single pixel
+    (2, 64, 72, 7, 33),         # one column past a tile boundary
+    (5, 128, 64, 24, 3),
+    (2, 72, 64, 2, 32),         # exactly one tile
+])
+def test_wgrad_split(cfg):
+    from radar_depth_amd import convdesc as cd, ops
+    n, ci, co, h, w = cfg
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(n, ci, h, w, generator=g)
+    wt = torch.randn(co, ci, 3, 3, generator=g, requires_grad=True)
+    y = F.conv2d(x, wt, padding=1)
+    gy = torch.randn(y.shape, generator=g)
+    y.backward(gy)
+    d = cd.conv_fwd(n, h, w, ci, co, 3, 1, 1)
+    assert ops.wgrad_split_supported(d)
+    slabs = torch.empty(ops.wgrad_split_workspace_floats(d), device="cuda")
+    ops.wgrad_split(d, ops.nchw_to_nhwc(x.cuda()), ops.nchw_to_nhwc(gy.cuda()), slabs)
+    grad = torch.full((co, ci, 3, 3), float("nan"), device="cuda")
+    ops.wgrad_split_reduce(d, slabs, grad)
+    torch.cuda.synchronize()
+    assert not torch.isnan(grad).any()
+    assert _rel(grad.cpu(), wt.grad) < 5e-5, (cfg, _rel(grad.cpu(), wt.grad))
+    ops.wgrad_split_reduce(d, slabs, grad, accumulate=True)
+    torch.cuda.synchronize()
+    assert _rel(grad.cpu(), 2 * wt.grad) < 5e-5
+
+
+def test_wgrad_split_unsupported_shapes_say_so():
+    from radar_depth_amd import convdesc as cd, ops
+    assert not ops.wgrad_split_supported(cd.conv_fwd(2, 57, 100, 64, 128, 3, 2, 1))      # stride 2
+    assert not ops.wgrad_split_supported(cd.conv_fwd(2, 15, 25, 640, 512, 1, 1, 0))      # 1x1
+    assert not ops.wgrad_split_supported(cd.conv_fwd(2, 57, 100, 32, 32, 3, 1, 1))       # < 64 channels
+    assert not ops.wgrad_split_supported(cd.upproj_fwd(2, 15, 25, 256, 256))
+
+
+@pytest.mark.parametrize("cfg", [(4, 64, 64, 113, 200), (4, 512, 512, 15, 25), (4, 256, 256, 29, 50)])
+def test_wgrad_split_is_as_close_to_fp64_as_the_fp32_mfma(cfg):
+    """Error against an fp64 weight gradient of the same fp32 inputs, next to the fp32-MFMA kernel's and torch's CPU fp32 gradient."""
+    from radar_depth_amd import convdesc as cd, ops
+    n, ci, co, h, w = cfg
+    g = torch.Generator().manual_seed(11)
+    x = torch.randn(n, ci, h, w, generator=g)
+    gy = torch.randn(n, co, h, w, generator=g)
+    wt = torch.zeros(co, ci, 3, 3, dtype=torch.float64, requires_grad=True)
+    F.conv2d(x.double(), wt, padding=1).backward(gy.double())
+    d = cd.conv_fwd(n, h, w, ci, co, 3, 1, 1)
+    xg, gg = ops.nchw_to_nhwc(x.cuda()), ops.nchw_to_nhwc(gy.cuda())
+    s1 = torch.empty(ops.wgrad_workspace_floats(d), device="cuda")
+    s2 = torch.empty(ops.wgrad_split_workspace_floats(d), device="cuda")
+    g1 = torch.empty(co, ci, 3, 3, device="cuda")
+    g2 = torch.empty(co, ci, 3, 3, device="cuda")
+    ops.wgrad(d, xg, gg, s1)
+    ops.wgrad_reduce(d, s1, g1)
+    ops.wgrad_split(d, xg, gg, s2)
+    ops.wgrad_split_reduce(d, s2, g2)
+    torch.cuda.synchronize()
+    e1 = g1.cpu().double() - wt.grad
+    e2 = g2.cpu().double() - wt.grad
+    # the same gradient from torch's CPU fp32 convolution (oneDNN): a third fp32 evaluation, for scale
+    w32 = torch.zeros(co, ci, 3, 3, requires_grad=True)
+    F.conv2d(x, w32, padding=1).backward(gy)
+    e3 = w32.grad.double() - wt.grad
+    scale = wt.grad.abs().max()
+    print("fp32 MFMA: max %.3e rms %.3e | split: max %.3e rms %.3e | torch CPU fp32: max %.3e rms %.3e | gradient max %.3e"
+          % (e1.abs().max(), e1.pow(2).mean().sqrt(), e2.abs().max(), e2.pow(2).mean().sqrt(), e3.abs().max(), e3.pow(2).mean().sqrt(), scale))
+    # a long reduction (up to 360 k pixels per element): the dropped piece products (< 2^-24 of each product, random sign) add up next
+    # to the accumulator roundings, so the split kernel sits a little above the fp32 MFMA kernel here -- by a factor below 2, and two
+    # orders of magnitude inside the kernel tolerance (5e-5 of the gradient's max)
+    assert e2.abs().max() <= 2.0 * max(e1.abs().max(), e3.abs().max())
+    assert e2.pow(2).mean().sqrt() <= 2.0 * max(e1.pow(2).mean().sqrt(), e3.pow(2).mean().sqrt())
+    assert e2.abs().max() < 5e-6 * scale
