@@ -299,6 +299,8 @@ def main():
                     help="headline = resnet18_latefusion (BASELINE configs[1]); the multistage arch is configs[3] (use --batch 8)")
     ap.add_argument("--graph", action="store_true", help="replay the step as hipGraphs (slower than plain stream launches here)")
     ap.add_argument("--no-graph", action="store_true", help="(default; kept for older command lines)")
+    ap.add_argument("--no-alt", action="store_true", help="skip the extra `alt_split` measurement (the same workload on the opt-in split plan; also skipped by --no-roofline / "
+                                                        "--no-cpu-baseline, i.e. by the profiling command lines)")
     ap.add_argument("--operands", default="fp32", choices=["fp32", "bf16", "split"],
                     help="conv operand precision.  fp32 (default) is the BASELINE.json configs[1] measurement; bf16 (configs 2/4) runs the "
                          "forward / input-gradient / weight-gradient convolutions on bf16 MFMA with fp32 tensors + accumulation and is reported with "
@@ -504,6 +506,35 @@ def main():
             by_kernel = {k: [round(v[0], 3), v[1], round(v[3] / (v[0] * 1e-3) / 1e9, 0)] for k, v in sorted(agg.items(), key=lambda kv: -kv[1][0])}
         out["roofline"]["eager_ms_by_family"] = {k: round(v, 3) for k, v in sorted(fam.items(), key=lambda kv: -kv[1])}
         out["roofline"]["eager_ms_by_kernel"] = by_kernel
+    if (rank == 0 and world == 1 and args.operands == "fp32" and args.storage == "fp32" and not args.no_alt and not args.graph
+            and not args.no_roofline and not args.no_cpu_baseline and os.environ.get("RD_FORCE_DP") != "1"):
+        # the same workload once more on the opt-in split plan (fp32 arithmetic on the bf16 matrix cores), timed the
+        # same way in this process, reported NEXT TO the metric -- `value` above is the plain fp32-MFMA plan and is not affected
+        try:
+            torch.manual_seed(0)
+            made2 = create_model(types.SimpleNamespace(arch=args.arch, decoder="upproj", modality="rgbd", pretrained=False), [args.height, args.width])
+            model2, lw2 = made2 if isinstance(made2, tuple) else (made2, None)
+            ts2 = HipTrainStep(model2.cuda(), args.batch, args.height, args.width, lr=0.01, momentum=0.9, weight_decay=1e-4, loss_weights=lw2,
+                               operands="split", comm="auto")
+            for _ in range(args.warmup):
+                ts2.step(x, t)
+            torch.cuda.synchronize()
+            a0 = time.perf_counter()
+            for _ in range(args.steps):
+                loss2, _ = ts2.step(x, t)
+            torch.cuda.synchronize()
+            adt = time.perf_counter() - a0
+            kinds = [k for pl in ts2.plans for k, _ in pl.meta.values()]
+            out["alt_split"] = {"operands": "split", "value": round(args.batch * args.steps / adt, 2), "unit": "samples/s", "ms_per_step": round(1e3 * adt / args.steps, 3),
+                                "steps": args.steps, "warmup": args.warmup, "final_loss": round(float(loss2.item()), 5),
+                                "launches_on_the_bf16_matrix_cores": {k: kinds.count(k) for k in ("gconv_split", "wgrad_split")},
+                                "note": "same workload, same process, opt-in plan: every fp32 operand of the >= 64-channel 3x3 / 5x5 convolutions "
+                                        "(forward, input gradient, 3x3 weight gradient) as three bf16 pieces, six MFMA terms per product, fp32 accumulate; "
+                                        "error vs fp64 at the level of the fp32 MFMA kernels (tests/test_gpu_gconv_split.py, test_gpu_wgrad_split.py); "
+                                        "NOT the metric's value"}
+            ts2.close()
+        except Exception as e:      # the alternative line must never take the metric down with it
+            out["alt_split"] = {"error": "%s: %s" % (type(e).__name__, e)}
     if world > 1:
         torch.distributed.barrier()
     # communicator teardown BEFORE the result line, and C stdio flushed around it: RCCL writes its version banner through C
