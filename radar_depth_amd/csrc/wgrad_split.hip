@@ -1,4 +1,5 @@
-// fp32 weight gradient of the 3x3 / stride-1 convolutions on the bf16 matrix cores: both operands of
+// fp32 weight gradient of the 3x3 / stride-1 convolutions and of the UpProj 5x5 (its four parity phases: 3x3 / 2x3 / 3x2 / 2x2 sub-stencils
+// against the output gradient sampled at stride 2, one launch each) on the bf16 matrix cores: both operands of
 //     dW[tap][ci][co] = sum over output pixels p of  x[p + tap][ci] * dy[p][co]
 // are activations, so both are split into three bf16 pieces while they are staged (x = x0 + x1 + x2 exactly) and every product is
 // rebuilt from the six bf16 MFMAs whose terms are not below 2^-24 of it, with fp32 accumulation -- gconv_split.hip's arithmetic
@@ -58,7 +59,11 @@ struct WsArgs {
     float* slabs;
     int N, Hi, Wi, Cin, ldi, Ho, Wo, Cout, ldo;
     int tiles_h, tiles_w, total_tiles, tiles_per_split, n_splits, n_cib, n_cob;
-    int dh0, dw0;               // offset of tap (0, 0): x pixel = output pixel + (dh0 + i, dw0 + j), slab index 3 i + j
+    int dh0, dw0;               // offset of tap (0, 0): x pixel = logical pixel + (dh0 + i, dw0 + j)
+    int OS, off_h, off_w;       // dy pixel = OS * logical pixel + (off_h, off_w)
+    int lh, lw;                 // logical grid (= the x grid for these descriptors)
+    int S;                      // weight slabs per split
+    int widx[9];                // slab of tap (i, j) = widx[i * TC + j]
 };
 
 __device__ __forceinline__ unsigned ws_cvt_pk(float a, float b) {
@@ -96,7 +101,9 @@ __device__ __forceinline__ wsbf16x8 ws_frag(unsigned base, int off) {
     return __builtin_bit_cast(wsbf16x8, r);
 }
 
+template <int TR, int TC>
 __global__ __launch_bounds__(512) void wgrad_split_kernel(const WsArgs a) {
+    constexpr int NT = TR * TC;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -111,7 +118,7 @@ __global__ __launch_bounds__(512) void wgrad_split_kernel(const WsArgs a) {
     const int tile_end = min(tile_begin + a.tiles_per_split, a.total_tiles);
     const int ntiles = tile_end - tile_begin;
 
-    f32x16 acc[9];       // (zeroed in the compute branch only: live registers of the staging waves otherwise)
+    f32x16 acc[NT];      // (zeroed in the compute branch only: live registers of the staging waves otherwise)
 
     if (loader) {
         // ------------------------------------------------------------------------------------------ staging waves
@@ -157,8 +164,9 @@ __global__ __launch_bounds__(512) void wgrad_split_kernel(const WsArgs a) {
                     v0[u] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rx, (int)off, 0, 0));
                     v1[u] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rx, (int)off + 16, 0, 0));
                 } else {
-                    const int oh = r0 + upr[u], ow = c0 + upc[u], ch = cob0 + uch[u];
-                    off = (oh < a.Ho && ow < a.Wo && ch < a.Cout && udst[u] >= 0) ? (unsigned)(((oh * a.Wo + ow) * a.ldo + ch) * 4) : WS_OOB;
+                    const int lr = r0 + upr[u], lc = c0 + upc[u], ch = cob0 + uch[u];
+                    const int oh = a.OS * lr + a.off_h, ow = a.OS * lc + a.off_w;
+                    off = (lr < a.lh && lc < a.lw && ch < a.Cout && udst[u] >= 0) ? (unsigned)(((oh * a.Wo + ow) * a.ldo + ch) * 4) : WS_OOB;
                     v0[u] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(ry, (int)off, 0, 0));
                     v1[u] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(ry, (int)off + 16, 0, 0));
                 }
@@ -201,7 +209,7 @@ __global__ __launch_bounds__(512) void wgrad_split_kernel(const WsArgs a) {
     } else {
         // ------------------------------------------------------------------------------------------ compute waves
 #pragma unroll
-        for (int t = 0; t < 9; ++t)
+        for (int t = 0; t < NT; ++t)
 #pragma unroll
             for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
         const int ti = wave >> 1, to = wave & 1;          // 32-channel tile of the block on the ci / co side
@@ -213,14 +221,14 @@ __global__ __launch_bounds__(512) void wgrad_split_kernel(const WsArgs a) {
         for (int i = 0; i < ntiles; ++i) {
             rd_sync();                            // B(i)
             const unsigned xa = xb + (i & 1) * WS_BUF, ya = yb + (i & 1) * WS_BUF;
-            // 36 steps per tile = (row, 16-pixel reduction step, tap); the fragments of step s + 1 are read in front of the MFMAs of
+            // 4 NT steps per tile = (row, 16-pixel reduction step, tap); the fragments of step s + 1 are read in front of the MFMAs of
             // step s and the order is pinned (left alone the compiler hoists a whole reduction step's reads and spills them)
-            constexpr int NSTEP = WS_R * (WS_TW / 16) * 9;
+            constexpr int NSTEP = WS_R * (WS_TW / 16) * NT;
             wsbf16x8 A[2][3], B[2][3];
             auto loadA = [&](int s_, wsbf16x8 (&F)[3]) {
-                const int rk = s_ / 9, t = s_ % 9, r = rk / (WS_TW / 16), ks = rk % (WS_TW / 16);
+                const int rk = s_ / NT, t = s_ % NT, r = rk / (WS_TW / 16), ks = rk % (WS_TW / 16);
 #pragma unroll
-                for (int p = 0; p < 3; ++p) F[p] = ws_frag(xa, p * 2 * WS_XPLANE + ((r + t / 3) * WS_XW + ks * 16 + t % 3) * 64);
+                for (int p = 0; p < 3; ++p) F[p] = ws_frag(xa, p * 2 * WS_XPLANE + ((r + t / TC) * WS_XW + ks * 16 + t % TC) * 64);
             };
             auto loadB = [&](int rk, wsbf16x8 (&F)[3]) {
                 const int r = rk / (WS_TW / 16), ks = rk % (WS_TW / 16);
@@ -231,10 +239,10 @@ __global__ __launch_bounds__(512) void wgrad_split_kernel(const WsArgs a) {
             loadA(0, A[0]);
 #pragma unroll
             for (int s_ = 0; s_ < NSTEP; ++s_) {
-                const int rk = s_ / 9, t = s_ % 9;
+                const int rk = s_ / NT, t = s_ % NT;
                 if (s_ + 1 < NSTEP) {
                     loadA(s_ + 1, A[(s_ + 1) & 1]);
-                    if (t == 8) loadB(rk + 1, B[(rk + 1) & 1]);
+                    if (t == NT - 1) loadB(rk + 1, B[(rk + 1) & 1]);
                 }
                 __builtin_amdgcn_sched_barrier(0);
                 f32x16 c = acc[t];
@@ -251,11 +259,11 @@ __global__ __launch_bounds__(512) void wgrad_split_kernel(const WsArgs a) {
         rd_sync();
         // slab [tap][Cin][Cout] of this split (zeros when the split has no tiles: every element of the block is written)
         const int l31 = lane & 31, hh = lane >> 5;
-        float* slab = a.slabs + (size_t)split * 9 * a.Cin * a.Cout;
+        float* slab = a.slabs + (size_t)split * a.S * a.Cin * a.Cout;
         const int co = cob0 + to * 32 + l31;
 #pragma unroll
-        for (int t = 0; t < 9; ++t) {
-            float* dst = slab + (size_t)t * a.Cin * a.Cout;
+        for (int t = 0; t < NT; ++t) {
+            float* dst = slab + (size_t)a.widx[t] * a.Cin * a.Cout;
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
                 const int ci = cib0 + ti * 32 + (i & 3) + 8 * (i >> 2) + 4 * hh;
@@ -267,17 +275,33 @@ __global__ __launch_bounds__(512) void wgrad_split_kernel(const WsArgs a) {
 
 // ------------------------------------------------------------------------------------------ host
 struct WsPlan {
-    int ok, tiles_h, tiles_w, total_tiles, tiles_per_split, n_splits, n_cib, n_cob, J;
+    int ok, tiles_h, tiles_w, total_tiles, tiles_per_split, n_splits, n_cib, n_cob, J, S;
 };
+
+// taps of a phase = a full TR x TC rectangle in row-major order, TR, TC in {2, 3}
+static bool ws_phase_ok(const RdPhase& p, int& tr, int& tc) {
+    tr = p.dh_max - p.dh_min + 1;
+    tc = p.dw_max - p.dw_min + 1;
+    if (tr < 2 || tr > 3 || tc < 2 || tc > 3 || p.n_taps != tr * tc) return false;
+    for (int t = 0; t < p.n_taps; ++t)
+        if (p.dh[t] != p.dh_min + t / tc || p.dw[t] != p.dw_min + t % tc || p.widx[t] < 0) return false;
+    return true;
+}
 
 static bool ws_shape_ok(const RdConvDesc& d) {
     static const char* off = getenv("RD_WGRAD_NO_SPLIT");       // diagnostics: keep every weight gradient on the fp32 kernels
     if (off) return false;
-    if (d.n_phases != 1 || d.in_stride != 1 || d.out_stride != 1) return false;
-    const RdPhase& p = d.phase[0];
-    if (p.n_taps != 9 || p.out_off_h != 0 || p.out_off_w != 0 || p.lh != d.Ho || p.lw != d.Wo) return false;
-    for (int t = 0; t < 9; ++t)
-        if (p.dh[t] != p.dh[0] + t / 3 || p.dw[t] != p.dw[0] + t % 3 || p.widx[t] != t) return false;      // full 3x3, row-major taps and slabs
+    if (d.n_phases < 1 || d.n_phases > RD_MAX_PHASES || d.in_stride != 1 || d.out_stride < 1 || d.out_stride > 2) return false;
+    if (d.n_phases == 1 && d.out_stride != 1) return false;      // the 3x3 convolution ...
+    if (d.n_phases > 1 && d.out_stride != 2) return false;       // ... or the UpProj parity phases
+    for (int i = 0; i < d.n_phases; ++i) {
+        const RdPhase& p = d.phase[i];
+        int tr, tc;
+        if (!ws_phase_ok(p, tr, tc)) return false;
+        if (p.lh != d.phase[0].lh || p.lw != d.phase[0].lw || p.lh > d.Hi || p.lw > d.Wi) return false;
+        if (d.out_stride * (p.lh - 1) + p.out_off_h >= d.Ho || d.out_stride * (p.lw - 1) + p.out_off_w >= d.Wo) return false;
+    }
+    if (d.n_phases == 1 && d.phase[0].n_taps != 9) return false;
     if (d.Cin < 64 || d.Cout < 64 || d.Cin % 8 != 0 || d.Cout % 8 != 0 || d.ldi % 4 != 0 || d.ldo % 4 != 0) return false;
     if ((int64_t)d.Hi * d.Wi * d.ldi * 4 >= (int64_t)WS_OOB || (int64_t)d.Ho * d.Wo * d.ldo * 4 >= (int64_t)WS_OOB) return false;
     return true;
@@ -287,11 +311,13 @@ static WsPlan ws_plan(const RdConvDesc& d) {
     WsPlan pl{};
     pl.ok = ws_shape_ok(d) ? 1 : 0;
     if (!pl.ok) return pl;
-    pl.tiles_h = cdiv(d.Ho, WS_R);
-    pl.tiles_w = cdiv(d.Wo, WS_TW);
+    pl.tiles_h = cdiv(d.phase[0].lh, WS_R);
+    pl.tiles_w = cdiv(d.phase[0].lw, WS_TW);
     pl.total_tiles = d.N * pl.tiles_h * pl.tiles_w;
     pl.n_cib = cdiv(d.Cin, 64);
     pl.n_cob = cdiv(d.Cout, 64);
+    for (int i = 0; i < d.n_phases; ++i)
+        for (int t = 0; t < d.phase[i].n_taps; ++t) pl.S = pl.S > d.phase[i].widx[t] + 1 ? pl.S : d.phase[i].widx[t] + 1;
     // one workgroup per CU: about num_cus workgroups in all, at least four tiles per split (the first tile's staging is exposed)
     static const char* wpc = getenv("RD_WGRAD_SPLIT_WG_PER_CU");      // diagnostics
     int ns = (wpc ? atoi(wpc) : 1) * num_cus() / (pl.n_cib * pl.n_cob);
@@ -304,6 +330,19 @@ static WsPlan ws_plan(const RdConvDesc& d) {
     return pl;
 }
 
+template <int TR, int TC>
+static int launch_ws(const WsArgs& a, int grid, hipStream_t s) {
+    static bool attr_set = false;
+    auto k = wgrad_split_kernel<TR, TC>;
+    if (!attr_set) {
+        RD_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(k, dim3(grid), dim3(512), 2 * WS_BUF, s, a);
+    RD_CHECK_LAUNCH("wgrad_split_kernel");
+    return RD_OK;
+}
+
 }  // namespace rd
 
 using namespace rd;
@@ -314,10 +353,10 @@ extern "C" int64_t rd_wgrad_split_workspace_floats(const RdConvDesc* d) {
     if (!d) return RD_EINVAL;
     const WsPlan pl = ws_plan(*d);
     if (!pl.ok) return RD_EINVAL;
-    return (int64_t)(pl.n_splits + pl.J) * 9 * d->Cin * d->Cout;
+    return (int64_t)(pl.n_splits + pl.J) * pl.S * d->Cin * d->Cout;
 }
 
-// diagnostics: out[0..3] = splits, tiles per split, workgroups, tiles
+// diagnostics: out[0..3] = splits, tiles per split, workgroups per launch, tiles
 extern "C" int rd_wgrad_split_plan_info(const RdConvDesc* d, int32_t* out) {
     if (!d || !out) return RD_EINVAL;
     const WsPlan pl = ws_plan(*d);
@@ -336,14 +375,23 @@ extern "C" int rd_wgrad_split(const RdConvDesc* d, const float* in, const float*
     a.N = d->N; a.Hi = d->Hi; a.Wi = d->Wi; a.Cin = d->Cin; a.ldi = d->ldi; a.Ho = d->Ho; a.Wo = d->Wo; a.Cout = d->Cout; a.ldo = d->ldo;
     a.tiles_h = pl.tiles_h; a.tiles_w = pl.tiles_w; a.total_tiles = pl.total_tiles; a.tiles_per_split = pl.tiles_per_split;
     a.n_splits = pl.n_splits; a.n_cib = pl.n_cib; a.n_cob = pl.n_cob;
-    a.dh0 = d->phase[0].dh[0]; a.dw0 = d->phase[0].dw[0];
-    static bool attr_set = false;
-    if (!attr_set) {
-        RD_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_split_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        attr_set = true;
+    a.OS = d->out_stride; a.S = pl.S;
+    const int grid = pl.n_splits * pl.n_cib * pl.n_cob;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    // one launch per phase (the 3x3 convolution has one); the phases write disjoint slabs of the same splits
+    for (int i = 0; i < d->n_phases; ++i) {
+        const RdPhase& p = d->phase[i];
+        int tr, tc;
+        ws_phase_ok(p, tr, tc);
+        a.dh0 = p.dh_min; a.dw0 = p.dw_min; a.off_h = p.out_off_h; a.off_w = p.out_off_w; a.lh = p.lh; a.lw = p.lw;
+        for (int t = 0; t < 9; ++t) a.widx[t] = t < p.n_taps ? p.widx[t] : 0;
+        int rc;
+        if (tr == 3 && tc == 3) rc = launch_ws<3, 3>(a, grid, s);
+        else if (tr == 2 && tc == 3) rc = launch_ws<2, 3>(a, grid, s);
+        else if (tr == 3 && tc == 2) rc = launch_ws<3, 2>(a, grid, s);
+        else rc = launch_ws<2, 2>(a, grid, s);
+        if (rc != RD_OK) return rc;
     }
-    hipLaunchKernelGGL(wgrad_split_kernel, dim3(pl.n_splits * pl.n_cib * pl.n_cob), dim3(512), 2 * WS_BUF, static_cast<hipStream_t>(stream), a);
-    RD_CHECK_LAUNCH("wgrad_split_kernel");
     return RD_OK;
 }
 
@@ -352,8 +400,8 @@ extern "C" int rd_wgrad_split_reduce(const RdConvDesc* d, const float* slabs, fl
     RD_CHECK_ARG(d && slabs && grad_oihw, "wgrad_split_reduce: null argument");
     const WsPlan pl = ws_plan(*d);
     if (!pl.ok) { set_error("wgrad_split_reduce: descriptor not supported"); return RD_EINVAL; }
-    RD_CHECK_ARG(KH * KW == 9 && I == d->Cin && co_off >= 0 && co_off + O <= d->Cout, "wgrad_split_reduce: gradient shape does not match the descriptor");
-    const int64_t E = (int64_t)9 * d->Cin * d->Cout;
+    RD_CHECK_ARG(KH * KW == pl.S && I == d->Cin && co_off >= 0 && co_off + O <= d->Cout, "wgrad_split_reduce: gradient shape does not match the descriptor");
+    const int64_t E = (int64_t)pl.S * d->Cin * d->Cout;
     float* tmp = const_cast<float*>(slabs) + (int64_t)pl.n_splits * E;
-    return launch_slab_reduce(slabs, pl.n_splits, E, tmp, grad_oihw, 9, d->Cin, d->Cout, O, I, co_off, accumulate, static_cast<hipStream_t>(stream));
+    return launch_slab_reduce(slabs, pl.n_splits, E, tmp, grad_oihw, pl.S, d->Cin, d->Cout, O, I, co_off, accumulate, static_cast<hipStream_t>(stream));
 }

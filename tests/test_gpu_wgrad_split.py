@@ -52,7 +52,34 @@ def test_wgrad_split_unsupported_shapes_say_so():
     assert not ops.wgrad_split_supported(cd.conv_fwd(2, 57, 100, 64, 128, 3, 2, 1))      # stride 2
     assert not ops.wgrad_split_supported(cd.conv_fwd(2, 15, 25, 640, 512, 1, 1, 0))      # 1x1
     assert not ops.wgrad_split_supported(cd.conv_fwd(2, 57, 100, 32, 32, 3, 1, 1))       # < 64 channels
-    assert not ops.wgrad_split_supported(cd.upproj_fwd(2, 15, 25, 256, 256))
+    assert not ops.wgrad_split_supported(cd.upproj_fwd(2, 15, 25, 32, 32))
+
+
+@pytest.mark.parametrize("c,h,w", [(256, 15, 25), (64, 60, 100), (128, 25, 51), (64, 5, 3), (96, 13, 33)])
+def test_wgrad_split_upproj(c, h, w):
+    """UpProj 5x5 (four parity phases of 9 / 6 / 6 / 4 taps against the output gradient sampled at stride 2, one launch each, 25 slabs),
+    reduced into the two branch weights (column ranges of one slab set)."""
+    from radar_depth_amd import convdesc as cd, ops
+    n = 2
+    g = torch.Generator().manual_seed(4)
+    x = torch.randn(n, c, h, w, generator=g)
+    wcat = torch.randn(c, c, 5, 5, generator=g, requires_grad=True)
+    u = torch.zeros(n, c, 2 * h, 2 * w)
+    u[:, :, ::2, ::2] = x
+    y = F.conv2d(u, wcat, padding=2)
+    gy = torch.randn(y.shape, generator=g)
+    y.backward(gy)
+    d = cd.upproj_fwd(n, h, w, c, c)
+    assert ops.wgrad_split_supported(d)
+    slabs = torch.empty(ops.wgrad_split_workspace_floats(d), device="cuda")
+    ops.wgrad_split(d, ops.nchw_to_nhwc(x.cuda()), ops.nchw_to_nhwc(gy.cuda()), slabs)
+    g_up = torch.full((c // 2, c, 5, 5), float("nan"), device="cuda")
+    g_bt = torch.full((c // 2, c, 5, 5), float("nan"), device="cuda")
+    ops.wgrad_split_reduce(d, slabs, g_up, co_off=0)
+    ops.wgrad_split_reduce(d, slabs, g_bt, co_off=c // 2)
+    torch.cuda.synchronize()
+    assert _rel(g_up.cpu(), wcat.grad[:c // 2]) < 5e-5
+    assert _rel(g_bt.cpu(), wcat.grad[c // 2:]) < 5e-5
 
 
 @pytest.mark.parametrize("cfg", [(4, 64, 64, 113, 200), (4, 512, 512, 15, 25), (4, 256, 256, 29, 50)])

@@ -33,4 +33,31 @@ for name, cnt, ci, co, k, s, p, h, w in CONVS:
           % (name, cnt, fl / 1e9, t1 * 1e6, fl / t1 / 1e12, r1 * 1e6, t2 * 1e6, fl / t2 / 1e12, r2 * 1e6, t1 / t2, v[0], v[1], v[2]))
     tot[0] += cnt * (t1 + r1)
     tot[1] += cnt * (t2 + r2)
+from bench_ops import UPPROJ  # noqa: E402
+for name, c, h, w in UPPROJ:
+    d = cd.upproj_fwd(B, h, w, c, c)
+    if not ops.wgrad_split_supported(d):
+        continue
+    x = torch.randn(B, h, w, c, device="cuda")
+    y = torch.randn(B, 2 * h, 2 * w, c, device="cuda")
+    s1 = torch.empty(ops.wgrad_workspace_floats(d), device="cuda")
+    s2 = torch.empty(ops.wgrad_split_workspace_floats(d), device="cuda")
+    g = torch.empty(c // 2, c, 5, 5, device="cuda")
+
+    def red1():
+        ops.wgrad_reduce(d, s1, g, co_off=0)
+        ops.wgrad_reduce(d, s1, g, co_off=c // 2)
+
+    def red2():
+        ops.wgrad_split_reduce(d, s2, g, co_off=0)
+        ops.wgrad_split_reduce(d, s2, g, co_off=c // 2)
+    t1 = timeit(lambda: ops.wgrad(d, x, y, s1))
+    r1 = timeit(red1)
+    t2 = timeit(lambda: ops.wgrad_split(d, x, y, s2))
+    r2 = timeit(red2)
+    fl = 2.0 * B * h * w * c * c * 25
+    print("%-18s x1 %6.2f GF | fp32 %7.1f us %6.1f TF (+reduce %5.1f) | split %7.1f us %6.1f TF (+reduce %5.1f) x%.2f"
+          % (name, fl / 1e9, t1 * 1e6, fl / t1 / 1e12, r1 * 1e6, t2 * 1e6, fl / t2 / 1e12, r2 * 1e6, t1 / t2))
+    tot[0] += t1 + r1
+    tot[1] += t2 + r2
 print("TOTAL weight gradients of these layers (kernel + slab reduction): fp32 MFMA %.2f ms, split %.2f ms" % (tot[0] * 1e3, tot[1] * 1e3))
