@@ -470,7 +470,7 @@ def main():
                 pass
         common = {"kernel": name, "launches_per_step": n, "avg_launch_us": round(1e3 * ms / n, 2), "traffic": traffic,
                   "traffic_source": traffic_source}
-        if not bf16 and name.startswith("gconv_split_kernel"):
+        if not bf16 and name.startswith(("gconv_split_kernel", "wgrad_split_kernel")):
             # the dominant kernel runs six bf16 MFMAs per fp32 multiply-add: priced against the dense bf16 peak on the MFMA FLOPs it
             # actually issues (6 x algorithmic); `fp32_equivalent_tflops` is the algorithmic rate next to the fp32 MFMA peak
             achieved = 6.0 * flops / (ms * 1e-3) / 1e12

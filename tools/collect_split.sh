@@ -7,6 +7,8 @@ python bench.py --steps 40 --warmup 10 --operands split 2>/dev/null | tail -1 > 
 python bench.py --steps 40 --warmup 10 --no-cpu-baseline 2>/dev/null | tail -1 > $O/bench_c2_fp32_same_box.json
 python bench.py --config 4 --steps 30 --warmup 8 --operands split --no-cpu-baseline 2>/dev/null | tail -1 > $O/bench_c4_split.json
 python tools/bench_split.py > $O/bench_split.txt 2>&1
+python tools/bench_wgrad_split.py 2>&1 | grep -v amdgpu.ids > $O/bench_wgrad_split.txt
+python bench.py 2>/dev/null | tail -1 > $O/bench_c2_default_with_alt.json
 RD_GCONV_SPLIT_ALL=1 python tools/bench_split.py > $O/bench_split_all_shapes.txt 2>&1
 for r in 1 2; do RD_GCONV_SPLIT_TRACE=$r python tools/trace_gconv_split.py 2>&1 | grep -v amdgpu.ids; done > $O/trace_gconv_split.txt
 tools/micro/mfma_bf16_peak > $O/mfma_bf16_peak.txt 2>&1
