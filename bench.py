@@ -455,7 +455,8 @@ def main():
     if rank == 0 and not args.no_roofline:
         agg, fam = instrumented_pass(ts)
         name, (ms, n, flops, nbytes) = max(agg.items(), key=lambda kv: kv[1][0])
-        tfile = {("fp32", "fp32"): "r03_pmc_traffic.json", ("bf16", "bf16"): "r03_pmc_traffic_bf16_storage.json"}.get((args.operands, args.storage))
+        tfile = {("fp32", "fp32"): "r03_pmc_traffic.json", ("bf16", "bf16"): "r03_pmc_traffic_bf16_storage.json",
+                 ("split", "fp32"): "r03_pmc_traffic_split.json"}.get((args.operands, args.storage))
         traffic, traffic_source = None, None
         if tfile and not multistage and (args.batch, args.height, args.width) == (16, 450, 800) and os.path.exists(os.path.join(REPO, "profiles", tfile)):
             # HBM bytes per launch of that kernel from the committed rocprofv3 --pmc passes of THIS command line (FETCH_SIZE x2 +
