@@ -243,7 +243,6 @@ __global__ __launch_bounds__(512) void gconv_split_kernel(const GsArgs a) {
                 }
         };
         constexpr std::integral_constant<int, 0> U0{};
-        constexpr std::integral_constant<int, GS_UPP / 2> UH{};
         constexpr std::integral_constant<int, GS_UPP> UN{};
         issue_slab(0, 0, 0);
         if (total_groups > 1) issue_slab(1, ngroups > 1 ? 0 : GS_CKP, ngroups > 1 ? 1 : 0);
@@ -256,7 +255,8 @@ __global__ __launch_bounds__(512) void gconv_split_kernel(const GsArgs a) {
         int c2 = 0, g2 = 2;                       // (chunk, group) of group it + 2
         while (g2 >= ngroups) { g2 -= ngroups; ++c2; }
         // the patch of chunk c + 1 is fetched one chunk ahead (in the last group of chunk c - 1: HBM latency under load is more than a
-        // tap group), split into pieces in the first two groups of chunk c and written in its last group
+        // tap group), split into pieces in the second group of chunk c and written in its last group
+        const int gsplit = ngroups > 2 ? 1 : 0;
         unsigned long long* ltr = (a.trace && a.trace_role == 2 && tid == 256) ? a.trace + (size_t)blockIdx.x * 64 : nullptr;
         for (int c = 0; c < nchunks; ++c) {
             const bool more = c + 1 < nchunks;
@@ -270,14 +270,9 @@ __global__ __launch_bounds__(512) void gconv_split_kernel(const GsArgs a) {
                 if (++g2 == ngroups) { g2 = 0; ++c2; }
                 const bool refetch = g == ngroups - 1 && c + 2 < nchunks;
                 if (more) {
-                    // the split arithmetic goes half into the first group (whose only other work is waiting for its weight copies)
-                    // and half into the second; the stores stay in the last one (spreading THEM as well was slower)
-                    if (ngroups >= 3) {
-                        if (g == 0) split_units(U0, UH);
-                        else if (g == 1) split_units(UH, UN);
-                    } else if (g == 0) {
-                        split_units(U0, UN);
-                    }
+                    // (spreading the split arithmetic over the first two groups was slower, with the stores -- 3x2 tile 139 -> 150 us on
+                    //  layer3 -- and without -- 170 -> 189 us on layer1: in the first group the patch loads have not landed yet)
+                    if (g == gsplit) split_units(U0, UN);
                     if (g == ngroups - 1) {
                         if constexpr (!PDB) rd_sync();    // B2: the compute waves are done with this chunk's patch
                         put_units(PDB ? ((c + 1) & 1) : 0, U0, UN);
