@@ -16,12 +16,14 @@
 //               fragment reads and MFMAs; waves 4-7 stage: weight pieces by global_load_lds, the next 16-channel chunk of the
 //               patch through registers, where they split it into pieces (11 VALU instructions per pair of values: hidden
 //               beside the other waves' MFMAs; inside one wave they would sit between MFMA bursts).
-//   LDS       : patch [piece][pixel][16 + 8] bf16 (pixel pitch 48 B: the 16 lanes of a b128 read pass fall into 16 bank groups);
-//               weights [buffer][piece][tap of the group][2][BN] x 16 B, staged in groups of <= 3 taps, double-buffered: three
-//               pieces of everything do not fit otherwise (9 taps x 64 channels x 3 pieces x 2 buffers = 110 KB).
-//   loop      : per (16-channel chunk, tap group): barrier; the loaders start the next group's weights (and, in a chunk's first
-//               group, fetch and split the next chunk's patch); the compute waves walk the group; after a chunk's last group a
-//               second barrier lets the loaders overwrite the patch.
+//   LDS       : patch [piece][pixel][16 + 8] bf16 (pixel pitch 48 B: the 16 lanes of a b128 read pass fall into 16 bank groups), two
+//               buffers of it where they fit (PDB: the 2 x 2 tile); weights [ring of 3][piece][3 taps][2][BN] x 16 B, staged in
+//               groups of three taps (all nine at once x 3 pieces x 2 buffers = 110 KB); a phase's last group is padded with
+//               zero-weight taps, so every group is three MFMA steps.
+//   loop      : one barrier per (16-channel chunk, tap group); it publishes the NEXT group's weights (issued a group earlier), so the
+//               compute waves read that group's first fragments before the barrier and continue straight behind it.  The patch of
+//               the next chunk is fetched a chunk ahead, split in its second group and stored in its last one -- into the other
+//               buffer (PDB), or behind a second barrier into the only one.  Details at the loops below.
 //   operand   : packed weights [piece][slab][Cin/8][ldw][8] bf16 (rd_pack_weights_batched, quad == 3).
 #include <math.h>
 #include <stdlib.h>
