@@ -155,6 +155,51 @@ __global__ __launch_bounds__(512) void gconv_split_kernel(const GsArgs a) {
 
     const int nchunks = D.Cin / GS_CKP;
     const int total_groups = nchunks * ngroups;
+    const char* in_n = reinterpret_cast<const char*>(a.in) + (size_t)n * D.Hi * D.Wi * D.ldi * 4;
+    const unsigned img_bytes = (unsigned)(D.Hi * D.Wi * D.ldi) * 4u;
+    // patch units: 64-unit row segments (two 8-channel units per pixel of a 16-channel chunk)
+    const int rowu = PW * 2;
+    const int nseg = (rowu + 63) >> 6;
+    const int nsegs = PH * nseg;
+    auto unit_of = [&](int seg, unsigned& goff, int& ldst) {
+        const int row = nseg == 1 ? seg : seg / nseg;
+        const int cu = ((seg - row * nseg) << 6) + lane;
+        const int px = cu >> 1, qq = cu & 1;
+        const int ih = ih0 + row, iw = iw0 + px;
+        const bool ok = seg < nsegs && cu < rowu;
+        ldst = ok ? (row * PW + px) * GS_PSB + qq * 16 : -1;
+        goff = (ok && ih >= 0 && ih < D.Hi && iw >= 0 && iw < D.Wi) ? (unsigned)(((ih * D.Wi + iw) * D.ldi + qq * 8) * 4) : GS_OOB;
+    };
+    // The FIRST chunk's patch is staged by all eight waves (segment = wave + 8 k): the MFMA waves have nothing else to do before
+    // the first barrier, and the prologue -- HBM latency + split + store of a whole patch by four waves -- was ~10 k clocks of a
+    // 64-channel layer's ~65 k per workgroup.
+    auto stage_first_chunk = [&]() {
+        constexpr int UP8 = (GS_UPP + 1) / 2;
+        const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(in_n), 0, img_bytes, 0x00020000);
+        float4 f0[UP8], f1[UP8];
+        int dst[UP8];
+#pragma unroll
+        for (int u = 0; u < UP8; ++u) {
+            unsigned go;
+            unit_of(wave + 8 * u, go, dst[u]);
+            f0[u] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)go, 0, 0));
+            f1[u] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)go + 16, 0, 0));
+        }
+        const unsigned base = (unsigned)(size_t)s_patch;
+#pragma unroll
+        for (int u = 0; u < UP8; ++u) {
+            sbf16x8 q0, q1, q2;
+            split8(f0[u], f1[u], q0, q1, q2);
+            if (dst[u] >= 0) {
+                const su32x4 d0 = __builtin_bit_cast(su32x4, q0), d1 = __builtin_bit_cast(su32x4, q1), d2 = __builtin_bit_cast(su32x4, q2);
+                const unsigned ad = base + dst[u];
+                asm volatile("ds_write_b128 %0, %1" ::"v"(ad), "v"(d0) : "memory");
+                asm volatile("ds_write_b128 %0, %1" ::"v"(ad + pplane), "v"(d1) : "memory");
+                asm volatile("ds_write_b128 %0, %1" ::"v"(ad + 2 * pplane), "v"(d2) : "memory");
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
 
     // Barrier protocol (B1 once per tap group g of chunk c, iteration `it`; every wave of the workgroup takes part):
     //   B1(it) publishes weight group it + 1 (issued behind B1(it - 1), awaited by the loaders before they arrive) and frees the
@@ -169,25 +214,11 @@ __global__ __launch_bounds__(512) void gconv_split_kernel(const GsArgs a) {
         const int ltid = tid - 256;
         const int lw = wave - 4;
         const int cin8 = D.Cin >> 3;
-        const char* in_n = reinterpret_cast<const char*>(a.in) + (size_t)n * D.Hi * D.Wi * D.ldi * 4;
-        const unsigned img_bytes = (unsigned)(D.Hi * D.Wi * D.ldi) * 4u;
-        // patch units of this thread: wave lw copies the 64-unit row segments lw, lw + 4, ... (two 8-channel units per pixel)
-        const int rowu = PW * 2;
-        const int nseg = (rowu + 63) >> 6;
-        const int nsegs = PH * nseg;
+        // patch units of this thread in the steady state: wave lw copies the row segments lw, lw + 4, ...
         unsigned pgo[GS_UPP];     // byte offset of the unit inside the image at channel 0; GS_OOB: outside -> zeros
         int pdst[GS_UPP];         // LDS byte offset inside a patch plane, -1: no such unit
 #pragma unroll
-        for (int u = 0; u < GS_UPP; ++u) {
-            const int seg = lw + 4 * u;
-            const int row = nseg == 1 ? seg : seg / nseg;
-            const int cu = ((seg - row * nseg) << 6) + lane;
-            const int px = cu >> 1, qq = cu & 1;
-            const int ih = ih0 + row, iw = iw0 + px;
-            const bool ok = seg < nsegs && cu < rowu;
-            pdst[u] = ok ? (row * PW + px) * GS_PSB + qq * 16 : -1;
-            pgo[u] = (ok && ih >= 0 && ih < D.Hi && iw >= 0 && iw < D.Wi) ? (unsigned)(((ih * D.Wi + iw) * D.ldi + qq * 8) * 4) : GS_OOB;
-        }
+        for (int u = 0; u < GS_UPP; ++u) unit_of(lw + 4 * u, pgo[u], pdst[u]);
         auto issue_slab = [&](int buf, int cb, int g) {
             const int tap0 = g * GS_TPS;
             constexpr int welems = (GS_TPS * 2) << LBN;  // 16-byte units of one piece: [tap][2][BN]
@@ -248,11 +279,16 @@ __global__ __launch_bounds__(512) void gconv_split_kernel(const GsArgs a) {
         constexpr std::integral_constant<int, GS_UPP> UN{};
         issue_slab(0, 0, 0);
         if (total_groups > 1) issue_slab(1, ngroups > 1 ? 0 : GS_CKP, ngroups > 1 ? 1 : 0);
-        fetch(0);
-        split_units(U0, UN);
-        put_units(0, U0, UN);
-        if (nchunks > 1) fetch(GS_CKP);
-        glds_wait();
+        stage_first_chunk();
+        // the second chunk's patch is fetched behind the FIRST barrier when its split comes a group later (three or more tap groups:
+        // issuing the loads here cost the prologue ~1.4 k clocks); else here, with a counted wait that leaves them in flight
+        const bool defer_fetch = ngroups >= 3;
+        if (nchunks > 1 && !defer_fetch) {
+            fetch(GS_CKP);
+            asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(2 * GS_UPP) : "memory");
+        } else {
+            glds_wait();
+        }
         int it = 0, wi = 2;                       // wi: ring buffer of group it + 2
         int c2 = 0, g2 = 2;                       // (chunk, group) of group it + 2
         while (g2 >= ngroups) { g2 -= ngroups; ++c2; }
@@ -270,7 +306,8 @@ __global__ __launch_bounds__(512) void gconv_split_kernel(const GsArgs a) {
                 if (it + 2 < total_groups) issue_slab(wi, c2 * GS_CKP, g2);
                 wi = wi == 2 ? 0 : wi + 1;
                 if (++g2 == ngroups) { g2 = 0; ++c2; }
-                const bool refetch = g == ngroups - 1 && c + 2 < nchunks;
+                const bool first_fetch = it == 0 && nchunks > 1 && defer_fetch;
+                const bool refetch = (g == ngroups - 1 && c + 2 < nchunks) || first_fetch;
                 if (more) {
                     // (spreading the split arithmetic over the first two groups was slower, with the stores -- 3x2 tile 139 -> 150 us on
                     //  layer3 -- and without -- 170 -> 189 us on layer1: in the first group the patch loads have not landed yet)
@@ -280,7 +317,7 @@ __global__ __launch_bounds__(512) void gconv_split_kernel(const GsArgs a) {
                         put_units(PDB ? ((c + 1) & 1) : 0, U0, UN);
                     }
                 }
-                if (refetch) fetch((c + 2) * GS_CKP);
+                if (refetch) fetch(first_fetch ? GS_CKP : (c + 2) * GS_CKP);
                 // the weights issued above must have landed before the next barrier; the patch loads issued BEHIND them in this
                 // group (2 * GS_UPP buffer loads per wave, unconditionally) need not: a plain vmcnt(0) would hold the next barrier
                 // back by the HBM latency (~1400 clocks of the MFMA waves per chunk, tools/trace_gconv_split.py)
@@ -290,6 +327,7 @@ __global__ __launch_bounds__(512) void gconv_split_kernel(const GsArgs a) {
         }
     } else {
         // ------------------------------------------------------------------------------------------ compute waves
+        stage_first_chunk();
         // (s_setprio(3) for these waves starves the staging waves' split arithmetic: 1880 -> 4760 clocks per chunk, the MFMA waves then
         //  wait for the patch: 2x2 tile 182 -> 195 us on layer1)
 #pragma unroll
