@@ -263,3 +263,59 @@ def test_split_step_is_bitwise_reproducible():
         assert l1.item() == l2.item()
     for p1, p2 in zip(m1.parameters(), m2.parameters()):
         assert torch.equal(p1, p2)
+
+
+def test_multistage_split_step_matches_oracle():
+    """HipTrainStep(operands="split") on resnet18_multistage_uncertainty_fixs (two stages, uncertainty-weighted losses, SGD incl. w_stage1/2)
+    against the CPU oracle at the fp32 plan's tolerances (tests/test_gpu_model.py::test_multistage_fused_step_matches_oracle)."""
+    import types
+
+    import numpy as np
+    from oracle import train as otrain
+    from radar_depth_amd import main as hmain
+    from radar_depth_amd.synthetic import make_batch, procedural_fill_
+    b, h, w = 2, 97, 161
+    args = types.SimpleNamespace(arch="resnet18_multistage_uncertainty_fixs", decoder="upproj", modality="rgbd", pretrained=False)
+    torch.manual_seed(0)
+    hm, hw_ = hmain.create_model(args, [h, w])
+    om, ow = otrain.create_model(args, [h, w])
+    procedural_fill_(hm)
+    procedural_fill_(om)
+    hm = hm.cuda()
+    om.train()
+    opt = torch.optim.SGD(om.parameters(), 0.01, momentum=0.9, weight_decay=1e-4)
+    crit = otrain.make_criterion(args.arch)
+    ts = hmain.HipTrainStep(hm, b, h, w, lr=0.01, momentum=0.9, weight_decay=1e-4, loss_weights=hw_, operands="split")
+    kinds = [k for pl in ts.plans for k, _ in pl.meta.values()]
+    assert kinds.count("gconv_split") > 80 and kinds.count("wgrad_split") > 40
+    for it in range(3):
+        x, t = make_batch(b, h, w, 500 + it, ref_pixels=h * w)
+        lo, _, _ = otrain.train_step(args.arch, om, crit, opt, x, t, ow)
+        lg, _ = ts.step(x.cuda(), t.cuda())
+        torch.cuda.synchronize()
+        assert abs(lg.item() - lo.item()) / abs(lo.item()) < 2e-3, (it, lg.item(), lo.item())
+    assert abs(hm.w_stage1.item() - om.w_stage1.item()) < 1e-3 and abs(hm.w_stage2.item() - om.w_stage2.item()) < 1e-3
+    po = np.array([p.double().norm().item() for p in om.parameters()])
+    pg = np.array([p.double().norm().item() for p in hm.parameters()])
+    assert np.abs(po - pg).max() / po.max() < 5e-3
+
+
+def test_split_forward_at_the_bench_geometry():
+    """b = 16, 450 x 800 (BASELINE config 2's own size): the split plan's first training-mode prediction and loss against the fp32 plan's
+    from identical parameters -- both within the north-star 1e-3 of each other by a wide margin."""
+    from radar_depth_amd.main import HipTrainStep
+    from radar_depth_amd.synthetic import make_batch
+    b, h, w = 16, 450, 800
+    x, t = make_batch(b, h, w, 1234)
+    res = []
+    for operands in ("fp32", "split"):
+        m = _build(h, w)
+        ts = HipTrainStep(m, b, h, w, operands=operands)
+        lg, pred = ts.step(x.cuda(), t.cuda())
+        torch.cuda.synchronize()
+        res.append((lg.item(), pred.float().cpu().clone()))
+        ts.close()
+        del ts, m
+        torch.cuda.empty_cache()
+    assert abs(res[0][0] - res[1][0]) / abs(res[0][0]) < 1e-5
+    assert _rel(res[1][1], res[0][1]) < 1e-4
