@@ -52,6 +52,10 @@ int launch_wgrad16(const RdConvDesc& d, const float* x, const float* dout, float
 bool wgrad1x1_eligible(const RdConvDesc& d);
 void wgrad1x1_splits(const RdConvDesc& d, int& n_splits, long long& pix_per_split);
 int launch_wgrad1x1(const RdConvDesc& d, const float* x, const float* dout, float* slabs, hipStream_t s);
+// stem16.hip: forward of the 16-channel depth stem on the 16x16x4 MFMA (dispatched from stem.hip's rd_stem_fwd[_t])
+bool stem16_eligible(int Cin, int Cout);
+int launch_stem16_fwd(int io16, const float* const* planes, const int64_t* strides, int Cin, int N, int H, int W, const float* w_packed, int Cout,
+                      void* out, float* stat_partial, hipStream_t s);
 int launch_conv16(const RdConvDesc& d, const float* in, const float* w_packed, float* out, const float* addend, int ld_add,
                   float* stat, hipStream_t s);
 

@@ -490,6 +490,8 @@ static int stem_fwd_impl(int io16, const float* const* planes, const int64_t* st
     int rc = stem_fill(a, planes, strides, Cin, N, H, W, Cout);
     if (rc != RD_OK) return rc;
     RD_CHECK_ARG(w_packed && out, "stem_fwd: null tensor");
+    if (stem16_eligible(Cin, Cout))       // the 16-channel depth stem: its own 16-wide kernel (same tiles, same statistics layout)
+        return launch_stem16_fwd(io16, planes, strides, Cin, N, H, W, w_packed, Cout, out, stat_partial, static_cast<hipStream_t>(stream));
     a.w = w_packed; a.out = out; a.stat = stat_partial; a.dout = nullptr;
     { static const char* dbg = getenv("RD_STEM_DEBUG"); a.debug = dbg ? atoi(dbg) : 0; }
     a.tiles_h = cdiv(a.Ho, 8); a.tiles_w = cdiv(a.Wo, ST_TW);
