@@ -16,7 +16,8 @@
 //   workgroup : 8 waves, one per CU.  Waves 0-3: one 32 x 32 (ci, co) pair each of a 64 x 64 block of dW, all nine taps: nine
 //               accumulators = 144 registers, and nothing but fragment reads and MFMAs.  Waves 4-7 stage: 8-channel units of the
 //               next pixel tile through registers (split into pieces there), two LDS buffers, ONE barrier per tile.
-//   pixel tile: 2 rows x 32 columns of one image (x patch 4 x 34 with the halo); four 16-pixel reduction steps.
+//   pixel tile: 64 pixels of one image, 2 rows x 32 columns (x patch 4 x 34 with the halo) or 4 x 16 (6 x 18), whichever pads the
+//               grid less; four 16-pixel reduction steps.
 //   split-K   : contiguous ranges of pixel tiles per workgroup, per-split slabs [split][tap][Cin][Cout] like rd_wgrad, reduced in
 //               a fixed order by the same slab reduction.
 #include <math.h>
@@ -40,18 +41,25 @@ typedef float wsf32x2 __attribute__((ext_vector_type(2)));
 typedef __bf16 wsbf16x2 __attribute__((ext_vector_type(2)));
 
 constexpr unsigned WS_OOB = 0x80000000u;
-constexpr int WS_R = 2, WS_TW = 32;                 // output rows / columns of a pixel tile
-constexpr int WS_XW = WS_TW + 2, WS_XH = WS_R + 2;   // x patch with the 3x3 halo
-constexpr int WS_XPIX = WS_XW * WS_XH;              // 136
-constexpr int WS_YPIX = WS_R * WS_TW;               // 64
-constexpr int WS_XPLANE = WS_XPIX * 64;             // bytes of one [pixel][32 channels] bf16 plane of the patch: 8704 (a multiple of 256)
-constexpr int WS_YPLANE = WS_YPIX * 64;             // 4096
-constexpr int WS_XBYTES = 3 * 2 * WS_XPLANE;        // [piece][channel tile][plane]
-constexpr int WS_YBYTES = 3 * 2 * WS_YPLANE;
-constexpr int WS_BUF = WS_XBYTES + WS_YBYTES;       // 76800 bytes per buffer, two of them
-constexpr int WS_XUNITS = WS_XPIX * 8;              // 8-channel units of a 64-channel patch: 1088 = 17 waves' worth
-constexpr int WS_UNITS = WS_XUNITS + WS_YPIX * 8;   // 1600
-constexpr int WS_UPT = (WS_UNITS + 255) / 256;      // units per staging thread: 7
+// pixel-tile geometries: 64 output pixels as R rows x TW columns (TW a multiple of the 16-pixel reduction step)
+template <int R_, int TW_>
+struct WsGeo {
+    static constexpr int R = R_, TW = TW_;
+    static constexpr int XW = TW + 2, XH = R + 2;                // x patch with the 3x3 halo
+    static constexpr int XPIX = XW * XH, YPIX = R * TW;
+    static constexpr int XPLANE = ((XPIX * 64 + 255) / 256) * 256;      // bytes of one [pixel][32 channels] bf16 plane of the patch (multiple of 256)
+    static constexpr int YPLANE = YPIX * 64;
+    static constexpr int XBYTES = 3 * 2 * XPLANE;                // [piece][channel tile][plane]
+    static constexpr int YBYTES = 3 * 2 * YPLANE;
+    static constexpr int BUF = XBYTES + YBYTES;                  // bytes per buffer, two of them
+    static constexpr int XUNITS = XPIX * 8;                      // 8-channel units of a 64-channel patch ...
+    static constexpr int XUNITS_PAD = ((XUNITS + 63) / 64) * 64; // ... rounded up to whole waves: a wave's unit is entirely x or entirely dy
+    static constexpr int UNITS = XUNITS_PAD + YPIX * 8;
+    static constexpr int UPT = (UNITS + 255) / 256;              // units per staging thread
+    static_assert(YPIX == 64 && TW % 16 == 0, "a tile is 64 pixels in 16-pixel reduction steps");
+};
+typedef WsGeo<2, 32> WsWide;      // 2 x 32: 76800 bytes per buffer, 7 units per thread
+typedef WsGeo<4, 16> WsTall;      // 4 x 16: less halo (1.69 vs 2.1 patch pixels per output pixel), fits 100- and 200-column grids better
 
 struct WsArgs {
     const float* x;
@@ -101,7 +109,7 @@ __device__ __forceinline__ wsbf16x8 ws_frag(unsigned base, int off) {
     return __builtin_bit_cast(wsbf16x8, r);
 }
 
-template <int TR, int TC>
+template <int TR, int TC, typename G>
 __global__ __launch_bounds__(512) void wgrad_split_kernel(const WsArgs a) {
     constexpr int NT = TR * TC;
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -125,38 +133,38 @@ __global__ __launch_bounds__(512) void wgrad_split_kernel(const WsArgs a) {
         const int ltid = tid - 256;
         // this thread's units: e = ltid + 256 u; e < 1088: x patch unit (tile t, pixel, quad q), else dy unit.  1088 = 17 * 64, so a
         // wave's unit u is entirely x or entirely dy (wave-uniform buffer resource)
-        int upr[WS_UPT], upc[WS_UPT], uch[WS_UPT], udst[WS_UPT];
+        int upr[G::UPT], upc[G::UPT], uch[G::UPT], udst[G::UPT];
 #pragma unroll
-        for (int u = 0; u < WS_UPT; ++u) {
+        for (int u = 0; u < G::UPT; ++u) {
             const int e = ltid + 256 * u;
-            if (e < WS_XUNITS) {
-                const int t = e / (WS_XPIX * 4), rem = e - t * (WS_XPIX * 4);
+            if (e < G::XUNITS) {
+                const int t = e / (G::XPIX * 4), rem = e - t * (G::XPIX * 4);
                 const int px = rem >> 2, q = rem & 3;
-                upr[u] = px / WS_XW; upc[u] = px - upr[u] * WS_XW;
+                upr[u] = px / G::XW; upc[u] = px - upr[u] * G::XW;
                 uch[u] = t * 32 + q * 8;
-                udst[u] = t * WS_XPLANE + rem * 16;
-            } else if (e < WS_UNITS) {
-                const int e2 = e - WS_XUNITS;
+                udst[u] = t * G::XPLANE + rem * 16;
+            } else if (e >= G::XUNITS_PAD && e < G::UNITS) {
+                const int e2 = e - G::XUNITS_PAD;
                 const int t = e2 >> 8, rem = e2 & 255;
                 const int px = rem >> 2, q = rem & 3;
-                upr[u] = px / WS_TW; upc[u] = px - upr[u] * WS_TW;
+                upr[u] = px / G::TW; upc[u] = px - upr[u] * G::TW;
                 uch[u] = t * 32 + q * 8;
-                udst[u] = WS_XBYTES + t * WS_YPLANE + rem * 16;
+                udst[u] = G::XBYTES + t * G::YPLANE + rem * 16;
             } else {
                 upr[u] = upc[u] = uch[u] = 0;
                 udst[u] = -1;
             }
         }
         const unsigned ximg = (unsigned)(a.Hi * a.Wi * a.ldi) * 4u, yimg = (unsigned)(a.Ho * a.Wo * a.ldo) * 4u;
-        float4 v0[WS_UPT], v1[WS_UPT];
+        float4 v0[G::UPT], v1[G::UPT];
         auto fetch = [&](int tile) {
             const int n = tile / (a.tiles_h * a.tiles_w), tr = tile - n * (a.tiles_h * a.tiles_w);
-            const int r0 = (tr / a.tiles_w) * WS_R, c0 = (tr % a.tiles_w) * WS_TW;
+            const int r0 = (tr / a.tiles_w) * G::R, c0 = (tr % a.tiles_w) * G::TW;
             const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.x) + (size_t)n * a.Hi * a.Wi * a.ldi, 0, ximg, 0x00020000);
             const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.dy) + (size_t)n * a.Ho * a.Wo * a.ldo, 0, yimg, 0x00020000);
 #pragma unroll
-            for (int u = 0; u < WS_UPT; ++u) {
-                const bool is_x = __builtin_amdgcn_readfirstlane(ltid + 256 * u) < WS_XUNITS;      // wave-uniform
+            for (int u = 0; u < G::UPT; ++u) {
+                const bool is_x = __builtin_amdgcn_readfirstlane(ltid + 256 * u) < G::XUNITS_PAD;      // wave-uniform
                 unsigned off;
                 if (is_x) {
                     const int ih = r0 + a.dh0 + upr[u], iw = c0 + a.dw0 + upc[u], ch = cib0 + uch[u];
@@ -173,14 +181,14 @@ __global__ __launch_bounds__(512) void wgrad_split_kernel(const WsArgs a) {
             }
         };
         auto split_put = [&](int buf) {
-            const unsigned base = lds0 + buf * WS_BUF;
+            const unsigned base = lds0 + buf * G::BUF;
 #pragma unroll
-            for (int u = 0; u < WS_UPT; ++u) {
+            for (int u = 0; u < G::UPT; ++u) {
                 wsu32x4 w0, w1, w2;
                 ws_split8(v0[u], v1[u], w0, w1, w2);
                 if (udst[u] >= 0) {
-                    const bool is_x = udst[u] < WS_XBYTES;
-                    const unsigned pstride = is_x ? 2 * WS_XPLANE : 2 * WS_YPLANE;
+                    const bool is_x = udst[u] < G::XBYTES;
+                    const unsigned pstride = is_x ? 2 * G::XPLANE : 2 * G::YPLANE;
                     const unsigned ad = base + udst[u];
                     asm volatile("ds_write_b128 %0, %1" ::"v"(ad), "v"(w0) : "memory");
                     asm volatile("ds_write_b128 %0, %1" ::"v"(ad + pstride), "v"(w1) : "memory");
@@ -216,24 +224,24 @@ __global__ __launch_bounds__(512) void wgrad_split_kernel(const WsArgs a) {
         // lane part of every fragment address: pixel row (lane & 15) / 4 of the group's four, 8-byte chunk lane & 3, second 16
         // channels for lanes 16..31 of each half, pixels 8.. for the upper half wave
         const unsigned lpart = (unsigned)((((lane & 15) >> 2) + (lane >> 5) * 8) * 64 + ((lane >> 4) & 1) * 32 + (lane & 3) * 8);
-        const unsigned xb = lds0 + ti * WS_XPLANE + lpart;
-        const unsigned yb = lds0 + WS_XBYTES + to * WS_YPLANE + lpart;
+        const unsigned xb = lds0 + ti * G::XPLANE + lpart;
+        const unsigned yb = lds0 + G::XBYTES + to * G::YPLANE + lpart;
         for (int i = 0; i < ntiles; ++i) {
             rd_sync();                            // B(i)
-            const unsigned xa = xb + (i & 1) * WS_BUF, ya = yb + (i & 1) * WS_BUF;
+            const unsigned xa = xb + (i & 1) * G::BUF, ya = yb + (i & 1) * G::BUF;
             // 4 NT steps per tile = (row, 16-pixel reduction step, tap); the fragments of step s + 1 are read in front of the MFMAs of
             // step s and the order is pinned (left alone the compiler hoists a whole reduction step's reads and spills them)
-            constexpr int NSTEP = WS_R * (WS_TW / 16) * NT;
+            constexpr int NSTEP = G::R * (G::TW / 16) * NT;
             wsbf16x8 A[2][3], B[2][3];
             auto loadA = [&](int s_, wsbf16x8 (&F)[3]) {
-                const int rk = s_ / NT, t = s_ % NT, r = rk / (WS_TW / 16), ks = rk % (WS_TW / 16);
+                const int rk = s_ / NT, t = s_ % NT, r = rk / (G::TW / 16), ks = rk % (G::TW / 16);
 #pragma unroll
-                for (int p = 0; p < 3; ++p) F[p] = ws_frag(xa, p * 2 * WS_XPLANE + ((r + t / TC) * WS_XW + ks * 16 + t % TC) * 64);
+                for (int p = 0; p < 3; ++p) F[p] = ws_frag(xa, p * 2 * G::XPLANE + ((r + t / TC) * G::XW + ks * 16 + t % TC) * 64);
             };
             auto loadB = [&](int rk, wsbf16x8 (&F)[3]) {
-                const int r = rk / (WS_TW / 16), ks = rk % (WS_TW / 16);
+                const int r = rk / (G::TW / 16), ks = rk % (G::TW / 16);
 #pragma unroll
-                for (int p = 0; p < 3; ++p) F[p] = ws_frag(ya, p * 2 * WS_YPLANE + (r * WS_TW + ks * 16) * 64);
+                for (int p = 0; p < 3; ++p) F[p] = ws_frag(ya, p * 2 * G::YPLANE + (r * G::TW + ks * 16) * 64);
             };
             loadB(0, B[0]);
             loadA(0, A[0]);
@@ -276,6 +284,7 @@ __global__ __launch_bounds__(512) void wgrad_split_kernel(const WsArgs a) {
 // ------------------------------------------------------------------------------------------ host
 struct WsPlan {
     int ok, tiles_h, tiles_w, total_tiles, tiles_per_split, n_splits, n_cib, n_cob, J, S;
+    int tall;       // pixel tile 4 x 16 (WsTall) instead of 2 x 32 (WsWide)
 };
 
 // taps of a phase = a full TR x TC rectangle in row-major order, TR, TC in {2, 3}
@@ -311,8 +320,17 @@ static WsPlan ws_plan(const RdConvDesc& d) {
     WsPlan pl{};
     pl.ok = ws_shape_ok(d) ? 1 : 0;
     if (!pl.ok) return pl;
-    pl.tiles_h = cdiv(d.phase[0].lh, WS_R);
-    pl.tiles_w = cdiv(d.phase[0].lw, WS_TW);
+    // tile geometry: the tall one (fewer staged halo pixels: layer1 158 -> 143 us, layer2 171 -> 153, UpProj-64 192 -> 163) unless it
+    // pads the logical grid more than 10 % beyond the wide one (measured level within 7 %: 29 / 30 x 50 grids)
+    {
+        const int lh = d.phase[0].lh, lw = d.phase[0].lw;
+        const long long wide_px = (long long)cdiv(lh, WsWide::R) * WsWide::R * cdiv(lw, WsWide::TW) * WsWide::TW;
+        const long long tall_px = (long long)cdiv(lh, WsTall::R) * WsTall::R * cdiv(lw, WsTall::TW) * WsTall::TW;
+        static const char* force = getenv("RD_WGRAD_SPLIT_TILE");       // diagnostics: "wide" / "tall"
+        pl.tall = force ? (force[0] == 't') : (tall_px * 10 <= wide_px * 11);
+        pl.tiles_h = cdiv(lh, pl.tall ? WsTall::R : WsWide::R);
+        pl.tiles_w = cdiv(lw, pl.tall ? WsTall::TW : WsWide::TW);
+    }
     pl.total_tiles = d.N * pl.tiles_h * pl.tiles_w;
     pl.n_cib = cdiv(d.Cin, 64);
     pl.n_cob = cdiv(d.Cout, 64);
@@ -330,15 +348,15 @@ static WsPlan ws_plan(const RdConvDesc& d) {
     return pl;
 }
 
-template <int TR, int TC>
+template <int TR, int TC, typename G>
 static int launch_ws(const WsArgs& a, int grid, hipStream_t s) {
     static bool attr_set = false;
-    auto k = wgrad_split_kernel<TR, TC>;
+    auto k = wgrad_split_kernel<TR, TC, G>;
     if (!attr_set) {
         RD_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr_set = true;
     }
-    hipLaunchKernelGGL(k, dim3(grid), dim3(512), 2 * WS_BUF, s, a);
+    hipLaunchKernelGGL(k, dim3(grid), dim3(512), 2 * G::BUF, s, a);
     RD_CHECK_LAUNCH("wgrad_split_kernel");
     return RD_OK;
 }
@@ -356,12 +374,12 @@ extern "C" int64_t rd_wgrad_split_workspace_floats(const RdConvDesc* d) {
     return (int64_t)(pl.n_splits + pl.J) * pl.S * d->Cin * d->Cout;
 }
 
-// diagnostics: out[0..3] = splits, tiles per split, workgroups per launch, tiles
+// diagnostics: out[0..3] = splits, tiles per split, workgroups per launch, tiles (+ 2^30 when the pixel tile is 4 x 16)
 extern "C" int rd_wgrad_split_plan_info(const RdConvDesc* d, int32_t* out) {
     if (!d || !out) return RD_EINVAL;
     const WsPlan pl = ws_plan(*d);
     if (!pl.ok) return RD_EINVAL;
-    out[0] = pl.n_splits; out[1] = pl.tiles_per_split; out[2] = pl.n_splits * pl.n_cib * pl.n_cob; out[3] = pl.total_tiles;
+    out[0] = pl.n_splits; out[1] = pl.tiles_per_split; out[2] = pl.n_splits * pl.n_cib * pl.n_cob; out[3] = pl.total_tiles + (pl.tall ? 1 << 30 : 0);
     return RD_OK;
 }
 
@@ -386,10 +404,17 @@ extern "C" int rd_wgrad_split(const RdConvDesc* d, const float* in, const float*
         a.dh0 = p.dh_min; a.dw0 = p.dw_min; a.off_h = p.out_off_h; a.off_w = p.out_off_w; a.lh = p.lh; a.lw = p.lw;
         for (int t = 0; t < 9; ++t) a.widx[t] = t < p.n_taps ? p.widx[t] : 0;
         int rc;
-        if (tr == 3 && tc == 3) rc = launch_ws<3, 3>(a, grid, s);
-        else if (tr == 2 && tc == 3) rc = launch_ws<2, 3>(a, grid, s);
-        else if (tr == 3 && tc == 2) rc = launch_ws<3, 2>(a, grid, s);
-        else rc = launch_ws<2, 2>(a, grid, s);
+        if (pl.tall) {
+            if (tr == 3 && tc == 3) rc = launch_ws<3, 3, WsTall>(a, grid, s);
+            else if (tr == 2 && tc == 3) rc = launch_ws<2, 3, WsTall>(a, grid, s);
+            else if (tr == 3 && tc == 2) rc = launch_ws<3, 2, WsTall>(a, grid, s);
+            else rc = launch_ws<2, 2, WsTall>(a, grid, s);
+        } else {
+            if (tr == 3 && tc == 3) rc = launch_ws<3, 3, WsWide>(a, grid, s);
+            else if (tr == 2 && tc == 3) rc = launch_ws<2, 3, WsWide>(a, grid, s);
+            else if (tr == 3 && tc == 2) rc = launch_ws<3, 2, WsWide>(a, grid, s);
+            else rc = launch_ws<2, 2, WsWide>(a, grid, s);
+        }
         if (rc != RD_OK) return rc;
     }
     return RD_OK;
