@@ -11,7 +11,12 @@ seed = 1234 + 1000*rank).  Timed region: K steps bracketed by barrier + synchron
 prints ONE JSON line.  Extra objects:
   roofline     -- the dominant kernel (largest total time among the conv kernel instantiations) measured with HIP
                   events in an instrumented eager pass on the step's own stream: algorithmic FLOPs per launch /
-                  average launch duration against the fp32 MFMA/vector peak (157.3 TFLOP/s);
+                  average launch duration.  The default plan ("split", config.arith) computes every fp32 product from six
+                  bf16 MFMA terms: `frac` prices the bf16 MFMA FLOPs it issues against the dense bf16 peak (2500 TFLOP/s;
+                  equivalently algorithmic fp32 FLOPs against 2500/6), and `frac_of_fp32_mfma_peak` the algorithmic
+                  rate against the fp32 MFMA/vector peak (157.3 TFLOP/s); `--operands fp32` runs every
+                  convolution on the fp32 MFMA and is priced against 157.3 only;
+  alt_fp32_mfma-- the same workload on the plain fp32-MFMA plan, timed the same way in the same process;
   cpu_baseline -- the CPU oracle (plain PyTorch restatement of the reference) timed on the host cores of this
                   box on a bounded sample (rank 0, N=1 only).
 """
@@ -178,8 +183,8 @@ def cpu_baseline(arch, batch, height, width):
     for b in sorted({x2.shape[0], batch}):
         x, t = (x2, t2) if b == x2.shape[0] else make_batch(b, height, width, 1234)
         first = steps(x, t, 1)[0]
-        n_warm = 1 if first > 6 else 2
-        n_timed = max(1, min(5, int(20.0 / max(first, 1e-3)) - n_warm))
+        n_warm = 1 if first > 6 else 2                        # 2 warm-up + 5 timed steps (fewer only when a step takes > 5 s)
+        n_timed = max(1, min(5, int(36.0 / max(first, 1e-3)) - n_warm))
         tt = steps(x, t, n_warm - 1 + n_timed)[n_warm - 1:]
         res[b] = (b / min(tt), b / statistics.median(tt), min(tt))
         plan_txt.append("b=%d: %d warm-up + %d timed steps" % (b, n_warm, n_timed))
@@ -269,14 +274,19 @@ def dry_run(args, world, rank):
     covered = sum(hi - lo for bk in buckets for lo, hi in bk)
     ok = bool((grads == want).all().item()) and covered == grads.numel()
     per_rank = [dt]
+    # the self-verification fields of the real line: identical parameters on every rank (same seed -> same checksum), per-rank values
+    checksum = int(sum(int(p.detach().view(torch.int32).to(torch.int64).sum().item()) for p in model.parameters()))
+    sums = [checksum]
     if world > 1:
         box = [None] * world
-        dist.all_gather_object(box, dt)
-        per_rank = box
+        dist.all_gather_object(box, (dt, checksum))
+        per_rank = [b[0] for b in box]
+        sums = [b[1] for b in box]
         dist.destroy_process_group()
     if rank == 0:
         print(json.dumps({"metric": METRIC, "value": None, "unit": "samples/s", "n_gpus": world, "steps": 0, "warmup": 0, "dry_run": True,
-                          "comm": "gloo" if world > 1 else "none", "gradient_buckets": len(buckets), "exchange_ok": ok,
+                          "comm": "gloo" if world > 1 else "none", "rccl_world_size": None, "params_identical_across_ranks": len(set(sums)) == 1,
+                          "final_loss_per_rank": None, "final_loss_spread": None, "gradient_buckets": len(buckets), "exchange_ok": ok,
                           "exchange_s_per_rank": [round(v, 4) for v in per_rank], "plan_ops": len(plan.prep + plan.fwd + plan.bwd)}), flush=True)
     if not ok:
         raise SystemExit("dry run: the bucketed exchange did not produce the all-rank sum over the whole arena")
@@ -299,14 +309,14 @@ def main():
                     help="headline = resnet18_latefusion (BASELINE configs[1]); the multistage arch is configs[3] (use --batch 8)")
     ap.add_argument("--graph", action="store_true", help="replay the step as hipGraphs (slower than plain stream launches here)")
     ap.add_argument("--no-graph", action="store_true", help="(default; kept for older command lines)")
-    ap.add_argument("--no-alt", action="store_true", help="skip the extra `alt_split` measurement (the same workload on the opt-in split plan; also skipped by --no-roofline / "
-                                                        "--no-cpu-baseline, i.e. by the profiling command lines)")
-    ap.add_argument("--operands", default="fp32", choices=["fp32", "bf16", "split"],
-                    help="conv operand precision.  fp32 (default) is the BASELINE.json configs[1] measurement; bf16 (configs 2/4) runs the "
-                         "forward / input-gradient / weight-gradient convolutions on bf16 MFMA with fp32 tensors + accumulation and is reported with "
-                         "dtype \"bf16\" and its own metric name -- never as the fp32 headline; split = fp32 arithmetic on the bf16 matrix cores "
-                         "(csrc/gconv_split.hip: three bf16 pieces per fp32 operand, six MFMAs per product, fp32 accumulation; fp32 tensors, fp32 "
-                         "tolerances) for the forward / input-gradient convolutions the library plans that way, reported under its own metric name")
+    ap.add_argument("--no-alt", action="store_true", help="skip the extra `alt_fp32_mfma` measurement (the same workload on the plain fp32-MFMA plan; also skipped by "
+                                                        "--no-roofline / --no-cpu-baseline, i.e. by the profiling command lines)")
+    ap.add_argument("--operands", default=None, choices=["fp32", "bf16", "split"],
+                    help="arithmetic of the convolutions.  split (default for fp32 storage; config.arith) = fp32 arithmetic on the bf16 matrix cores: "
+                         "every fp32 operand as three bf16 pieces, six MFMA terms per product, fp32 accumulation (csrc/gconv_split.hip, wgrad_split.hip; "
+                         "fp32 tensors; pinned against the CPU oracle at the fp32 tolerances at BASELINE's own batch sizes, tests/test_gpu_configs.py); "
+                         "fp32 = every convolution on v_mfma_f32_32x32x2_f32; bf16 (BASELINE configs 3/5) rounds the operands to bf16 and is reported "
+                         "with dtype \"bf16\" under its own metric name -- never as the fp32 headline")
     ap.add_argument("--storage", default=None, choices=["fp32", "bf16"],
                     help="element type of the NHWC activation / gradient tensors in HBM.  bf16 (BASELINE.json configs 3 / 5) implies "
                          "--operands bf16; statistics, parameters, their gradients and the optimizer stay fp32")
@@ -333,6 +343,8 @@ def main():
     args.storage = args.storage or (cfg[4] if args.config is not None else "fp32")
     if args.storage == "bf16":
         args.operands = "bf16"
+    if args.operands is None:
+        args.operands = "split"
 
     # `python bench.py --gpus N` with no launcher around it: start the N ranks ourselves
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -414,6 +426,20 @@ def main():
         per_rank_ms = [1e3 * b.item() / args.steps for b in box]
         dt = max(b.item() for b in box)
     final_loss = float(loss.item())
+    # self-verification of the data-parallel run (outside the timed region; one 16-byte all-gather): every rank must hold the SAME
+    # parameters after the timed steps (checksum = integer sum of the arena's bit patterns, exact), the per-rank losses differ only
+    # through the rank-distinct data, and RCCL's own communicator reports the world size the line claims
+    checksum = int(ts.st["arena"].view(torch.int32).to(torch.int64).sum().item())
+    rank_losses, rank_sums = [final_loss], [checksum]
+    if world > 1:
+        box = [torch.zeros(2, device="cuda", dtype=torch.float64) for _ in range(world)]
+        torch.distributed.all_gather(box, torch.tensor([final_loss, float(checksum % (1 << 52))], device="cuda", dtype=torch.float64))
+        rank_losses = [b[0].item() for b in box]
+        rank_sums = [int(b[1].item()) for b in box]
+    rccl_world = None
+    if comm_used == "rccl":
+        from radar_depth_amd import comm as rd_comm
+        rccl_world = rd_comm.world()
 
     multistage = args.arch != "resnet18_latefusion"
     bf16 = args.operands == "bf16"
@@ -428,9 +454,12 @@ def main():
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": "%s --decoder upproj --modality rgbd, b=%d/GPU %dx%d fp32, full step "
                                "(fwd + loss + bwd + SGD momentum .9 wd 1e-4), random init" % (args.arch, args.batch, args.height, args.width),
-                   "baseline_config": args.config if args.config is not None else (2 if (args.arch, args.batch, args.height, args.width, args.storage, args.operands) == CONFIGS[2] + ("fp32",) else None),
+                   "baseline_config": args.config if args.config is not None else (2 if (args.arch, args.batch, args.height, args.width, args.storage) == CONFIGS[2] and args.operands in ("fp32", "split") else None),
                    "global_batch": world * args.batch, "parallelism": "dp%d" % world if world > 1 else ("dp1 (forced data-parallel code path)" if os.environ.get("RD_FORCE_DP") == "1" else "single"),
-                   "hipgraph": args.graph, "comm": comm_used, "autotuned_plans": bool(args.autotune), "final_loss": round(final_loss, 5),
+                   "hipgraph": args.graph, "comm": comm_used, "rccl_world_size": rccl_world,
+                   "params_identical_across_ranks": len(set(rank_sums)) == 1, "final_loss_per_rank": [round(v, 5) for v in rank_losses],
+                   "final_loss_spread": round(max(rank_losses) - min(rank_losses), 6),
+                   "autotuned_plans": bool(args.autotune), "final_loss": round(final_loss, 5),
                    "step_issue": "one rd_optable_run call per step (%d ops)" % len(ts._ops),
                    "rd_env": env_knobs},
     }
@@ -445,18 +474,25 @@ def main():
             out["config"]["workload"] = out["config"]["workload"].replace(" bf16-operand convs,", " bf16 storage + bf16 convs,")
     split = args.operands == "split"
     if split:
-        out["metric"] += (" [fp32 arithmetic on the bf16 matrix cores: forward / input-gradient convolutions with >= 32 channels split each fp32 "
-                          "operand into three bf16 pieces and rebuild the product from six v_mfma_f32_32x32x16_bf16 terms, fp32 accumulation "
-                          "(error vs fp64 <= the fp32 MFMA's, tests/test_gpu_gconv_split.py); weight gradients, stems, head, 1x1 and 16-channel "
-                          "layers on the fp32 MFMA; fp32 tensors]")
-        out["config"]["workload"] = out["config"]["workload"].replace(" fp32,", " fp32 (split-bf16 MFMA convolutions),")
-        out["config"]["arith"] = "fp32 operands as 3 bf16 pieces, 6 of 9 piece products kept (dropped terms < 2^-24 of the product), fp32 accumulate"
+        kinds0 = [k for pl in ts.plans for k, _ in pl.meta.values()]
+        out["config"]["arith"] = ("fp32 tensors and fp32 results; the convolutions the library has a split plan for (%d forward / input-gradient and %d "
+                                  "weight-gradient launches per step) compute every fp32 product on the bf16 matrix cores from three bf16 pieces per "
+                                  "operand (x = x0 + x1 + x2 exactly), six v_mfma_f32_32x32x16_bf16 terms per product (the three dropped terms are below "
+                                  "2^-24 of it), fp32 accumulation; error vs fp64 at the level of the fp32 MFMA kernels, pinned against the CPU oracle at "
+                                  "this batch size at the fp32 bars (tests/test_gpu_configs.py, tests/test_gpu_gconv_split.py, tests/test_gpu_wgrad_split.py); "
+                                  "all other kernels fp32 (v_mfma_f32_32x32x2_f32 / VALU)" % (kinds0.count("gconv_split"), kinds0.count("wgrad_split")))
+    elif not bf16:
+        out["config"]["arith"] = "fp32 everywhere: every convolution on v_mfma_f32_32x32x2_f32 (the alternate plan of the default line)"
     per_gpu = out["value"] / world
     if rank == 0 and not args.no_roofline:
         agg, fam = instrumented_pass(ts)
         name, (ms, n, flops, nbytes) = max(agg.items(), key=lambda kv: kv[1][0])
-        tfile = {("fp32", "fp32"): "r03_pmc_traffic.json", ("bf16", "bf16"): "r03_pmc_traffic_bf16_storage.json",
-                 ("split", "fp32"): "r03_pmc_traffic_split.json"}.get((args.operands, args.storage))
+        suffix = {("fp32", "fp32"): "_fp32_mfma", ("bf16", "bf16"): "_bf16_storage", ("split", "fp32"): ""}.get((args.operands, args.storage))
+        tfile = None
+        if suffix is not None:
+            import glob
+            cands = sorted(glob.glob(os.path.join(REPO, "profiles", "r[0-9][0-9]_pmc_traffic%s.json" % suffix)))
+            tfile = os.path.basename(cands[-1]) if cands else None       # the newest round's counter passes of THIS command line
         traffic, traffic_source = None, None
         if tfile and not multistage and (args.batch, args.height, args.width) == (16, 450, 800) and os.path.exists(os.path.join(REPO, "profiles", tfile)):
             # HBM bytes per launch of that kernel from the committed rocprofv3 --pmc passes of THIS command line (FETCH_SIZE x2 +
@@ -477,9 +513,12 @@ def main():
             achieved = 6.0 * flops / (ms * 1e-3) / 1e12
             step_flops = bnd["gflop"] * 1e9 * args.batch
             out["roofline"] = dict(common, bound="mfma", achieved=round(achieved, 1), peak=2500.0, unit="TFLOP/s", frac=round(achieved / 2500.0, 4),
-                                   note="bf16 MFMA FLOPs issued (6 per algorithmic fp32 FLOP) against the dense bf16 peak; random-data "
-                                        "sustained rate of this device is ~1850 TFLOP/s (tools/micro/mfma_agpr.hip: the clock drops to 1.85 GHz)",
-                                   fp32_equivalent_tflops=round(flops / (ms * 1e-3) / 1e12, 1), fp32_mfma_peak=PEAK_FP32_TFLOPS,
+                                   note="bf16 MFMA FLOPs issued (6 per algorithmic fp32 FLOP) against the dense bf16 peak, i.e. algorithmic fp32 FLOPs "
+                                        "against 2500/6 = 416.7 TFLOP/s; random-data sustained rate of this device is ~1850 TFLOP/s "
+                                        "(tools/micro/mfma_agpr.hip: the clock drops to 1.85 GHz)",
+                                   fp32_equivalent_tflops=round(flops / (ms * 1e-3) / 1e12, 1), fp32_equivalent_peak=round(2500.0 / 6, 1),
+                                   fp32_mfma_peak=PEAK_FP32_TFLOPS, frac_of_fp32_mfma_peak=round(flops / (ms * 1e-3) / 1e12 / PEAK_FP32_TFLOPS, 4),
+                                   step_frac_of_split_bound=round(step_flops * args.steps / dt / 1e12 / (2500.0 / 6), 4),
                                    algorithmic_gflop_per_sample=round(bnd["gflop"], 2),
                                    step_conv_tflops=round(step_flops * args.steps / dt / 1e12, 2),
                                    bound_samples_per_s_per_gpu=round(bnd["fp32"], 1), step_frac_of_fp32_mfma_bound=round(per_gpu / bnd["fp32"], 4))
@@ -507,16 +546,17 @@ def main():
             by_kernel = {k: [round(v[0], 3), v[1], round(v[3] / (v[0] * 1e-3) / 1e9, 0)] for k, v in sorted(agg.items(), key=lambda kv: -kv[1][0])}
         out["roofline"]["eager_ms_by_family"] = {k: round(v, 3) for k, v in sorted(fam.items(), key=lambda kv: -kv[1])}
         out["roofline"]["eager_ms_by_kernel"] = by_kernel
-    if (rank == 0 and world == 1 and args.operands == "fp32" and args.storage == "fp32" and not args.no_alt and not args.graph
+    if (rank == 0 and world == 1 and args.operands == "split" and args.storage == "fp32" and not args.no_alt and not args.graph
             and not args.no_roofline and not args.no_cpu_baseline and os.environ.get("RD_FORCE_DP") != "1"):
-        # the same workload once more on the opt-in split plan (fp32 arithmetic on the bf16 matrix cores), timed the
-        # same way in this process, reported NEXT TO the metric -- `value` above is the plain fp32-MFMA plan and is not affected
+        # the same workload once more on the plain fp32-MFMA plan (every convolution on v_mfma_f32_32x32x2_f32), timed the same way in
+        # this process, reported NEXT TO the metric -- `value` above is the default (split) plan and is not affected
         try:
+            ts.close()
             torch.manual_seed(0)
             made2 = create_model(types.SimpleNamespace(arch=args.arch, decoder="upproj", modality="rgbd", pretrained=False), [args.height, args.width])
             model2, lw2 = made2 if isinstance(made2, tuple) else (made2, None)
             ts2 = HipTrainStep(model2.cuda(), args.batch, args.height, args.width, lr=0.01, momentum=0.9, weight_decay=1e-4, loss_weights=lw2,
-                               operands="split", comm="auto")
+                               operands="fp32", comm="auto")
             for _ in range(args.warmup):
                 ts2.step(x, t)
             torch.cuda.synchronize()
@@ -525,17 +565,14 @@ def main():
                 loss2, _ = ts2.step(x, t)
             torch.cuda.synchronize()
             adt = time.perf_counter() - a0
-            kinds = [k for pl in ts2.plans for k, _ in pl.meta.values()]
-            out["alt_split"] = {"operands": "split", "value": round(args.batch * args.steps / adt, 2), "unit": "samples/s", "ms_per_step": round(1e3 * adt / args.steps, 3),
-                                "steps": args.steps, "warmup": args.warmup, "final_loss": round(float(loss2.item()), 5),
-                                "launches_on_the_bf16_matrix_cores": {k: kinds.count(k) for k in ("gconv_split", "wgrad_split")},
-                                "note": "same workload, same process, opt-in plan: every fp32 operand of the >= 64-channel 3x3 / 5x5 convolutions "
-                                        "(forward, input gradient, 3x3 weight gradient) as three bf16 pieces, six MFMA terms per product, fp32 accumulate; "
-                                        "error vs fp64 at the level of the fp32 MFMA kernels (tests/test_gpu_gconv_split.py, test_gpu_wgrad_split.py); "
-                                        "NOT the metric's value"}
+            out["alt_fp32_mfma"] = {"operands": "fp32", "value": round(args.batch * args.steps / adt, 2), "unit": "samples/s", "ms_per_step": round(1e3 * adt / args.steps, 3),
+                                    "steps": args.steps, "warmup": args.warmup, "final_loss": round(float(loss2.item()), 5),
+                                    "step_frac_of_bound": round(args.batch * args.steps / adt / bnd["fp32"], 4),
+                                    "note": "same workload, same process, every convolution on the fp32 MFMA (v_mfma_f32_32x32x2_f32; rounds 1-3's headline "
+                                            "plan); NOT the metric's value"}
             ts2.close()
         except Exception as e:      # the alternative line must never take the metric down with it
-            out["alt_split"] = {"error": "%s: %s" % (type(e).__name__, e)}
+            out["alt_fp32_mfma"] = {"error": "%s: %s" % (type(e).__name__, e)}
     if world > 1:
         torch.distributed.barrier()
     # communicator teardown BEFORE the result line, and C stdio flushed around it: RCCL writes its version banner through C

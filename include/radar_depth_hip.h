@@ -129,12 +129,31 @@ int rd_gconv_bf16_trace_read(unsigned long long* host, int n_wg);
  * rd_gconv_split_supported: 1 when the library has a plan for d (>= 32 channels on both sides, Cin a multiple of 16, a tile whose
  * three-piece patch fits the LDS), else 0 -- callers keep rd_gconv for those.  Replaces the F.conv2d / conv_transpose2d call sites
  * of models.py:27,203-206 and their autograd input gradients, like rd_gconv. */
+/* Range: exact for every finite fp32 operand whose third piece is a normal bf16 number (|x| >= 2^-110; below that x2 falls into
+ * bf16's subnormals and the product keeps ~16 significant bits, far below any activation of these networks).  Non-finite inputs:
+ * x = +-inf gives x - bf16(x) = NaN, so an output that rd_gconv reports as +-inf is NaN here; NaN stays NaN.  Outputs that do not
+ * touch the non-finite element are unaffected (tests/test_gpu_gconv_split.py::test_split_dynamic_range_and_non_finite). */
 int rd_gconv_split_supported(const RdConvDesc* d);
+/* tests / sweeps: on != 0 makes the planner accept every shape the kernel can run (also those it leaves to rd_gconv because they
+ * measured slower); returns the previous setting.  Do not toggle between sizing buffers on a plan and launching it. */
+int rd_gconv_split_plan_all(int on);
 int rd_gconv_split(const RdConvDesc* d, const float* in, const void* w_split, int64_t piece_elems, float* out, const float* bias,
                    int32_t act, int32_t act_cols, const float* addend, int32_t ld_add, float* stat_partial, void* stream);
 int rd_gconv_split_stat_tiles(const RdConvDesc* d);
 /* diagnostics: out[0..7] = MT, NT, TH, TW, patch pixels, lds_bytes, workgroups, tap groups of the largest phase */
 int rd_gconv_split_plan_info(const RdConvDesc* d, int32_t* out);
+/* Pre-split activations: an fp32 NHWC tensor x[M][C] (row stride ldx) as three bf16 piece planes, each [C/16][M][16], piece_elems
+ * elements apart (x = p0 + p1 + p2 exactly).  rd_split_pieces is the stand-alone producer; in the training plan the BatchNorm /
+ * activation kernels write the planes from their epilogues (rd_bn_act_p, rd_bn_bwd_apply*_p, rd_bnact_maxpool_fwd_p), so the split
+ * arithmetic leaves the convolutions: rd_gconv_split_pre is rd_gconv_split with `in` replaced by such planes -- its staging waves
+ * issue nothing but global_load_lds copies.  Same result bit for bit as rd_gconv_split on the tensor the planes were made from when
+ * both run the same tile; the plan (hence rd_gconv_split_pre_stat_tiles) is its own. */
+int rd_split_pieces(const float* x, int32_t ldx, int64_t M, int32_t C, void* pieces, int64_t piece_elems, void* stream);
+int rd_gconv_split_pre_supported(const RdConvDesc* d);
+int rd_gconv_split_pre(const RdConvDesc* d, const void* in_pieces, int64_t in_piece_elems, const void* w_split, int64_t piece_elems, float* out,
+                       const float* bias, int32_t act, int32_t act_cols, const float* addend, int32_t ld_add, float* stat_partial, void* stream);
+int rd_gconv_split_pre_stat_tiles(const RdConvDesc* d);
+int rd_gconv_split_pre_plan_info(const RdConvDesc* d, int32_t* out);
 /* diagnostics: with RD_GCONV_SPLIT_TRACE=1 (an MFMA wave) / =2 (a staging wave) every workgroup records cycle-counter stamps around
  * the barrier of its first 30 tap groups (64 slots per workgroup); copies the last traced launch to the host (tools/trace_gconv_split.py) */
 int rd_gconv_split_trace_read(unsigned long long* host, int n_wg);
@@ -150,6 +169,11 @@ int rd_wgrad_split_reduce(const RdConvDesc* d, const float* slabs, float* grad_o
                           int32_t co_off, int32_t accumulate, void* stream);
 /* diagnostics: out[0..3] = splits, tiles per split, workgroups, pixel tiles */
 int rd_wgrad_split_plan_info(const RdConvDesc* d, int32_t* out);
+/* rd_wgrad_split with both operands already split by their producers (piece planes as for rd_gconv_split_pre): same plan, slabs and
+ * reduction (rd_wgrad_split_workspace_floats / rd_wgrad_split_reduce); channel counts multiples of 16. */
+int rd_wgrad_split_pre_supported(const RdConvDesc* d);
+int rd_wgrad_split_pre(const RdConvDesc* d, const void* x_pieces, int64_t x_piece_elems, const void* dy_pieces, int64_t dy_piece_elems,
+                       float* slabs, void* stream);
 /* diagnostics: out[0..9] = MT, NT, WM, WN, pipelined*10000+ksplit*100+CKW, CKP, TH, TW, lds_bytes, workgroups chosen for d
  * (workspace plan) */
 int rd_gconv_plan_info(const RdConvDesc* d, int32_t* out);

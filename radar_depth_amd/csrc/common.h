@@ -120,6 +120,31 @@ __device__ __forceinline__ float ld1(const bf16s* p) { return __uint_as_float((u
 __device__ __forceinline__ void st1(float* p, float v) { *p = v; }
 __device__ __forceinline__ void st1(bf16s* p, float v) { p->v = __builtin_bit_cast(unsigned short, (__bf16)v); }
 
+// ---- pre-split activations (gconv_split.hip / wgrad_split.hip, PRE forms): an fp32 NHWC tensor [M pixels][C] as three bf16 piece
+// planes, each [C/16][M][16]: x = p0 + p1 + p2 exactly (p0 = bf16(x), p1 = bf16(x - p0), p2 = bf16(x - p0 - p1), round to nearest
+// even).  store_pieces4 writes the four channels c..c+3 (c % 4 == 0) of pixel r: 8 bytes per plane.
+__device__ __forceinline__ unsigned cvt_pk_bf16(float a, float b) {
+    typedef float f32x2_ __attribute__((ext_vector_type(2)));
+    typedef __bf16 bf16x2_ __attribute__((ext_vector_type(2)));
+    f32x2_ v;
+    v[0] = a; v[1] = b;
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2_));
+}
+__device__ __forceinline__ void store_pieces4(unsigned short* pc, int64_t plane, int64_t M, int64_t r, int c, const float4 v) {
+    float a = v.x, b = v.y, e = v.z, f = v.w;
+    const unsigned u0 = cvt_pk_bf16(a, b), w0 = cvt_pk_bf16(e, f);
+    a -= __uint_as_float(u0 << 16); b -= __uint_as_float(u0 & 0xffff0000u);
+    e -= __uint_as_float(w0 << 16); f -= __uint_as_float(w0 & 0xffff0000u);
+    const unsigned u1 = cvt_pk_bf16(a, b), w1 = cvt_pk_bf16(e, f);
+    a -= __uint_as_float(u1 << 16); b -= __uint_as_float(u1 & 0xffff0000u);
+    e -= __uint_as_float(w1 << 16); f -= __uint_as_float(w1 & 0xffff0000u);
+    const unsigned u2 = cvt_pk_bf16(a, b), w2 = cvt_pk_bf16(e, f);
+    unsigned short* p = pc + ((int64_t)(c >> 4) * M + r) * 16 + (c & 15);
+    *reinterpret_cast<uint2*>(p) = make_uint2(u0, w0);
+    *reinterpret_cast<uint2*>(p + plane) = make_uint2(u1, w1);
+    *reinterpret_cast<uint2*>(p + 2 * plane) = make_uint2(u2, w2);
+}
+
 // quad exchanges (DPP quad_perm) and the in-register 4x4 transposition used by the epilogue: on entry lane q of a quad holds
 // (row j, column q) in a_j; on exit it holds (row q, column c) in a_c.
 __device__ __forceinline__ float dpp_xor1(float v) {

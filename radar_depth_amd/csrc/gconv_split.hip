@@ -63,7 +63,25 @@ struct GsArgs {
     int tapoff[RD_MAX_PHASES][RD_MAX_TAPS];   // byte offset of tap t inside a patch plane
     unsigned long long* trace;    // diagnostics (RD_GCONV_SPLIT_TRACE=1 compute wave 0, =2 staging wave 4): 64 stamps per workgroup
     int trace_role;
+    // PRE: the activation arrives already split (rd_split_pieces / the producers' epilogues): piece planes [piece][Cin/16][pixel][16] bf16
+    const unsigned short* inp;
+    long long xplane;             // bytes per piece plane of the pre-split activation
+    long long mpix;               // pixels per 16-channel block of a plane (= N * Hi * Wi)
+    int kplane;                   // PRE: bytes per 8-channel unit plane of the LDS patch ([piece][unit][pixel] x 16 B)
 };
+
+// wait until at most n of this wave's vector-memory operations (global_load_lds copies included) are outstanding, n known only at
+// run time (s_waitcnt takes an immediate); n beyond the table waits for a few more than necessary, which is always safe
+__device__ __forceinline__ void vm_wait_upto(int n) {
+#define RD_VMW(k) case k: asm volatile("s_waitcnt vmcnt(" #k ") lgkmcnt(0)" ::: "memory"); break;
+    switch (n < 47 ? n : 47) {
+        RD_VMW(0) RD_VMW(1) RD_VMW(2) RD_VMW(3) RD_VMW(4) RD_VMW(5) RD_VMW(6) RD_VMW(7) RD_VMW(8) RD_VMW(9) RD_VMW(10) RD_VMW(11)
+        RD_VMW(12) RD_VMW(13) RD_VMW(14) RD_VMW(15) RD_VMW(16) RD_VMW(17) RD_VMW(18) RD_VMW(19) RD_VMW(20) RD_VMW(21) RD_VMW(22) RD_VMW(23)
+        RD_VMW(24) RD_VMW(25) RD_VMW(26) RD_VMW(27) RD_VMW(28) RD_VMW(29) RD_VMW(30) RD_VMW(31) RD_VMW(32) RD_VMW(33) RD_VMW(34) RD_VMW(35)
+        RD_VMW(36) RD_VMW(37) RD_VMW(38) RD_VMW(39) RD_VMW(40) RD_VMW(41) RD_VMW(42) RD_VMW(43) RD_VMW(44) RD_VMW(45) RD_VMW(46) RD_VMW(47)
+    }
+#undef RD_VMW
+}
 
 // the three bf16 pieces of eight fp32 values (round to nearest even at every level; the remainders are exact), two values at a
 // time so that every conversion is one v_cvt_pk_bf16_f32 and the packed result IS the piece operand: 11 VALU instructions per pair
@@ -96,8 +114,13 @@ __device__ __forceinline__ void split8(const float4 v0, const float4 v1, sbf16x8
     p2 = __builtin_bit_cast(sbf16x8, w2);
 }
 
-template <int MT, int NT, bool PDB>
+// PRE: the input was split by its producer (piece planes in HBM): the staging waves issue nothing but global_load_lds copies -- patch
+// rows land as [piece][8-channel unit][patch pixel] x 16 B (lane-linear: consecutive pixels in consecutive 16-byte slots, which is
+// also what keeps the compute waves' ds_read_b128 passes conflict-free), out-of-image positions are zeroed once per workgroup and
+// never written again (their lanes are masked in every copy).
+template <int MT, int NT, bool PDB, bool PRE>
 __global__ __launch_bounds__(512) void gconv_split_kernel(const GsArgs a) {
+    static_assert(!PRE || PDB, "the pre-split form copies the next chunk's patch while the current one is read: two patch buffers");
     constexpr int BM = 4 * MT * 32;
     constexpr int BN = NT * 32;
     constexpr int LBN = NT == 2 ? 6 : 5;
@@ -149,6 +172,11 @@ __global__ __launch_bounds__(512) void gconv_split_kernel(const GsArgs a) {
         s_apix[m] = ok ? ((r * IS) * PW + c * IS) : 0;
     }
     if (tid < ntaps) s_widx[tid] = P.widx[tid];
+    if constexpr (PRE) {
+        // both patch buffers start as zeros: padding pixels (and rows) of the halo are never copied
+        const int n16 = (2 * 3 * pplane) >> 4;
+        for (int e = tid; e < n16; e += 512) *reinterpret_cast<uint4*>(s_patch + (size_t)e * 16) = make_uint4(0u, 0u, 0u, 0u);
+    }
     rd_sync();
 
     f32x16 acc[MT][NT];      // (zeroed in the compute branch only: live registers of the staging waves otherwise)
@@ -217,8 +245,38 @@ __global__ __launch_bounds__(512) void gconv_split_kernel(const GsArgs a) {
         // patch units of this thread in the steady state: wave lw copies the row segments lw, lw + 4, ...
         unsigned pgo[GS_UPP];     // byte offset of the unit inside the image at channel 0; GS_OOB: outside -> zeros
         int pdst[GS_UPP];         // LDS byte offset inside a patch plane, -1: no such unit
+        if constexpr (!PRE) {
 #pragma unroll
-        for (int u = 0; u < GS_UPP; ++u) unit_of(lw + 4 * u, pgo[u], pdst[u]);
+            for (int u = 0; u < GS_UPP; ++u) unit_of(lw + 4 * u, pgo[u], pdst[u]);
+        }
+        // PRE: copy the patch of 16-channel block `blk` into patch buffer pbuf: one global_load_lds per (patch row, 64-pixel segment,
+        // piece, 8-channel unit), rows lw, lw + 4, ... of this wave; returns the number of copies issued (the caller's counted wait)
+        auto issue_patch = [&](int pbuf, int blk) -> int {
+            int cnt = 0;
+            const char* src0 = reinterpret_cast<const char*>(a.inp) + ((size_t)blk * a.mpix + (size_t)n * D.Hi * D.Wi) * 32;
+            char* dst0 = s_patch + pbuf * 3 * pplane;
+            const int nsg = (PW + 63) >> 6;
+            for (int r = lw; r < PH; r += 4) {
+                const int ih = ih0 + r;
+                if (ih < 0 || ih >= D.Hi) continue;
+                for (int sg = 0; sg < nsg; ++sg) {
+                    const int col = (sg << 6) + lane, iw = iw0 + col;
+                    const bool ok = col < PW && iw >= 0 && iw < D.Wi;
+                    if (!__any(ok)) continue;
+                    const char* src = src0 + ((size_t)ih * D.Wi + iw) * 32;
+                    char* dst = dst0 + ((size_t)r * PW + (sg << 6)) * 16;
+                    if (ok) {
+#pragma unroll
+                        for (int p = 0; p < 3; ++p)
+#pragma unroll
+                            for (int u = 0; u < 2; ++u)
+                                glds16(reinterpret_cast<const float*>(src + p * a.xplane + u * 16), reinterpret_cast<float*>(dst + p * pplane + u * a.kplane));
+                    }
+                    cnt += 6;
+                }
+            }
+            return cnt;
+        };
         auto issue_slab = [&](int buf, int cb, int g) {
             const int tap0 = g * GS_TPS;
             constexpr int welems = (GS_TPS * 2) << LBN;  // 16-byte units of one piece: [tap][2][BN]
@@ -279,6 +337,30 @@ __global__ __launch_bounds__(512) void gconv_split_kernel(const GsArgs a) {
         constexpr std::integral_constant<int, GS_UPP> UN{};
         issue_slab(0, 0, 0);
         if (total_groups > 1) issue_slab(1, ngroups > 1 ? 0 : GS_CKP, ngroups > 1 ? 1 : 0);
+        if constexpr (PRE) {
+            // B1(it) publishes what was issued before B1(it - 1) ... except that every copy is awaited in the iteration it was issued in,
+            // bar one case: the next chunk's patch, issued behind the chunk's first barrier, stays in flight over the first group when
+            // the chunk has more than one (counted wait), so that HBM latency never holds a barrier back
+            issue_patch(0, 0);
+            glds_wait();
+            int it = 0, wi = 2, c2 = 0, g2 = 2;
+            while (g2 >= ngroups) { g2 -= ngroups; ++c2; }
+            unsigned long long* ltr = (a.trace && a.trace_role == 2 && tid == 256) ? a.trace + (size_t)blockIdx.x * 64 : nullptr;
+            for (int c = 0; c < nchunks; ++c) {
+                for (int g = 0; g < ngroups; ++g, ++it) {
+                    if (ltr && it < 30) ltr[2 * it] = __builtin_readcyclecounter();
+                    rd_sync();                        // B1(it)
+                    if (ltr && it < 30) ltr[2 * it + 1] = __builtin_readcyclecounter();
+                    if (it + 2 < total_groups) issue_slab(wi, c2 * GS_CKP, g2);
+                    wi = wi == 2 ? 0 : wi + 1;
+                    if (++g2 == ngroups) { g2 = 0; ++c2; }
+                    int np = 0;
+                    if (g == 0 && c + 1 < nchunks) np = issue_patch((c + 1) & 1, c + 1);
+                    if (g == 0 && ngroups > 1) vm_wait_upto(np);
+                    else glds_wait();
+                }
+            }
+        } else {
         stage_first_chunk();
         // the second chunk's patch is fetched behind the FIRST barrier when its split comes a group later (three or more tap groups:
         // issuing the loads here cost the prologue ~1.4 k clocks); else here, with a counted wait that leaves them in flight
@@ -325,9 +407,10 @@ __global__ __launch_bounds__(512) void gconv_split_kernel(const GsArgs a) {
                 else glds_wait();
             }
         }
+        }
     } else {
         // ------------------------------------------------------------------------------------------ compute waves
-        stage_first_chunk();
+        if constexpr (!PRE) stage_first_chunk();
         // (s_setprio(3) for these waves starves the staging waves' split arithmetic: 1880 -> 4760 clocks per chunk, the MFMA waves then
         //  wait for the patch: 2x2 tile 182 -> 195 us on layer1)
 #pragma unroll
@@ -338,7 +421,8 @@ __global__ __launch_bounds__(512) void gconv_split_kernel(const GsArgs a) {
                 for (int i = 0; i < 16; ++i) acc[mt][nt][i] = 0.f;
         int aoffB[MT];
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt) aoffB[mt] = s_apix[(wm * MT + mt) * 32 + l31] * GS_PSB + hh * 16;
+        for (int mt = 0; mt < MT; ++mt)
+            aoffB[mt] = PRE ? s_apix[(wm * MT + mt) * 32 + l31] * 16 + hh * a.kplane : s_apix[(wm * MT + mt) * 32 + l31] * GS_PSB + hh * 16;
         const int boffB = (hh * BN + l31) * 16;
         // tap offsets in the lanes of one VGPR, fetched with v_readlane (an s_load in the walk would force lgkmcnt(0) waits);
         // the padding taps of the last group read tap 0's pixels against zero weights
@@ -600,7 +684,7 @@ static int gs_patch_pixels(const RdConvDesc& d, const RdPhase& p, int TH, int TW
     return PH * PW;
 }
 
-static bool plan_gconv_split(const RdConvDesc& d, GsPlan& best) {
+static bool plan_gconv_split(const RdConvDesc& d, GsPlan& best, bool pre) {
     struct Cfg { int MT, NT; };
     static const Cfg cfgs[] = {{3, 2}, {2, 2}, {1, 2}, {2, 1}, {1, 1}};
     int taps_max = 0;
@@ -634,10 +718,12 @@ static bool plan_gconv_split(const RdConvDesc& d, GsPlan& best) {
                 const int sg = rows * cdiv(cols * 2, 64);
                 segs = segs > sg ? segs : sg;
             }
-            if (segs > 4 * GS_UPP) continue;                 // the next chunk's patch is one register batch of the staging waves
-            const int pplane = (((PP + 1) * GS_PSB) + 15) & ~15;
+            if (!pre && segs > 4 * GS_UPP) continue;         // the next chunk's patch is one register batch of the staging waves
+            if (pre && 6 * segs > 4 * 44) continue;          // pre-split: at most 44 copies per staging wave and chunk in flight (vm_wait_upto)
+            // pre-split: [unit][pixel] x 16 B per piece, no padding (consecutive pixels = consecutive 16-byte slots)
+            const int pplane = pre ? 2 * (((PP * 16) + 63) & ~63) : ((((PP + 1) * GS_PSB) + 15) & ~15);
             static const char* nopdb = getenv("RD_GCONV_SPLIT_NOPDB");       // diagnostics
-            for (int pdb = nopdb ? 0 : 1; pdb >= 0; --pdb) {
+            for (int pdb = (nopdb && !pre) ? 0 : 1; pdb >= (pre ? 1 : 0); --pdb) {
                 const size_t lds = (size_t)(2 * BM + 32) * 4 + (size_t)3 * 3 * GS_TPS * 2 * BN * 16 + (size_t)(pdb ? 2 : 1) * 3 * pplane + 64;
                 if (lds > 160 * 1024 - 512) continue;
                 // matrix-core bound, one workgroup per CU: rounds of workgroups x (clocks of one: three-step tap groups of
@@ -672,10 +758,10 @@ static bool plan_gconv_split(const RdConvDesc& d, GsPlan& best) {
     return best_cost > 0;
 }
 
-template <int MT, int NT, bool PDB>
+template <int MT, int NT, bool PDB, bool PRE>
 static int launch_gs(const GsArgs& a, int grid, size_t lds, hipStream_t s) {
     static bool attr_set = false;
-    auto k = gconv_split_kernel<MT, NT, PDB>;
+    auto k = gconv_split_kernel<MT, NT, PDB, PRE>;
     if (!attr_set) {
         RD_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr_set = true;
@@ -685,12 +771,21 @@ static int launch_gs(const GsArgs& a, int grid, size_t lds, hipStream_t s) {
     return RD_OK;
 }
 
+static std::mutex g_gs_mu;
+static int g_gs_all = -1;         // -1: not set yet (the environment decides at first use)
+static unsigned g_gs_epoch = 0;   // bumped by rd_gconv_split_plan_all: plans cached under another setting are dropped
+static bool gs_plan_all() {
+    std::lock_guard<std::mutex> lk(g_gs_mu);
+    if (g_gs_all < 0) g_gs_all = getenv("RD_GCONV_SPLIT_ALL") ? 1 : 0;
+    return g_gs_all == 1;
+}
+
 static bool gs_shape_ok(const RdConvDesc* d) {
     if (!d || d->n_phases < 1 || d->n_phases > RD_MAX_PHASES) return false;
     if (d->Cin % 16 != 0 || d->ldi % 4 != 0 || d->Cin < 32 || d->Cout < 32) return false;      // (the 16-channel layers stay on conv16.hip)
     if (d->in_stride < 1 || d->in_stride > 2 || d->out_stride < 1 || d->out_stride > 2) return false;
-    static const char* all = getenv("RD_GCONV_SPLIT_ALL");      // diagnostics: plan every shape the kernel can run
-    if (!all) {
+    // (rd_gconv_split_plan_all(1), tests: plan every shape the kernel can run; RD_GCONV_SPLIT_ALL=1 sets the initial value)
+    if (!gs_plan_all()) {
         // measured slower than (or level with) gconv.hip at the bench geometry (tools/bench_split.py, profiles/r03_bench_split.txt):
         //   * one-tap layers (0.4-0.8x: a chunk is 36 MFMAs, nothing to hide the staging behind);
         //   * fewer than 64 channels on a side (0.8-1.0x on the 32-channel decoder layers: the 32-wide output tile halves the reuse
@@ -715,20 +810,25 @@ static bool gs_shape_ok(const RdConvDesc* d) {
 }
 
 // 1: planned, 0: no plan (shape outside the kernel's domain or no tiling fits the LDS)
-static int gs_plan_query(const RdConvDesc* d, GsPlan& pl, RdConvDesc& dd) {
+static int gs_plan_query(const RdConvDesc* d, GsPlan& pl, RdConvDesc& dd, bool pre = false) {
     struct Entry { int ok; GsPlan pl; RdConvDesc dd; };
     static std::mutex mu;
     static std::unordered_map<std::string, Entry> cache;
+    static unsigned cache_epoch = 0;
     if (!d) return 0;
     std::string key(reinterpret_cast<const char*>(d), sizeof(RdConvDesc));
+    key.push_back(pre ? 'P' : 'R');
     {
+        unsigned ep;
+        { std::lock_guard<std::mutex> lk(g_gs_mu); ep = g_gs_epoch; }
         std::lock_guard<std::mutex> lk(mu);
+        if (ep != cache_epoch) { cache.clear(); cache_epoch = ep; }
         auto it = cache.find(key);
         if (it != cache.end()) { pl = it->second.pl; dd = it->second.dd; return it->second.ok; }
     }
     Entry e{};
     e.dd = *d;
-    e.ok = gs_shape_ok(d) && plan_gconv_split(e.dd, e.pl) ? 1 : 0;
+    e.ok = gs_shape_ok(d) && plan_gconv_split(e.dd, e.pl, pre) ? 1 : 0;
     if (e.ok) {
         int tb = 0;
         for (int i = 0; i < e.dd.n_phases; ++i) {
@@ -756,6 +856,17 @@ extern "C" int rd_gconv_split_trace_read(unsigned long long* host, int n_wg) {
     return RD_OK;
 }
 
+// tests / sweeps: on != 0 plans every shape the kernel can run, also those the library leaves to rd_gconv because they measured
+// slower there.  Returns the previous setting.  Plans cached under the other setting are dropped; callers that sized buffers on a
+// plan (statistics tiles) must not toggle this between the query and the launch.
+extern "C" int rd_gconv_split_plan_all(int on) {
+    gs_plan_all();
+    std::lock_guard<std::mutex> lk(g_gs_mu);
+    const int prev = g_gs_all;
+    if ((on != 0) != (prev == 1)) { g_gs_all = on ? 1 : 0; ++g_gs_epoch; }
+    return prev;
+}
+
 extern "C" int rd_gconv_split_supported(const RdConvDesc* d) {
     GsPlan pl; RdConvDesc dd;
     return gs_plan_query(d, pl, dd);
@@ -776,19 +887,26 @@ extern "C" int rd_gconv_split_stat_tiles(const RdConvDesc* d) {
     return d->N * pl.tiles_total;
 }
 
-extern "C" int rd_gconv_split(const RdConvDesc* d, const float* in, const void* w_split, int64_t piece_elems, float* out, const float* bias,
-                              int32_t act, int32_t act_cols, const float* addend, int32_t ld_add, float* stat_partial, void* stream) {
-    RD_CHECK_ARG(d && in && w_split && out, "gconv_split: null argument");
+static int gs_launch(const RdConvDesc* d, const float* in, const void* in_pieces, int64_t in_piece_elems, const void* w_split, int64_t piece_elems,
+                     float* out, const float* bias, int32_t act, int32_t act_cols, const float* addend, int32_t ld_add, float* stat_partial, void* stream) {
+    const bool pre = in_pieces != nullptr;
+    RD_CHECK_ARG(d && (in || in_pieces) && w_split && out, "gconv_split: null argument");
     GsArgs a;
     GsPlan pl;
-    if (gs_plan_query(d, pl, a.d) != 1) { set_error("gconv_split: descriptor not supported (rd_gconv_split_supported)"); return RD_EINVAL; }
-    RD_CHECK_ARG(reinterpret_cast<uintptr_t>(in) % 16 == 0 && reinterpret_cast<uintptr_t>(w_split) % 16 == 0, "gconv_split: unaligned tensor");
+    if (gs_plan_query(d, pl, a.d, pre) != 1) { set_error("gconv_split: descriptor not supported (rd_gconv_split_supported)"); return RD_EINVAL; }
+    RD_CHECK_ARG(reinterpret_cast<uintptr_t>(pre ? in_pieces : (const void*)in) % 16 == 0 && reinterpret_cast<uintptr_t>(w_split) % 16 == 0, "gconv_split: unaligned tensor");
     a.in = in; a.w = static_cast<const unsigned short*>(w_split); a.out = out;
     a.addend = addend; a.bias = bias; a.stat = stat_partial;
     a.act = act; a.act_cols = act_cols; a.ld_add = ld_add; a.ldw = d->Cout;
     a.TH = pl.TH; a.TW = pl.TW; a.PP = pl.PP;
     a.tiles_total = pl.tiles_total; a.n_cotiles = pl.n_cotiles; a.taps_max = pl.taps_max;
     a.pplane = pl.pplane;
+    a.inp = static_cast<const unsigned short*>(in_pieces);
+    a.mpix = (long long)d->N * d->Hi * d->Wi;
+    a.xplane = (long long)in_piece_elems * 2;
+    a.kplane = pl.pplane / 2;
+    if (pre) RD_CHECK_ARG(in_piece_elems >= (int64_t)(d->Cin / 16) * a.mpix * 16 && in_piece_elems % 8 == 0, "gconv_split: activation piece stride %lld too small for %d x %lld",
+                          (long long)in_piece_elems, d->Cin, a.mpix);
     int S = 0;
     for (int i = 0; i < d->n_phases; ++i)
         for (int t = 0; t < d->phase[i].n_taps; ++t) S = S > d->phase[i].widx[t] + 1 ? S : d->phase[i].widx[t] + 1;
@@ -801,7 +919,7 @@ extern "C" int rd_gconv_split(const RdConvDesc* d, const float* in, const void* 
     for (int i = 0; i < d->n_phases; ++i) {
         const RdPhase& p = d->phase[i];
         const int PW_ = (pl.TW - 1) * d->in_stride + (p.dw_max - p.dw_min) + 1;
-        for (int t = 0; t < p.n_taps; ++t) a.tapoff[i][t] = ((p.dh[t] - p.dh_min) * PW_ + (p.dw[t] - p.dw_min)) * GS_PSB;
+        for (int t = 0; t < p.n_taps; ++t) a.tapoff[i][t] = ((p.dh[t] - p.dh_min) * PW_ + (p.dw[t] - p.dw_min)) * (pre ? 16 : GS_PSB);
     }
     const int grid = d->N * pl.tiles_total * pl.n_cotiles;
     hipStream_t s = static_cast<hipStream_t>(stream);
@@ -815,10 +933,75 @@ extern "C" int rd_gconv_split(const RdConvDesc* d, const float* in, const void* 
             a.trace_role = atoi(tr);
         }
     }
-#define RD_GS(MT_, NT_) \
-    if (pl.MT == MT_ && pl.NT == NT_) return pl.pdb ? launch_gs<MT_, NT_, true>(a, grid, pl.lds_bytes, s) : launch_gs<MT_, NT_, false>(a, grid, pl.lds_bytes, s);
+#define RD_GS(MT_, NT_)                                                                                                         \
+    if (pl.MT == MT_ && pl.NT == NT_)                                                                                           \
+        return pre ? launch_gs<MT_, NT_, true, true>(a, grid, pl.lds_bytes, s)                                                  \
+                   : pl.pdb ? launch_gs<MT_, NT_, true, false>(a, grid, pl.lds_bytes, s) : launch_gs<MT_, NT_, false, false>(a, grid, pl.lds_bytes, s);
     RD_GS(3, 2) RD_GS(2, 2) RD_GS(1, 2) RD_GS(2, 1) RD_GS(1, 1)
 #undef RD_GS
     set_error("gconv_split: no kernel for tile %dx%d", pl.MT, pl.NT);
     return RD_EINVAL;
+}
+
+extern "C" int rd_gconv_split(const RdConvDesc* d, const float* in, const void* w_split, int64_t piece_elems, float* out, const float* bias,
+                              int32_t act, int32_t act_cols, const float* addend, int32_t ld_add, float* stat_partial, void* stream) {
+    RD_CHECK_ARG(in != nullptr, "gconv_split: null argument");
+    return gs_launch(d, in, nullptr, 0, w_split, piece_elems, out, bias, act, act_cols, addend, ld_add, stat_partial, stream);
+}
+
+// The same convolution with the activation ALREADY split by its producer (rd_split_pieces, or the piece outputs of rd_bn_act_p and
+// friends): in_pieces = three planes [piece][Cin/16][N*Hi*Wi][16] bf16, in_piece_elems elements apart.  The staging waves then do
+// nothing but global_load_lds copies.  The plan (tile, statistics tiles) differs from rd_gconv_split's: query with the _pre forms.
+extern "C" int rd_gconv_split_pre(const RdConvDesc* d, const void* in_pieces, int64_t in_piece_elems, const void* w_split, int64_t piece_elems, float* out,
+                                  const float* bias, int32_t act, int32_t act_cols, const float* addend, int32_t ld_add, float* stat_partial, void* stream) {
+    RD_CHECK_ARG(in_pieces != nullptr, "gconv_split_pre: null argument");
+    return gs_launch(d, nullptr, in_pieces, in_piece_elems, w_split, piece_elems, out, bias, act, act_cols, addend, ld_add, stat_partial, stream);
+}
+
+extern "C" int rd_gconv_split_pre_supported(const RdConvDesc* d) {
+    GsPlan pl; RdConvDesc dd;
+    return gs_plan_query(d, pl, dd, true);
+}
+
+extern "C" int rd_gconv_split_pre_stat_tiles(const RdConvDesc* d) {
+    GsPlan pl; RdConvDesc dd;
+    if (gs_plan_query(d, pl, dd, true) != 1) return RD_EINVAL;
+    return d->N * pl.tiles_total;
+}
+
+// diagnostics: rd_gconv_split_plan_info for the pre-split plan
+extern "C" int rd_gconv_split_pre_plan_info(const RdConvDesc* d, int32_t* out) {
+    GsPlan pl; RdConvDesc dd;
+    if (!out || gs_plan_query(d, pl, dd, true) != 1) return RD_EINVAL;
+    const int v[8] = {pl.MT, pl.NT, pl.TH, pl.TW, pl.PP, (int)pl.lds_bytes, d->N * pl.tiles_total * pl.n_cotiles, (pl.taps_max + GS_TPS - 1) / GS_TPS + 100 * pl.pdb};
+    for (int i = 0; i < 8; ++i) out[i] = v[i];
+    return RD_OK;
+}
+
+// ---- fp32 NHWC tensor -> three bf16 piece planes [piece][C/16][M][16] (x = p0 + p1 + p2 exactly); the stand-alone form of what the
+// BatchNorm / activation kernels emit from their epilogues (norm_act.hip)
+namespace rd {
+__global__ __launch_bounds__(256) void split_pieces_kernel(const float* __restrict__ x, int ldx, int64_t M, int C, unsigned short* __restrict__ pc, int64_t plane) {
+    const int Q = C >> 2;
+    const int lq = quad_log2(Q);
+    const int64_t total = M * Q;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+        int64_t r;
+        int c;
+        split_quad(e, Q, lq, r, c);
+        store_pieces4(pc, plane, M, r, c, ld4(x + r * ldx + c));
+    }
+}
+}  // namespace rd
+
+extern "C" int rd_split_pieces(const float* x, int32_t ldx, int64_t M, int32_t C, void* pieces, int64_t piece_elems, void* stream) {
+    RD_CHECK_ARG(x && pieces && M > 0 && C >= 16 && C % 16 == 0 && ldx % 4 == 0, "split_pieces: bad arguments (C must be a multiple of 16)");
+    RD_CHECK_ARG(piece_elems >= (int64_t)C * M && piece_elems % 8 == 0, "split_pieces: piece stride too small");
+    const int64_t total = M * (C / 4);
+    int64_t g = cdiv64(total, 256);
+    const int64_t cap = (int64_t)num_cus() * 8;
+    hipLaunchKernelGGL(split_pieces_kernel, dim3((unsigned)(g < cap ? g : cap)), dim3(256), 0, static_cast<hipStream_t>(stream), x, ldx, M, C,
+                       static_cast<unsigned short*>(pieces), piece_elems);
+    RD_CHECK_LAUNCH("split_pieces_kernel");
+    return RD_OK;
 }

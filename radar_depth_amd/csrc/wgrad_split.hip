@@ -57,6 +57,17 @@ struct WsGeo {
     static constexpr int UNITS = XUNITS_PAD + YPIX * 8;
     static constexpr int UPT = (UNITS + 255) / 256;              // units per staging thread
     static_assert(YPIX == 64 && TW % 16 == 0, "a tile is 64 pixels in 16-pixel reduction steps");
+    // PRE (operands split by their producers, staged by global_load_lds): [piece][16-channel block (4)][pixel][16 channels], 32 bytes
+    // per pixel; a block plane is = 128 mod 256 bytes so that the two halves of a transposing read pass (channels 0-15 / 16-31 of a
+    // 32-channel tile = two neighbouring block planes) fall into different halves of the 64 banks
+    static constexpr int XP16 = ((XPIX * 32 + 127) / 256) * 256 + 128;
+    static constexpr int YP16 = ((YPIX * 32 + 127) / 256) * 256 + 128;
+    static constexpr int XBYTES_P = 3 * 4 * XP16;
+    static constexpr int YBYTES_P = 3 * 4 * YP16;
+    static constexpr int BUF_P = XBYTES_P + YBYTES_P;
+    static constexpr int XSEG = (XW + 31) / 32, YSEG = (TW + 31) / 32;      // 64-lane copies (32 pixels x two 16-byte halves) per row
+    static constexpr int XU_P = 3 * 4 * XH * XSEG;               // copies per tile: (piece, block, patch row, segment)
+    static constexpr int YU_P = 3 * 4 * R * YSEG;
 };
 typedef WsGeo<2, 32> WsWide;      // 2 x 32: 76800 bytes per buffer, 7 units per thread
 typedef WsGeo<4, 16> WsTall;      // 4 x 16: less halo (1.69 vs 2.1 patch pixels per output pixel), fits 100- and 200-column grids better
@@ -72,6 +83,11 @@ struct WsArgs {
     int lh, lw;                 // logical grid (= the x grid for these descriptors)
     int S;                      // weight slabs per split
     int widx[9];                // slab of tap (i, j) = widx[i * TC + j]
+    // PRE: piece planes [piece][C/16][pixels][16] bf16 of x and dy (rd_split_pieces / the producers' epilogues)
+    const unsigned short* xp;
+    const unsigned short* yp;
+    long long xplane, yplane;   // bytes per piece plane
+    long long xm, ym;           // pixels per 16-channel block of a plane (N*Hi*Wi, N*Ho*Wo)
 };
 
 __device__ __forceinline__ unsigned ws_cvt_pk(float a, float b) {
@@ -98,10 +114,11 @@ __device__ __forceinline__ void ws_split8(const float4 v0, const float4 v1, wsu3
 }
 
 // eight consecutive pixels of one channel: two transposing reads of four pixels each
+template <int PITCH = 64>
 __device__ __forceinline__ wsbf16x8 ws_frag(unsigned base, int off) {
     typedef __attribute__((address_space(3))) wss16x4* lp;
     const wss16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(reinterpret_cast<lp>(base + off));
-    const wss16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(reinterpret_cast<lp>(base + off + 4 * 64));
+    const wss16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(reinterpret_cast<lp>(base + off + 4 * PITCH));
     typedef short s16x8 __attribute__((ext_vector_type(8)));
     s16x8 r;
     r[0] = lo[0]; r[1] = lo[1]; r[2] = lo[2]; r[3] = lo[3];
@@ -109,9 +126,11 @@ __device__ __forceinline__ wsbf16x8 ws_frag(unsigned base, int off) {
     return __builtin_bit_cast(wsbf16x8, r);
 }
 
-template <int TR, int TC, typename G>
+template <int TR, int TC, typename G, bool PRE>
 __global__ __launch_bounds__(512) void wgrad_split_kernel(const WsArgs a) {
     constexpr int NT = TR * TC;
+    constexpr int BUFB = PRE ? G::BUF_P : G::BUF;          // bytes per LDS buffer
+    constexpr int PIT = PRE ? 32 : 64;                     // bytes per pixel of an LDS plane
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -128,7 +147,56 @@ __global__ __launch_bounds__(512) void wgrad_split_kernel(const WsArgs a) {
 
     f32x16 acc[NT];      // (zeroed in the compute branch only: live registers of the staging waves otherwise)
 
-    if (loader) {
+    if (loader && PRE) {
+        // ------------------------------------------------------------------------------------------ staging waves, pre-split operands:
+        // one global_load_lds per (piece, 16-channel block, patch row): lane l = (pixel l >> 1, 16-byte half l & 1) of the row, which is
+        // both contiguous in the plane and lane-linear in the LDS image; lanes outside the image / the logical grid / the channel
+        // range store zeros instead (the buffers are reused from tile to tile, every slot is written for every tile)
+        const int lw = wave - 4;
+        const char* xsrc = reinterpret_cast<const char*>(a.xp);
+        const char* ysrc = reinterpret_cast<const char*>(a.yp);
+        const int pxl = lane >> 1, hf = lane & 1;
+        auto stage = [&](int tile, int buf) {
+            const int n = tile / (a.tiles_h * a.tiles_w), tr = tile - n * (a.tiles_h * a.tiles_w);
+            const int r0 = (tr / a.tiles_w) * G::R, c0 = (tr % a.tiles_w) * G::TW;
+            const unsigned base = lds0 + buf * BUFB;
+            for (int u = lw; u < G::XU_P + G::YU_P; u += 4) {
+                if (u < G::XU_P) {
+                    const int sg = u % G::XSEG, u1 = u / G::XSEG;
+                    const int row = u1 % G::XH, t = u1 / G::XH, blk = t & 3, p = t >> 2;
+                    const int px = sg * 32 + pxl;
+                    const int ih = r0 + a.dh0 + row, iw = c0 + a.dw0 + px, ch = cib0 + blk * 16;
+                    const bool rok = ih >= 0 && ih < a.Hi && ch < a.Cin;                    // wave-uniform
+                    const bool ok = rok && px < G::XW && iw >= 0 && iw < a.Wi;
+                    const unsigned dst = base + (p * 4 + blk) * G::XP16 + (row * G::XW + sg * 32) * 32;   // wave base: lane l lands at + 16 l
+                    if (ok) glds16(reinterpret_cast<const float*>(xsrc + p * a.xplane + (((size_t)(ch >> 4) * a.xm + ((size_t)n * a.Hi + ih) * a.Wi + iw) * 32 + hf * 16)),
+                                   reinterpret_cast<float*>((size_t)dst));
+                    else if (px < G::XW) asm volatile("ds_write_b128 %0, %1" ::"v"(dst + lane * 16), "v"(wsu32x4{0u, 0u, 0u, 0u}) : "memory");
+                } else {
+                    const int v = u - G::XU_P;
+                    const int sg = v % G::YSEG, v1 = v / G::YSEG;
+                    const int row = v1 % G::R, t = v1 / G::R, blk = t & 3, p = t >> 2;
+                    const int px = sg * 32 + pxl;
+                    const int lr = r0 + row, lc = c0 + px, ch = cob0 + blk * 16;
+                    const int oh = a.OS * lr + a.off_h, ow = a.OS * lc + a.off_w;
+                    const bool ok = lr < a.lh && ch < a.Cout && px < G::TW && lc < a.lw;
+                    const unsigned dst = base + G::XBYTES_P + (p * 4 + blk) * G::YP16 + (row * G::TW + sg * 32) * 32;
+                    if (ok) glds16(reinterpret_cast<const float*>(ysrc + p * a.yplane + (((size_t)(ch >> 4) * a.ym + ((size_t)n * a.Ho + oh) * a.Wo + ow) * 32 + hf * 16)),
+                                   reinterpret_cast<float*>((size_t)dst));
+                    else if (px < G::TW) asm volatile("ds_write_b128 %0, %1" ::"v"(dst + lane * 16), "v"(wsu32x4{0u, 0u, 0u, 0u}) : "memory");
+                }
+            }
+        };
+        // tile i lives in buffer i & 1; iteration i: barrier B(i) (tile i published, buffer (i + 1) & 1 free), copy tile i + 1, wait for it
+        if (ntiles > 0) stage(tile_begin, 0);
+        glds_wait();
+        for (int i = 0; i < ntiles; ++i) {
+            rd_sync();                            // B(i)
+            if (i + 1 < ntiles) stage(tile_begin + i + 1, (i + 1) & 1);
+            glds_wait();
+        }
+        rd_sync();                                // matches the compute waves' final barrier
+    } else if (loader) {
         // ------------------------------------------------------------------------------------------ staging waves
         const int ltid = tid - 256;
         // this thread's units: e = ltid + 256 u; e < 1088: x patch unit (tile t, pixel, quad q), else dy unit.  1088 = 17 * 64, so a
@@ -181,7 +249,7 @@ __global__ __launch_bounds__(512) void wgrad_split_kernel(const WsArgs a) {
             }
         };
         auto split_put = [&](int buf) {
-            const unsigned base = lds0 + buf * G::BUF;
+            const unsigned base = lds0 + buf * BUFB;
 #pragma unroll
             for (int u = 0; u < G::UPT; ++u) {
                 wsu32x4 w0, w1, w2;
@@ -223,12 +291,15 @@ __global__ __launch_bounds__(512) void wgrad_split_kernel(const WsArgs a) {
         const int ti = wave >> 1, to = wave & 1;          // 32-channel tile of the block on the ci / co side
         // lane part of every fragment address: pixel row (lane & 15) / 4 of the group's four, 8-byte chunk lane & 3, second 16
         // channels for lanes 16..31 of each half, pixels 8.. for the upper half wave
-        const unsigned lpart = (unsigned)((((lane & 15) >> 2) + (lane >> 5) * 8) * 64 + ((lane >> 4) & 1) * 32 + (lane & 3) * 8);
-        const unsigned xb = lds0 + ti * G::XPLANE + lpart;
-        const unsigned yb = lds0 + G::XBYTES + to * G::YPLANE + lpart;
+        // (PRE: 32 bytes per pixel, the second 16 channels live in the next 16-channel block plane)
+        const unsigned lrow = (unsigned)(((lane & 15) >> 2) + (lane >> 5) * 8) * PIT + (lane & 3) * 8;
+        const unsigned xb = PRE ? lds0 + (2 * ti + ((lane >> 4) & 1)) * G::XP16 + lrow : lds0 + ti * G::XPLANE + lrow + ((lane >> 4) & 1) * 32;
+        const unsigned yb = PRE ? lds0 + G::XBYTES_P + (2 * to + ((lane >> 4) & 1)) * G::YP16 + lrow : lds0 + G::XBYTES + to * G::YPLANE + lrow + ((lane >> 4) & 1) * 32;
+        constexpr int XPS = PRE ? 4 * G::XP16 : 2 * G::XPLANE;      // bytes between pieces
+        constexpr int YPS = PRE ? 4 * G::YP16 : 2 * G::YPLANE;
         for (int i = 0; i < ntiles; ++i) {
             rd_sync();                            // B(i)
-            const unsigned xa = xb + (i & 1) * G::BUF, ya = yb + (i & 1) * G::BUF;
+            const unsigned xa = xb + (i & 1) * BUFB, ya = yb + (i & 1) * BUFB;
             // 4 NT steps per tile = (row, 16-pixel reduction step, tap); the fragments of step s + 1 are read in front of the MFMAs of
             // step s and the order is pinned (left alone the compiler hoists a whole reduction step's reads and spills them)
             constexpr int NSTEP = G::R * (G::TW / 16) * NT;
@@ -236,12 +307,12 @@ __global__ __launch_bounds__(512) void wgrad_split_kernel(const WsArgs a) {
             auto loadA = [&](int s_, wsbf16x8 (&F)[3]) {
                 const int rk = s_ / NT, t = s_ % NT, r = rk / (G::TW / 16), ks = rk % (G::TW / 16);
 #pragma unroll
-                for (int p = 0; p < 3; ++p) F[p] = ws_frag(xa, p * 2 * G::XPLANE + ((r + t / TC) * G::XW + ks * 16 + t % TC) * 64);
+                for (int p = 0; p < 3; ++p) F[p] = ws_frag<PIT>(xa, p * XPS + ((r + t / TC) * G::XW + ks * 16 + t % TC) * PIT);
             };
             auto loadB = [&](int rk, wsbf16x8 (&F)[3]) {
                 const int r = rk / (G::TW / 16), ks = rk % (G::TW / 16);
 #pragma unroll
-                for (int p = 0; p < 3; ++p) F[p] = ws_frag(ya, p * 2 * G::YPLANE + (r * G::TW + ks * 16) * 64);
+                for (int p = 0; p < 3; ++p) F[p] = ws_frag<PIT>(ya, p * YPS + (r * G::TW + ks * 16) * PIT);
             };
             loadB(0, B[0]);
             loadA(0, A[0]);
@@ -348,15 +419,15 @@ static WsPlan ws_plan(const RdConvDesc& d) {
     return pl;
 }
 
-template <int TR, int TC, typename G>
+template <int TR, int TC, typename G, bool PRE>
 static int launch_ws(const WsArgs& a, int grid, hipStream_t s) {
     static bool attr_set = false;
-    auto k = wgrad_split_kernel<TR, TC, G>;
+    auto k = wgrad_split_kernel<TR, TC, G, PRE>;
     if (!attr_set) {
         RD_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr_set = true;
     }
-    hipLaunchKernelGGL(k, dim3(grid), dim3(512), 2 * G::BUF, s, a);
+    hipLaunchKernelGGL(k, dim3(grid), dim3(512), 2 * (PRE ? G::BUF_P : G::BUF), s, a);
     RD_CHECK_LAUNCH("wgrad_split_kernel");
     return RD_OK;
 }
@@ -383,19 +454,9 @@ extern "C" int rd_wgrad_split_plan_info(const RdConvDesc* d, int32_t* out) {
     return RD_OK;
 }
 
-extern "C" int rd_wgrad_split(const RdConvDesc* d, const float* in, const float* dout, float* slabs, void* stream) {
-    RD_CHECK_ARG(d && in && dout && slabs, "wgrad_split: null argument");
-    const WsPlan pl = ws_plan(*d);
-    if (!pl.ok) { set_error("wgrad_split: descriptor not supported (rd_wgrad_split_supported)"); return RD_EINVAL; }
-    RD_CHECK_ARG(reinterpret_cast<uintptr_t>(in) % 16 == 0 && reinterpret_cast<uintptr_t>(dout) % 16 == 0, "wgrad_split: unaligned tensor");
-    WsArgs a;
-    a.x = in; a.dy = dout; a.slabs = slabs;
-    a.N = d->N; a.Hi = d->Hi; a.Wi = d->Wi; a.Cin = d->Cin; a.ldi = d->ldi; a.Ho = d->Ho; a.Wo = d->Wo; a.Cout = d->Cout; a.ldo = d->ldo;
-    a.tiles_h = pl.tiles_h; a.tiles_w = pl.tiles_w; a.total_tiles = pl.total_tiles; a.tiles_per_split = pl.tiles_per_split;
-    a.n_splits = pl.n_splits; a.n_cib = pl.n_cib; a.n_cob = pl.n_cob;
-    a.OS = d->out_stride; a.S = pl.S;
+template <bool PRE>
+static int ws_launch_all(const RdConvDesc* d, WsArgs& a, const WsPlan& pl, hipStream_t s) {
     const int grid = pl.n_splits * pl.n_cib * pl.n_cob;
-    hipStream_t s = static_cast<hipStream_t>(stream);
     // one launch per phase (the 3x3 convolution has one); the phases write disjoint slabs of the same splits
     for (int i = 0; i < d->n_phases; ++i) {
         const RdPhase& p = d->phase[i];
@@ -405,19 +466,60 @@ extern "C" int rd_wgrad_split(const RdConvDesc* d, const float* in, const float*
         for (int t = 0; t < 9; ++t) a.widx[t] = t < p.n_taps ? p.widx[t] : 0;
         int rc;
         if (pl.tall) {
-            if (tr == 3 && tc == 3) rc = launch_ws<3, 3, WsTall>(a, grid, s);
-            else if (tr == 2 && tc == 3) rc = launch_ws<2, 3, WsTall>(a, grid, s);
-            else if (tr == 3 && tc == 2) rc = launch_ws<3, 2, WsTall>(a, grid, s);
-            else rc = launch_ws<2, 2, WsTall>(a, grid, s);
+            if (tr == 3 && tc == 3) rc = launch_ws<3, 3, WsTall, PRE>(a, grid, s);
+            else if (tr == 2 && tc == 3) rc = launch_ws<2, 3, WsTall, PRE>(a, grid, s);
+            else if (tr == 3 && tc == 2) rc = launch_ws<3, 2, WsTall, PRE>(a, grid, s);
+            else rc = launch_ws<2, 2, WsTall, PRE>(a, grid, s);
         } else {
-            if (tr == 3 && tc == 3) rc = launch_ws<3, 3, WsWide>(a, grid, s);
-            else if (tr == 2 && tc == 3) rc = launch_ws<2, 3, WsWide>(a, grid, s);
-            else if (tr == 3 && tc == 2) rc = launch_ws<3, 2, WsWide>(a, grid, s);
-            else rc = launch_ws<2, 2, WsWide>(a, grid, s);
+            if (tr == 3 && tc == 3) rc = launch_ws<3, 3, WsWide, PRE>(a, grid, s);
+            else if (tr == 2 && tc == 3) rc = launch_ws<2, 3, WsWide, PRE>(a, grid, s);
+            else if (tr == 3 && tc == 2) rc = launch_ws<3, 2, WsWide, PRE>(a, grid, s);
+            else rc = launch_ws<2, 2, WsWide, PRE>(a, grid, s);
         }
         if (rc != RD_OK) return rc;
     }
     return RD_OK;
+}
+
+static void ws_fill_args(const RdConvDesc* d, const WsPlan& pl, WsArgs& a) {
+    a.N = d->N; a.Hi = d->Hi; a.Wi = d->Wi; a.Cin = d->Cin; a.ldi = d->ldi; a.Ho = d->Ho; a.Wo = d->Wo; a.Cout = d->Cout; a.ldo = d->ldo;
+    a.tiles_h = pl.tiles_h; a.tiles_w = pl.tiles_w; a.total_tiles = pl.total_tiles; a.tiles_per_split = pl.tiles_per_split;
+    a.n_splits = pl.n_splits; a.n_cib = pl.n_cib; a.n_cob = pl.n_cob;
+    a.OS = d->out_stride; a.S = pl.S;
+    a.x = nullptr; a.dy = nullptr; a.xp = nullptr; a.yp = nullptr; a.xplane = a.yplane = 0;
+    a.xm = (long long)d->N * d->Hi * d->Wi; a.ym = (long long)d->N * d->Ho * d->Wo;
+}
+
+extern "C" int rd_wgrad_split(const RdConvDesc* d, const float* in, const float* dout, float* slabs, void* stream) {
+    RD_CHECK_ARG(d && in && dout && slabs, "wgrad_split: null argument");
+    const WsPlan pl = ws_plan(*d);
+    if (!pl.ok) { set_error("wgrad_split: descriptor not supported (rd_wgrad_split_supported)"); return RD_EINVAL; }
+    RD_CHECK_ARG(reinterpret_cast<uintptr_t>(in) % 16 == 0 && reinterpret_cast<uintptr_t>(dout) % 16 == 0, "wgrad_split: unaligned tensor");
+    WsArgs a;
+    ws_fill_args(d, pl, a);
+    a.x = in; a.dy = dout; a.slabs = slabs;
+    return ws_launch_all<false>(d, a, pl, static_cast<hipStream_t>(stream));
+}
+
+// Both operands already split by their producers (piece planes [piece][C/16][pixels][16] bf16, rd_split_pieces): the staging waves
+// issue nothing but global_load_lds copies.  Same slabs, same plan, same reduction as rd_wgrad_split; the channel counts must be
+// multiples of 16 (rd_wgrad_split_pre_supported).
+extern "C" int rd_wgrad_split_pre_supported(const RdConvDesc* d) { return d && ws_shape_ok(*d) && d->Cin % 16 == 0 && d->Cout % 16 == 0 ? 1 : 0; }
+
+extern "C" int rd_wgrad_split_pre(const RdConvDesc* d, const void* x_pieces, int64_t x_piece_elems, const void* dy_pieces, int64_t dy_piece_elems,
+                                  float* slabs, void* stream) {
+    RD_CHECK_ARG(d && x_pieces && dy_pieces && slabs, "wgrad_split_pre: null argument");
+    const WsPlan pl = ws_plan(*d);
+    if (!pl.ok || d->Cin % 16 || d->Cout % 16) { set_error("wgrad_split_pre: descriptor not supported (rd_wgrad_split_pre_supported)"); return RD_EINVAL; }
+    RD_CHECK_ARG(reinterpret_cast<uintptr_t>(x_pieces) % 16 == 0 && reinterpret_cast<uintptr_t>(dy_pieces) % 16 == 0, "wgrad_split_pre: unaligned tensor");
+    WsArgs a;
+    ws_fill_args(d, pl, a);
+    RD_CHECK_ARG(x_piece_elems >= (int64_t)d->Cin * a.xm && dy_piece_elems >= (int64_t)d->Cout * a.ym && x_piece_elems % 8 == 0 && dy_piece_elems % 8 == 0,
+                 "wgrad_split_pre: piece stride too small");
+    a.xp = static_cast<const unsigned short*>(x_pieces); a.yp = static_cast<const unsigned short*>(dy_pieces);
+    a.xplane = (long long)x_piece_elems * 2; a.yplane = (long long)dy_piece_elems * 2;
+    a.slabs = slabs;
+    return ws_launch_all<true>(d, a, pl, static_cast<hipStream_t>(stream));
 }
 
 extern "C" int rd_wgrad_split_reduce(const RdConvDesc* d, const float* slabs, float* grad_oihw, int32_t O, int32_t I, int32_t KH, int32_t KW,

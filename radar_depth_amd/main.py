@@ -117,7 +117,10 @@ class HipTrainStep:
     slower than the plain stream launches (661 vs 679 samples/s for latefusion b=16, 272 vs 288 for multistage b=8, and the
     data-parallel path loses 2.5 % as five graphs but nothing as plain launches).
 
-    operands: "fp32" (default, the parity path) or "bf16": forward, input-gradient and stride-1 3x3 weight-gradient convolutions
+    operands: None (default) = "split" for fp32 storage -- fp32 arithmetic on the bf16 matrix cores wherever the library has a plan
+    for it, pinned against the CPU oracle at BASELINE.json's own batch sizes (tests/test_gpu_configs.py, both operand modes at the
+    same bars); "fp32" = every convolution on the fp32 MFMA (v_mfma_f32_32x32x2_f32; the plan the eager autograd forward uses);
+    "bf16": forward, input-gradient and stride-1 3x3 weight-gradient convolutions
     with bf16 operands on the bf16 matrix cores (csrc/gconv_bf16.hip, csrc/wgrad_bf16.hip; fp32 tensors, fp32 accumulation, fp32
     BatchNorm / loss / SGD and the remaining weight gradients) -- the
     torch.autocast(bfloat16) analogue for BASELINE.json configs 2/4; tolerances in tests/test_gpu_bf16.py.
@@ -127,7 +130,7 @@ class HipTrainStep:
     fp32 tolerances unchanged; everything else is the fp32 path."""
 
     def __init__(self, model, batch, height, width, lr=0.01, momentum=0.9, weight_decay=1e-4, loss_weights=None, use_graph=False,
-                 operands="fp32", criterion="l1", comm="auto", storage="fp32", autotune=None):
+                 operands=None, criterion="l1", comm="auto", storage="fp32", autotune=None):
         """criterion: "l1" (MaskedL1Loss, the default of utils.parse_command) or "l2" (MaskedMSELoss, `-c l2`, main.py:294-305).
         comm: "rccl" = the C ABI's own communicator (radar_depth_amd.comm, rd_allreduce_bucket on a dedicated communication
         stream, event-chained behind each backward segment); "torch" = torch.distributed.all_reduce (the cross-check);
@@ -137,6 +140,8 @@ class HipTrainStep:
         # storage="bf16": NHWC activations and their gradients live in HBM as bf16 (implies bf16 conv operands); BatchNorm
         # statistics, losses, parameters, their gradients and the optimizer stay fp32 -- BASELINE.json configs 3 / 5
         assert storage in ("fp32", "bf16"), storage
+        if operands is None:
+            operands = "split"
         assert operands in ("fp32", "bf16", "split"), operands
         if storage == "bf16":
             operands = "bf16"

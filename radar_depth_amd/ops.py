@@ -77,6 +77,37 @@ def gconv_split(desc, x, w_split, out, bias=None, act=0, act_cols=0, addend=None
     return out
 
 
+def split_pieces(x_nhwc):
+    """fp32 NHWC tensor -> three bf16 piece planes [3][C/16][M][16] (rd_split_pieces; x = p0 + p1 + p2 exactly)."""
+    import torch
+    n, h, w, c = x_nhwc.shape
+    m = n * h * w
+    pc = torch.empty(3, c // 16, m, 16, dtype=torch.bfloat16, device=x_nhwc.device)
+    check(lib().rd_split_pieces(ptr(_f32(x_nhwc)), c, C.c_int64(m), c, ptr(pc), C.c_int64(pc[0].numel()), current_stream()), "rd_split_pieces")
+    return pc
+
+
+def gconv_split_pre_supported(desc):
+    return lib().rd_gconv_split_pre_supported(C.byref(desc)) == 1
+
+
+def gconv_split_pre(desc, x_pieces, w_split, out, bias=None, act=0, act_cols=0, addend=None, ld_add=0, stat=None):
+    """rd_gconv_split with the activation already split by its producer (ops.split_pieces)."""
+    import torch
+    _poison()
+    assert x_pieces.dtype == torch.bfloat16 and x_pieces.shape[0] == 3 and w_split.dtype == torch.bfloat16 and w_split.shape[0] == 3
+    check(lib().rd_gconv_split_pre(C.byref(desc), ptr(x_pieces), C.c_int64(x_pieces[0].numel()), ptr(w_split), C.c_int64(w_split[0].numel()),
+                                   ptr(_f32(out)), ptr(bias), act, act_cols, ptr(addend), ld_add, ptr(stat), current_stream()), "rd_gconv_split_pre")
+    return out
+
+
+def gconv_split_pre_stat_tiles(desc):
+    n = lib().rd_gconv_split_pre_stat_tiles(C.byref(desc))
+    if n < 0:
+        check(n, "rd_gconv_split_pre_stat_tiles")
+    return n
+
+
 def gconv_split_stat_tiles(desc):
     n = lib().rd_gconv_split_stat_tiles(C.byref(desc))
     if n < 0:
@@ -225,6 +256,17 @@ def wgrad_split(desc, x, dout, slabs):
     """fp32 weight gradient rebuilt from six bf16 MFMAs per product (three-piece operands): rd_wgrad_split."""
     _poison()
     check(lib().rd_wgrad_split(C.byref(desc), ptr(_f32(x)), ptr(_f32(dout)), ptr(slabs), current_stream()), "rd_wgrad_split")
+
+
+def wgrad_split_pre_supported(desc):
+    return lib().rd_wgrad_split_pre_supported(C.byref(desc)) == 1
+
+
+def wgrad_split_pre(desc, x_pieces, dy_pieces, slabs):
+    """rd_wgrad_split with both operands already split by their producers (ops.split_pieces)."""
+    _poison()
+    check(lib().rd_wgrad_split_pre(C.byref(desc), ptr(x_pieces), C.c_int64(x_pieces[0].numel()), ptr(dy_pieces), C.c_int64(dy_pieces[0].numel()),
+                                   ptr(slabs), current_stream()), "rd_wgrad_split_pre")
 
 
 def wgrad_split_reduce(desc, slabs, grad, co_off=0, accumulate=False):

@@ -8,9 +8,16 @@ import torch
 import torch.nn.functional as F
 
 pytestmark = pytest.mark.gpu
-# plan every shape the kernel can run, also those the library leaves to rd_gconv because they measured slower there (read once,
-# at the library's first split plan: set at collection time)
-os.environ["RD_GCONV_SPLIT_ALL"] = "1"
+
+
+@pytest.fixture(autouse=True)
+def _plan_every_shape():
+    """Plan every shape the kernel can run, also those the library leaves to rd_gconv because they measured slower there -- for the
+    tests of THIS file only (rd_gconv_split_plan_all is a per-process switch of the library, restored behind every test)."""
+    from radar_depth_amd._lib import lib
+    prev = lib().rd_gconv_split_plan_all(1)
+    yield
+    lib().rd_gconv_split_plan_all(1 if prev == 1 else 0)
 
 
 def _rel(a, b):
@@ -319,3 +326,202 @@ def test_split_forward_at_the_bench_geometry():
         torch.cuda.empty_cache()
     assert abs(res[0][0] - res[1][0]) / abs(res[0][0]) < 1e-5
     assert _rel(res[1][1], res[0][1]) < 1e-4
+
+
+@pytest.mark.parametrize("ex,ew", [(60, -60), (-60, 60), (-30, -30), (40, 0), (-100, 100)])
+def test_split_dynamic_range(ex, ew):
+    """Operands scaled by 2^+-60 (and the activation down to 2^-100: its third piece 2^-16 |x| is still a normal bf16 number): the
+    split convolution against an fp64 convolution of the same fp32 operands, at the kernel's own 2e-5 bar, side by side with rd_gconv."""
+    from radar_depth_amd import convdesc as cd, ops
+    n, ci, co, h, w = 2, 128, 128, 29, 50
+    g = torch.Generator().manual_seed(11)
+    x = torch.randn(n, ci, h, w, generator=g) * 2.0 ** ex
+    wt = torch.randn(co, ci, 3, 3, generator=g) * (2.0 / (9 * ci)) ** 0.5 * 2.0 ** ew
+    y64 = F.conv2d(x.double(), wt.double(), padding=1)
+    assert torch.isfinite(y64.float()).all()
+    d = cd.conv_fwd(n, h, w, ci, co, 3, 1, 1)
+    xg = ops.nchw_to_nhwc(x.cuda())
+    osp = torch.empty(n, h, w, co, device="cuda")
+    o32 = torch.empty(n, h, w, co, device="cuda")
+    ops.gconv_split(d, xg, ops.pack_weights_split(wt.cuda()), osp)
+    ops.gconv(d, xg, ops.pack_weights(wt.cuda()), o32)
+    torch.cuda.synchronize()
+    esp = _rel(osp.permute(0, 3, 1, 2).cpu().double(), y64)
+    e32 = _rel(o32.permute(0, 3, 1, 2).cpu().double(), y64)
+    print("scale 2^%d x 2^%d: split %.3e, fp32 MFMA %.3e" % (ex, ew, esp, e32))
+    assert esp < 2e-5 and esp <= 1.5 * e32 + 1e-7
+
+
+def test_split_dynamic_range_and_non_finite():
+    """Non-finite activations (include/radar_depth_hip.h, rd_gconv_split): an output that touches a NaN / +-inf input is non-finite
+    in both kernels (inf - bf16(inf) = NaN, so the split kernel reports NaN where rd_gconv reports +-inf); every output outside the
+    3x3 footprint of the poisoned pixels is bit-for-bit what the clean input gives."""
+    from radar_depth_amd import convdesc as cd, ops
+    n, ci, co, h, w = 2, 64, 64, 40, 60
+    g = torch.Generator().manual_seed(12)
+    x = torch.randn(n, ci, h, w, generator=g)
+    wt = torch.randn(co, ci, 3, 3, generator=g) * (2.0 / (9 * ci)) ** 0.5
+    bad = [(0, 5, 10, 20, float("inf")), (1, 33, 0, 0, float("-inf")), (1, 7, 39, 59, float("nan"))]
+    xb = x.clone()
+    touched = torch.zeros(n, h, w, dtype=torch.bool)
+    for (i, c, r, q, v) in bad:
+        xb[i, c, r, q] = v
+        touched[i, max(r - 1, 0):r + 2, max(q - 1, 0):q + 2] = True
+    d = cd.conv_fwd(n, h, w, ci, co, 3, 1, 1)
+    wp, wp32 = ops.pack_weights_split(wt.cuda()), ops.pack_weights(wt.cuda())
+    outs = []
+    for src in (x, xb):
+        osp = torch.empty(n, h, w, co, device="cuda")
+        o32 = torch.empty(n, h, w, co, device="cuda")
+        ops.gconv_split(d, ops.nchw_to_nhwc(src.cuda()), wp, osp)
+        ops.gconv(d, ops.nchw_to_nhwc(src.cuda()), wp32, o32)
+        torch.cuda.synchronize()
+        outs.append((osp.cpu(), o32.cpu()))
+    (clean_sp, _), (bad_sp, bad_32) = outs
+    assert torch.isfinite(clean_sp).all()
+    assert not torch.isfinite(bad_sp[touched]).any() and not torch.isfinite(bad_32[touched]).any()
+    assert torch.isnan(bad_sp[touched]).all()                       # (the fp32 MFMA keeps +-inf where no NaN joins the sum)
+    assert torch.equal(bad_sp[~touched], clean_sp[~touched])
+
+
+# ------------------------------------------------------------------------------------------------ pre-split activations
+def test_split_pieces_are_exact():
+    """rd_split_pieces: three bf16 planes [piece][C/16][M][16] whose sum is the fp32 value EXACTLY, for values of every magnitude."""
+    from radar_depth_amd import ops
+    g = torch.Generator().manual_seed(21)
+    x = torch.randn(3, 7, 11, 48, generator=g) * torch.exp2(torch.randint(-40, 40, (3, 7, 11, 48), generator=g).float())
+    x[0, 0, 0, :4] = torch.tensor([0.0, -0.0, 1.0, -3.5])
+    pc = ops.split_pieces(x.cuda())
+    torch.cuda.synchronize()
+    m = 3 * 7 * 11
+    back = pc.double().sum(0).permute(1, 0, 2).reshape(m, 48)          # [C/16][M][16] -> [M][C]
+    assert torch.equal(back.float().cpu(), x.reshape(m, 48))
+    assert torch.equal(back.cpu(), x.reshape(m, 48).double())           # the three pieces add up without any rounding
+    p0 = pc[0].permute(1, 0, 2).reshape(m, 48).float().cpu()
+    assert torch.equal(p0, x.reshape(m, 48).to(torch.bfloat16).float())  # piece 0 is the round-to-nearest-even bf16 value
+
+
+PRE_FWD = [
+    (2, 64, 64, 3, 1, 1, 113, 200),   # layer1
+    (2, 128, 128, 3, 1, 1, 57, 100),
+    (2, 256, 256, 3, 1, 1, 29, 50),
+    (2, 512, 512, 3, 1, 1, 15, 25),   # layer4
+    (2, 64, 128, 3, 2, 1, 113, 200),  # stride 2: wide patch
+    (2, 640, 512, 1, 1, 0, 15, 25),   # conv_fusion
+    (2, 32, 32, 3, 1, 1, 120, 200),   # decoder.layer3 conv2
+    (3, 32, 48, 3, 1, 1, 9, 7),       # tiny / ragged
+    (2, 48, 80, 3, 1, 1, 31, 17),     # channels that do not fill a block, 48-channel reduction
+    (1, 96, 48, 3, 2, 1, 33, 45),
+    (3, 64, 64, 3, 1, 1, 1, 1),
+    (2, 32, 32, 3, 1, 1, 40, 1),
+    (16, 64, 64, 3, 1, 1, 57, 100),
+]
+
+
+@pytest.mark.parametrize("cfg", PRE_FWD)
+def test_gconv_split_pre_forward(cfg):
+    """rd_gconv_split_pre (activation split by its producer, staging = global_load_lds only) at rd_gconv_split's own bar, statistics
+    partials included; NaN-filled output must be fully overwritten."""
+    from radar_depth_amd import convdesc as cd, ops
+    n, ci, co, k, s, p, h, w = cfg
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(n, ci, h, w, generator=g)
+    wt = torch.randn(co, ci, k, k, generator=g) * (2.0 / (k * k * ci)) ** 0.5
+    y = F.conv2d(x, wt, stride=s, padding=p)
+    d = cd.conv_fwd(n, h, w, ci, co, k, s, p)
+    if not ops.gconv_split_pre_supported(d):
+        pytest.skip("no pre-split plan for this descriptor")
+    xp = ops.split_pieces(ops.nchw_to_nhwc(x.cuda()))
+    wp = ops.pack_weights_split(wt.cuda())
+    out = torch.full((n, d.Ho, d.Wo, co), float("nan"), device="cuda")
+    stat = torch.zeros(ops.gconv_split_pre_stat_tiles(d), 2, co, device="cuda")
+    ops.gconv_split_pre(d, xp, wp, out, stat=stat)
+    torch.cuda.synchronize()
+    got = out.permute(0, 3, 1, 2).cpu()
+    assert not torch.isnan(got).any()
+    assert _rel(got, y) < 2e-5, (_rel(got, y), cfg)
+    s_ = stat.sum(0).cpu().double()
+    ref_q = (y.double() ** 2).sum((0, 2, 3))
+    assert ((s_[0] - y.double().sum((0, 2, 3))).abs().max() / ref_q.sqrt().max()).item() < 1e-4
+    assert _rel(s_[1], ref_q) < 1e-4
+
+
+@pytest.mark.parametrize("cfg", [
+    (2, 64, 64, 3, 1, 1, 113, 200),
+    (2, 64, 128, 3, 2, 1, 113, 200),
+    (2, 256, 512, 3, 2, 1, 29, 50),
+    (16, 512, 512, 3, 1, 1, 15, 25),
+    (2, 48, 80, 3, 1, 1, 31, 17),
+    (3, 64, 64, 3, 1, 1, 1, 1),
+])
+def test_gconv_split_pre_dgrad(cfg):
+    """Input gradient through the pre-split form (dy split by its producer), with a residual-gradient addend in the epilogue."""
+    from radar_depth_amd import convdesc as cd, ops
+    n, ci, co, k, s, p, h, w = cfg
+    g = torch.Generator().manual_seed(1)
+    x = torch.randn(n, ci, h, w, generator=g, requires_grad=True)
+    wt = torch.randn(co, ci, k, k, generator=g) * (2.0 / (k * k * ci)) ** 0.5
+    y = F.conv2d(x, wt, stride=s, padding=p)
+    gy = torch.randn(y.shape, generator=g)
+    y.backward(gy)
+    dd, zero_fill = cd.conv_dgrad(n, h, w, ci, co, k, s, p)
+    if not ops.gconv_split_pre_supported(dd):
+        pytest.skip("no pre-split plan for this descriptor")
+    add = torch.randn(n, h, w, ci, generator=g) if not zero_fill else None
+    dx = torch.zeros(n, h, w, ci, device="cuda") if zero_fill else torch.full((n, h, w, ci), float("nan"), device="cuda")
+    gp = ops.split_pieces(ops.nchw_to_nhwc(gy.cuda()))
+    addg = add.cuda() if add is not None else None
+    ops.gconv_split_pre(dd, gp, ops.pack_weights_split(wt.cuda(), transpose=True), dx, addend=addg, ld_add=ci if add is not None else 0)
+    torch.cuda.synchronize()
+    want = x.grad + (add.permute(0, 3, 1, 2) if add is not None else 0)
+    got = dx.permute(0, 3, 1, 2).cpu()
+    assert not torch.isnan(got).any()
+    assert _rel(got, want) < 2e-5, (_rel(got, want), cfg)
+
+
+@pytest.mark.parametrize("c,h,w", [(256, 15, 25), (64, 60, 100), (32, 13, 9)])
+def test_gconv_split_pre_upproj(c, h, w):
+    """UpProj 4-phase forward (9/6/6/4 taps on the low-resolution input) and its 25-tap stride-2 input gradient, pre-split form."""
+    from radar_depth_amd import convdesc as cd, ops
+    n = 2
+    g = torch.Generator().manual_seed(2)
+    x = torch.randn(n, c, h, w, generator=g, requires_grad=True)
+    wt = torch.randn(c, c, 5, 5, generator=g) * (2.0 / (25 * c)) ** 0.5
+    u = torch.zeros(n, c, 2 * h, 2 * w)
+    u[:, :, ::2, ::2] = x
+    y = F.conv2d(u, wt, padding=2)
+    gy = torch.randn(y.shape, generator=g)
+    y.backward(gy)
+    d, dd = cd.upproj_fwd(n, h, w, c, c), cd.upproj_dgrad(n, h, w, c, c)
+    if not (ops.gconv_split_pre_supported(d) and ops.gconv_split_pre_supported(dd)):
+        pytest.skip("no pre-split plan")
+    out = torch.full((n, 2 * h, 2 * w, c), float("nan"), device="cuda")
+    ops.gconv_split_pre(d, ops.split_pieces(ops.nchw_to_nhwc(x.detach().cuda())), ops.pack_weights_split(wt.cuda()), out)
+    dx = torch.full((n, h, w, c), float("nan"), device="cuda")
+    ops.gconv_split_pre(dd, ops.split_pieces(ops.nchw_to_nhwc(gy.cuda())), ops.pack_weights_split(wt.cuda(), transpose=True), dx)
+    torch.cuda.synchronize()
+    assert _rel(out.permute(0, 3, 1, 2).cpu(), y.detach()) < 2e-5
+    assert _rel(dx.permute(0, 3, 1, 2).cpu(), x.grad) < 2e-5
+
+
+def test_gconv_split_pre_launches_are_bitwise_reproducible():
+    """200 launches of two shapes under NaN-poisoned LDS: every output bit-identical to the first (the copies' completion is the
+    only thing that orders the staging against the matrix waves: a missing wait shows up here)."""
+    from radar_depth_amd import convdesc as cd, ops
+    from radar_depth_amd._lib import lib
+    g = torch.Generator().manual_seed(5)
+    for (n, ci, co, h, w) in ((2, 64, 64, 57, 100), (2, 256, 256, 29, 50)):
+        x = torch.randn(n, h, w, ci, generator=g).cuda()
+        wp = ops.pack_weights_split((torch.randn(co, ci, 3, 3, generator=g) * 0.05).cuda())
+        d = cd.conv_fwd(n, h, w, ci, co, 3, 1, 1)
+        xp = ops.split_pieces(x)
+        first = None
+        for it in range(100):
+            lib().rd_debug_poison_lds(ops.current_stream())
+            out = torch.empty(n, h, w, co, device="cuda")
+            ops.gconv_split_pre(d, xp, wp, out)
+            if first is None:
+                first = out.clone()
+            else:
+                assert torch.equal(out, first), it
+    torch.cuda.synchronize()

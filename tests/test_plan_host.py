@@ -251,6 +251,9 @@ def test_bench_launches_its_own_ranks():
     out = json.loads(lines[0])
     assert out["n_gpus"] == 2 and out["dry_run"] is True and out["comm"] == "gloo"
     assert out["exchange_ok"] is True and out["gradient_buckets"] == 4 and len(out["exchange_s_per_rank"]) == 2
+    # the self-verification fields of the multi-rank line (identical parameter checksums on every rank; RCCL's own world size and the
+    # per-rank losses are filled in by the GPU run)
+    assert out["params_identical_across_ranks"] is True and "rccl_world_size" in out and "final_loss_spread" in out
     # a rank count that contradicts the surrounding job is refused, not silently run
     r = subprocess.run([sys.executable, os.path.join(repo, "bench.py"), "--gpus", "2", "--dry-run"], capture_output=True, text=True,
                        env=dict(env, WORLD_SIZE="3", RANK="0"), timeout=120)

@@ -26,6 +26,12 @@ for name, cnt, ci, co, k, s, p, h, w in CONVS:
     r1 = timeit(lambda: ops.wgrad_reduce(d, s1, g))
     t2 = timeit(lambda: ops.wgrad_split(d, x, y, s2))
     r2 = timeit(lambda: ops.wgrad_split_reduce(d, s2, g))
+    if ops.wgrad_split_pre_supported(d):
+        xp, yp = ops.split_pieces(x), ops.split_pieces(y)
+        t3 = timeit(lambda: ops.wgrad_split_pre(d, xp, yp, s2))
+        print("%-18s pre-split operands: %7.1f us %6.1f TF  x%.2f vs split" % (name, t3 * 1e6, 2.0 * B * d.Ho * d.Wo * ci * co * k * k / t3 / 1e12, t2 / t3))
+        tot.append(cnt * (t3 + r2)) if len(tot) == 2 else tot.__setitem__(2, tot[2] + cnt * (t3 + r2))
+        del xp, yp
     v = (C.c_int32 * 4)()
     lib().rd_wgrad_split_plan_info(C.byref(d), v)
     fl = 2.0 * B * d.Ho * d.Wo * ci * co * k * k
@@ -56,8 +62,15 @@ for name, c, h, w in UPPROJ:
     t2 = timeit(lambda: ops.wgrad_split(d, x, y, s2))
     r2 = timeit(red2)
     fl = 2.0 * B * h * w * c * c * 25
+    if ops.wgrad_split_pre_supported(d):
+        xp, yp = ops.split_pieces(x), ops.split_pieces(y)
+        t3 = timeit(lambda: ops.wgrad_split_pre(d, xp, yp, s2))
+        print("%-18s pre-split operands: %7.1f us %6.1f TF  x%.2f vs split" % (name, t3 * 1e6, fl / t3 / 1e12, t2 / t3))
+        tot.append(t3 + r2) if len(tot) == 2 else tot.__setitem__(2, tot[2] + t3 + r2)
+        del xp, yp
     print("%-18s x1 %6.2f GF | fp32 %7.1f us %6.1f TF (+reduce %5.1f) | split %7.1f us %6.1f TF (+reduce %5.1f) x%.2f"
           % (name, fl / 1e9, t1 * 1e6, fl / t1 / 1e12, r1 * 1e6, t2 * 1e6, fl / t2 / 1e12, r2 * 1e6, t1 / t2))
     tot[0] += t1 + r1
     tot[1] += t2 + r2
-print("TOTAL weight gradients of these layers (kernel + slab reduction): fp32 MFMA %.2f ms, split %.2f ms" % (tot[0] * 1e3, tot[1] * 1e3))
+print("TOTAL weight gradients of these layers (kernel + slab reduction): fp32 MFMA %.2f ms, split %.2f ms%s"
+      % (tot[0] * 1e3, tot[1] * 1e3, ", pre-split operands %.2f ms" % (tot[2] * 1e3) if len(tot) > 2 else ""))
