@@ -487,6 +487,16 @@ int rd_bn_bwd_apply_t(int32_t dtype, const void* g, int32_t ldg, const void* x, 
 int rd_bn_bwd_apply_x2_t(int32_t dtype, const void* dy, int32_t lddy, const void* x1, int32_t ldx1, const void* x2, int32_t ldx2, const float* red_partial, int32_t n_tiles, const float* gamma1, const float* mean1, const float* invstd1, const float* scale1, const float* shift1, const float* gamma2, const float* mean2, const float* invstd2, const float* scale2, const float* shift2, int32_t act, float* dgamma1, float* dbeta1, float* dgamma2, float* dbeta2, float* coef_ws6, void* dx1, int32_t lddx1, void* dx2, int32_t lddx2, int64_t M, int32_t C, void* stream);
 int rd_bn_bwd_apply_x_t(int32_t dtype, const void* dy, int32_t lddy, const void* x, int32_t ldx, const float* red_partial, int32_t n_tiles, const float* gamma, const float* mean, const float* invstd, const float* scale, const float* shift, int32_t act, float* dgamma, float* dbeta, float* coef_ws, void* dx, int32_t lddx, int64_t M, int32_t C, void* stream);
 int rd_bnact_maxpool_fwd_t(int32_t dtype, const void* x, const float* scale, const float* shift, int32_t act, int32_t N, int32_t H, int32_t W, int32_t C, void* y, int32_t ldy, uint8_t* idx, void* stream);
+/* fp32 forms that ALSO write the result as pre-split piece planes (see rd_split_pieces: [piece][C/16][M][16] bf16, piece_elems elements
+ * apart; pieces may be NULL = the plain kernel) -- the producers of the operands of rd_gconv_split_pre / rd_wgrad_split_pre: the split
+ * arithmetic runs in these HBM-bound passes, where the VALU is idle, instead of in the staging waves of the MFMA-bound convolutions.
+ * Same arguments as rd_bn_act / rd_bn_bwd_apply / rd_bn_bwd_apply_x / rd_bn_bwd_apply_x2 / rd_bnact_maxpool_fwd otherwise
+ * (models.py:96-112,203-208,633-650 and their backward). */
+int rd_bn_act_p(const float* x1, int32_t ldx1, const float* scale1, const float* shift1, const float* x2, int32_t ldx2, const float* scale2, const float* shift2, float* y, int32_t ldy, int64_t M, int32_t C, int32_t act, void* pieces, int64_t piece_elems, void* stream);
+int rd_bn_bwd_apply_p(const float* g, int32_t ldg, const float* x, int32_t ldx, const float* red_partial, int32_t n_tiles, int32_t which, const float* gamma, const float* mean, const float* invstd, float* dgamma, float* dbeta, float* coef_ws, float* dx, int32_t lddx, int64_t M, int32_t C, void* pieces, int64_t piece_elems, void* stream);
+int rd_bn_bwd_apply_x_p(const float* dy, int32_t lddy, const float* x, int32_t ldx, const float* red_partial, int32_t n_tiles, const float* gamma, const float* mean, const float* invstd, const float* scale, const float* shift, int32_t act, float* dgamma, float* dbeta, float* coef_ws, float* dx, int32_t lddx, int64_t M, int32_t C, void* pieces, int64_t piece_elems, void* stream);
+int rd_bn_bwd_apply_x2_p(const float* dy, int32_t lddy, const float* x1, int32_t ldx1, const float* x2, int32_t ldx2, const float* red_partial, int32_t n_tiles, const float* gamma1, const float* mean1, const float* invstd1, const float* scale1, const float* shift1, const float* gamma2, const float* mean2, const float* invstd2, const float* scale2, const float* shift2, int32_t act, float* dgamma1, float* dbeta1, float* dgamma2, float* dbeta2, float* coef_ws6, float* dx1, int32_t lddx1, float* dx2, int32_t lddx2, int64_t M, int32_t C, void* pieces1, int64_t piece_elems1, void* pieces2, int64_t piece_elems2, void* stream);
+int rd_bnact_maxpool_fwd_p(const float* x, const float* scale, const float* shift, int32_t act, int32_t N, int32_t H, int32_t W, int32_t C, float* y, int32_t ldy, uint8_t* idx, void* pieces, int64_t piece_elems, void* stream);
 int rd_bnact_maxpool_bwd_t(int32_t dtype, const void* dy, int32_t lddy, const uint8_t* idx, const void* x, const float* scale, const float* shift, int32_t act, int32_t N, int32_t H, int32_t W, int32_t C, void* g, void* stream);
 int rd_bnact_maxpool_bwd_stats_t(int32_t dtype, const void* dy, int32_t lddy, const uint8_t* idx, const void* x, const float* scale, const float* shift, int32_t act, int32_t N, int32_t H, int32_t W, int32_t C, void* g, const float* mean, float* red_partial, void* stream);
 /* Two-pass form of the stem's pool + BatchNorm backward that never materialises the full-resolution gradient g (the largest tensor

@@ -68,6 +68,10 @@ struct GsArgs {
     long long xplane;             // bytes per piece plane of the pre-split activation
     long long mpix;               // pixels per 16-channel block of a plane (= N * Hi * Wi)
     int kplane;                   // PRE: bytes per 8-channel unit plane of the LDS patch ([piece][unit][pixel] x 16 B)
+    int stagger;                  // gconv_sp2_kernel: start delay of every second group of 256 blocks, in units of 64 clocks
+    int dbg;                      // diagnostics (RD_GCONV_SPLIT_DEBUG, ablations for tools/ablate_gconv_split.py; results are then garbage):
+                                  // 4 no weight copies, 8 no patch copies / staging, 16 no epilogue; 1 no MFMAs, 2 no fragment reads
+                                  // (the last two as template instantiations of gconv_sp2_kernel<2,2> only)
 };
 
 // wait until at most n of this wave's vector-memory operations (global_load_lds copies included) are outstanding, n known only at
@@ -253,6 +257,7 @@ __global__ __launch_bounds__(512) void gconv_split_kernel(const GsArgs a) {
         // piece, 8-channel unit), rows lw, lw + 4, ... of this wave; returns the number of copies issued (the caller's counted wait)
         auto issue_patch = [&](int pbuf, int blk) -> int {
             int cnt = 0;
+            if (a.dbg & 8) return 0;
             const char* src0 = reinterpret_cast<const char*>(a.inp) + ((size_t)blk * a.mpix + (size_t)n * D.Hi * D.Wi) * 32;
             char* dst0 = s_patch + pbuf * 3 * pplane;
             const int nsg = (PW + 63) >> 6;
@@ -278,6 +283,7 @@ __global__ __launch_bounds__(512) void gconv_split_kernel(const GsArgs a) {
             return cnt;
         };
         auto issue_slab = [&](int buf, int cb, int g) {
+            if (a.dbg & 4) return;
             const int tap0 = g * GS_TPS;
             constexpr int welems = (GS_TPS * 2) << LBN;  // 16-byte units of one piece: [tap][2][BN]
             const char* src = reinterpret_cast<const char*>(a.w) + (size_t)(cb >> 3) * a.ldw * 16;
@@ -547,7 +553,7 @@ __global__ __launch_bounds__(512) void gconv_split_kernel(const GsArgs a) {
     float ssum[NT], ssq[NT];
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) ssum[nt] = ssq[nt] = 0.f;
-    if (!loader) {
+    if (!loader && !(a.dbg & 16)) {
         const bool has_add = a.addend != nullptr;
         const bool has_bias = a.bias != nullptr;
         const int cob = co0 + l31;
@@ -668,11 +674,392 @@ __global__ __launch_bounds__(512) void gconv_split_kernel(const GsArgs a) {
     if (a.trace && a.trace_role == 1 && tid == 0) a.trace[(size_t)blockIdx.x * 64 + 61] = __builtin_readcyclecounter();
 }
 
+// ================================================================================================================================
+// gconv_sp2_kernel: the pre-split form with TWO workgroups per CU (round 4).
+//
+// Measured on the 8-wave kernel above (tools/ablate_gconv_split.py, tools/trace_gconv_split.py --pre, profiles/r04_*): with the split
+// arithmetic gone from the staging waves the kernel did not get faster -- the MFMA waves' own stream (fragment-read bursts, 4.9 k clocks
+// per tap group against 3.5 k of MFMA issue), the barrier waits behind copies that take 2-4 k clocks to land when every CU of the chip
+// asks for the same weight slab at once, and an exposed prologue / VALU-heavy epilogue (a quarter of a 64-channel layer's lifetime)
+// all sit on ONE workgroup's critical path, because one workgroup per CU has nobody to yield the matrix pipe to.  This kernel is the
+// same arithmetic laid out the way the fp32 kernel of gconv.hip hides the same things: four waves per workgroup, no role split (staging
+// is a handful of global_load_lds issues per tap group), at most 80 KB of LDS and 256 registers, so that two workgroups share a CU
+// and one's copies-in-flight, barriers and epilogue run under the other's MFMAs.
+//
+//   tile      : BM = 4 waves x MT x 32 output pixels (MT <= 2), BN = NT x 32 channels.
+//   LDS       : patch [piece][8-channel unit][patch pixel] x 16 B, ONE buffer (the next chunk's copy is issued behind a barrier at the
+//               chunk's end and lands under the other workgroup's work); weights [2][piece][3 taps][2][BN] x 16 B, the next tap group's
+//               copy issued at the start of each group.
+//   loop      : per tap group: wait for the own copies, barrier, issue the next group's weights, three MFMA steps with the next step's
+//               fragment reads interleaved; per chunk one more barrier before the patch is overwritten.
+template <int MT, int NT, int DBG = 0>      // DBG (diagnostics, tools/ablate_gconv_split.py): 1 no MFMAs, 2 no fragment reads -- compile-time: a
+                                            // run-time test inside the step splits the basic block the read / MFMA interleaving lives in
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void gconv_sp2_kernel(const GsArgs a) {
+    constexpr int BM = 4 * MT * 32;
+    constexpr int BN = NT * 32;
+    constexpr int LBN = NT == 2 ? 6 : 5;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wm = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, hh = lane >> 5;
+    const RdConvDesc& D = a.d;
+
+    if (a.trace && tid == 0) {
+        a.trace[(size_t)blockIdx.x * 64 + 62] = __builtin_readcyclecounter();
+        a.trace[(size_t)blockIdx.x * 64 + 59] = __builtin_amdgcn_s_memrealtime();                                   // 100 MHz, chip-wide
+        a.trace[(size_t)blockIdx.x * 64 + 57] = ((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 32) |      // XCC_ID
+                                                 (unsigned)__builtin_amdgcn_s_getreg((31 << 11) | 4);                // HW_ID
+    }
+    // The two workgroups of a CU start together and would run in lockstep: the second "wave" of 256 blocks the dispatcher hands out
+    // (blocks 256..511, 768..1023, ...: the co-residents of the first) starts a.stagger x 64 clocks late, so that one's chunk
+    // boundaries (a barrier + the patch copy's latency) fall into the other's MFMA phases
+    if (a.stagger > 0 && ((blockIdx.x >> 8) & 1)) {
+        for (int i = 0; i < a.stagger; ++i) __builtin_amdgcn_s_sleep(1);
+    }
+    const int vid = xcd_remap(blockIdx.x, gridDim.x);
+    const int cot = vid % a.n_cotiles;
+    const int pt = vid / a.n_cotiles;
+    const int n = pt / a.tiles_total;
+    const int tt = pt - n * a.tiles_total;
+    int ph_ = 0;
+    for (int i = 1; i < D.n_phases; ++i)
+        if (tt >= D.phase[i].tile_begin) ph_ = i;
+    const int ph = __builtin_amdgcn_readfirstlane(ph_);
+    const RdPhase& P = D.phase[ph];
+    const int tloc = tt - P.tile_begin;
+    const int tiles_w = (P.lw + a.TW - 1) / a.TW;
+    const int r0 = (tloc / tiles_w) * a.TH, c0 = (tloc % tiles_w) * a.TW;
+    const int th_n = min(a.TH, P.lh - r0), tw_n = min(a.TW, P.lw - c0);
+    const int IS = D.in_stride, OS = D.out_stride;
+    const int PW = (a.TW - 1) * IS + (P.dw_max - P.dw_min) + 1;
+    const int PH = (th_n - 1) * IS + (P.dh_max - P.dh_min) + 1;
+    const int ih0 = r0 * IS + P.dh_min, iw0 = c0 * IS + P.dw_min;
+    const int ntaps = __builtin_amdgcn_readfirstlane(P.n_taps);
+    const int ngroups = (ntaps + GS_TPS - 1) / GS_TPS;
+    const int co0 = cot * BN;
+
+    int* s_opix = reinterpret_cast<int*>(smem);          // [BM] output pixel index or -1
+    int* s_apix = s_opix + BM;                           // [BM] patch pixel index of tap (0,0)
+    int* s_widx = s_apix + BM;                           // [32] weight slab index of each tap
+    char* s_w = reinterpret_cast<char*>(s_widx + 32);    // [2][3][GS_TPS][2][BN] x 16 B
+    constexpr int WPP = GS_TPS * 2 * BN * 16;
+    constexpr int SLAB = 3 * WPP;
+    char* s_patch = s_w + 2 * SLAB;                      // [3][pplane]
+    const int pplane = a.pplane;
+
+    for (int m = tid; m < BM; m += 256) {
+        const int r = m / a.TW, c = m - r * a.TW;
+        const bool ok = (r < th_n) && (c < tw_n);
+        s_opix[m] = ok ? ((n * D.Ho + (r0 + r) * OS + P.out_off_h) * D.Wo + (c0 + c) * OS + P.out_off_w) : -1;
+        s_apix[m] = ok ? ((r * IS) * PW + c * IS) : 0;
+    }
+    if (tid < ntaps) s_widx[tid] = P.widx[tid];
+    {   // the patch starts as zeros: padding pixels / rows of the halo are never copied (their lanes are masked in every copy)
+        const int n16 = (3 * pplane) >> 4;
+        for (int e = tid; e < n16; e += 256) *reinterpret_cast<uint4*>(s_patch + (size_t)e * 16) = make_uint4(0u, 0u, 0u, 0u);
+    }
+    rd_sync();
+
+    const int nchunks = D.Cin / GS_CKP;
+    const int total_groups = nchunks * ngroups;
+    const int cin8 = D.Cin >> 3;
+    // copy the patch of 16-channel block blk: one global_load_lds per (patch row, 64-pixel segment, piece, 8-channel unit); rows
+    // wm, wm + 4, ... of this wave
+    auto issue_patch = [&](int blk) {
+        if (a.dbg & 8) return;
+        const char* src0 = reinterpret_cast<const char*>(a.inp) + ((size_t)blk * a.mpix + (size_t)n * D.Hi * D.Wi) * 32;
+        const int nsg = (PW + 63) >> 6;
+        for (int r = wm; r < PH; r += 4) {
+            const int ih = ih0 + r;
+            if (ih < 0 || ih >= D.Hi) continue;
+            for (int sg = 0; sg < nsg; ++sg) {
+                const int col = (sg << 6) + lane, iw = iw0 + col;
+                const bool ok = col < PW && iw >= 0 && iw < D.Wi;
+                const char* src = src0 + ((size_t)ih * D.Wi + iw) * 32;
+                char* dst = s_patch + ((size_t)r * PW + (sg << 6)) * 16;
+                if (ok) {
+#pragma unroll
+                    for (int p = 0; p < 3; ++p)
+#pragma unroll
+                        for (int u = 0; u < 2; ++u)
+                            glds16(reinterpret_cast<const float*>(src + p * a.xplane + u * 16), reinterpret_cast<float*>(dst + p * pplane + u * a.kplane));
+                }
+            }
+        }
+    };
+    auto issue_slab = [&](int buf, int cb, int g) {
+        if (a.dbg & 4) return;
+        const int tap0 = g * GS_TPS;
+        constexpr int welems = (GS_TPS * 2) << LBN;      // 16-byte units of one piece: [tap][2][BN]
+        const char* src = reinterpret_cast<const char*>(a.w) + (size_t)(cb >> 3) * a.ldw * 16;
+        char* dst = s_w + buf * SLAB;
+#pragma unroll
+        for (int u = 0; u < GS_UW; ++u) {
+            const int e = tid + u * 256;
+            if (e < welems) {
+                const int j = e & (BN - 1), tk = e >> LBN;
+                const int k8 = tk & 1, t = tap0 + (tk >> 1);
+                if (t < ntaps && co0 + j < D.Cout) {
+                    const size_t go = (((size_t)s_widx[t] * cin8 + k8) * a.ldw + co0 + j) * 16;
+#pragma unroll
+                    for (int p = 0; p < 3; ++p)
+                        glds16(reinterpret_cast<const float*>(src + p * a.wplane + go), reinterpret_cast<float*>(dst + p * WPP + (e - lane) * 16));
+                } else {
+                    // (inline assembly: a plain LDS store behind outstanding global_load_lds copies makes the compiler wait for the copies)
+                    const su32x4 z = {0u, 0u, 0u, 0u};
+#pragma unroll
+                    for (int p = 0; p < 3; ++p) {
+                        const unsigned ad = (unsigned)(size_t)(dst + p * WPP + e * 16);
+                        asm volatile("ds_write_b128 %0, %1" ::"v"(ad), "v"(z) : "memory");
+                    }
+                }
+            }
+        }
+    };
+
+    f32x16 acc[MT][NT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[mt][nt][i] = 0.f;
+    int aoffB[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) aoffB[mt] = s_apix[(wm * MT + mt) * 32 + l31] * 16 + hh * a.kplane;
+    const int boffB = (hh * BN + l31) * 16;
+    const int tapv = a.tapoff[ph][lane < ntaps ? lane : 0];
+    auto loadA = [&](int tap, sbf16x8 (&A)[3][MT]) {
+        if constexpr (DBG & 2) return;
+        const char* pa = s_patch + __builtin_amdgcn_readlane(tapv, tap);
+#pragma unroll
+        for (int p = 0; p < 3; ++p)
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) A[p][mt] = *reinterpret_cast<const sbf16x8*>(pa + p * pplane + aoffB[mt]);
+    };
+    auto loadB = [&](const char* wbuf, int t, sbf16x8 (&B)[3][NT]) {
+        if constexpr (DBG & 2) return;
+        const char* wbl = wbuf + boffB;
+#pragma unroll
+        for (int p = 0; p < 3; ++p)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) B[p][nt] = *reinterpret_cast<const sbf16x8*>(wbl + p * WPP + t * 2 * BN * 16 + nt * 512);
+    };
+    // the next step's 3 (MT + NT) fragment reads go out between this step's first MFMAs, one read per two MFMAs
+    auto interleave = [&](int) {
+#pragma unroll
+        for (int i = 0; i < 3 * (MT + NT); ++i) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);      // 2 MFMA
+            __builtin_amdgcn_sched_group_barrier(0x002, 1, 0);      // 1 VALU (address)
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);      // 1 LDS read
+        }
+        if constexpr (6 * MT * NT - 6 * (MT + NT) > 0) __builtin_amdgcn_sched_group_barrier(0x008, 6 * MT * NT - 6 * (MT + NT), 0);
+    };
+    auto mma = [&](const sbf16x8 (&A)[3][MT], const sbf16x8 (&B)[3][NT]) {
+        if constexpr (DBG & 1) return;
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                f32x16 c = acc[mt][nt];
+                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[0][mt], B[2][nt], c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[1][mt], B[1][nt], c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[2][mt], B[0][nt], c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[0][mt], B[1][nt], c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[1][mt], B[0][nt], c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[0][mt], B[0][nt], c, 0, 0, 0);
+                acc[mt][nt] = c;
+            }
+    };
+    sbf16x8 fa[2][3][MT], fb[2][3][NT];
+    unsigned long long* trc = (a.trace && a.trace_role == 1 && tid == 0) ? a.trace + (size_t)blockIdx.x * 64 : nullptr;
+
+    // chunk order: workgroup-dependent rotation -- at any moment the workgroups of the chip then ask the L2 for DIFFERENT weight slabs
+    // instead of all for the same one (a copy took 2-4 k clocks to land when they did); the order is a function of the tile alone,
+    // so every output is still summed in one fixed order
+    const int rot = nchunks > 1 ? (int)((unsigned)pt % (unsigned)nchunks) : 0;
+    auto chunk_of = [&](int k) { const int q = k + rot; return q >= nchunks ? q - nchunks : q; };
+    issue_patch(chunk_of(0));
+    issue_slab(0, chunk_of(0) * GS_CKP, 0);
+    int it = 0, c = 0, g = 0;
+    int nc = ngroups > 1 ? 0 : 1, ng = ngroups > 1 ? 1 : 0;      // (chunk, group) of tap group it + 1
+    bool haveA = false;
+    // a group is three steps, so the fragment set holding a group's first step alternates from group to group: the loop body is a
+    // PAIR of groups (compile-time set indices)
+    auto group = [&](auto parity) {
+        constexpr int P0 = decltype(parity)::value, P1 = 1 - P0;
+        if (trc && it < 30) trc[2 * it] = __builtin_readcyclecounter();
+        glds_wait();                          // this wave's copies: weights of group it (and the chunk's patch when g == 0)
+        rd_sync();                            // B(it): they are published; every wave is done with group it - 1
+        if (trc && it < 30) trc[2 * it + 1] = __builtin_readcyclecounter();
+        if (it + 1 < total_groups) issue_slab((it + 1) & 1, chunk_of(nc) * GS_CKP, ng);
+        if (++ng == ngroups) { ng = 0; ++nc; }
+        const char* wb = s_w + (it & 1) * SLAB;
+        const int tap0 = g * GS_TPS;
+        const bool pref = g + 1 < ngroups;    // the next group reads the same patch: its first A fragments are prefetched
+        if (!haveA) loadA(min(tap0, ntaps - 1), fa[P0]);
+        loadB(wb, 0, fb[P0]);
+        __builtin_amdgcn_sched_barrier(0);
+        loadA(min(tap0 + 1, ntaps - 1), fa[P1]);
+        loadB(wb, 1, fb[P1]);
+        mma(fa[P0], fb[P0]);
+        interleave(0);
+        __builtin_amdgcn_sched_barrier(0);
+        loadA(min(tap0 + 2, ntaps - 1), fa[P0]);
+        loadB(wb, 2, fb[P0]);
+        mma(fa[P1], fb[P1]);
+        interleave(0);
+        __builtin_amdgcn_sched_barrier(0);
+        if (pref) loadA(min(tap0 + 3, ntaps - 1), fa[P1]);
+        mma(fa[P0], fb[P0]);
+        __builtin_amdgcn_sched_barrier(0);
+        haveA = pref;
+        ++it;
+        if (++g == ngroups) {
+            g = 0; ++c;
+            if (c < nchunks) {
+                rd_sync();                    // every wave is done with this chunk's patch
+                issue_patch(chunk_of(c));
+            }
+        }
+    };
+    while (it + 2 <= total_groups) {
+        group(std::integral_constant<int, 0>{});
+        group(std::integral_constant<int, 1>{});
+    }
+    if (it < total_groups) group(std::integral_constant<int, 0>{});
+    if (trc) { trc[60] = __builtin_readcyclecounter(); trc[63] = (unsigned long long)total_groups; }
+
+    // ---- epilogue (the 8-wave kernel's, every wave a compute wave)
+    float ssum[NT], ssq[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) ssum[nt] = ssq[nt] = 0.f;
+    if (!(a.dbg & 16)) {
+        const bool has_add = a.addend != nullptr;
+        const bool has_bias = a.bias != nullptr;
+        const int cob = co0 + l31;
+        float biasv[NT];
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) biasv[nt] = (has_bias && cob + nt * 32 < D.Cout) ? a.bias[cob + nt * 32] : 0.f;
+        const bool want_stat = a.stat != nullptr;
+        const int q4l = l31 & 3, k4l = l31 >> 2;
+        const bool odd1 = q4l & 1, odd2 = q4l & 2;
+        float4 ssum4[NT], ssq4[NT];
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) ssum4[nt] = ssq4[nt] = make_float4(0.f, 0.f, 0.f, 0.f);
+        bool any4 = false;
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            int ro4[4];
+            bool rows_ok = true;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                ro4[q] = s_opix[(wm * MT + mt) * 32 + q4l + 8 * q + 4 * hh];
+                rows_ok = rows_ok && ro4[q] >= 0;
+            }
+            if (a.vec4 && __all(rows_ok)) {
+                any4 = true;
+                const int cq = co0 + 4 * k4l;
+                float4 addv[NT][4];
+                if (has_add) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const float* ap = a.addend + (size_t)ro4[q] * a.ld_add + cq;
+#pragma unroll
+                        for (int nt = 0; nt < NT; ++nt) addv[nt][q] = (cq + nt * 32 < D.Cout) ? ld4(ap + nt * 32) : make_float4(0.f, 0.f, 0.f, 0.f);
+                    }
+                }
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) {
+                    const bool cok4 = cq + nt * 32 < D.Cout;
+                    float4 b4 = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (has_bias && cok4) b4 = *reinterpret_cast<const float4*>(a.bias + cq + nt * 32);
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        float e0 = acc[mt][nt][4 * q], e1 = acc[mt][nt][4 * q + 1], e2 = acc[mt][nt][4 * q + 2], e3 = acc[mt][nt][4 * q + 3];
+                        quad_transpose(e0, e1, e2, e3, odd1, odd2);
+                        float4 v = make_float4(e0 + b4.x, e1 + b4.y, e2 + b4.z, e3 + b4.w);
+                        if (has_add) { v.x += addv[nt][q].x; v.y += addv[nt][q].y; v.z += addv[nt][q].z; v.w += addv[nt][q].w; }
+                        const int cc = cq + nt * 32;
+                        if (cc < a.act_cols) {
+                            v.x = act_fwd(v.x, a.act); v.y = act_fwd(v.y, a.act); v.z = act_fwd(v.z, a.act); v.w = act_fwd(v.w, a.act);
+                        }
+                        if (cok4) st4(a.out + (size_t)ro4[q] * D.ldo + cc, v);
+                        if (want_stat) {
+                            ssum4[nt].x += v.x; ssum4[nt].y += v.y; ssum4[nt].z += v.z; ssum4[nt].w += v.w;
+                            ssq4[nt].x += v.x * v.x; ssq4[nt].y += v.y * v.y; ssq4[nt].z += v.z * v.z; ssq4[nt].w += v.w * v.w;
+                        }
+                    }
+                }
+            } else {
+                int ro[16];
+#pragma unroll
+                for (int i = 0; i < 16; ++i) ro[i] = s_opix[(wm * MT + mt) * 32 + (i & 3) + 8 * (i >> 2) + 4 * hh];
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) {
+                    const int co = cob + nt * 32;
+                    const bool cok = co < D.Cout;
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) {
+                        if (cok && ro[i] >= 0) {
+                            float v = acc[mt][nt][i] + biasv[nt];
+                            if (has_add) v += a.addend[(size_t)ro[i] * a.ld_add + co];
+                            if (co < a.act_cols) v = act_fwd(v, a.act);
+                            a.out[(size_t)ro[i] * D.ldo + co] = v;
+                            ssum[nt] += v;
+                            ssq[nt] += v * v;
+                        }
+                    }
+                }
+            }
+        }
+        if (want_stat && __any(any4)) {
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                float4 s4 = ssum4[nt], q4 = ssq4[nt];
+                s4.x += dpp_xor1(s4.x); s4.y += dpp_xor1(s4.y); s4.z += dpp_xor1(s4.z); s4.w += dpp_xor1(s4.w);
+                q4.x += dpp_xor1(q4.x); q4.y += dpp_xor1(q4.y); q4.z += dpp_xor1(q4.z); q4.w += dpp_xor1(q4.w);
+                s4.x += dpp_xor2(s4.x); s4.y += dpp_xor2(s4.y); s4.z += dpp_xor2(s4.z); s4.w += dpp_xor2(s4.w);
+                q4.x += dpp_xor2(q4.x); q4.y += dpp_xor2(q4.y); q4.z += dpp_xor2(q4.z); q4.w += dpp_xor2(q4.w);
+                ssum[nt] += odd2 ? (odd1 ? s4.w : s4.z) : (odd1 ? s4.y : s4.x);
+                ssq[nt] += odd2 ? (odd1 ? q4.w : q4.z) : (odd1 ? q4.y : q4.x);
+            }
+        }
+    }
+    if (a.stat) {
+        rd_sync();
+        float* red = reinterpret_cast<float*>(s_w);  // [4][2][BN]
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            const float s = ssum[nt] + __shfl_xor(ssum[nt], 32, 64);
+            const float q = ssq[nt] + __shfl_xor(ssq[nt], 32, 64);
+            if (hh == 0) {
+                red[(wm * 2 + 0) * BN + nt * 32 + l31] = s;
+                red[(wm * 2 + 1) * BN + nt * 32 + l31] = q;
+            }
+        }
+        rd_sync();
+        if (tid < 2 * BN) {
+            const int which = tid / BN, j = tid - which * BN;
+            float s = 0.f;
+#pragma unroll
+            for (int w = 0; w < 4; ++w) s += red[(w * 2 + which) * BN + j];
+            const int co = co0 + j;
+            if (co < D.Cout) a.stat[((size_t)pt * 2 + which) * D.Cout + co] = s;
+        }
+    }
+    if (a.trace && a.trace_role == 1 && tid == 0) {
+        a.trace[(size_t)blockIdx.x * 64 + 61] = __builtin_readcyclecounter();
+        a.trace[(size_t)blockIdx.x * 64 + 58] = __builtin_amdgcn_s_memrealtime();
+    }
+}
+
 // ------------------------------------------------------------------------------------------ host
 struct GsPlan {
     int MT, NT, TH, TW, PP, tiles_total, n_cotiles, taps_max, pplane;
     size_t lds_bytes;
     int pdb;        // two patch buffers: the next chunk's patch is written while the current one is read (no second barrier)
+    int sp2;        // pre-split input on gconv_sp2_kernel (four waves, two workgroups per CU)
 };
 
 static int gs_patch_pixels(const RdConvDesc& d, const RdPhase& p, int TH, int TW, int* rows, int* cols) {
@@ -749,13 +1136,88 @@ static bool plan_gconv_split(const RdConvDesc& d, GsPlan& best, bool pre) {
                 const double cost = rounds * per_wg;
                 if (best_cost < 0 || cost < best_cost) {
                     best_cost = cost;
-                    best = GsPlan{c.MT, c.NT, TH, TW, PP, 0, n_cot, taps_max, pplane, lds, pdb};
+                    best = GsPlan{c.MT, c.NT, TH, TW, PP, 0, n_cot, taps_max, pplane, lds, pdb, 0};
                 }
                 break;      // the double-buffered form of a tile is never worse than its single-buffered one
             }
         }
     }
     return best_cost > 0;
+}
+
+// gconv_sp2_kernel: tile for two workgroups per CU (<= 80 KB of LDS each)
+static bool plan_sp2(const RdConvDesc& d, GsPlan& best) {
+    struct Cfg { int MT, NT; };
+    static const Cfg cfgs[] = {{2, 2}, {1, 2}, {2, 1}, {1, 1}, {3, 1}};
+    int taps_max = 0;
+    for (int i = 0; i < d.n_phases; ++i) taps_max = taps_max > d.phase[i].n_taps ? taps_max : d.phase[i].n_taps;
+    int pr = 0;
+    for (int i = 1; i < d.n_phases; ++i)
+        if ((int64_t)d.phase[i].lh * d.phase[i].lw > (int64_t)d.phase[pr].lh * d.phase[pr].lw) pr = i;
+    const RdPhase& P = d.phase[pr];
+    double best_cost = -1;
+    static const char* force = getenv("RD_GCONV_SP2_FORCE");     // diagnostics: index into cfgs
+    int cfg_i = -1;
+    for (const Cfg& c : cfgs) {
+        ++cfg_i;
+        if (force && atoi(force) != cfg_i) continue;
+        const int BM = 4 * c.MT * 32, BN = c.NT * 32;
+        if (BN > 32 && d.Cout <= 32) continue;
+        const int n_cot = cdiv(d.Cout, BN);
+        for (int twt = 1; twt <= cdiv(P.lw, 4); ++twt) {
+            const int TW = cdiv(P.lw, twt);
+            if (TW > BM) continue;
+            int TH = BM / TW;
+            if (TH > P.lh) TH = P.lh;
+            TH = cdiv(P.lh, cdiv(P.lh, TH));
+            int PP = 0;
+            double copies = 0;
+            for (int i = 0; i < d.n_phases; ++i) {
+                int rows, cols;
+                const int pp = gs_patch_pixels(d, d.phase[i], TH, TW, &rows, &cols);
+                PP = PP > pp ? PP : pp;
+                copies = copies > 6.0 * rows * cdiv(cols, 64) ? copies : 6.0 * rows * cdiv(cols, 64);
+            }
+            const int pplane = 2 * (((PP * 16) + 63) & ~63);
+            const size_t lds = (size_t)(2 * BM + 32) * 4 + (size_t)2 * 3 * GS_TPS * 2 * BN * 16 + (size_t)3 * pplane + 64;
+            if (lds > 80 * 1024 - 256) continue;
+            double groups = 0, wgs = 0;
+            for (int i = 0; i < d.n_phases; ++i) {
+                const double t = (double)cdiv(d.phase[i].lh, TH) * cdiv(d.phase[i].lw, TW);
+                groups += t * cdiv(d.phase[i].n_taps, GS_TPS);
+                wgs += t;
+            }
+            const double groups_per_wg = groups / wgs;
+            wgs *= (double)d.N * n_cot;
+            // two workgroups share a CU's matrix pipe: a CU's time is the MFMA issue time of the workgroups it gets (34 clocks per MFMA
+            // incl. what the co-resident workgroup does not hide) plus per-group / per-chunk / per-workgroup costs that are only partly
+            // hidden; copies cost issue slots (~40 clocks each, a quarter per wave)
+            const double per_group = 3.0 * c.MT * c.NT * 6 * 34 + 250.0;
+            const double per_chunk = groups_per_wg * per_group + 600.0 + copies / 4 * 40.0;
+            const double per_wg = (double)(d.Cin / GS_CKP) * per_chunk + 3000.0 + 16.0 * c.MT * c.NT * 50;
+            // a CU runs its workgroups two at a time; an odd one out runs alone and hides nothing (measured ~0.6 of the shared rate)
+            const double per_cu = ceil(wgs / (double)num_cus());
+            const double cost = per_cu * per_wg + (((int)per_cu & 1) ? 0.5 * per_wg : 0.0);
+            if (best_cost < 0 || cost < best_cost) {
+                best_cost = cost;
+                best = GsPlan{c.MT, c.NT, TH, TW, PP, 0, n_cot, taps_max, pplane, lds, 0, 1};
+            }
+        }
+    }
+    return best_cost > 0;
+}
+
+template <int MT, int NT, int DBG = 0>
+static int launch_sp2(const GsArgs& a, int grid, size_t lds, hipStream_t s) {
+    static bool attr_set = false;
+    auto k = gconv_sp2_kernel<MT, NT, DBG>;
+    if (!attr_set) {
+        RD_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(k, dim3(grid), dim3(256), lds, s, a);
+    RD_CHECK_LAUNCH("gconv_sp2_kernel");
+    return RD_OK;
 }
 
 template <int MT, int NT, bool PDB, bool PRE>
@@ -828,7 +1290,9 @@ static int gs_plan_query(const RdConvDesc* d, GsPlan& pl, RdConvDesc& dd, bool p
     }
     Entry e{};
     e.dd = *d;
-    e.ok = gs_shape_ok(d) && plan_gconv_split(e.dd, e.pl, pre) ? 1 : 0;
+    static const char* no_sp2 = getenv("RD_GCONV_SP2");          // RD_GCONV_SP2=0: pre-split input on the 8-wave kernel (diagnostics)
+    const bool sp2 = pre && !(no_sp2 && atoi(no_sp2) == 0);
+    e.ok = gs_shape_ok(d) && (sp2 ? plan_sp2(e.dd, e.pl) : plan_gconv_split(e.dd, e.pl, pre)) ? 1 : 0;
     if (e.ok) {
         int tb = 0;
         for (int i = 0; i < e.dd.n_phases; ++i) {
@@ -926,12 +1390,28 @@ static int gs_launch(const RdConvDesc* d, const float* in, const void* in_pieces
     a.trace = nullptr;
     a.trace_role = 0;
     {
+        const char* dbg = getenv("RD_GCONV_SPLIT_DEBUG");     // (read at every launch: the ablation tool toggles it between launches)
+        a.dbg = dbg ? atoi(dbg) : 0;
+        const char* stg = getenv("RD_GCONV_SP2_STAGGER");     // (diagnostics / sweep)
+        a.stagger = stg ? atoi(stg) : 0;
+    }
+    {
         static const char* tr = getenv("RD_GCONV_SPLIT_TRACE");
         if (tr && atoi(tr)) {
             if (!g_gs_trace) RD_CHECK_HIP(hipMalloc(&g_gs_trace, (size_t)65536 * 64 * sizeof(unsigned long long)));
             a.trace = g_gs_trace;
             a.trace_role = atoi(tr);
         }
+    }
+    if (pl.sp2) {
+        if (pl.MT == 2 && pl.NT == 2 && (a.dbg & 3) == 1) return launch_sp2<2, 2, 1>(a, grid, pl.lds_bytes, s);      // (ablations of the main tile only)
+        if (pl.MT == 2 && pl.NT == 2 && (a.dbg & 3) == 2) return launch_sp2<2, 2, 2>(a, grid, pl.lds_bytes, s);
+        if (pl.MT == 2 && pl.NT == 2 && (a.dbg & 3) == 3) return launch_sp2<2, 2, 3>(a, grid, pl.lds_bytes, s);
+        if (pl.MT == 2 && pl.NT == 2) return launch_sp2<2, 2>(a, grid, pl.lds_bytes, s);
+        if (pl.MT == 1 && pl.NT == 2) return launch_sp2<1, 2>(a, grid, pl.lds_bytes, s);
+        if (pl.MT == 2 && pl.NT == 1) return launch_sp2<2, 1>(a, grid, pl.lds_bytes, s);
+        if (pl.MT == 1 && pl.NT == 1) return launch_sp2<1, 1>(a, grid, pl.lds_bytes, s);
+        if (pl.MT == 3 && pl.NT == 1) return launch_sp2<3, 1>(a, grid, pl.lds_bytes, s);
     }
 #define RD_GS(MT_, NT_)                                                                                                         \
     if (pl.MT == MT_ && pl.NT == NT_)                                                                                           \

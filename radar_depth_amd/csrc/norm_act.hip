@@ -139,7 +139,8 @@ template <typename T>
 __global__ __launch_bounds__(256) void bn_act_kernel(const T* __restrict__ x1, int ldx1, const float* __restrict__ s1,
                                                      const float* __restrict__ t1, const T* __restrict__ x2, int ldx2,
                                                      const float* __restrict__ s2, const float* __restrict__ t2,
-                                                     T* __restrict__ y, int ldy, int64_t M, int C, int act) {
+                                                     T* __restrict__ y, int ldy, int64_t M, int C, int act,
+                                                     unsigned short* __restrict__ pc, int64_t pplane) {
     const int Q = C >> 2;
     const int lq = quad_log2(Q);
     const int64_t total = M * Q;
@@ -162,6 +163,8 @@ __global__ __launch_bounds__(256) void bn_act_kernel(const T* __restrict__ x1, i
         }
         z.x = act_fwd(z.x, act); z.y = act_fwd(z.y, act); z.z = act_fwd(z.z, act); z.w = act_fwd(z.w, act);
         st4(y + r * ldy + c, z);
+        // the consumers' split arithmetic, done here where the VALU is idle (HBM-bound pass): three bf16 piece planes of y
+        if (pc) store_pieces4(pc, pplane, M, r, c, z);
     }
 }
 
@@ -271,7 +274,8 @@ template <typename T>
 __global__ __launch_bounds__(256) void bn_bwd_dx_kernel(const T* __restrict__ g, int ldg, const T* __restrict__ x, int ldx,
                                                         const float* __restrict__ mean, const float* __restrict__ coef,
                                                         T* __restrict__ dx, int lddx, int64_t M, int C,
-                                                        const float* __restrict__ s1, const float* __restrict__ t1, int act) {
+                                                        const float* __restrict__ s1, const float* __restrict__ t1, int act,
+                                                        unsigned short* __restrict__ pc, int64_t pplane) {
     const int Q = C >> 2;
     const int lq = quad_log2(Q);
     const int64_t total = M * Q;
@@ -296,6 +300,7 @@ __global__ __launch_bounds__(256) void bn_bwd_dx_kernel(const T* __restrict__ g,
         o.z = fmaf(A.z, gv.z, fmaf(B.z, xv.z - mu.z, K.z));
         o.w = fmaf(A.w, gv.w, fmaf(B.w, xv.w - mu.w, K.w));
         st4(dx + r * lddx + c, o);
+        if (pc) store_pieces4(pc, pplane, M, r, c, o);
     }
 }
 
@@ -308,7 +313,9 @@ __global__ __launch_bounds__(256) void bn_bwd_dx2_kernel(const T* __restrict__ d
                                                          const float* __restrict__ coef2, const float* __restrict__ s1,
                                                          const float* __restrict__ t1, const float* __restrict__ s2,
                                                          const float* __restrict__ t2, int act, T* __restrict__ dx1, int lddx1,
-                                                         T* __restrict__ dx2, int lddx2, int64_t M, int C) {
+                                                         T* __restrict__ dx2, int lddx2, int64_t M, int C,
+                                                         unsigned short* __restrict__ pc1, int64_t pplane1,
+                                                         unsigned short* __restrict__ pc2, int64_t pplane2) {
     const int Q = C >> 2;
     const int lq = quad_log2(Q);
     const int64_t total = M * Q;
@@ -333,9 +340,11 @@ __global__ __launch_bounds__(256) void bn_bwd_dx2_kernel(const T* __restrict__ d
         o.x = fmaf(A1.x, gv.x, fmaf(B1.x, v1.x - mu1.x, K1.x)); o.y = fmaf(A1.y, gv.y, fmaf(B1.y, v1.y - mu1.y, K1.y));
         o.z = fmaf(A1.z, gv.z, fmaf(B1.z, v1.z - mu1.z, K1.z)); o.w = fmaf(A1.w, gv.w, fmaf(B1.w, v1.w - mu1.w, K1.w));
         st4(dx1 + r * lddx1 + c, o);
+        if (pc1) store_pieces4(pc1, pplane1, M, r, c, o);
         o.x = fmaf(A2.x, gv.x, fmaf(B2.x, v2.x - mu2.x, K2.x)); o.y = fmaf(A2.y, gv.y, fmaf(B2.y, v2.y - mu2.y, K2.y));
         o.z = fmaf(A2.z, gv.z, fmaf(B2.z, v2.z - mu2.z, K2.z)); o.w = fmaf(A2.w, gv.w, fmaf(B2.w, v2.w - mu2.w, K2.w));
         st4(dx2 + r * lddx2 + c, o);
+        if (pc2) store_pieces4(pc2, pplane2, M, r, c, o);
     }
 }
 
@@ -345,7 +354,7 @@ template <typename T>
 __global__ __launch_bounds__(256) void bnact_maxpool_fwd_kernel(const T* __restrict__ x, const float* __restrict__ scale,
                                                                 const float* __restrict__ shift, int act, int N, int H, int W,
                                                                 int C, int Ho, int Wo, T* __restrict__ y, int ldy,
-                                                                uint8_t* __restrict__ idx) {
+                                                                uint8_t* __restrict__ idx, unsigned short* __restrict__ pc, int64_t pplane) {
     const int Q = C >> 2;
     const int lq = quad_log2(Q);
     const int64_t total = (int64_t)N * Ho * Wo * Q;
@@ -387,6 +396,7 @@ __global__ __launch_bounds__(256) void bnact_maxpool_fwd_kernel(const T* __restr
         const size_t o = ((size_t)n * Ho + oh) * Wo + ow;
         st4(y + o * ldy + c, make_float4(best[0], best[1], best[2], best[3]));
         *reinterpret_cast<uchar4*>(idx + o * C + c) = make_uchar4(bi[0], bi[1], bi[2], bi[3]);
+        if (pc) store_pieces4(pc, pplane, (int64_t)N * Ho * Wo, (int64_t)o, c, make_float4(best[0], best[1], best[2], best[3]));
     }
 }
 
@@ -550,16 +560,22 @@ extern "C" int rd_bn_stats_t(int32_t dtype, const void* x, int64_t M, int32_t C,
 }
 
 template <typename T>
-static int rd_bn_act_T(const T* x1, int32_t ldx1, const float* scale1, const float* shift1, const T* x2, int32_t ldx2, const float* scale2, const float* shift2, T* y, int32_t ldy, int64_t M, int32_t C, int32_t act, void* stream) {
+static int rd_bn_act_T(const T* x1, int32_t ldx1, const float* scale1, const float* shift1, const T* x2, int32_t ldx2, const float* scale2, const float* shift2, T* y, int32_t ldy, int64_t M, int32_t C, int32_t act, void* stream,
+                       void* pieces = nullptr, int64_t piece_elems = 0) {
     RD_CHECK_ARG(x1 && scale1 && shift1 && y && M > 0 && C % 4 == 0 && ldx1 % 4 == 0 && ldy % 4 == 0 && (!x2 || ldx2 % 4 == 0),
                  "bn_act: bad arguments");
+    RD_CHECK_ARG(!pieces || (C % 16 == 0 && piece_elems >= (int64_t)C * M && reinterpret_cast<uintptr_t>(pieces) % 16 == 0), "bn_act: bad piece planes");
     hipLaunchKernelGGL((bn_act_kernel<T>), dim3(ew_grid(M * (C / 4))), dim3(256), 0, static_cast<hipStream_t>(stream), x1, ldx1,
-                       scale1, shift1, x2, ldx2, scale2, shift2, y, ldy, M, C, act);
+                       scale1, shift1, x2, ldx2, scale2, shift2, y, ldy, M, C, act, static_cast<unsigned short*>(pieces), piece_elems);
     RD_CHECK_LAUNCH("bn_act_kernel");
     return RD_OK;
 }
 extern "C" int rd_bn_act(const float* x1, int32_t ldx1, const float* scale1, const float* shift1, const float* x2, int32_t ldx2, const float* scale2, const float* shift2, float* y, int32_t ldy, int64_t M, int32_t C, int32_t act, void* stream) {
     return rd_bn_act_T<float>(x1, ldx1, scale1, shift1, x2, ldx2, scale2, shift2, y, ldy, M, C, act, stream);
+}
+// + piece planes of y for the pre-split convolutions (include/radar_depth_hip.h, rd_split_pieces): pieces may be NULL
+extern "C" int rd_bn_act_p(const float* x1, int32_t ldx1, const float* scale1, const float* shift1, const float* x2, int32_t ldx2, const float* scale2, const float* shift2, float* y, int32_t ldy, int64_t M, int32_t C, int32_t act, void* pieces, int64_t piece_elems, void* stream) {
+    return rd_bn_act_T<float>(x1, ldx1, scale1, shift1, x2, ldx2, scale2, shift2, y, ldy, M, C, act, stream, pieces, piece_elems);
 }
 // storage-typed form: dtype = RD_DTYPE_F32 / RD_DTYPE_BF16 selects the element type of the NHWC tensors (strides in elements)
 extern "C" int rd_bn_act_t(int32_t dtype, const void* x1, int32_t ldx1, const float* scale1, const float* shift1, const void* x2, int32_t ldx2, const float* scale2, const float* shift2, void* y, int32_t ldy, int64_t M, int32_t C, int32_t act, void* stream) {
@@ -617,20 +633,25 @@ extern "C" int rd_bn_bwd_reduce_x_t(int32_t dtype, const void* dy, int32_t lddy,
 }
 
 template <typename T>
-static int rd_bn_bwd_apply_T(const T* g, int32_t ldg, const T* x, int32_t ldx, const float* red_partial, int32_t n_tiles, int32_t which, const float* gamma, const float* mean, const float* invstd, float* dgamma, float* dbeta, float* coef_ws, T* dx, int32_t lddx, int64_t M, int32_t C, void* stream) {
+static int rd_bn_bwd_apply_T(const T* g, int32_t ldg, const T* x, int32_t ldx, const float* red_partial, int32_t n_tiles, int32_t which, const float* gamma, const float* mean, const float* invstd, float* dgamma, float* dbeta, float* coef_ws, T* dx, int32_t lddx, int64_t M, int32_t C, void* stream,
+                             void* pieces = nullptr, int64_t piece_elems = 0) {
     RD_CHECK_ARG(g && x && red_partial && gamma && mean && invstd && coef_ws && dx && (which == 1 || which == 2) && M > 0 &&
                      C % 4 == 0, "bn_bwd_apply: bad arguments");
+    RD_CHECK_ARG(!pieces || (C % 16 == 0 && piece_elems >= (int64_t)C * M && reinterpret_cast<uintptr_t>(pieces) % 16 == 0), "bn_bwd_apply: bad piece planes");
     hipStream_t s = static_cast<hipStream_t>(stream);
     hipLaunchKernelGGL(bn_bwd_coeffs_kernel, dim3(C), dim3(256), 0, s, red_partial, n_tiles, C, which, (double)M, gamma, invstd,
                        dgamma, dbeta, coef_ws);
     RD_CHECK_LAUNCH("bn_bwd_coeffs_kernel");
     hipLaunchKernelGGL((bn_bwd_dx_kernel<T>), dim3(ew_grid(M * (C / 4))), dim3(256), 0, s, g, ldg, x, ldx, mean, coef_ws, dx, lddx, M, C,
-                       (const float*)nullptr, (const float*)nullptr, RD_ACT_NONE);
+                       (const float*)nullptr, (const float*)nullptr, RD_ACT_NONE, static_cast<unsigned short*>(pieces), piece_elems);
     RD_CHECK_LAUNCH("bn_bwd_dx_kernel");
     return RD_OK;
 }
 extern "C" int rd_bn_bwd_apply(const float* g, int32_t ldg, const float* x, int32_t ldx, const float* red_partial, int32_t n_tiles, int32_t which, const float* gamma, const float* mean, const float* invstd, float* dgamma, float* dbeta, float* coef_ws, float* dx, int32_t lddx, int64_t M, int32_t C, void* stream) {
     return rd_bn_bwd_apply_T<float>(g, ldg, x, ldx, red_partial, n_tiles, which, gamma, mean, invstd, dgamma, dbeta, coef_ws, dx, lddx, M, C, stream);
+}
+extern "C" int rd_bn_bwd_apply_p(const float* g, int32_t ldg, const float* x, int32_t ldx, const float* red_partial, int32_t n_tiles, int32_t which, const float* gamma, const float* mean, const float* invstd, float* dgamma, float* dbeta, float* coef_ws, float* dx, int32_t lddx, int64_t M, int32_t C, void* pieces, int64_t piece_elems, void* stream) {
+    return rd_bn_bwd_apply_T<float>(g, ldg, x, ldx, red_partial, n_tiles, which, gamma, mean, invstd, dgamma, dbeta, coef_ws, dx, lddx, M, C, stream, pieces, piece_elems);
 }
 // storage-typed form: dtype = RD_DTYPE_F32 / RD_DTYPE_BF16 selects the element type of the NHWC tensors (strides in elements)
 extern "C" int rd_bn_bwd_apply_t(int32_t dtype, const void* g, int32_t ldg, const void* x, int32_t ldx, const float* red_partial, int32_t n_tiles, int32_t which, const float* gamma, const float* mean, const float* invstd, float* dgamma, float* dbeta, float* coef_ws, void* dx, int32_t lddx, int64_t M, int32_t C, void* stream) {
@@ -659,9 +680,11 @@ extern "C" int rd_bn_bwd_reduce_x2_t(int32_t dtype, const void* dy, int32_t lddy
     return RD_EINVAL;
 }
 template <typename T>
-static int rd_bn_bwd_apply_x2_T(const T* dy, int32_t lddy, const T* x1, int32_t ldx1, const T* x2, int32_t ldx2, const float* red_partial, int32_t n_tiles, const float* gamma1, const float* mean1, const float* invstd1, const float* scale1, const float* shift1, const float* gamma2, const float* mean2, const float* invstd2, const float* scale2, const float* shift2, int32_t act, float* dgamma1, float* dbeta1, float* dgamma2, float* dbeta2, float* coef_ws6, T* dx1, int32_t lddx1, T* dx2, int32_t lddx2, int64_t M, int32_t C, void* stream) {
+static int rd_bn_bwd_apply_x2_T(const T* dy, int32_t lddy, const T* x1, int32_t ldx1, const T* x2, int32_t ldx2, const float* red_partial, int32_t n_tiles, const float* gamma1, const float* mean1, const float* invstd1, const float* scale1, const float* shift1, const float* gamma2, const float* mean2, const float* invstd2, const float* scale2, const float* shift2, int32_t act, float* dgamma1, float* dbeta1, float* dgamma2, float* dbeta2, float* coef_ws6, T* dx1, int32_t lddx1, T* dx2, int32_t lddx2, int64_t M, int32_t C, void* stream,
+                                void* pieces1 = nullptr, int64_t piece_elems1 = 0, void* pieces2 = nullptr, int64_t piece_elems2 = 0) {
     RD_CHECK_ARG(dy && x1 && x2 && red_partial && gamma1 && gamma2 && mean1 && mean2 && invstd1 && invstd2 && scale1 && shift1 && scale2 &&
                      shift2 && coef_ws6 && dx1 && dx2 && M > 0 && C % 4 == 0, "bn_bwd_apply_x2: bad arguments");
+    RD_CHECK_ARG((!pieces1 || (C % 16 == 0 && piece_elems1 >= (int64_t)C * M)) && (!pieces2 || (C % 16 == 0 && piece_elems2 >= (int64_t)C * M)), "bn_bwd_apply_x2: bad piece planes");
     hipStream_t s = static_cast<hipStream_t>(stream);
     hipLaunchKernelGGL(bn_bwd_coeffs_kernel, dim3(C), dim3(256), 0, s, red_partial, n_tiles, C, 1, (double)M, gamma1, invstd1, dgamma1, dbeta1,
                        coef_ws6);
@@ -670,12 +693,16 @@ static int rd_bn_bwd_apply_x2_T(const T* dy, int32_t lddy, const T* x1, int32_t 
                        coef_ws6 + 3 * C);
     RD_CHECK_LAUNCH("bn_bwd_coeffs_kernel");
     hipLaunchKernelGGL((bn_bwd_dx2_kernel<T>), dim3(ew_grid(M * (C / 4))), dim3(256), 0, s, dy, lddy, x1, ldx1, x2, ldx2, mean1, mean2, coef_ws6,
-                       coef_ws6 + 3 * C, scale1, shift1, scale2, shift2, act, dx1, lddx1, dx2, lddx2, M, C);
+                       coef_ws6 + 3 * C, scale1, shift1, scale2, shift2, act, dx1, lddx1, dx2, lddx2, M, C,
+                       static_cast<unsigned short*>(pieces1), piece_elems1, static_cast<unsigned short*>(pieces2), piece_elems2);
     RD_CHECK_LAUNCH("bn_bwd_dx2_kernel");
     return RD_OK;
 }
 extern "C" int rd_bn_bwd_apply_x2(const float* dy, int32_t lddy, const float* x1, int32_t ldx1, const float* x2, int32_t ldx2, const float* red_partial, int32_t n_tiles, const float* gamma1, const float* mean1, const float* invstd1, const float* scale1, const float* shift1, const float* gamma2, const float* mean2, const float* invstd2, const float* scale2, const float* shift2, int32_t act, float* dgamma1, float* dbeta1, float* dgamma2, float* dbeta2, float* coef_ws6, float* dx1, int32_t lddx1, float* dx2, int32_t lddx2, int64_t M, int32_t C, void* stream) {
     return rd_bn_bwd_apply_x2_T<float>(dy, lddy, x1, ldx1, x2, ldx2, red_partial, n_tiles, gamma1, mean1, invstd1, scale1, shift1, gamma2, mean2, invstd2, scale2, shift2, act, dgamma1, dbeta1, dgamma2, dbeta2, coef_ws6, dx1, lddx1, dx2, lddx2, M, C, stream);
+}
+extern "C" int rd_bn_bwd_apply_x2_p(const float* dy, int32_t lddy, const float* x1, int32_t ldx1, const float* x2, int32_t ldx2, const float* red_partial, int32_t n_tiles, const float* gamma1, const float* mean1, const float* invstd1, const float* scale1, const float* shift1, const float* gamma2, const float* mean2, const float* invstd2, const float* scale2, const float* shift2, int32_t act, float* dgamma1, float* dbeta1, float* dgamma2, float* dbeta2, float* coef_ws6, float* dx1, int32_t lddx1, float* dx2, int32_t lddx2, int64_t M, int32_t C, void* pieces1, int64_t piece_elems1, void* pieces2, int64_t piece_elems2, void* stream) {
+    return rd_bn_bwd_apply_x2_T<float>(dy, lddy, x1, ldx1, x2, ldx2, red_partial, n_tiles, gamma1, mean1, invstd1, scale1, shift1, gamma2, mean2, invstd2, scale2, shift2, act, dgamma1, dbeta1, dgamma2, dbeta2, coef_ws6, dx1, lddx1, dx2, lddx2, M, C, stream, pieces1, piece_elems1, pieces2, piece_elems2);
 }
 // storage-typed form: dtype = RD_DTYPE_F32 / RD_DTYPE_BF16 selects the element type of the NHWC tensors (strides in elements)
 extern "C" int rd_bn_bwd_apply_x2_t(int32_t dtype, const void* dy, int32_t lddy, const void* x1, int32_t ldx1, const void* x2, int32_t ldx2, const float* red_partial, int32_t n_tiles, const float* gamma1, const float* mean1, const float* invstd1, const float* scale1, const float* shift1, const float* gamma2, const float* mean2, const float* invstd2, const float* scale2, const float* shift2, int32_t act, float* dgamma1, float* dbeta1, float* dgamma2, float* dbeta2, float* coef_ws6, void* dx1, int32_t lddx1, void* dx2, int32_t lddx2, int64_t M, int32_t C, void* stream) {
@@ -687,20 +714,25 @@ extern "C" int rd_bn_bwd_apply_x2_t(int32_t dtype, const void* dy, int32_t lddy,
 
 // Apply pass paired with rd_bn_bwd_reduce_x(g = NULL): dy is the raw output gradient, the activation factor is recomputed from x.
 template <typename T>
-static int rd_bn_bwd_apply_x_T(const T* dy, int32_t lddy, const T* x, int32_t ldx, const float* red_partial, int32_t n_tiles, const float* gamma, const float* mean, const float* invstd, const float* scale, const float* shift, int32_t act, float* dgamma, float* dbeta, float* coef_ws, T* dx, int32_t lddx, int64_t M, int32_t C, void* stream) {
+static int rd_bn_bwd_apply_x_T(const T* dy, int32_t lddy, const T* x, int32_t ldx, const float* red_partial, int32_t n_tiles, const float* gamma, const float* mean, const float* invstd, const float* scale, const float* shift, int32_t act, float* dgamma, float* dbeta, float* coef_ws, T* dx, int32_t lddx, int64_t M, int32_t C, void* stream,
+                               void* pieces = nullptr, int64_t piece_elems = 0) {
     RD_CHECK_ARG(dy && x && red_partial && gamma && mean && invstd && scale && shift && coef_ws && dx && M > 0 && C % 4 == 0,
                  "bn_bwd_apply_x: bad arguments");
+    RD_CHECK_ARG(!pieces || (C % 16 == 0 && piece_elems >= (int64_t)C * M && reinterpret_cast<uintptr_t>(pieces) % 16 == 0), "bn_bwd_apply_x: bad piece planes");
     hipStream_t s = static_cast<hipStream_t>(stream);
     hipLaunchKernelGGL(bn_bwd_coeffs_kernel, dim3(C), dim3(256), 0, s, red_partial, n_tiles, C, 1, (double)M, gamma, invstd, dgamma,
                        dbeta, coef_ws);
     RD_CHECK_LAUNCH("bn_bwd_coeffs_kernel");
     hipLaunchKernelGGL((bn_bwd_dx_kernel<T>), dim3(ew_grid(M * (C / 4))), dim3(256), 0, s, dy, lddy, x, ldx, mean, coef_ws, dx, lddx, M, C,
-                       scale, shift, act);
+                       scale, shift, act, static_cast<unsigned short*>(pieces), piece_elems);
     RD_CHECK_LAUNCH("bn_bwd_dx_kernel");
     return RD_OK;
 }
 extern "C" int rd_bn_bwd_apply_x(const float* dy, int32_t lddy, const float* x, int32_t ldx, const float* red_partial, int32_t n_tiles, const float* gamma, const float* mean, const float* invstd, const float* scale, const float* shift, int32_t act, float* dgamma, float* dbeta, float* coef_ws, float* dx, int32_t lddx, int64_t M, int32_t C, void* stream) {
     return rd_bn_bwd_apply_x_T<float>(dy, lddy, x, ldx, red_partial, n_tiles, gamma, mean, invstd, scale, shift, act, dgamma, dbeta, coef_ws, dx, lddx, M, C, stream);
+}
+extern "C" int rd_bn_bwd_apply_x_p(const float* dy, int32_t lddy, const float* x, int32_t ldx, const float* red_partial, int32_t n_tiles, const float* gamma, const float* mean, const float* invstd, const float* scale, const float* shift, int32_t act, float* dgamma, float* dbeta, float* coef_ws, float* dx, int32_t lddx, int64_t M, int32_t C, void* pieces, int64_t piece_elems, void* stream) {
+    return rd_bn_bwd_apply_x_T<float>(dy, lddy, x, ldx, red_partial, n_tiles, gamma, mean, invstd, scale, shift, act, dgamma, dbeta, coef_ws, dx, lddx, M, C, stream, pieces, piece_elems);
 }
 // storage-typed form: dtype = RD_DTYPE_F32 / RD_DTYPE_BF16 selects the element type of the NHWC tensors (strides in elements)
 extern "C" int rd_bn_bwd_apply_x_t(int32_t dtype, const void* dy, int32_t lddy, const void* x, int32_t ldx, const float* red_partial, int32_t n_tiles, const float* gamma, const float* mean, const float* invstd, const float* scale, const float* shift, int32_t act, float* dgamma, float* dbeta, float* coef_ws, void* dx, int32_t lddx, int64_t M, int32_t C, void* stream) {
@@ -711,16 +743,21 @@ extern "C" int rd_bn_bwd_apply_x_t(int32_t dtype, const void* dy, int32_t lddy, 
 }
 
 template <typename T>
-static int rd_bnact_maxpool_fwd_T(const T* x, const float* scale, const float* shift, int32_t act, int32_t N, int32_t H, int32_t W, int32_t C, T* y, int32_t ldy, uint8_t* idx, void* stream) {
+static int rd_bnact_maxpool_fwd_T(const T* x, const float* scale, const float* shift, int32_t act, int32_t N, int32_t H, int32_t W, int32_t C, T* y, int32_t ldy, uint8_t* idx, void* stream,
+                                  void* pieces = nullptr, int64_t piece_elems = 0) {
     RD_CHECK_ARG(x && scale && shift && y && idx && C % 4 == 0 && ldy % 4 == 0, "bnact_maxpool_fwd: bad arguments");
+    RD_CHECK_ARG(!pieces || (C % 16 == 0 && reinterpret_cast<uintptr_t>(pieces) % 16 == 0), "bnact_maxpool_fwd: bad piece planes");
     const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
     hipLaunchKernelGGL((bnact_maxpool_fwd_kernel<T>), dim3(ew_grid((int64_t)N * Ho * Wo * (C / 4))), dim3(256), 0,
-                       static_cast<hipStream_t>(stream), x, scale, shift, act, N, H, W, C, Ho, Wo, y, ldy, idx);
+                       static_cast<hipStream_t>(stream), x, scale, shift, act, N, H, W, C, Ho, Wo, y, ldy, idx, static_cast<unsigned short*>(pieces), piece_elems);
     RD_CHECK_LAUNCH("bnact_maxpool_fwd_kernel");
     return RD_OK;
 }
 extern "C" int rd_bnact_maxpool_fwd(const float* x, const float* scale, const float* shift, int32_t act, int32_t N, int32_t H, int32_t W, int32_t C, float* y, int32_t ldy, uint8_t* idx, void* stream) {
     return rd_bnact_maxpool_fwd_T<float>(x, scale, shift, act, N, H, W, C, y, ldy, idx, stream);
+}
+extern "C" int rd_bnact_maxpool_fwd_p(const float* x, const float* scale, const float* shift, int32_t act, int32_t N, int32_t H, int32_t W, int32_t C, float* y, int32_t ldy, uint8_t* idx, void* pieces, int64_t piece_elems, void* stream) {
+    return rd_bnact_maxpool_fwd_T<float>(x, scale, shift, act, N, H, W, C, y, ldy, idx, stream, pieces, piece_elems);
 }
 // storage-typed form: dtype = RD_DTYPE_F32 / RD_DTYPE_BF16 selects the element type of the NHWC tensors (strides in elements)
 extern "C" int rd_bnact_maxpool_fwd_t(int32_t dtype, const void* x, const float* scale, const float* shift, int32_t act, int32_t N, int32_t H, int32_t W, int32_t C, void* y, int32_t ldy, uint8_t* idx, void* stream) {

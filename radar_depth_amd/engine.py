@@ -103,6 +103,12 @@ class LateFusionPlan:
         # split: fp32 arithmetic on the bf16 matrix cores for the forward / input-gradient convolutions the library plans that way
         # (csrc/gconv_split.hip: three bf16 pieces per operand, six MFMAs per product, fp32 accumulation); the rest is the fp32 plan
         self.split = bool(split) and not self.bf16
+        # pre: the operands of the split convolutions / weight gradients are split into their three bf16 pieces by the kernels that
+        # PRODUCE them (BatchNorm / activation / pooling passes: HBM-bound, idle VALU) and reach the matrix kernels as piece planes
+        # [piece][C/16][pixels][16] -- rd_gconv_split_pre / rd_wgrad_split_pre stage with global_load_lds only (RD_SPLIT_PRE=0: split
+        # while staging, as in round 3)
+        self.pre = self.split and storage == "fp32" and os.environ.get("RD_SPLIT_PRE", "1") == "1"
+        self._pc = {}          # data_ptr of an NHWC buffer -> dict(t=buffer, pc=piece planes or None, plane=c_int64, prod=[(slot, c0, C)])
         self.dev = next(module.parameters()).device
         # dry_run: record the op lists against host buffers without ever launching (CPU tests of the host logic)
         assert dry_run or self.dev.type == "cuda", "the HIP path needs the module on a GPU"
@@ -173,6 +179,54 @@ class LateFusionPlan:
 
     def op(self, lst, name, fn, *args):
         lst.append((name, fn, args))
+
+    # ------------------------------------------------------------------ pre-split piece planes of an activation / gradient tensor
+    def _pc_entry(self, a):
+        return self._pc.setdefault(a.t.data_ptr(), dict(t=a.t, pc=None, plane=C.c_int64(0), prod=[]))
+
+    def _pc_bind(self, ent):
+        base, t = ent["pc"].data_ptr(), ent["t"]
+        m = t.shape[0] * t.shape[1] * t.shape[2]
+        ent["plane"].value = t.shape[3] * m
+        for slot, c0, _ in ent["prod"]:
+            slot.value = base + (c0 // 16) * m * 32
+
+    def pc_out(self, a):
+        """For the kernel that PRODUCES Act a: (piece pointer, plane stride) arguments -- NULL until a consumer asks for the planes
+        (pc_in), in which case the producer's op writes them next to the fp32 tensor."""
+        if not self.pre or a.C % 16 or a.c0 % 16 or a.ld % 16 or a.t.dtype != torch.float32:
+            return C.c_void_p(0), C.c_int64(0)
+        ent = self._pc_entry(a)
+        slot = C.c_void_p(0)
+        ent["prod"].append((slot, a.c0, a.C))
+        if ent["pc"] is not None:
+            self._pc_bind(ent)
+        return slot, ent["plane"]
+
+    def pc_in(self, a, lst):
+        """For a kernel that CONSUMES Act a as piece planes: (pointer to a's first 16-channel block, plane stride).  The planes are
+        allocated on first request; channels no producer op covers are split by a stand-alone rd_split_pieces pass emitted here."""
+        assert self.pre and a.C % 16 == 0 and a.c0 % 16 == 0 and a.ld % 16 == 0
+        ent = self._pc_entry(a)
+        if ent["pc"] is None:
+            t = ent["t"]
+            ent["pc"] = self.buf(3, t.shape[3] // 16, t.shape[0] * t.shape[1] * t.shape[2], 16, dtype=torch.bfloat16)
+            self._pc_bind(ent)
+        m = a.M
+        ptr_ = C.c_void_p(ent["pc"].data_ptr() + (a.c0 // 16) * m * 32)
+        covered = sorted((c0, c0 + cc) for _, c0, cc in ent["prod"])
+        pos = a.c0
+        for lo, hi in covered:
+            if lo <= pos < hi:
+                pos = hi
+        if pos < a.c0 + a.C and not ent.get("standalone_%d_%d" % (a.c0, a.C)):
+            ent["standalone_%d_%d" % (a.c0, a.C)] = True
+            ent["prod"].append((C.c_void_p(0), a.c0, a.C))
+            self.op(lst, "split_pieces@%x+%d" % (a.t.data_ptr(), a.c0), self.L.rd_split_pieces, a.ptr, a.ld, C.c_int64(m), a.C, ptr_, ent["plane"], self.stream)
+        return ptr_, ent["plane"]
+
+    def _pre_ok(self, a):
+        return self.pre and a.C % 16 == 0 and a.c0 % 16 == 0 and a.ld % 16 == 0 and a.t.dtype == torch.float32
 
     @property
     def stream(self):
@@ -251,11 +305,12 @@ class LateFusionPlan:
         quad = 2 if self.bf16 else 1
         # split plans: each of the two operands (forward, input gradient) is packed as three bf16 piece planes when the library has a
         # split plan for that descriptor, and stays the fp32 operand of rd_gconv otherwise
-        sp_f = sp_d = False
+        sp_f = sp_d = pre_f = False
         if self.split:
             sp_f = self.L.rd_gconv_split_supported(C.byref(d)) == 1
             dd0 = (cd.upproj_dgrad(N, H, W, cin, cout) if upproj else cd.conv_dgrad(N, H, W, cin, cout, k, stride, pad)[0])
             sp_d = self.L.rd_gconv_split_supported(C.byref(dd0)) == 1
+            pre_f = sp_f and self._pre_ok(x) and self.L.rd_gconv_split_pre_supported(C.byref(d)) == 1
         wp = self.buf(3, S, cin, cout, dtype=torch.bfloat16) if sp_f else self.buf(S, cin, cout, dtype=wdt)
         wd = self.buf(3, S, cout, cin, dtype=torch.bfloat16) if sp_d else self.buf(S, cout, cin, dtype=wdt)
         for w, off in weights:
@@ -264,12 +319,17 @@ class LateFusionPlan:
             self.pack_jobs.append((w, wd, o, i, kh * kw, cin, off, cout, 1, None, 3 if sp_d else quad))
         if not sp_f:
             self._tune(d)
-        tiles = (self.L.rd_gconv_split_stat_tiles if sp_f else self.L.rd_gconv_bf16_stat_tiles if self.bf16 else self.L.rd_gconv_stat_tiles_ws)(C.byref(d))
+        tiles = (self.L.rd_gconv_split_pre_stat_tiles if pre_f else self.L.rd_gconv_split_stat_tiles if sp_f else
+                 self.L.rd_gconv_bf16_stat_tiles if self.bf16 else self.L.rd_gconv_stat_tiles_ws)(C.byref(d))
         if tiles < 0:
             check(tiles, "rd_gconv_stat_tiles(%s)" % name)
         stat = self.buf(tiles, 2, cout) if self.train else None
         self.keep.append(d)
-        if sp_f:
+        if pre_f:
+            xp, xplane = self.pc_in(x, lst)
+            self.op(lst, name, self.L.rd_gconv_split_pre, C.byref(d), xp, xplane, _p(wp), C.c_int64(S * cin * cout), out.ptr, C.c_void_p(0), 0, 0,
+                    C.c_void_p(0), 0, _p(stat), self.stream)
+        elif sp_f:
             self.op(lst, name, self.L.rd_gconv_split, C.byref(d), x.ptr, _p(wp), C.c_int64(S * cin * cout), out.ptr, C.c_void_p(0), 0, 0,
                     C.c_void_p(0), 0, _p(stat), self.stream)
         elif self.bf16:
@@ -279,7 +339,7 @@ class LateFusionPlan:
             ws = self._gconv_ws(d, name)
             self.op(lst, name, self.L.rd_gconv_ws, C.byref(d), x.ptr, _p(wp), out.ptr, C.c_void_p(0), 0, _p(stat), _p(ws), self.stream)
         self.taps[name] = out
-        self.meta[name] = ("gconv_split" if sp_f else "gconv_bf16" if self.bf16 else "gconv", d)
+        self.meta[name] = ("gconv_split_pre" if pre_f else "gconv_split" if sp_f else "gconv_bf16" if self.bf16 else "gconv", d)
         ctx = dict(name=name, d=d, x=x, out=out, weights=weights, wd=wd, k=k, stride=stride, pad=pad, upproj=upproj,
                    stat=stat, tiles=tiles, cin=cin, cout=cout, split_dgrad=sp_d)
         return out, ctx
@@ -320,6 +380,16 @@ class LateFusionPlan:
         if nws < 0:
             check(int(nws), "rd_wgrad_workspace_floats(%s)" % name)
         ws = self.buf(int(nws))
+        # pre-split operands: both piece-plane sets are requested HERE, on the current stream in front of the dgrad / wgrad fork, so a
+        # stand-alone split pass (an operand without a piece-writing producer) is ordered before both consumers
+        wg_pre = wg_split and self._pre_ok(x) and self._pre_ok(dout) and self.L.rd_wgrad_split_pre_supported(C.byref(dwd)) == 1
+        sp_d0 = bool(ctx.get("split_dgrad"))
+        dg_pre = need_dx and sp_d0 and self._pre_ok(dout)
+        yp = yplane = xp = xplane = None
+        if wg_pre or dg_pre:
+            yp, yplane = self.pc_in(dout, self.bwd)
+        if wg_pre:
+            xp, xplane = self.pc_in(x, self.bwd)
         # the weight-gradient chain (wgrad + its slab reductions) gates nothing until the bucket boundary: it runs on the
         # wgrad stream, concurrently with the dgrad / BatchNorm chain that continues on the current stream
         cur = self.streams.index(self._s) if self._s in self.streams else 0
@@ -330,9 +400,11 @@ class LateFusionPlan:
             with self.on(wst):
                 if wg_bf16:
                     self.op(self.bwd, name + ".wgrad", self.L.rd_wgrad_bf16_t, self.dt, C.byref(dwd), x.ptr, dout.ptr, _p(ws), self.stream)
+                elif wg_pre:
+                    self.op(self.bwd, name + ".wgrad", self.L.rd_wgrad_split_pre, C.byref(dwd), xp, xplane, yp, yplane, _p(ws), self.stream)
                 else:
                     self.op(self.bwd, name + ".wgrad", f_wgrad, C.byref(dwd), x.ptr, dout.ptr, _p(ws), self.stream)
-                self.meta[name + ".wgrad"] = (fam, dwd)
+                self.meta[name + ".wgrad"] = ("wgrad_split_pre" if wg_pre else fam, dwd)
                 for w, off in sorted(ctx["weights"], key=lambda t: t[1]):
                     o, i, kh, kw = w.shape
                     if self.batch_reduces:
@@ -370,11 +442,16 @@ class LateFusionPlan:
         sp_d = bool(ctx.get("split_dgrad"))
         if sp_d and self.L.rd_gconv_split_supported(C.byref(dd)) != 1:
             raise RuntimeError("%s: the input-gradient operand was packed for rd_gconv_split, but the library has no split plan for the final descriptor" % name)
-        self.meta[name + ".dgrad"] = ("gconv_split" if sp_d else "gconv_bf16" if self.bf16 else "gconv", dd)
+        dg_pre = dg_pre and sp_d and self.L.rd_gconv_split_pre_supported(C.byref(dd)) == 1
+        self.meta[name + ".dgrad"] = ("gconv_split_pre" if dg_pre else "gconv_split" if sp_d else "gconv_bf16" if self.bf16 else "gconv", dd)
         # (bf16 plans keep the separate BatchNorm-backward reduce pass: the same fusion in gconv_bf16's epilogue -- parity-green in
         #  round 3 -- made the bf16-storage step 5 % SLOWER, 1790 -> 1697 samples/s: that kernel's epilogue is already its longest
         #  phase, and the extra x loads sit on it)
-        if sp_d:
+        if dg_pre:
+            self.op(self.bwd, name + ".dgrad", self.L.rd_gconv_split_pre, C.byref(dd), yp, yplane, _p(ctx["wd"]), C.c_int64(k * k * cin * cout), dx.ptr,
+                    C.c_void_p(0), 0, 0, addend.ptr if addend is not None else C.c_void_p(0), addend.ld if addend is not None else 0,
+                    C.c_void_p(0), self.stream)
+        elif sp_d:
             # (no BatchNorm-backward sums from this epilogue: the caller keeps its reduce pass, as in the bf16 plans)
             self.op(self.bwd, name + ".dgrad", self.L.rd_gconv_split, C.byref(dd), dout.ptr, _p(ctx["wd"]), C.c_int64(k * k * cin * cout), dx.ptr,
                     C.c_void_p(0), 0, 0, addend.ptr if addend is not None else C.c_void_p(0), addend.ld if addend is not None else 0,
@@ -486,6 +563,14 @@ class LateFusionPlan:
         """out = act(bn1(x1) [+ bn2(x2) | + x2])."""
         if out is None:
             out = self.act(x1.N, x1.H, x1.W, x1.C)
+        if self._pre_ok(out):
+            pcp, pcs = self.pc_out(out)
+            self.op(self.fwd, name, self.L.rd_bn_act_p, x1.ptr, x1.ld, _p(co1["scale"]), _p(co1["shift"]),
+                    x2.ptr if x2 is not None else C.c_void_p(0), x2.ld if x2 is not None else 0,
+                    _p(co2["scale"]) if co2 is not None else C.c_void_p(0), _p(co2["shift"]) if co2 is not None else C.c_void_p(0),
+                    out.ptr, out.ld, C.c_int64(x1.M), x1.C, act, pcp, pcs, self.stream)
+            self.taps[name] = out
+            return out
         self.op(self.fwd, name, self.L.rd_bn_act_t, self.dt, x1.ptr, x1.ld, _p(co1["scale"]), _p(co1["shift"]),
                 x2.ptr if x2 is not None else C.c_void_p(0), x2.ld if x2 is not None else 0,
                 _p(co2["scale"]) if co2 is not None else C.c_void_p(0), _p(co2["shift"]) if co2 is not None else C.c_void_p(0),
@@ -523,6 +608,15 @@ class LateFusionPlan:
                 dx2 = self.act(x2.N, x2.H, x2.W, Cc)
             b1, b2 = co1["bn"], co2["bn"]
             coef = self.buf(6 * Cc)
+            if self._pre_ok(dx1) and self._pre_ok(dx2):
+                p1, s1_ = self.pc_out(dx1)
+                p2, s2_ = self.pc_out(dx2)
+                self.op(self.bwd, name + ".bwd_apply", self.L.rd_bn_bwd_apply_x2_p, dy.ptr, dy.ld, x1.ptr, x1.ld, x2.ptr, x2.ld, _p(red), tiles,
+                        _p(b1.weight), _p(co1["mean"]), _p(co1["invstd"]), _p(co1["scale"]), _p(co1["shift"]),
+                        _p(b2.weight), _p(co2["mean"]), _p(co2["invstd"]), _p(co2["scale"]), _p(co2["shift"]), act,
+                        _p(self.grad_of(b1.weight)), _p(self.grad_of(b1.bias)), _p(self.grad_of(b2.weight)), _p(self.grad_of(b2.bias)),
+                        _p(coef), dx1.ptr, dx1.ld, dx2.ptr, dx2.ld, C.c_int64(M), Cc, p1, s1_, p2, s2_, self.stream)
+                return dx1, dx2
             self.op(self.bwd, name + ".bwd_apply", self.L.rd_bn_bwd_apply_x2_t, self.dt, dy.ptr, dy.ld, x1.ptr, x1.ld, x2.ptr, x2.ld, _p(red), tiles,
                     _p(b1.weight), _p(co1["mean"]), _p(co1["invstd"]), _p(co1["scale"]), _p(co1["shift"]),
                     _p(b2.weight), _p(co2["mean"]), _p(co2["invstd"]), _p(co2["scale"]), _p(co2["shift"]), act,
@@ -549,6 +643,12 @@ class LateFusionPlan:
     def _bn_apply(self, name, g, x, red, tiles, which, co, dx):
         bn = co["bn"]
         coef = self.buf(3 * co["C"])
+        if self._pre_ok(dx):
+            pcp, pcs = self.pc_out(dx)
+            self.op(self.bwd, name + ".bwd_apply", self.L.rd_bn_bwd_apply_p, g.ptr, g.ld, x.ptr, x.ld, _p(red), tiles, which,
+                    _p(bn.weight), _p(co["mean"]), _p(co["invstd"]), _p(self.grad_of(bn.weight)), _p(self.grad_of(bn.bias)),
+                    _p(coef), dx.ptr, dx.ld, C.c_int64(x.M), co["C"], pcp, pcs, self.stream)
+            return
         self.op(self.bwd, name + ".bwd_apply", self.L.rd_bn_bwd_apply_t, self.dt, g.ptr, g.ld, x.ptr, x.ld, _p(red), tiles, which,
                 _p(bn.weight), _p(co["mean"]), _p(co["invstd"]), _p(self.grad_of(bn.weight)), _p(self.grad_of(bn.bias)),
                 _p(coef), dx.ptr, dx.ld, C.c_int64(x.M), co["C"], self.stream)
@@ -556,6 +656,12 @@ class LateFusionPlan:
     def _bn_apply_x(self, name, dy, x, red, tiles, co, act, dx):
         bn = co["bn"]
         coef = self.buf(3 * co["C"])
+        if self._pre_ok(dx):
+            pcp, pcs = self.pc_out(dx)
+            self.op(self.bwd, name + ".bwd_apply", self.L.rd_bn_bwd_apply_x_p, dy.ptr, dy.ld, x.ptr, x.ld, _p(red), tiles,
+                    _p(bn.weight), _p(co["mean"]), _p(co["invstd"]), _p(co["scale"]), _p(co["shift"]), act,
+                    _p(self.grad_of(bn.weight)), _p(self.grad_of(bn.bias)), _p(coef), dx.ptr, dx.ld, C.c_int64(x.M), co["C"], pcp, pcs, self.stream)
+            return
         self.op(self.bwd, name + ".bwd_apply", self.L.rd_bn_bwd_apply_x_t, self.dt, dy.ptr, dy.ld, x.ptr, x.ld, _p(red), tiles,
                 _p(bn.weight), _p(co["mean"]), _p(co["invstd"]), _p(co["scale"]), _p(co["shift"]), act,
                 _p(self.grad_of(bn.weight)), _p(self.grad_of(bn.bias)), _p(coef), dx.ptr, dx.ld, C.c_int64(x.M), co["C"], self.stream)
@@ -582,8 +688,13 @@ class LateFusionPlan:
         Hp, Wp = (Hc - 1) // 2 + 1, (Wc - 1) // 2 + 1
         pooled = self.act(N, Hp, Wp, cout)
         idx = self.buf(N, Hp, Wp, cout, dtype=torch.uint8)
-        self.op(self.fwd, name + ".bnact_pool", self.L.rd_bnact_maxpool_fwd_t, self.dt, raw.ptr, _p(co["scale"]), _p(co["shift"]), act, N, Hc, Wc,
-                cout, pooled.ptr, pooled.ld, _p(idx), self.stream)
+        if self._pre_ok(pooled):
+            pcp, pcs = self.pc_out(pooled)
+            self.op(self.fwd, name + ".bnact_pool", self.L.rd_bnact_maxpool_fwd_p, raw.ptr, _p(co["scale"]), _p(co["shift"]), act, N, Hc, Wc,
+                    cout, pooled.ptr, pooled.ld, _p(idx), pcp, pcs, self.stream)
+        else:
+            self.op(self.fwd, name + ".bnact_pool", self.L.rd_bnact_maxpool_fwd_t, self.dt, raw.ptr, _p(co["scale"]), _p(co["shift"]), act, N, Hc, Wc,
+                    cout, pooled.ptr, pooled.ld, _p(idx), self.stream)
         self.taps[out_name] = pooled
         return pooled, dict(name=name, pl=pl, st=st, cin=cin, cout=cout, raw=raw, wp=wp, co=co, idx=idx, act=act, conv=conv,
                             pooled=pooled, Hc=Hc, Wc=Wc)
