@@ -61,7 +61,11 @@ def kernel_identity(L, kind, d, io16=False):
         info = (C.c_int32 * 8)()
         L.rd_gconv_split_plan_info(C.byref(d), info)          # MT, NT, TH, TW, PP, lds, workgroups, tap groups + 100 * double-buffered patch
         return "gconv_split_kernel<%d,%d,%s>" % (info[0], info[1], tb_(info[7] >= 100))
-    if kind == "wgrad_split":
+    if kind == "gconv_split_pre":
+        info = (C.c_int32 * 8)()
+        L.rd_gconv_split_pre_plan_info(C.byref(d), info)
+        return "gconv_sp2_kernel<%d,%d,0>" % (info[0], info[1])
+    if kind in ("wgrad_split", "wgrad_split_pre"):
         return "wgrad_split_kernel"
     if kind == "wgrad_bf16":
         info = (C.c_int32 * 8)()
@@ -480,7 +484,7 @@ def main():
                                   "operand (x = x0 + x1 + x2 exactly), six v_mfma_f32_32x32x16_bf16 terms per product (the three dropped terms are below "
                                   "2^-24 of it), fp32 accumulation; error vs fp64 at the level of the fp32 MFMA kernels, pinned against the CPU oracle at "
                                   "this batch size at the fp32 bars (tests/test_gpu_configs.py, tests/test_gpu_gconv_split.py, tests/test_gpu_wgrad_split.py); "
-                                  "all other kernels fp32 (v_mfma_f32_32x32x2_f32 / VALU)" % (kinds0.count("gconv_split"), kinds0.count("wgrad_split")))
+                                  "all other kernels fp32 (v_mfma_f32_32x32x2_f32 / VALU)" % (kinds0.count("gconv_split") + kinds0.count("gconv_split_pre"), kinds0.count("wgrad_split") + kinds0.count("wgrad_split_pre")))
     elif not bf16:
         out["config"]["arith"] = "fp32 everywhere: every convolution on v_mfma_f32_32x32x2_f32 (the alternate plan of the default line)"
     per_gpu = out["value"] / world
@@ -507,7 +511,7 @@ def main():
                 pass
         common = {"kernel": name, "launches_per_step": n, "avg_launch_us": round(1e3 * ms / n, 2), "traffic": traffic,
                   "traffic_source": traffic_source}
-        if not bf16 and name.startswith(("gconv_split_kernel", "wgrad_split_kernel")):
+        if not bf16 and name.startswith(("gconv_split_kernel", "wgrad_split_kernel", "gconv_sp2_kernel")):
             # the dominant kernel runs six bf16 MFMAs per fp32 multiply-add: priced against the dense bf16 peak on the MFMA FLOPs it
             # actually issues (6 x algorithmic); `fp32_equivalent_tflops` is the algorithmic rate next to the fp32 MFMA peak
             achieved = 6.0 * flops / (ms * 1e-3) / 1e12

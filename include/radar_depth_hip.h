@@ -150,6 +150,9 @@ int rd_gconv_split_plan_info(const RdConvDesc* d, int32_t* out);
  * both run the same tile; the plan (hence rd_gconv_split_pre_stat_tiles) is its own. */
 int rd_split_pieces(const float* x, int32_t ldx, int64_t M, int32_t C, void* pieces, int64_t piece_elems, void* stream);
 int rd_gconv_split_pre_supported(const RdConvDesc* d);
+/* 1 when the pre-split form is expected to be the fastest plan for d including its producer's extra piece pass (planner rule from the
+ * measurements in profiles/r04_*): what engine.py asks before it routes a convolution through rd_gconv_split_pre */
+int rd_gconv_split_pre_preferred(const RdConvDesc* d);
 int rd_gconv_split_pre(const RdConvDesc* d, const void* in_pieces, int64_t in_piece_elems, const void* w_split, int64_t piece_elems, float* out,
                        const float* bias, int32_t act, int32_t act_cols, const float* addend, int32_t ld_add, float* stat_partial, void* stream);
 int rd_gconv_split_pre_stat_tiles(const RdConvDesc* d);

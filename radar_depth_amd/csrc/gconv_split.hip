@@ -1242,7 +1242,7 @@ static bool gs_plan_all() {
     return g_gs_all == 1;
 }
 
-static bool gs_shape_ok(const RdConvDesc* d) {
+static bool gs_shape_ok(const RdConvDesc* d, bool sp2 = false) {
     if (!d || d->n_phases < 1 || d->n_phases > RD_MAX_PHASES) return false;
     if (d->Cin % 16 != 0 || d->ldi % 4 != 0 || d->Cin < 32 || d->Cout < 32) return false;      // (the 16-channel layers stay on conv16.hip)
     if (d->in_stride < 1 || d->in_stride > 2 || d->out_stride < 1 || d->out_stride > 2) return false;
@@ -1257,7 +1257,8 @@ static bool gs_shape_ok(const RdConvDesc* d) {
         int taps_max = 0;
         for (int i = 0; i < d->n_phases; ++i) taps_max = taps_max > d->phase[i].n_taps ? taps_max : d->phase[i].n_taps;
         if (taps_max < 4) return false;
-        if (d->Cin < 64 || d->Cout < 64) return false;
+        // (gconv_sp2_kernel has 32-wide output tiles at two workgroups per CU: the 32-channel decoder / depth-encoder layers pay there)
+        if (!sp2 && (d->Cin < 64 || d->Cout < 64)) return false;
         if (d->in_stride == 2 && taps_max <= 9) return false;       // stride-2 forward (the UpProj input gradient has 25 taps)
         if (d->out_stride == 2 && taps_max <= 4) return false;      // stride-2 input gradient (phases of 1 / 2 / 2 / 4 taps)
     }
@@ -1292,7 +1293,7 @@ static int gs_plan_query(const RdConvDesc* d, GsPlan& pl, RdConvDesc& dd, bool p
     e.dd = *d;
     static const char* no_sp2 = getenv("RD_GCONV_SP2");          // RD_GCONV_SP2=0: pre-split input on the 8-wave kernel (diagnostics)
     const bool sp2 = pre && !(no_sp2 && atoi(no_sp2) == 0);
-    e.ok = gs_shape_ok(d) && (sp2 ? plan_sp2(e.dd, e.pl) : plan_gconv_split(e.dd, e.pl, pre)) ? 1 : 0;
+    e.ok = gs_shape_ok(d, sp2) && (sp2 ? plan_sp2(e.dd, e.pl) : plan_gconv_split(e.dd, e.pl, pre)) ? 1 : 0;
     if (e.ok) {
         int tb = 0;
         for (int i = 0; i < e.dd.n_phases; ++i) {
@@ -1441,6 +1442,22 @@ extern "C" int rd_gconv_split_pre(const RdConvDesc* d, const void* in_pieces, in
 extern "C" int rd_gconv_split_pre_supported(const RdConvDesc* d) {
     GsPlan pl; RdConvDesc dd;
     return gs_plan_query(d, pl, dd, true);
+}
+
+// 1 when the pre-split form is expected to beat BOTH rd_gconv_split (split while staging) and rd_gconv on d by more than the extra
+// 6 bytes per element its producer has to write -- measured at b = 16, 450 x 800 (profiles/r04_bench_split_pre.txt): the shapes
+// rd_gconv_split does not serve at all (32-channel layers: gconv_sp2_kernel's 32-wide tiles at two workgroups per CU), and the
+// 64-channel-input layers with >= 5 workgroups per CU on the 2 x 2 tile (layer1: 178 -> 142 us; UpProj 64: 134 -> 123 us), where the
+// prologue / epilogue of one-workgroup-per-CU launches is a quarter of the lifetime.  Callers (engine.py) use the plain forms otherwise.
+extern "C" int rd_gconv_split_pre_preferred(const RdConvDesc* d) {
+    GsPlan pl; RdConvDesc dd;
+    if (gs_plan_query(d, pl, dd, true) != 1 || !pl.sp2) return 0;
+    static const char* force = getenv("RD_GCONV_PRE_PREFER");    // diagnostics: "all" / "none"
+    if (force) return force[0] == 'a';
+    GsPlan p8; RdConvDesc d8;
+    if (gs_plan_query(d, p8, d8, false) != 1) return 1;
+    const int wgs = d->N * pl.tiles_total * pl.n_cotiles;
+    return pl.MT == 2 && pl.NT == 2 && wgs >= 5 * num_cus() && d->Cin <= 64 ? 1 : 0;
 }
 
 extern "C" int rd_gconv_split_pre_stat_tiles(const RdConvDesc* d) {

@@ -305,12 +305,20 @@ class LateFusionPlan:
         quad = 2 if self.bf16 else 1
         # split plans: each of the two operands (forward, input gradient) is packed as three bf16 piece planes when the library has a
         # split plan for that descriptor, and stays the fp32 operand of rd_gconv otherwise
-        sp_f = sp_d = pre_f = False
+        sp_f = sp_d = pre_f = pre_d = False
         if self.split:
             sp_f = self.L.rd_gconv_split_supported(C.byref(d)) == 1
             dd0 = (cd.upproj_dgrad(N, H, W, cin, cout) if upproj else cd.conv_dgrad(N, H, W, cin, cout, k, stride, pad)[0])
             sp_d = self.L.rd_gconv_split_supported(C.byref(dd0)) == 1
-            pre_f = sp_f and self._pre_ok(x) and self.L.rd_gconv_split_pre_supported(C.byref(d)) == 1
+            # the pre-split form (operand split by its producer, gconv_sp2_kernel) where the library expects it to win even after the
+            # producer's extra piece pass -- incl. 32-channel layers rd_gconv_split does not serve
+            pre_f = (self._pre_ok(x) and self.L.rd_gconv_split_pre_supported(C.byref(d)) == 1
+                     and self.L.rd_gconv_split_pre_preferred(C.byref(d)) == 1)
+            sp_f = sp_f or pre_f
+            # (the input gradient's operand is a [N,Ho,Wo,cout] tensor the BatchNorm backward produces: same alignment rule)
+            pre_d = (self.pre and cout % 16 == 0 and self.L.rd_gconv_split_pre_supported(C.byref(dd0)) == 1
+                     and self.L.rd_gconv_split_pre_preferred(C.byref(dd0)) == 1)
+            sp_d = sp_d or pre_d
         wp = self.buf(3, S, cin, cout, dtype=torch.bfloat16) if sp_f else self.buf(S, cin, cout, dtype=wdt)
         wd = self.buf(3, S, cout, cin, dtype=torch.bfloat16) if sp_d else self.buf(S, cout, cin, dtype=wdt)
         for w, off in weights:
@@ -341,7 +349,7 @@ class LateFusionPlan:
         self.taps[name] = out
         self.meta[name] = ("gconv_split_pre" if pre_f else "gconv_split" if sp_f else "gconv_bf16" if self.bf16 else "gconv", d)
         ctx = dict(name=name, d=d, x=x, out=out, weights=weights, wd=wd, k=k, stride=stride, pad=pad, upproj=upproj,
-                   stat=stat, tiles=tiles, cin=cin, cout=cout, split_dgrad=sp_d)
+                   stat=stat, tiles=tiles, cin=cin, cout=cout, split_dgrad=sp_d, pre_dgrad=self.split and pre_d)
         return out, ctx
 
     def conv_bwd(self, ctx, dout, need_dx=True, addend=None, dx=None, bnb=None):
@@ -382,9 +390,12 @@ class LateFusionPlan:
         ws = self.buf(int(nws))
         # pre-split operands: both piece-plane sets are requested HERE, on the current stream in front of the dgrad / wgrad fork, so a
         # stand-alone split pass (an operand without a piece-writing producer) is ordered before both consumers
-        wg_pre = wg_split and self._pre_ok(x) and self._pre_ok(dout) and self.L.rd_wgrad_split_pre_supported(C.byref(dwd)) == 1
+        # (the weight gradient keeps splitting while it stages: its pre-split form measured 0.8-0.9x, profiles/r04_bench_wgrad_split.txt;
+        #  RD_WGRAD_PRE=1 opts in)
+        wg_pre = (wg_split and os.environ.get("RD_WGRAD_PRE", "0") == "1" and self._pre_ok(x) and self._pre_ok(dout)
+                  and self.L.rd_wgrad_split_pre_supported(C.byref(dwd)) == 1)
         sp_d0 = bool(ctx.get("split_dgrad"))
-        dg_pre = need_dx and sp_d0 and self._pre_ok(dout)
+        dg_pre = need_dx and sp_d0 and bool(ctx.get("pre_dgrad")) and self._pre_ok(dout)
         yp = yplane = xp = xplane = None
         if wg_pre or dg_pre:
             yp, yplane = self.pc_in(dout, self.bwd)
@@ -440,9 +451,10 @@ class LateFusionPlan:
             if addend is not None:
                 raise NotImplementedError("addend with a zero-filled stride-2 dgrad")
         sp_d = bool(ctx.get("split_dgrad"))
-        if sp_d and self.L.rd_gconv_split_supported(C.byref(dd)) != 1:
-            raise RuntimeError("%s: the input-gradient operand was packed for rd_gconv_split, but the library has no split plan for the final descriptor" % name)
         dg_pre = dg_pre and sp_d and self.L.rd_gconv_split_pre_supported(C.byref(dd)) == 1
+        if sp_d and not dg_pre and self.L.rd_gconv_split_supported(C.byref(dd)) != 1:
+            raise RuntimeError("%s: the input-gradient operand was packed as three bf16 pieces, but the library has neither a split plan for "
+                               "the final descriptor nor piece planes for its output-gradient tensor" % name)
         self.meta[name + ".dgrad"] = ("gconv_split_pre" if dg_pre else "gconv_split" if sp_d else "gconv_bf16" if self.bf16 else "gconv", dd)
         # (bf16 plans keep the separate BatchNorm-backward reduce pass: the same fusion in gconv_bf16's epilogue -- parity-green in
         #  round 3 -- made the bf16-storage step 5 % SLOWER, 1790 -> 1697 samples/s: that kernel's epilogue is already its longest

@@ -210,7 +210,7 @@ def test_split_step_matches_oracle():
     opt = torch.optim.SGD(o.parameters(), 0.01, momentum=0.9, weight_decay=1e-4)
     ts = HipTrainStep(m, b, h, w, lr=0.01, momentum=0.9, weight_decay=1e-4, operands="split")
     kinds = [k for k, _ in ts.plan.meta.values()]
-    assert kinds.count("gconv_split") > 40, "the split plan must route its convolutions to rd_gconv_split"
+    assert kinds.count("gconv_split") + kinds.count("gconv_split_pre") > 40, "the split plan must route its convolutions to rd_gconv_split"
     crit = OL1()
     for it in range(3):
         x, t = make_batch(b, h, w, 99 + it, ref_pixels=h * w)
@@ -294,7 +294,7 @@ def test_multistage_split_step_matches_oracle():
     crit = otrain.make_criterion(args.arch)
     ts = hmain.HipTrainStep(hm, b, h, w, lr=0.01, momentum=0.9, weight_decay=1e-4, loss_weights=hw_, operands="split")
     kinds = [k for pl in ts.plans for k, _ in pl.meta.values()]
-    assert kinds.count("gconv_split") > 80 and kinds.count("wgrad_split") > 40
+    assert kinds.count("gconv_split") + kinds.count("gconv_split_pre") > 80 and kinds.count("wgrad_split") > 40
     for it in range(3):
         x, t = make_batch(b, h, w, 500 + it, ref_pixels=h * w)
         lo, _, _ = otrain.train_step(args.arch, om, crit, opt, x, t, ow)

@@ -32,9 +32,10 @@ def one(name, cnt, flops, dsc, a, o, wt, tr):
     t32 = timeit(lambda: ops.gconv(dsc, a, wp, o))
     tsp = tpre = t32
     tpc = 0.0
-    if ops.gconv_split_supported(dsc):
+    if ops.gconv_split_supported(dsc) or ops.gconv_split_pre_supported(dsc):
         ws = ops.pack_weights_split(wt, transpose=tr)
-        tsp = timeit(lambda: ops.gconv_split(dsc, a, ws, o))
+        if ops.gconv_split_supported(dsc):
+            tsp = timeit(lambda: ops.gconv_split(dsc, a, ws, o))
         if ops.gconv_split_pre_supported(dsc):
             ap = ops.split_pieces(a)
             tpre = timeit(lambda: ops.gconv_split_pre(dsc, ap, ws, o))
