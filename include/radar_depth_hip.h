@@ -534,6 +534,11 @@ int rd_head_conv_bwd_t(int32_t dtype, const void* x, int32_t ldx, const float* w
  * allow_split: 1 for the rd_gconv_ws form (with workspace), 0 for rd_gconv. */
 int rd_gconv_tune_candidates(const RdConvDesc* d, int32_t allow_split, int32_t* out, int32_t max_candidates);
 int rd_gconv_tune_pin(const RdConvDesc* d, int32_t allow_split, const int32_t* candidate);
+/* rd_gconv_tune_commit: the pinned (or, if none, the heuristic) plan of d is final -- call it after the last pin and BEFORE sizing
+ * statistics tiles / workspaces on the plan; afterwards rd_gconv_tune_candidates returns 0 and rd_gconv_tune_pin refuses for d.
+ * rd_gconv_plan_state: 0 not planned, 1 pinned and still replaceable, 2 in use. */
+int rd_gconv_tune_commit(const RdConvDesc* d, int32_t allow_split);
+int rd_gconv_plan_state(const RdConvDesc* d, int32_t allow_split);
 
 /* diagnostics: fill every CU's LDS with NaN bit patterns (LDS is not cleared between kernels): a kernel that consumes an LDS
  * word it never wrote then yields NaN instead of depending on its predecessor's leftovers (tools/fuzz_conv.py --poison) */

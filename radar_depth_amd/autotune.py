@@ -154,7 +154,25 @@ def pin_from_table(L, d, allow_split=True):
     ent = _table().get(desc_key(d, allow_split))
     if ent is None:
         return False
-    return L.rd_gconv_tune_pin(C.byref(d), int(allow_split), (C.c_int32 * 9)(*ent["plan"])) == 0
+    if L.rd_gconv_plan_state(C.byref(d), int(allow_split)) == 2:      # already planned and in use (buffers sized on it): keep it, silently
+        return False
+    if L.rd_gconv_tune_pin(C.byref(d), int(allow_split), (C.c_int32 * 9)(*ent["plan"])) != 0:
+        # a table entry the planner no longer accepts (planner change, different CU count): fall back to the heuristic, loudly once
+        global _TABLE_REJECTS
+        _TABLE_REJECTS += 1
+        if _TABLE_REJECTS == 1:
+            import warnings
+            warnings.warn("radar_depth_amd.autotune: tuned_plans.json holds a plan the library rejects for this device (%s); using the "
+                          "heuristic plan -- regenerate the table with tools/make_tuned_table.py" % L.rd_last_error().decode())
+        return False
+    return True
+
+
+_TABLE_REJECTS = 0
+
+
+def table_rejects():
+    return _TABLE_REJECTS
 
 
 def time_plans(L, d, device, plans, rounds=5, allow_split=True):

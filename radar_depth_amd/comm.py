@@ -64,6 +64,10 @@ def init_from_file(path, rank_, world_, timeout_s=120.0, job_id=None):
     tag = ("" if job_id is None else str(job_id)).encode()
     if rank_ == 0:
         if os.path.exists(path):
+            if job_id is None:
+                import warnings
+                warnings.warn("radar_depth_amd.comm.init_from_file: %s already exists (a crashed earlier run?) and no job_id was given: a rank "
+                              "that read the stale token before this one is replaced will hang in ncclCommInitRank -- pass job_id" % path)
             os.unlink(path)
         token = _new_token()
         with open(path + ".tmp", "wb") as f:

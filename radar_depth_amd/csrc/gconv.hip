@@ -1061,6 +1061,31 @@ extern "C" int rd_gconv_tune_pin(const RdConvDesc* d, int32_t allow_split, const
     return RD_OK;
 }
 
+// A pinned plan is provisional (tuner_owned) until it is COMMITTED: callers commit right after their last pin for a descriptor and
+// before they size statistics tiles / workspaces on it.  From then on the entry behaves like a heuristic plan somebody uses:
+// rd_gconv_tune_candidates returns 0 for it and rd_gconv_tune_pin refuses, so a later tuner (or table lookup) in the same process
+// cannot swap the plan under buffers that were sized on it.  A descriptor nobody planned yet is planned (heuristically) and committed.
+extern "C" int rd_gconv_tune_commit(const RdConvDesc* d, int32_t allow_split) {
+    GconvPlan pl; RdConvDesc dd;
+    int rc = plan_query(d, allow_split != 0, pl, dd, false);
+    if (rc != RD_OK) return rc;
+    std::string key(reinterpret_cast<const char*>(d), sizeof(RdConvDesc));
+    key.push_back(allow_split ? 1 : 0);
+    std::lock_guard<std::mutex> lk(g_plan_mu);
+    auto it = g_plan_cache.find(key);
+    if (it != g_plan_cache.end()) it->second.tuner_owned = 0;
+    return RD_OK;
+}
+// 0: not planned yet, 1: pinned by a tuner and still replaceable, 2: in use (heuristic plan handed out, or a committed pin)
+extern "C" int rd_gconv_plan_state(const RdConvDesc* d, int32_t allow_split) {
+    if (!d) return RD_EINVAL;
+    std::string key(reinterpret_cast<const char*>(d), sizeof(RdConvDesc));
+    key.push_back(allow_split ? 1 : 0);
+    std::lock_guard<std::mutex> lk(g_plan_mu);
+    auto it = g_plan_cache.find(key);
+    return it == g_plan_cache.end() ? 0 : it->second.tuner_owned ? 1 : 2;
+}
+
 // The plan a launch uses.  With a workspace: the split-allowed plan.  Without one: the split-allowed plan when it does not split
 // (callers size the statistics tiles with the _ws query and pass no workspace when it asks for none -- the tuner may have pinned a
 // plan under that key that differs from the no-split heuristic), otherwise the no-split plan.  The heuristic gives the same plan

@@ -146,11 +146,21 @@ extern "C" int rd_optable_run(void* table, int32_t begin, int32_t end, void* con
                  begin, end, static_cast<int>(t->ops.size()));
     RD_CHECK_ARG(n_streams > t->max_slot && (streams != nullptr || t->max_slot < 0), "rd_optable_run: the table uses stream slot %d, %d streams given",
                  t->max_slot, n_streams);
+    // stream slots are patched into a per-call copy of the op's words (<= 48 of them): the table itself is never written, so one
+    // table may be replayed from several threads / streams at once and a failed run leaves no half-patched state behind
+    constexpr int MAX_ARGS = 48;
+    uint64_t local[MAX_ARGS];
     for (int i = begin; i < end; ++i) {
         const Op& op = t->ops[i];
-        for (int p = op.first_patch; p < op.first_patch + op.n_patch; ++p)
-            t->words[t->patches[p].first] = static_cast<uint64_t>(reinterpret_cast<uintptr_t>(streams[t->patches[p].second]));
-        const int rc = op.fn(t->words.data() + op.first_word);
+        const uint64_t* words = t->words.data() + op.first_word;
+        if (op.n_patch > 0) {
+            RD_CHECK_ARG(op.nargs <= MAX_ARGS, "rd_optable_run: op %d has %d arguments", i, op.nargs);
+            memcpy(local, words, sizeof(uint64_t) * op.nargs);
+            for (int p = op.first_patch; p < op.first_patch + op.n_patch; ++p)
+                local[t->patches[p].first - op.first_word] = static_cast<uint64_t>(reinterpret_cast<uintptr_t>(streams[t->patches[p].second]));
+            words = local;
+        }
+        const int rc = op.fn(words);
         if (rc != 0) {
             if (failed_op) *failed_op = i;
             return rc;

@@ -278,6 +278,9 @@ class LateFusionPlan:
         else:
             # offline-tuned plan table (radar_depth_amd/tuned_plans.json): a deterministic lookup, identical on every rank
             self.table_pins += 1 if _at.pin_from_table(self.L, d) else 0
+        # whatever was pinned (or the heuristic) is final from here on: the statistics tiles / workspace sized next depend on it, and a
+        # later tuner or table lookup in this process must not swap it
+        check(self.L.rd_gconv_tune_commit(C.byref(d), 1), "rd_gconv_tune_commit")
 
     def _gconv_ws(self, d, name):
         """Split-K workspace of a descriptor (None when the library's plan does not split)."""

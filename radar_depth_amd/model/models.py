@@ -153,9 +153,18 @@ def _evict_plans(cache, version, room_for=1):
     rebuilt parameter arena go first, then the least recently used.  Eviction only drops the CACHE's reference: a HipTrainStep /
     HipInference / autograd node fetched its plan once and keeps using it, so the plan's HBM and hipEvents go when its last holder
     does (LateFusionPlan.__del__), never under a live step."""
+    import sys
     stale = [k for k in cache if k[4] != version]
     for k in stale + [k for k in cache if k not in stale][:max(0, len(cache) - len(stale) + room_for - PLAN_CACHE_SIZE)]:
-        cache.pop(k)
+        plan = cache.pop(k)
+        # nobody but the cache held it (this frame's name + getrefcount's argument = 2): free its ~11 GB and its hipEvents NOW instead of
+        # whenever the garbage collector gets to a plan that sits in a reference cycle -- ragged last batches plus validate() at
+        # 900x1600 could otherwise briefly hold more than PLAN_CACHE_SIZE plans
+        if sys.getrefcount(plan) <= 2:
+            for pl in ([plan.p1, plan.p2] if hasattr(plan, "p1") else [plan]):
+                if hasattr(pl, "close"):
+                    pl.close()
+                    pl.keep = []
 
 
 # ------------------------------------------------------------------------------------------------

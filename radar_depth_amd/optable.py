@@ -54,10 +54,15 @@ class OpTable:
             n = len(args)
             words = (C.c_uint64 * max(n, 1))()
             slots = (C.c_int32 * max(n, 1))()
+            stream_vals = {s.value for s in self.stream_objs if s.value}
             for i, a in enumerate(args):
                 k = slot_of.get(id(a), -1) if isinstance(a, C.c_void_p) else -1
                 slots[i] = k
                 words[i] = 0 if k >= 0 else _word(a)
+                # a stream handed over as a FRESH c_void_p (equal value, different object) would be baked in and silently survive a
+                # later set_stream(): the last argument of every launching entry point is its stream -- it must be a slot
+                if k < 0 and i == n - 1 and isinstance(a, C.c_void_p) and a.value and a.value in stream_vals:
+                    raise ValueError("op-table: %s passes a stream by value (a new c_void_p), not the plan's stream object" % name)
             rc = L.rd_optable_add(self.h, fn.__name__.encode(), n, words, slots)
             if rc < 0:
                 check(rc, "rd_optable_add(%s -> %s)" % (name, fn.__name__))

@@ -642,3 +642,44 @@ def test_autotuned_plans_keep_parity_and_do_not_disturb_existing_plans():
     l_twin, _ = t1.step(x.cuda(), t.cuda())
     torch.cuda.synchronize()
     assert l_after.item() == l_twin.item() and np.isfinite(l_after.item())
+
+
+@pytest.mark.parametrize("order", ["table_then_tuner", "tuner_then_table"])
+def test_committed_plans_survive_a_later_tuner_at_a_table_geometry(order):
+    """at a geometry the offline-tuned table has entries for (b=16, 450x800), a plan whose buffers were sized on a pinned plan
+    must not be re-pinned by a later HipTrainStep(autotune=True) in the same process -- nor a tuned plan by a later table lookup.  Both
+    orders: the second model's step must leave the first model's step bit-reproducible, and every gconv plan the first one committed
+    must still be the plan the library reports."""
+    import ctypes as C
+    from radar_depth_amd.main import HipTrainStep
+    from radar_depth_amd.synthetic import make_batch
+    b, h, w = 16, 450, 800
+    x, t = make_batch(b, h, w, 77)
+    x, t = x.cuda(), t.cuda()
+    first_tuned = order == "tuner_then_table"
+    m1, _ = _latefusion_pair(h, w)
+    t1 = HipTrainStep(m1, b, h, w, lr=0.0, momentum=0.0, weight_decay=0.0, operands="fp32", autotune=first_tuned)
+    L = t1.L
+
+    def plans(ts):
+        out = {}
+        for name, (kind, d) in ts.plan.meta.items():
+            if kind == "gconv":
+                info = (C.c_int32 * 10)()
+                assert L.rd_gconv_plan_info(C.byref(d), info) == 0
+                out[name] = tuple(info)
+                assert L.rd_gconv_plan_state(C.byref(d), 1) == 2, name          # committed: in use
+        return out
+    before = plans(t1)
+    l1, _ = t1.step(x, t)
+    torch.cuda.synchronize()
+    ref = l1.item()
+    m2, _ = _latefusion_pair(h, w)
+    t2 = HipTrainStep(m2, b, h, w, lr=0.0, momentum=0.0, weight_decay=0.0, operands="fp32", autotune=not first_tuned)
+    l2, _ = t2.step(x, t)
+    torch.cuda.synchronize()
+    assert plans(t1) == before, "a later plan build re-pinned a committed plan"
+    assert plans(t2) == before, "the same descriptors must resolve to the same committed plans"
+    l1b, _ = t1.step(x, t)                       # lr = 0: the step is a pure function of (parameters, batch)
+    torch.cuda.synchronize()
+    assert l1b.item() == ref and l2.item() == ref
