@@ -156,8 +156,9 @@ def test_plan_cache_is_a_small_lru():
         def __init__(self, i):
             self.i = i
 
-        def close(self):
-            closed.append(self.i)
+        def close(self):                                      # idempotent, like LateFusionPlan.close(): eviction closes an un-held plan
+            if self.i not in closed:                          # eagerly, its __del__ then finds nothing left to do
+                closed.append(self.i)
 
         def __del__(self):
             self.close()
