@@ -282,8 +282,10 @@ __global__ __launch_bounds__(512) void gconv_split_kernel(const GsArgs a) {
             }
             return cnt;
         };
-        auto issue_slab = [&](int buf, int cb, int g) {
-            if (a.dbg & 4) return;
+        // (returns the number of copies this wave issued: the pre-split protocol's counted waits)
+        auto issue_slab = [&](int buf, int cb, int g) -> int {
+            if (a.dbg & 4) return 0;
+            int cnt = 0;
             const int tap0 = g * GS_TPS;
             constexpr int welems = (GS_TPS * 2) << LBN;  // 16-byte units of one piece: [tap][2][BN]
             const char* src = reinterpret_cast<const char*>(a.w) + (size_t)(cb >> 3) * a.ldw * 16;
@@ -294,17 +296,25 @@ __global__ __launch_bounds__(512) void gconv_split_kernel(const GsArgs a) {
                 if (e < welems) {
                     const int j = e & (BN - 1), tk = e >> LBN;
                     const int k8 = tk & 1, t = tap0 + (tk >> 1);
-                    if (t < ntaps && co0 + j < D.Cout) {
+                    const bool live = t < ntaps && co0 + j < D.Cout;
+                    if (__any(live)) cnt += 3;
+                    if (live) {
                         const size_t go = (((size_t)s_widx[t] * cin8 + k8) * a.ldw + co0 + j) * 16;
 #pragma unroll
                         for (int p = 0; p < 3; ++p)
                             glds16(reinterpret_cast<const float*>(src + p * a.wplane + go), reinterpret_cast<float*>(dst + p * WPP + (e - lane) * 16));
                     } else {                             // padding taps of the last group, output channels beyond Cout
+                        // (inline assembly: a plain LDS store behind outstanding global_load_lds copies makes the compiler wait for them)
+                        const su32x4 z = {0u, 0u, 0u, 0u};
 #pragma unroll
-                        for (int p = 0; p < 3; ++p) *reinterpret_cast<uint4*>(dst + p * WPP + e * 16) = make_uint4(0u, 0u, 0u, 0u);
+                        for (int p = 0; p < 3; ++p) {
+                            const unsigned ad = (unsigned)(size_t)(dst + p * WPP + e * 16);
+                            asm volatile("ds_write_b128 %0, %1" ::"v"(ad), "v"(z) : "memory");
+                        }
                     }
                 }
             }
+            return cnt;
         };
         sbf16x8 pc[GS_UPP][3];
         float4 v0[GS_UPP], v1[GS_UPP];
@@ -344,26 +354,33 @@ __global__ __launch_bounds__(512) void gconv_split_kernel(const GsArgs a) {
         issue_slab(0, 0, 0);
         if (total_groups > 1) issue_slab(1, ngroups > 1 ? 0 : GS_CKP, ngroups > 1 ? 1 : 0);
         if constexpr (PRE) {
-            // B1(it) publishes what was issued before B1(it - 1) ... except that every copy is awaited in the iteration it was issued in,
-            // bar one case: the next chunk's patch, issued behind the chunk's first barrier, stays in flight over the first group when
-            // the chunk has more than one (counted wait), so that HBM latency never holds a barrier back
+            // Lazy protocol: a copy issued behind B1(it) has until B1(it + 2) to land.  B1(it + 1) only needs what was issued BEFORE this
+            // iteration (weights of group it + 1; at a chunk's end the successor's patch, issued in the chunk's first group), so the
+            // wait in front of it leaves this iteration's own copies in flight (counted: vmcnt retires in order).  The barriers are raw
+            // s_barriers behind an explicit LDS wait: __syncthreads would add a vmcnt(0) for the copies in flight (measured: 7.5 k clocks
+            // in a chunk's first group against 4.9 k of MFMA work, profiles/r04_trace_gconv_split_pre.txt).  The compute waves therefore
+            // read a group's weights only behind its own barrier (no fragment prefetch across it).
+            auto lbarrier = [&]() {
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+                asm volatile("" ::: "memory");
+            };
             issue_patch(0, 0);
-            glds_wait();
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
             int it = 0, wi = 2, c2 = 0, g2 = 2;
             while (g2 >= ngroups) { g2 -= ngroups; ++c2; }
             unsigned long long* ltr = (a.trace && a.trace_role == 2 && tid == 256) ? a.trace + (size_t)blockIdx.x * 64 : nullptr;
             for (int c = 0; c < nchunks; ++c) {
                 for (int g = 0; g < ngroups; ++g, ++it) {
                     if (ltr && it < 30) ltr[2 * it] = __builtin_readcyclecounter();
-                    rd_sync();                        // B1(it)
+                    lbarrier();                       // B1(it)
                     if (ltr && it < 30) ltr[2 * it + 1] = __builtin_readcyclecounter();
-                    if (it + 2 < total_groups) issue_slab(wi, c2 * GS_CKP, g2);
+                    int n_now = 0;
+                    if (it + 2 < total_groups) n_now += issue_slab(wi, c2 * GS_CKP, g2);
                     wi = wi == 2 ? 0 : wi + 1;
                     if (++g2 == ngroups) { g2 = 0; ++c2; }
-                    int np = 0;
-                    if (g == 0 && c + 1 < nchunks) np = issue_patch((c + 1) & 1, c + 1);
-                    if (g == 0 && ngroups > 1) vm_wait_upto(np);
-                    else glds_wait();
+                    if (g == 0 && c + 1 < nchunks) n_now += issue_patch((c + 1) & 1, c + 1);
+                    vm_wait_upto(ngroups > 1 ? n_now : 0);        // (one group per chunk: the patch issued here is needed at the next barrier)
                 }
             }
         } else {
@@ -452,6 +469,20 @@ __global__ __launch_bounds__(512) void gconv_split_kernel(const GsArgs a) {
                 for (int nt = 0; nt < NT; ++nt) B[p][nt] = *reinterpret_cast<const sbf16x8*>(wbl + p * WPP + t * 2 * BN * 16 + nt * 512);
             }
         };
+        auto loadA = [&](const char* pbase, int tap, sbf16x8 (&A)[3][MT]) {
+            const char* pa = pbase + __builtin_amdgcn_readlane(tapv, tap);
+#pragma unroll
+            for (int p = 0; p < 3; ++p)
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) A[p][mt] = *reinterpret_cast<const sbf16x8*>(pa + abase[p][mt]);
+        };
+        auto loadB = [&](const char* wbuf, int t, sbf16x8 (&B)[3][NT]) {
+            const char* wbl = wbuf + boffB;
+#pragma unroll
+            for (int p = 0; p < 3; ++p)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) B[p][nt] = *reinterpret_cast<const sbf16x8*>(wbl + p * WPP + t * 2 * BN * 16 + nt * 512);
+        };
         // issue order of one step: the 3 (MT + NT) fragment reads of the NEXT step go out between this step's first MFMAs, one
         // read (and its address add) per two MFMAs: a burst of reads in front of the MFMAs costs ~250 clocks per step in which
         // the matrix pipe is idle (an in-order wave issues nothing else while it issues them)
@@ -499,9 +530,53 @@ __global__ __launch_bounds__(512) void gconv_split_kernel(const GsArgs a) {
             const char* wbn = s_w + wn * SLAB;
             const int tap0 = g * GS_TPS;
             const bool pref = g + 1 < ngroups;
-            if (!have) load(pbase, wb, min(tap0, ntaps - 1), 0, fa[P0], fb[P0]);
+            if constexpr (PRE && MT == 3 && NT == 2) {      // (rotating form: one A set, the group's first B always in set 0)
+                if (!have) loadA(pbase, min(tap0, ntaps - 1), fa[0]);
+                loadB(wb, 0, fb[0]);
+            } else {
+                if (!have) load(pbase, wb, min(tap0, ntaps - 1), 0, fa[P0], fb[P0]);
+                else if constexpr (PRE) loadB(wb, 0, fb[P0]);
+            }
             __builtin_amdgcn_sched_barrier(0);
-            if constexpr (MT * NT < 4 || (MT * NT == 4 && PDB)) {
+            if constexpr (PRE && MT == 3 && NT == 2) {
+                // The 3 x 2 tile has no registers for two full fragment sets next to its 96 accumulators (the form below reads a step's
+                // 15 fragments in one burst in front of its MFMAs: ~27 clocks each with the matrix pipe idle, 4.9 k clocks per tap group
+                // against 3.5 k of MFMA issue).  Rotating form: ONE set of A fragments, overwritten row by row as soon as a row's twelve
+                // MFMAs have been issued, and two sets of B; the 15 reads of the next step go out two or three at a time between the
+                // 6-MFMA blocks of this one.  B of a group's first step is read behind the group's barrier (lazy weight protocol).
+                auto rstep = [&](sbf16x8 (&A)[3][MT], const sbf16x8 (&Bc)[3][NT], sbf16x8 (&Bn)[3][NT], int tapn, int tn, bool doA, bool doB) {
+                    const char* pa = pbase + __builtin_amdgcn_readlane(tapv, tapn);
+                    const char* wbl = wb + boffB;
+#pragma unroll
+                    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                        for (int nt = 0; nt < NT; ++nt) {
+                            f32x16 c = acc[mt][nt];
+                            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[0][mt], Bc[2][nt], c, 0, 0, 0);
+                            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[1][mt], Bc[1][nt], c, 0, 0, 0);
+                            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[2][mt], Bc[0][nt], c, 0, 0, 0);
+                            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[0][mt], Bc[1][nt], c, 0, 0, 0);
+                            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[1][mt], Bc[0][nt], c, 0, 0, 0);
+                            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[0][mt], Bc[0][nt], c, 0, 0, 0);
+                            acc[mt][nt] = c;
+                            __builtin_amdgcn_sched_barrier(0);
+                            if (nt == 0) {
+                                if (doB) {
+#pragma unroll
+                                    for (int q = 2 * mt; q < 2 * mt + 2; ++q)
+                                        Bn[q / NT][q % NT] = *reinterpret_cast<const sbf16x8*>(wbl + (q / NT) * WPP + tn * 2 * BN * 16 + (q % NT) * 512);
+                                }
+                            } else if (doA) {
+#pragma unroll
+                                for (int pp = 0; pp < 3; ++pp) A[pp][mt] = *reinterpret_cast<const sbf16x8*>(pa + abase[pp][mt]);
+                            }
+                            __builtin_amdgcn_sched_barrier(0);
+                        }
+                };
+                rstep(fa[0], fb[0], fb[1], min(tap0 + 1, ntaps - 1), 1, true, true);
+                rstep(fa[0], fb[1], fb[0], min(tap0 + 2, ntaps - 1), 2, true, true);
+                rstep(fa[0], fb[0], fb[1], min(tap0 + 3, ntaps - 1), 0, pref, false);
+            } else if constexpr (MT * NT < 4 || (MT * NT == 4 && PDB)) {
                 load(pbase, wb, min(tap0 + 1, ntaps - 1), 1, fa[P1], fb[P1]);
                 mma(fa[P0], fb[P0]);
                 interleave();
@@ -511,7 +586,8 @@ __global__ __launch_bounds__(512) void gconv_split_kernel(const GsArgs a) {
                 interleave();
                 __builtin_amdgcn_sched_barrier(0);
                 if (pref) {
-                    load(pbase, wbn, min(tap0 + 3, ntaps - 1), 0, fa[P1], fb[P1]);      // first step of the next group (same chunk)
+                    if constexpr (PRE) loadA(pbase, min(tap0 + 3, ntaps - 1), fa[P1]);     // (the next group's weights are published by ITS barrier)
+                    else load(pbase, wbn, min(tap0 + 3, ntaps - 1), 0, fa[P1], fb[P1]);      // first step of the next group (same chunk)
                     mma(fa[P0], fb[P0]);
                     interleave();
                 } else {
@@ -528,7 +604,10 @@ __global__ __launch_bounds__(512) void gconv_split_kernel(const GsArgs a) {
                 __builtin_amdgcn_sched_barrier(0);
                 mma(fa[P1], fb[P1]);
                 __builtin_amdgcn_sched_barrier(0);
-                if (pref) load(pbase, wbn, min(tap0 + 3, ntaps - 1), 0, fa[P1], fb[P1]);
+                if (pref) {
+                    if constexpr (PRE) loadA(pbase, min(tap0 + 3, ntaps - 1), fa[P1]);
+                    else load(pbase, wbn, min(tap0 + 3, ntaps - 1), 0, fa[P1], fb[P1]);
+                }
                 __builtin_amdgcn_sched_barrier(0);
                 mma(fa[P0], fb[P0]);
             }
