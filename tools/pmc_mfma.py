@@ -34,6 +34,9 @@ for (name, grid), (n, c) in sorted(agg.items(), key=lambda kv: -kv[1][1].get("GR
     if "gconv" not in name and "wgrad" not in name:
         continue
     g = {k: v / n for k, v in c.items()}
+    if "SQ_LDS_IDX_ACTIVE" in g:       # the LDS pass (SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE): extra cycles / all LDS-array cycles
+        print("%s grid=%s: LDS bank conflict cycles / LDS active cycles = %.4f" % (name, grid, g.get("SQ_LDS_BANK_CONFLICT", 0) / max(g["SQ_LDS_IDX_ACTIVE"], 1)))
+        continue
     act = g.get("GRBM_GUI_ACTIVE", 0) / 8.0
     wc = max(g.get("SQ_WAVE_CYCLES", 0), 1.0)
     print("%s grid=%s (%d dispatches)" % (name, grid, n))

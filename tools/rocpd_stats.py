@@ -72,7 +72,8 @@ if "--timeline" in sys.argv:   # how full is the device: union of kernel interva
               sorted(gaps)[len(gaps) // 2] / 1e3 if gaps else 0.0))
     sys.exit(0)
 tot = sum(a[1] for a in agg.values())
-print("# rocprofv3 --kernel-trace summary of %s (%d dispatches, %.3f ms of kernel time%s)" % (sys.argv[1], len(rows), tot / 1e6, steady))
+print("# rocprofv3 --kernel-trace summary of %s (%d dispatches, %.3f ms of kernel time%s) -- collected at git %s"
+      % (sys.argv[1], len(rows), tot / 1e6, steady, __import__("os").environ.get("RD_HEAD", "unknown")))
 print("%-72s %8s %12s %10s %7s" % ("kernel", "calls", "total_ms", "avg_us", "share"))
 for name, (n, t) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
     print("%-72s %8d %12.3f %10.2f %6.1f%%" % (name[:72], n, t / 1e6, t / n / 1e3, 100.0 * t / tot))
