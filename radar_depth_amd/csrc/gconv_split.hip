@@ -1526,7 +1526,7 @@ extern "C" int rd_gconv_split_pre_supported(const RdConvDesc* d) {
 // 1 when the pre-split form is expected to beat BOTH rd_gconv_split (split while staging) and rd_gconv on d by more than the extra
 // 6 bytes per element its producer has to write -- measured at b = 16, 450 x 800 (profiles/r04_bench_split_pre.txt): the shapes
 // rd_gconv_split does not serve at all (32-channel layers: gconv_sp2_kernel's 32-wide tiles at two workgroups per CU), and the
-// 64-channel-input layers with >= 5 workgroups per CU on the 2 x 2 tile (layer1: 178 -> 142 us; UpProj 64: 134 -> 123 us), where the
+// 64-channel-input layers with >= 2.5 workgroups per CU on the 2 x 2 tile (layer1: 178 -> 142 us; UpProj 64: 134 -> 123 us), where the
 // prologue / epilogue of one-workgroup-per-CU launches is a quarter of the lifetime.  Callers (engine.py) use the plain forms otherwise.
 extern "C" int rd_gconv_split_pre_preferred(const RdConvDesc* d) {
     GsPlan pl; RdConvDesc dd;
@@ -1536,7 +1536,9 @@ extern "C" int rd_gconv_split_pre_preferred(const RdConvDesc* d) {
     GsPlan p8; RdConvDesc d8;
     if (gs_plan_query(d, p8, d8, false) != 1) return 1;
     const int wgs = d->N * pl.tiles_total * pl.n_cotiles;
-    return pl.MT == 2 && pl.NT == 2 && wgs >= 5 * num_cus() && d->Cin <= 64 ? 1 : 0;
+    // (>= 2.5 workgroups per CU: b = 8 of BASELINE config 4 -- 736 workgroups on layer1 -- gains like b = 16 does, 389.6 -> 393.6 -> 398.5
+    //  samples/s with none / the b = 16 rule / all pre-split, profiles/r04_*)
+    return pl.MT == 2 && pl.NT == 2 && 2 * wgs >= 5 * num_cus() && d->Cin <= 64 ? 1 : 0;
 }
 
 extern "C" int rd_gconv_split_pre_stat_tiles(const RdConvDesc* d) {
