@@ -60,7 +60,7 @@ def kernel_identity(L, kind, d, io16=False):
     if kind == "gconv_split":
         info = (C.c_int32 * 8)()
         L.rd_gconv_split_plan_info(C.byref(d), info)          # MT, NT, TH, TW, PP, lds, workgroups, tap groups + 100 * double-buffered patch
-        return "gconv_split_kernel<%d,%d,%s>" % (info[0], info[1], tb_(info[7] >= 100))
+        return "gconv_split_kernel<%d,%d,%s,false>" % (info[0], info[1], tb_(info[7] >= 100))
     if kind == "gconv_split_pre":
         info = (C.c_int32 * 8)()
         L.rd_gconv_split_pre_plan_info(C.byref(d), info)
@@ -504,14 +504,18 @@ def main():
             try:
                 tj = json.load(open(os.path.join(REPO, "profiles", tfile)))
                 key = name.replace(" ", "")
-                if key in tj["kernels"]:
-                    traffic = tj["kernels"][key]["hbm_read_bytes_per_launch"] + tj["kernels"][key]["hbm_write_bytes_per_launch"]
+                # exact instantiation, or -- a kernel family the plan runs in several instantiations (wgrad_split_kernel<...>) -- the
+                # dispatch-weighted mean over the instantiations whose name starts with the family's
+                hits = [v for k, v in tj["kernels"].items() if k == key] or [v for k, v in tj["kernels"].items() if k.startswith(key + "<")]
+                if hits:
+                    nd = sum(v["dispatches"] for v in hits)
+                    traffic = int(sum((v["hbm_read_bytes_per_launch"] + v["hbm_write_bytes_per_launch"]) * v["dispatches"] for v in hits) / max(nd, 1))
                     traffic_source = "profiles/%s@%s" % (tfile, tj.get("collected_at", "unknown"))
             except (OSError, KeyError, ValueError):
                 pass
         common = {"kernel": name, "launches_per_step": n, "avg_launch_us": round(1e3 * ms / n, 2), "traffic": traffic,
                   "traffic_source": traffic_source}
-        if not bf16 and name.startswith(("gconv_split_kernel", "wgrad_split_kernel", "gconv_sp2_kernel")):
+        if split and name.startswith(("gconv_split_kernel", "wgrad_split_kernel", "gconv_sp2_kernel")):
             # the dominant kernel runs six bf16 MFMAs per fp32 multiply-add: priced against the dense bf16 peak on the MFMA FLOPs it
             # actually issues (6 x algorithmic); `fp32_equivalent_tflops` is the algorithmic rate next to the fp32 MFMA peak
             achieved = 6.0 * flops / (ms * 1e-3) / 1e12
