@@ -88,6 +88,8 @@ struct WsArgs {
     const unsigned short* yp;
     long long xplane, yplane;   // bytes per piece plane
     long long xm, ym;           // pixels per 16-channel block of a plane (N*Hi*Wi, N*Ho*Wo)
+    int dbg;                    // diagnostics (RD_WGRAD_SPLIT_DEBUG; results are garbage): 1 staging without the split arithmetic, 2 no LDS stores
+                                // in the staging waves, 4 no global loads in the staging waves
 };
 
 __device__ __forceinline__ unsigned ws_cvt_pk(float a, float b) {
@@ -226,6 +228,7 @@ __global__ __launch_bounds__(512) void wgrad_split_kernel(const WsArgs a) {
         const unsigned ximg = (unsigned)(a.Hi * a.Wi * a.ldi) * 4u, yimg = (unsigned)(a.Ho * a.Wo * a.ldo) * 4u;
         float4 v0[G::UPT], v1[G::UPT];
         auto fetch = [&](int tile) {
+            if (a.dbg & 4) return;
             const int n = tile / (a.tiles_h * a.tiles_w), tr = tile - n * (a.tiles_h * a.tiles_w);
             const int r0 = (tr / a.tiles_w) * G::R, c0 = (tr % a.tiles_w) * G::TW;
             const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.x) + (size_t)n * a.Hi * a.Wi * a.ldi, 0, ximg, 0x00020000);
@@ -253,8 +256,9 @@ __global__ __launch_bounds__(512) void wgrad_split_kernel(const WsArgs a) {
 #pragma unroll
             for (int u = 0; u < G::UPT; ++u) {
                 wsu32x4 w0, w1, w2;
-                ws_split8(v0[u], v1[u], w0, w1, w2);
-                if (udst[u] >= 0) {
+                if (a.dbg & 1) { w0 = __builtin_bit_cast(wsu32x4, v0[u]); w1 = __builtin_bit_cast(wsu32x4, v1[u]); w2 = w0; }
+                else ws_split8(v0[u], v1[u], w0, w1, w2);
+                if (udst[u] >= 0 && !(a.dbg & 2)) {
                     const bool is_x = udst[u] < G::XBYTES;
                     const unsigned pstride = is_x ? 2 * G::XPLANE : 2 * G::YPLANE;
                     const unsigned ad = base + udst[u];
@@ -487,6 +491,7 @@ static void ws_fill_args(const RdConvDesc* d, const WsPlan& pl, WsArgs& a) {
     a.n_splits = pl.n_splits; a.n_cib = pl.n_cib; a.n_cob = pl.n_cob;
     a.OS = d->out_stride; a.S = pl.S;
     a.x = nullptr; a.dy = nullptr; a.xp = nullptr; a.yp = nullptr; a.xplane = a.yplane = 0;
+    { const char* dbg = getenv("RD_WGRAD_SPLIT_DEBUG"); a.dbg = dbg ? atoi(dbg) : 0; }
     a.xm = (long long)d->N * d->Hi * d->Wi; a.ym = (long long)d->N * d->Ho * d->Wo;
 }
 
