@@ -533,20 +533,22 @@ __global__ __launch_bounds__(512) void gconv_split_kernel(const GsArgs a) {
             if constexpr (PRE && MT == 3 && NT == 2) {      // (rotating form: one A set, the group's first B always in set 0)
                 if (!have) loadA(pbase, min(tap0, ntaps - 1), fa[0]);
                 loadB(wb, 0, fb[0]);
+            } else if constexpr (MT == 3 && NT == 2) {      // (rotating form, weights published a group ahead: B prefetched like A)
+                if (!have) { loadA(pbase, min(tap0, ntaps - 1), fa[0]); loadB(wb, 0, fb[P0]); }
             } else {
                 if (!have) load(pbase, wb, min(tap0, ntaps - 1), 0, fa[P0], fb[P0]);
                 else if constexpr (PRE) loadB(wb, 0, fb[P0]);
             }
             __builtin_amdgcn_sched_barrier(0);
-            if constexpr (PRE && MT == 3 && NT == 2) {
+            if constexpr (MT == 3 && NT == 2) {
                 // The 3 x 2 tile has no registers for two full fragment sets next to its 96 accumulators (the form below reads a step's
                 // 15 fragments in one burst in front of its MFMAs: ~27 clocks each with the matrix pipe idle, 4.9 k clocks per tap group
                 // against 3.5 k of MFMA issue).  Rotating form: ONE set of A fragments, overwritten row by row as soon as a row's twelve
                 // MFMAs have been issued, and two sets of B; the 15 reads of the next step go out two or three at a time between the
                 // 6-MFMA blocks of this one.  B of a group's first step is read behind the group's barrier (lazy weight protocol).
-                auto rstep = [&](sbf16x8 (&A)[3][MT], const sbf16x8 (&Bc)[3][NT], sbf16x8 (&Bn)[3][NT], int tapn, int tn, bool doA, bool doB) {
+                auto rstep = [&](sbf16x8 (&A)[3][MT], const sbf16x8 (&Bc)[3][NT], sbf16x8 (&Bn)[3][NT], int tapn, const char* wnext, int tn, bool doA, bool doB) {
                     const char* pa = pbase + __builtin_amdgcn_readlane(tapv, tapn);
-                    const char* wbl = wb + boffB;
+                    const char* wbl = wnext + boffB;
 #pragma unroll
                     for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
@@ -573,9 +575,15 @@ __global__ __launch_bounds__(512) void gconv_split_kernel(const GsArgs a) {
                             __builtin_amdgcn_sched_barrier(0);
                         }
                 };
-                rstep(fa[0], fb[0], fb[1], min(tap0 + 1, ntaps - 1), 1, true, true);
-                rstep(fa[0], fb[1], fb[0], min(tap0 + 2, ntaps - 1), 2, true, true);
-                rstep(fa[0], fb[0], fb[1], min(tap0 + 3, ntaps - 1), 0, pref, false);
+                if constexpr (PRE) {
+                    rstep(fa[0], fb[0], fb[1], min(tap0 + 1, ntaps - 1), wb, 1, true, true);
+                    rstep(fa[0], fb[1], fb[0], min(tap0 + 2, ntaps - 1), wb, 2, true, true);
+                    rstep(fa[0], fb[0], fb[1], min(tap0 + 3, ntaps - 1), wb, 0, pref, false);
+                } else {      // (split while staging: the next group's weights were published by THIS group's barrier -- its first B is prefetched too)
+                    rstep(fa[0], fb[P0], fb[P1], min(tap0 + 1, ntaps - 1), wb, 1, true, true);
+                    rstep(fa[0], fb[P1], fb[P0], min(tap0 + 2, ntaps - 1), wb, 2, true, true);
+                    rstep(fa[0], fb[P0], fb[P1], min(tap0 + 3, ntaps - 1), wbn, 0, pref, pref);
+                }
             } else if constexpr (MT * NT < 4 || (MT * NT == 4 && PDB)) {
                 load(pbase, wb, min(tap0 + 1, ntaps - 1), 1, fa[P1], fb[P1]);
                 mma(fa[P0], fb[P0]);
