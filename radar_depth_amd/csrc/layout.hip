@@ -70,8 +70,55 @@ __device__ __forceinline__ void store_split3(__bf16* dst, int64_t idx, int64_t p
     dst[idx + 2 * plane] = (__bf16)r;
 }
 constexpr int PACK_CHUNK = 2048;
+// bf16 operands (quad 2: one plane; quad 3: the three piece planes of gconv_split.hip): a thread owns ONE 16-byte unit position -- eight
+// consecutive reduction rows of one column -- for ALL taps: it reads its 8 x T source values (OIHW: the T taps of an (o, i) pair are
+// contiguous) and writes T whole units per plane, consecutive threads consecutive columns.  (Round 4: element by element this kernel
+// wrote 2-byte values 16 bytes apart -- 264 us for 1.05 GB of HBM traffic per step in the split plan, at the start of the step where
+// nothing overlaps it.)
+__device__ __forceinline__ void pack_units_bf16(const PackJob& j, int64_t u) {
+    const int R = j.transpose ? j.O : j.I;              // reduction rows this job contributes
+    const int Cn = j.transpose ? j.I : j.O;             // columns
+    const int64_t units = (int64_t)(R >> 3) * Cn;
+    if (u >= units) return;
+    const int col = (int)(u % Cn), r8 = (int)(u / Cn);
+    const int rows_total = j.transpose ? j.rows_total : j.I;
+    const int row0 = (j.transpose ? j.off : 0) + r8 * 8, colp = (j.transpose ? 0 : j.off) + col;
+    __bf16* dst = reinterpret_cast<__bf16*>(j.dst);
+    const int64_t plane = (int64_t)j.T * rows_total * j.ldc;
+    for (int t = 0; t < j.T; ++t) {
+        float v[8];
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+            const int o = j.transpose ? r8 * 8 + r : col, i = j.transpose ? col : r8 * 8 + r;
+            v[r] = j.src[((int64_t)o * j.I + i) * j.T + t];
+            if (j.scale) v[r] *= j.scale[o];
+        }
+        const int64_t idx = packed_index_bf16(t, rows_total, row0, j.ldc, colp);      // (row0 % 8 == 0: the unit's first element)
+        unsigned w0[4], w1[4], w2[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            float a = v[2 * q], b = v[2 * q + 1];
+            w0[q] = cvt_pk_bf16(a, b);
+            a -= __uint_as_float(w0[q] << 16); b -= __uint_as_float(w0[q] & 0xffff0000u);
+            w1[q] = cvt_pk_bf16(a, b);
+            a -= __uint_as_float(w1[q] << 16); b -= __uint_as_float(w1[q] & 0xffff0000u);
+            w2[q] = cvt_pk_bf16(a, b);
+        }
+        *reinterpret_cast<uint4*>(dst + idx) = make_uint4(w0[0], w0[1], w0[2], w0[3]);
+        if (j.quad == 3) {
+            *reinterpret_cast<uint4*>(dst + idx + plane) = make_uint4(w1[0], w1[1], w1[2], w1[3]);
+            *reinterpret_cast<uint4*>(dst + idx + 2 * plane) = make_uint4(w2[0], w2[1], w2[2], w2[3]);
+        }
+    }
+}
 __global__ __launch_bounds__(256) void pack_weights_batched_kernel(const PackJob* __restrict__ jobs, const int* __restrict__ block_job) {
     const PackJob j = jobs[block_job[blockIdx.x]];
+    if (j.quad >= 2 && ((j.transpose ? (j.O | j.off | j.rows_total) : j.I) & 7) == 0) {
+        // (the job owns ceil(O I T / PACK_CHUNK) blocks, sized for the element-wise form: a block of this form covers 256 units = 2048 T
+        //  elements, so the surplus blocks find nothing to do)
+        pack_units_bf16(j, (int64_t)(blockIdx.x - j.first_block) * 256 + threadIdx.x);
+        return;
+    }
     const int64_t total = (int64_t)j.O * j.I * j.T;
     const int64_t base = (int64_t)(blockIdx.x - j.first_block) * PACK_CHUNK;
 #pragma unroll

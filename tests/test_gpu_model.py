@@ -504,3 +504,32 @@ def test_op_table_replay_ranges_streams_and_errors():
     side.synchronize()
     assert bool((t[0] == 1.5).all()) and t[3].abs().max().item() == 0.0          # ops behind the failing one were not issued
     tb.close()
+
+
+@pytest.mark.parametrize("storage,operands", [("fp32", None), ("bf16", None)])
+def test_batched_weight_pack_matches_the_single_tensor_packs(storage, operands):
+    """rd_pack_weights_batched's unit-per-thread form for bf16 / three-piece operands (one thread = eight reduction rows x all taps of
+    one column) against rd_pack_weights_bf16 per tensor and the piece definition w = p0 + p1 + p2: every packed buffer of the plan,
+    forward and transposed (dgrad) operands, concatenated jobs sharing one buffer included -- bit-exact."""
+    from radar_depth_amd import ops
+    from radar_depth_amd.main import HipTrainStep
+    from radar_depth_amd.synthetic import make_batch
+    b, h, w = 2, 97, 161
+    m = build(h, w)
+    ts = HipTrainStep(m, b, h, w, lr=0.0, momentum=0.0, weight_decay=0.0, storage=storage, operands=operands)
+    x, t = make_batch(b, h, w, 900, ref_pixels=h * w)
+    ts.step(x.cuda(), t.cuda())                                    # (lr = 0: the weights the pack read are the weights still there)
+    torch.cuda.synchronize()
+    by_dst, seen = {}, 0
+    for (src, dst, o, i, tt, ldc, off, rows, tr, scale, quad) in ts.plan.pack_jobs:
+        if quad < 2 or scale is not None:
+            continue
+        k, w4 = dst.data_ptr(), src.detach().reshape(o, i, -1, 1)
+        exp = ops.pack_weights_split(w4, bool(tr), ldc, off, rows) if quad == 3 else ops.pack_weights_bf16(w4, bool(tr), ldc, off, rows)[None]
+        if k not in by_dst:
+            by_dst[k] = [dst, torch.zeros_like(exp)]
+        by_dst[k][1] += exp                                         # (disjoint regions: adding zeros is exact)
+        seen += 1
+    assert seen > 20
+    for dst, exp in by_dst.values():
+        assert torch.equal(dst.reshape(-1)[:exp.numel()].view(torch.int16), exp.reshape(-1).view(torch.int16))
