@@ -1546,7 +1546,12 @@ extern "C" int rd_gconv_split_pre_preferred(const RdConvDesc* d) {
     const int wgs = d->N * pl.tiles_total * pl.n_cotiles;
     // (>= 2.5 workgroups per CU: b = 8 of BASELINE config 4 -- 736 workgroups on layer1 -- gains like b = 16 does, 389.6 -> 393.6 -> 398.5
     //  samples/s with none / the b = 16 rule / all pre-split, profiles/r04_*)
-    return pl.MT == 2 && pl.NT == 2 && 2 * wgs >= 5 * num_cus() && d->Cin <= 64 ? 1 : 0;
+    if (pl.MT == 2 && pl.NT == 2 && 2 * wgs >= 5 * num_cus() && d->Cin <= 64) return 1;
+    // small launches the 8-wave tiling cannot spread over the chip (depth encoder layer3, 64 channels at 29 x 50: 240 workgroups of one per CU,
+    // 23.8 us; 480 four-wave workgroups at two per CU: 19.1 us -- profiles/r04_bench_split_pre.txt with RD_GCONV_SPLIT_ALL=1)
+    static const bool small_rule = !(getenv("RD_GCONV_PRE_SMALL") && atoi(getenv("RD_GCONV_PRE_SMALL")) == 0);      // (A/B switch)
+    const int wgs8 = d->N * p8.tiles_total * p8.n_cotiles;
+    return small_rule && wgs8 < num_cus() && 2 * wgs >= 3 * wgs8 ? 1 : 0;
 }
 
 extern "C" int rd_gconv_split_pre_stat_tiles(const RdConvDesc* d) {
