@@ -144,6 +144,7 @@ class LateFusionPlan:
         self.reduce_batch_max = int(os.environ.get("RD_WGRAD_REDUCE_BATCH", "0"))
         self.batch_reduces = self.reduce_batch_max > 0
         self._pending_reduces, self.reduce_batches = {}, []
+        self.persistent = []   # buffers whose contents are plan state laid down at build time (not per-step scratch): tools/poison_global.py skips them
         self.table_pins = 0    # descriptors whose plan came from the offline-tuned table
         # RD_FUSE_BN_BWD=0 (diagnostics): every BatchNorm backward runs its own reduce pass, as in round 2
         self.fuse_bn_bwd = os.environ.get("RD_FUSE_BN_BWD", "1") == "1"
@@ -440,6 +441,7 @@ class LateFusionPlan:
             launch_wgrad()
         if not need_dx:
             return None
+        dx_owned = dx is None
         if dx is None:
             dx = self.act(N, H, W, cin)
         if ctx["upproj"]:
@@ -449,10 +451,17 @@ class LateFusionPlan:
         self.keep.append(dd)
         if zero_fill:
             assert dx.C == dx.ld, "zero-filled dgrad target must be a whole buffer"
-            self.op(self.bwd, name + ".zero", self.L.rd_fill, dx.ptr, C.c_int64(dx.t.numel() * dx.t.element_size() // 4), C.c_float(0.0),
-                    self.stream)
             if addend is not None:
                 raise NotImplementedError("addend with a zero-filled stride-2 dgrad")
+            if dx_owned:
+                # the launch writes only the pixels the stride touches; the buffer is this plan's own and nothing else ever writes it, so the
+                # zeros in between are laid down ONCE, here (it was an rd_fill in front of every such launch: 6 per step on the dependent
+                # chain of the backward, 8 us each alone and a kernel boundary beside the other streams' work)
+                dx.t.zero_()
+                self.persistent.append(dx.t)
+            else:
+                self.op(self.bwd, name + ".zero", self.L.rd_fill, dx.ptr, C.c_int64(dx.t.numel() * dx.t.element_size() // 4), C.c_float(0.0),
+                        self.stream)
         sp_d = bool(ctx.get("split_dgrad"))
         dg_pre = dg_pre and sp_d and self.L.rd_gconv_split_pre_supported(C.byref(dd)) == 1
         if sp_d and not dg_pre and self.L.rd_gconv_split_supported(C.byref(dd)) != 1:

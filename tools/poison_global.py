@@ -23,8 +23,9 @@ for arch, b, h, w in [("resnet18_latefusion", 5, 97, 161), ("resnet18_latefusion
     t2 = HipTrainStep(m2, b, h, w, loss_weights=lw2)
     n = 0
     for plan in t2.plans:
-        for t in plan.keep:
-            if torch.is_tensor(t) and t.dtype == torch.float32 and t.data_ptr() not in (plan.x_in.data_ptr(),):
+        state = {plan.x_in.data_ptr()} | {p.data_ptr() for p in getattr(plan, "persistent", [])}   # (build-time contents, e.g. the zeros
+        for t in plan.keep:                                                                          #  between a strided dgrad's pixels)
+            if torch.is_tensor(t) and t.dtype == torch.float32 and t.data_ptr() not in state:
                 t.fill_(float("nan")); n += 1
     ok = True
     for it in range(2):
