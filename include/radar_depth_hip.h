@@ -282,6 +282,13 @@ int rd_stem_stat_tiles(int32_t N, int32_t H, int32_t W);
 int rd_stem_fwd_bf16(const float* const* planes, const int64_t* strides, int32_t Cin, int32_t N, int32_t H,
                      int32_t W, const float* w_packed, int32_t Cout, float* out, float* stat_partial,
                      void* stream);
+/* fp32 form of the same kernel for the split plans (rd_gconv_split's arithmetic): input planes and weights are split into three bf16
+ * pieces while they are staged (x = x0 + x1 + x2 exactly), every product is rebuilt from six bf16 MFMAs with fp32 accumulation.  Same
+ * arguments, tensors, tile geometry and stat_partial layout as rd_stem_fwd; as close to an fp64 convolution as rd_stem_fwd is
+ * (tests/test_gpu_stem.py); range / non-finite behaviour as documented at rd_gconv_split. */
+int rd_stem_fwd_split(const float* const* planes, const int64_t* strides, int32_t Cin, int32_t N, int32_t H,
+                      int32_t W, const float* w_packed, int32_t Cout, float* out, float* stat_partial,
+                      void* stream);
 /* weight gradient (OIHW, overwritten) of the stem; ws needs rd_stem_wgrad_workspace_floats */
 int64_t rd_stem_wgrad_workspace_floats(int32_t N, int32_t H, int32_t W, int32_t Cin, int32_t Cout);
 int rd_stem_wgrad(const float* const* planes, const int64_t* strides, int32_t Cin, int32_t N, int32_t H,

@@ -706,8 +706,12 @@ class LateFusionPlan:
         self.keep += [pl, st]
         # bf16 plans: the 64-channel RGB stem forward runs on the bf16 matrix cores too (220 vs 574 us at b=16; its weight
         # gradient stays fp32); the 16-channel depth stem is faster on the fp32 kernel (175 vs 330 us)
-        self.op(self.fwd, name, self.L.rd_stem_fwd_bf16_t if (self.bf16 and cout >= 64) else self.L.rd_stem_fwd_t, self.dt, pl, st, cin, N, H, W,
-                _p(wp), cout, raw.ptr, _p(stat), self.stream)
+        # split plans: the 64-channel RGB stem on the bf16 matrix cores with three-piece operands (fp32 arithmetic, csrc/stem_bf16.hip NP = 3)
+        if self.split and not self.bf16 and cout >= 64 and os.environ.get("RD_STEM_SPLIT", "1") == "1":
+            self.op(self.fwd, name, self.L.rd_stem_fwd_split, pl, st, cin, N, H, W, _p(wp), cout, raw.ptr, _p(stat), self.stream)
+        else:
+            self.op(self.fwd, name, self.L.rd_stem_fwd_bf16_t if (self.bf16 and cout >= 64) else self.L.rd_stem_fwd_t, self.dt, pl, st, cin, N, H, W,
+                    _p(wp), cout, raw.ptr, _p(stat), self.stream)
         co = self.bn_coeffs(name + ".bn", bn, stat, tiles, cout, 0, N * Hc * Wc)
         Hp, Wp = (Hc - 1) // 2 + 1, (Wc - 1) // 2 + 1
         pooled = self.act(N, Hp, Wp, cout)

@@ -44,3 +44,50 @@ def test_stem_forward(cfg):
     ref_s, ref_q = y.double().sum((0, 2, 3)), (y.double() ** 2).sum((0, 2, 3))
     assert ((s_[0] - ref_s).abs().max() / ref_q.sqrt().max()).item() < 1e-4
     assert ((s_[1] - ref_q).abs().max() / ref_q.max()).item() < 1e-4
+
+
+@pytest.mark.parametrize("cfg", [
+    (2, 3, 64, 97, 161),      # RGB stem, ragged tiles
+    (16, 3, 64, 450, 800),    # BASELINE config 2's own stem launch
+    (2, 1, 16, 97, 161),      # (the kernel also takes the depth stem's shapes: one 16-wide channel tile)
+    (2, 2, 32, 64, 64),
+    (1, 3, 64, 15, 63),       # a single ragged tile row
+])
+def test_stem_forward_split(cfg):
+    """rd_stem_fwd_split (csrc/stem_bf16.hip, NP = 3: input and weights split into three bf16 pieces while staged, six MFMAs per product,
+    fp32 accumulation) against an fp64 convolution: as close as the fp32-MFMA stem (2e-6 of the output's max magnitude here; the fp32
+    kernel is held to 2e-5 against torch CPU fp32), same partial-sum layout, inputs spanning 2^-20 .. 2^20 in magnitude."""
+    from radar_depth_amd._lib import check, current_stream, lib, ptr
+    L = lib()
+    n, cin, cout, h, w = cfg
+    g = torch.Generator().manual_seed(6)
+    x = torch.randn(n, cin + 1, h, w, generator=g)
+    x[:, 1:, : h // 3] *= 2.0 ** 20                         # dynamic range: the pieces of large and of tiny values
+    x[:, 1:, 2 * h // 3:] *= 2.0 ** -20
+    wt = torch.randn(cout, cin, 7, 7, generator=g) * 0.1
+    xg, wg = x.cuda(), wt.cuda()
+    y = F.conv2d(xg[:, 1:].double(), wg.double(), stride=2, padding=3)
+    hw = h * w
+    planes = (C.c_void_p * 3)(*[xg.data_ptr() + 4 * hw * (1 + c) if c < cin else None for c in range(3)])
+    strides = (C.c_int64 * 3)(*[(cin + 1) * hw if c < cin else 0 for c in range(3)])
+    wp = wt.permute(2, 3, 1, 0).reshape(49, cin, cout).contiguous().cuda()
+    ho, wo = y.shape[2], y.shape[3]
+    tiles = L.rd_stem_stat_tiles(n, h, w)
+    res = {}
+    for name, fn in (("split", L.rd_stem_fwd_split), ("fp32", L.rd_stem_fwd)):
+        out = torch.full((n, ho, wo, cout), float("nan"), device="cuda")
+        stat = torch.zeros(tiles, 2, cout, device="cuda")
+        check(fn(planes, strides, cin, n, h, w, ptr(wp), cout, ptr(out), ptr(stat), current_stream()), name)
+        torch.cuda.synchronize()
+        got = out.permute(0, 3, 1, 2).double()
+        assert not torch.isnan(got).any()
+        # per third of the image (each has its own magnitude): error relative to that third's largest output
+        errs = []
+        for lo, hi in ((0, ho // 3 - 2), (ho // 3 + 2, 2 * ho // 3 - 2), (2 * ho // 3 + 2, ho)):
+            if hi > lo:
+                errs.append(((got[:, :, lo:hi] - y[:, :, lo:hi]).abs().max() / y[:, :, lo:hi].abs().max()).item())
+        res[name] = (max(errs), stat)
+    assert res["split"][0] < 2e-6, (cfg, res["split"][0], res["fp32"][0])
+    assert res["split"][0] < 2.0 * res["fp32"][0] + 1e-7
+    s_, f_ = res["split"][1].sum(0).double(), res["fp32"][1].sum(0).double()
+    assert ((s_ - f_).abs().max() / f_.abs().max()).item() < 1e-5
