@@ -532,6 +532,12 @@ int rd_head_conv_fwd_t(int32_t dtype, const void* x, int32_t ldx, const float* w
                        float* d, void* stream);
 int rd_head_conv_bwd_t(int32_t dtype, const void* x, int32_t ldx, const float* w_oihw, const float* dd, int32_t N, int32_t H,
                        int32_t W, int32_t C, void* dx, int32_t lddx, float* dw_oihw, float* ws, void* stream);
+/* the two halves of rd_head_conv_bwd_t as separate calls (same kernels): the input gradient is what the rest of the backward waits for,
+ * the weight gradient (+ its slab reduction; ws as for rd_head_conv_bwd) may run on another stream */
+int rd_head_conv_dgrad_t(int32_t dtype, const float* w_oihw, const float* dd, int32_t N, int32_t H, int32_t W, int32_t C, void* dx,
+                         int32_t lddx, void* stream);
+int rd_head_conv_wgrad_t(int32_t dtype, const void* x, int32_t ldx, const float* dd, int32_t N, int32_t H, int32_t W, int32_t C,
+                         float* dw_oihw, float* ws, void* stream);
 
 /* Plan tuner for rd_gconv / rd_gconv_ws (the role cudnn.benchmark plays for the reference's convolutions): list the candidate
  * execution plans of a descriptor (9 ints each: MT, NT, WM, WN, CKP, TH, TW, ksplit, loop form -- 0 plain, 1 software-pipelined,

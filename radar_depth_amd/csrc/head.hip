@@ -275,21 +275,47 @@ extern "C" int64_t rd_head_conv_bwd_workspace_floats(int32_t N, int32_t H, int32
     return (int64_t)(blocks + 16) * 9 * C;
 }
 
+// the two halves of the backward: the input gradient is what the rest of the backward waits for, the weight gradient (+ its slab
+// reduction) gates nothing until the gradient bucket closes -- callers may put it on another stream (engine.py does)
 template <typename T>
-static int head_conv_bwd_T(const T* x, int32_t ldx, const float* w_oihw, const float* dd, int32_t N, int32_t H, int32_t W, int32_t C,
-                           T* dx, int32_t lddx, float* dw_oihw, float* ws, void* stream) {
-    RD_CHECK_ARG(x && w_oihw && dd && dx && dw_oihw && ws && C == 16 && ldx % 4 == 0 && lddx % 4 == 0,
-                 "head_conv_bwd: bad arguments (C must be 16)");
-    hipStream_t s = static_cast<hipStream_t>(stream);
-    hipLaunchKernelGGL((head_conv_dgrad_kernel<16, T>), dim3(ew_grid64((int64_t)N * H * W * 4)), dim3(256), 0, s, dd, w_oihw, N, H, W,
-                       dx, lddx);
+static int head_conv_dgrad_T(const float* w_oihw, const float* dd, int32_t N, int32_t H, int32_t W, int32_t C, T* dx, int32_t lddx, void* stream) {
+    RD_CHECK_ARG(w_oihw && dd && dx && C == 16 && lddx % 4 == 0, "head_conv_dgrad: bad arguments (C must be 16)");
+    hipLaunchKernelGGL((head_conv_dgrad_kernel<16, T>), dim3(ew_grid64((int64_t)N * H * W * 4)), dim3(256), 0, static_cast<hipStream_t>(stream),
+                       dd, w_oihw, N, H, W, dx, lddx);
     RD_CHECK_LAUNCH("head_conv_dgrad_kernel");
+    return RD_OK;
+}
+template <typename T>
+static int head_conv_wgrad_T(const T* x, int32_t ldx, const float* dd, int32_t N, int32_t H, int32_t W, int32_t C, float* dw_oihw, float* ws,
+                             void* stream) {
+    RD_CHECK_ARG(x && dd && dw_oihw && ws && C == 16 && ldx % 4 == 0, "head_conv_wgrad: bad arguments (C must be 16)");
+    hipStream_t s = static_cast<hipStream_t>(stream);
     const int64_t pixels = (int64_t)N * H * W;
     const int blocks = head_wgrad_blocks(pixels);
     hipLaunchKernelGGL((head_conv_wgrad_kernel<16, T>), dim3(blocks), dim3(256), 0, s, x, ldx, dd, N, H, W, cdiv64(pixels, blocks), ws);
     RD_CHECK_LAUNCH("head_conv_wgrad_kernel");
     const int64_t E = 9 * C;
     return launch_slab_reduce(ws, blocks, E, ws + (int64_t)blocks * E, dw_oihw, 9, C, 1, 1, C, 0, 0, s);
+}
+template <typename T>
+static int head_conv_bwd_T(const T* x, int32_t ldx, const float* w_oihw, const float* dd, int32_t N, int32_t H, int32_t W, int32_t C,
+                           T* dx, int32_t lddx, float* dw_oihw, float* ws, void* stream) {
+    const int rc = head_conv_dgrad_T<T>(w_oihw, dd, N, H, W, C, dx, lddx, stream);
+    return rc != RD_OK ? rc : head_conv_wgrad_T<T>(x, ldx, dd, N, H, W, C, dw_oihw, ws, stream);
+}
+extern "C" int rd_head_conv_dgrad_t(int32_t dtype, const float* w_oihw, const float* dd, int32_t N, int32_t H, int32_t W, int32_t C, void* dx,
+                                    int32_t lddx, void* stream) {
+    if (dtype == RD_DTYPE_F32) return head_conv_dgrad_T<float>(w_oihw, dd, N, H, W, C, static_cast<float*>(dx), lddx, stream);
+    if (dtype == RD_DTYPE_BF16) return head_conv_dgrad_T<bf16s>(w_oihw, dd, N, H, W, C, static_cast<bf16s*>(dx), lddx, stream);
+    rd::set_error("head_conv_dgrad_t: bad dtype %d", dtype);
+    return RD_EINVAL;
+}
+extern "C" int rd_head_conv_wgrad_t(int32_t dtype, const void* x, int32_t ldx, const float* dd, int32_t N, int32_t H, int32_t W, int32_t C,
+                                    float* dw_oihw, float* ws, void* stream) {
+    if (dtype == RD_DTYPE_F32) return head_conv_wgrad_T<float>(static_cast<const float*>(x), ldx, dd, N, H, W, C, dw_oihw, ws, stream);
+    if (dtype == RD_DTYPE_BF16) return head_conv_wgrad_T<bf16s>(static_cast<const bf16s*>(x), ldx, dd, N, H, W, C, dw_oihw, ws, stream);
+    rd::set_error("head_conv_wgrad_t: bad dtype %d", dtype);
+    return RD_EINVAL;
 }
 extern "C" int rd_head_conv_bwd(const float* x, int32_t ldx, const float* w_oihw, const float* dd, int32_t N, int32_t H, int32_t W,
                                 int32_t C, float* dx, int32_t lddx, float* dw_oihw, float* ws, void* stream) {

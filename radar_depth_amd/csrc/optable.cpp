@@ -67,7 +67,7 @@ const std::unordered_map<std::string, Entry>& registry() {
         RD_ENTRY(rd_bn_bwd_reduce_t), RD_ENTRY(rd_bn_bwd_reduce_x_t), RD_ENTRY(rd_bn_bwd_reduce_x2_t),
         RD_ENTRY(rd_bn_bwd_apply_t), RD_ENTRY(rd_bn_bwd_apply_x_t), RD_ENTRY(rd_bn_bwd_apply_x2_t),
         RD_ENTRY(rd_bnact_maxpool_fwd_t), RD_ENTRY(rd_bnact_maxpool_bwd_stats_t), RD_ENTRY(rd_bnact_maxpool_bwd_apply_t),
-        RD_ENTRY(rd_head_conv_fwd_t), RD_ENTRY(rd_head_conv_bwd_t), RD_ENTRY(rd_bilinear_fwd), RD_ENTRY(rd_bilinear_bwd),
+        RD_ENTRY(rd_head_conv_fwd_t), RD_ENTRY(rd_head_conv_bwd_t), RD_ENTRY(rd_head_conv_dgrad_t), RD_ENTRY(rd_head_conv_wgrad_t), RD_ENTRY(rd_bilinear_fwd), RD_ENTRY(rd_bilinear_bwd),
         RD_ENTRY(rd_masked_l1_sums), RD_ENTRY(rd_masked_l1_bwd), RD_ENTRY(rd_masked_l2_sums), RD_ENTRY(rd_masked_l2_bwd),
         RD_ENTRY(rd_l1_total), RD_ENTRY(rd_smooth_fwd), RD_ENTRY(rd_smooth_bwd), RD_ENTRY(rd_uncertainty_total),
         RD_ENTRY(rd_radar_filter), RD_ENTRY(rd_sgd_step),

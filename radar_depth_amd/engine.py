@@ -1008,8 +1008,15 @@ class LateFusionPlan:
         self.op(self.bwd, "bilinear.bwd", self.L.rd_bilinear_bwd, _p(self.dpred), N, self.Ho, self.Wo, _p(ddm), z.H, z.W, self.stream)
         dz = self.act(N, z.H, z.W, z.C)
         ws = self.buf(int(self.L.rd_head_conv_bwd_workspace_floats(N, z.H, z.W, z.C)))
-        self.op(self.bwd, "conv3.bwd", self.L.rd_head_conv_bwd_t, self.dt, z.ptr, z.ld, _p(m.conv3.weight), _p(ddm), N, z.H, z.W, z.C, dz.ptr, dz.ld,
-                _p(self.grad_of(m.conv3.weight)), _p(ws), self.stream)
+        # input gradient on the main chain, weight gradient (+ slab reduction) on the weight-gradient stream beside the decoder's backward
+        self.op(self.bwd, "conv3.dgrad", self.L.rd_head_conv_dgrad_t, self.dt, _p(m.conv3.weight), _p(ddm), N, z.H, z.W, z.C, dz.ptr, dz.ld,
+                self.stream)
+        fork = os.environ.get("RD_HEAD_WGRAD_FORK", "1") == "1"
+        if fork:
+            self.edge(self.bwd, "conv3.fork_wgrad", 0, 2)
+        with self.on(2 if fork else 0):
+            self.op(self.bwd, "conv3.wgrad", self.L.rd_head_conv_wgrad_t, self.dt, z.ptr, z.ld, _p(ddm), N, z.H, z.W, z.C,
+                    _p(self.grad_of(m.conv3.weight)), _p(ws), self.stream)
         for ctx in reversed(self.ups):
             dz = self._upproj_bwd(ctx, dz)
         dr2, _ = self.bn_join_bwd("bn2", dz, None, ACT_NONE, self.r2, self.co_c2)
