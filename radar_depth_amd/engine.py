@@ -880,6 +880,13 @@ class LateFusionPlan:
         a, self.c_stem_rgb = self._stem("conv1", rgb_planes, rgb_strides, m.conv1, m.bn1, ACT_RELU, "maxpool")
         with self.on(1):
             d_, self.c_stem_d = self._stem("conv1_depth", dep_planes, dep_strides, m.conv1_depth, m.bn1_depth, ACT_LEAKY02, "maxpool_depth")
+        # The weight pack of everything but the stems runs on the (then idle) weight-gradient stream beside the stems and their pooling
+        # (_finish_pack_jobs): at the head of the step nothing else could overlap its ~0.2 ms.  Both encoder chains pick it up here.
+        self.pack_overlap = self.train and self.multi_stream and os.environ.get("RD_PACK_OVERLAP", "1") == "1"
+        if self.pack_overlap:
+            self.edge(self.fwd, "pack_join", 2, 0)
+            with self.on(1):
+                self.edge(self.fwd, "pack_join_depth", 2, 1)
         self.blocks_rgb, self.blocks_d = [], []
         layers_rgb = [("layer1", m.layer1), ("layer2", m.layer2), ("layer3", m.layer3), ("layer4", m.layer4)]
         layers_d = [("layer1_depth", m.layer1_depth), ("layer2_depth", m.layer2_depth), ("layer3_depth", m.layer3_depth),
@@ -961,19 +968,32 @@ class LateFusionPlan:
             self.op(self.prep, "evalcoef_all", self.L.rd_bn_eval_coeffs_batched, _p(self.evalcoef_table), len(self.evalcoef_jobs),
                     C.c_float(BN_EPS), self.streams[0])
         chunk = self.L.rd_pack_chunk()
-        jobs = (Job * len(self.pack_jobs))()
-        block_job, nb = [], 0
-        for k, (src, dst, o, i, t, ldc, off, rows, tr, scale, quad) in enumerate(self.pack_jobs):
-            assert o * i * t < 2 ** 31, "pack_weights_batched indexes one weight tensor with 32-bit arithmetic"
-            n = -(-(o * i * t) // chunk)
-            jobs[k] = Job(src.data_ptr(), dst.data_ptr(), scale.data_ptr() if scale is not None else None, o, i, t, ldc, off, rows, tr, nb, quad, 0)
-            block_job += [k] * n
-            nb += n
-        raw = np.frombuffer(bytes(jobs), dtype=np.uint8).copy()
-        self.pack_table = torch.from_numpy(raw).to(self.dev)
-        self.pack_blocks = torch.tensor(block_job, dtype=torch.int32, device=self.dev)
-        self.keep += [self.pack_table, self.pack_blocks]
-        self.op(self.prep, "pack_all", self.L.rd_pack_weights_batched, _p(self.pack_table), _p(self.pack_blocks), nb, self.stream)
+
+        def emit(name, job_list):
+            jobs = (Job * len(job_list))()
+            block_job, nb = [], 0
+            for k, (src, dst, o, i, t, ldc, off, rows, tr, scale, quad) in enumerate(job_list):
+                assert o * i * t < 2 ** 31, "pack_weights_batched indexes one weight tensor with 32-bit arithmetic"
+                n = -(-(o * i * t) // chunk)
+                jobs[k] = Job(src.data_ptr(), dst.data_ptr(), scale.data_ptr() if scale is not None else None, o, i, t, ldc, off, rows, tr, nb, quad, 0)
+                block_job += [k] * n
+                nb += n
+            raw = np.frombuffer(bytes(jobs), dtype=np.uint8).copy()
+            table = torch.from_numpy(raw).to(self.dev)
+            blocks = torch.tensor(block_job, dtype=torch.int32, device=self.dev)
+            self.keep += [table, blocks]
+            self.op(self.prep, name, self.L.rd_pack_weights_batched, _p(table), _p(blocks), nb, self.stream)
+            return table, blocks
+
+        stems = [j for j in self.pack_jobs if j[4] == 49 and j[10] == 0]          # (7x7 taps, plain layout: the two stem convolutions)
+        rest = [j for j in self.pack_jobs if not (j[4] == 49 and j[10] == 0)]
+        if getattr(self, "pack_overlap", False) and stems and rest:
+            emit("pack_stems", stems)
+            self.edge(self.prep, "pack_fork", 0, 2)          # (behind the previous step's SGD update, which ends on stream 0)
+            with self.on(2):
+                self.pack_table, self.pack_blocks = emit("pack_all", rest)
+        else:
+            self.pack_table, self.pack_blocks = emit("pack_all", self.pack_jobs)
 
     def _build_backward(self):
         """Backward as four bucket-aligned segments (self.bwd_segments): every segment ends with all streams joined, so
