@@ -66,7 +66,13 @@ def kernel_identity(L, kind, d, io16=False):
         L.rd_gconv_split_pre_plan_info(C.byref(d), info)
         return "gconv_sp2_kernel<%d,%d,0>" % (info[0], info[1])
     if kind in ("wgrad_split", "wgrad_split_pre"):
-        return "wgrad_split_kernel"
+        info = (C.c_int32 * 4)()
+        L.rd_wgrad_split_plan_info(C.byref(d), info)           # splits, tiles per split, workgroups, tiles | tall geometry << 30
+        geo = "WsGeo<4,16>" if info[3] >> 30 else "WsGeo<2,32>"
+        pre = tb_(kind == "wgrad_split_pre")
+        if d.n_phases == 1:                                    # 3x3: one launch per op -- the name rocprofv3 prints
+            return "wgrad_split_kernel<3,3,%s,%s>" % (geo, pre)
+        return "wgrad_split_kernel<3,3|3,2|2,3|2,2,%s,%s> (4 UpProj phase launches)" % (geo, pre)
     if kind == "wgrad_bf16":
         info = (C.c_int32 * 8)()
         L.rd_wgrad_bf16_plan_info(C.byref(d), info)           # cpi, cpo, ...
