@@ -57,6 +57,8 @@ def kernel_identity(L, kind, d, io16=False):
         info = (C.c_int32 * 8)()
         L.rd_gconv_bf16_plan_info(C.byref(d), info)           # MT, NT, pipe*1000 + CKP, ...
         return "gconv_bf16_kernel<%d,%d,%s,%s>" % (info[0], info[1], tb_(info[2] >= 1000), tb_(io16))
+    if kind == "conv16_split":
+        return "conv16_split_kernel<stat|add>"
     if kind == "gconv_split":
         info = (C.c_int32 * 8)()
         L.rd_gconv_split_plan_info(C.byref(d), info)          # MT, NT, TH, TW, PP, lds, workgroups, tap groups + 100 * double-buffered patch

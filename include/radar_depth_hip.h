@@ -289,6 +289,14 @@ int rd_stem_fwd_bf16(const float* const* planes, const int64_t* strides, int32_t
 int rd_stem_fwd_split(const float* const* planes, const int64_t* strides, int32_t Cin, int32_t N, int32_t H,
                       int32_t W, const float* w_packed, int32_t Cout, float* out, float* stat_partial,
                       void* stream);
+/* The 16 -> 16 channel 3x3 unit-stride layers (depth encoder layer1, the last decoder stage's conv2; inside rd_gconv they run on the
+ * 16x16x4 fp32 MFMA kernel of csrc/conv16.hip) with three-piece bf16 operands, six v_mfma_f32_16x16x32_bf16 per product, fp32
+ * accumulation -- the split plans' form.  rd_gconv's contract for those descriptors: fp32 tensors, the fp32 quad-packed weight operand
+ * of rd_pack_weights (forward or transposed), optional residual addend, optional BatchNorm partial sums with rd_gconv_stat_tiles_ws(d)
+ * rows.  rd_conv16_split_supported: 1 for exactly those descriptors. */
+int rd_conv16_split_supported(const RdConvDesc* d);
+int rd_conv16_split(const RdConvDesc* d, const float* in, const float* w_packed, float* out, const float* addend, int32_t ld_add,
+                    float* stat_partial, void* stream);
 /* weight gradient (OIHW, overwritten) of the stem; ws needs rd_stem_wgrad_workspace_floats */
 int64_t rd_stem_wgrad_workspace_floats(int32_t N, int32_t H, int32_t W, int32_t Cin, int32_t Cout);
 int rd_stem_wgrad(const float* const* planes, const int64_t* strides, int32_t Cin, int32_t N, int32_t H,

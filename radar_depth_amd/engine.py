@@ -309,7 +309,7 @@ class LateFusionPlan:
         quad = 2 if self.bf16 else 1
         # split plans: each of the two operands (forward, input gradient) is packed as three bf16 piece planes when the library has a
         # split plan for that descriptor, and stays the fp32 operand of rd_gconv otherwise
-        sp_f = sp_d = pre_f = pre_d = False
+        sp_f = sp_d = pre_f = pre_d = c16 = False
         if self.split:
             sp_f = self.L.rd_gconv_split_supported(C.byref(d)) == 1
             dd0 = (cd.upproj_dgrad(N, H, W, cin, cout) if upproj else cd.conv_dgrad(N, H, W, cin, cout, k, stride, pad)[0])
@@ -347,14 +347,23 @@ class LateFusionPlan:
         elif self.bf16:
             self.op(lst, name, self.L.rd_gconv_bf16_t, self.dt, C.byref(d), x.ptr, _p(wp), out.ptr, C.c_void_p(0), 0, 0, C.c_void_p(0), 0,
                     _p(stat), self.stream)
+        elif self._c16_split(d):
+            # split plans: the 16 -> 16 channel 3x3 layers (depth encoder layer1, dec4 conv2) with three-piece operands too
+            # (csrc/conv16_split.hip: conv16.hip's contract, tiling and fp32 weight operand)
+            c16 = True
+            self.op(lst, name, self.L.rd_conv16_split, C.byref(d), x.ptr, _p(wp), out.ptr, C.c_void_p(0), 0, _p(stat), self.stream)
         else:
             ws = self._gconv_ws(d, name)
             self.op(lst, name, self.L.rd_gconv_ws, C.byref(d), x.ptr, _p(wp), out.ptr, C.c_void_p(0), 0, _p(stat), _p(ws), self.stream)
         self.taps[name] = out
-        self.meta[name] = ("gconv_split_pre" if pre_f else "gconv_split" if sp_f else "gconv_bf16" if self.bf16 else "gconv", d)
+        self.meta[name] = ("gconv_split_pre" if pre_f else "gconv_split" if sp_f else "gconv_bf16" if self.bf16 else "conv16_split" if c16 else "gconv", d)
         ctx = dict(name=name, d=d, x=x, out=out, weights=weights, wd=wd, k=k, stride=stride, pad=pad, upproj=upproj,
                    stat=stat, tiles=tiles, cin=cin, cout=cout, split_dgrad=sp_d, pre_dgrad=self.split and pre_d)
         return out, ctx
+
+    def _c16_split(self, d):
+        return (self.split and not self.bf16 and os.environ.get("RD_CONV16_SPLIT", "1") == "1"
+                and self.L.rd_conv16_split_supported(C.byref(d)) == 1)
 
     def conv_bwd(self, ctx, dout, need_dx=True, addend=None, dx=None, bnb=None):
         """Appends wgrad (+ reduce into the parameters' gradient views) and, optionally, dgrad.  Returns dx Act.
@@ -484,6 +493,10 @@ class LateFusionPlan:
             self.op(self.bwd, name + ".dgrad", self.L.rd_gconv_bf16_t, self.dt, C.byref(dd), dout.ptr, _p(ctx["wd"]), dx.ptr, C.c_void_p(0), 0, 0,
                     addend.ptr if addend is not None else C.c_void_p(0), addend.ld if addend is not None else 0,
                     C.c_void_p(0), self.stream)
+        elif self._c16_split(dd):
+            self.op(self.bwd, name + ".dgrad", self.L.rd_conv16_split, C.byref(dd), dout.ptr, _p(ctx["wd"]), dx.ptr,
+                    addend.ptr if addend is not None else C.c_void_p(0), addend.ld if addend is not None else 0, C.c_void_p(0), self.stream)
+            self.meta[name + ".dgrad"] = ("conv16_split", dd)
         else:
             ws_d = self._gconv_ws(dd, name + ".dgrad")      # (plans the descriptor: table pin / tuner first)
             fuse = (bnb is not None and addend is None and not zero_fill and self.fuse_bn_bwd
