@@ -523,6 +523,10 @@ def main():
                 pass
         common = {"kernel": name, "launches_per_step": n, "avg_launch_us": round(1e3 * ms / n, 2), "traffic": traffic,
                   "traffic_source": traffic_source}
+        if name.startswith("wgrad_split_kernel<3,3,"):
+            # (a rocprofv3 summary averages this instantiation over MORE launches: the first phase of every UpProj weight gradient is a
+            #  <3,3> launch too -- smaller layers, counted here under the "(4 UpProj phase launches)" ops)
+            common["launch_scope"] = "single-phase 3x3 weight gradients only; rocprofv3's average for the name also includes the UpProj ops' <3,3> phase launches"
         if split and name.startswith(("gconv_split_kernel", "wgrad_split_kernel", "gconv_sp2_kernel")):
             # the dominant kernel runs six bf16 MFMAs per fp32 multiply-add: priced against the dense bf16 peak on the MFMA FLOPs it
             # actually issues (6 x algorithmic); `fp32_equivalent_tflops` is the algorithmic rate next to the fp32 MFMA peak

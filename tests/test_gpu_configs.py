@@ -312,7 +312,11 @@ def test_plain_multistage_step_vs_oracle():
         lo, po, ex = otrain.train_step(args.arch, om, crit, opt, x, t, None)
         lg, pred = ts.step(x.cuda(), t.cuda())
         torch.cuda.synchronize()
-        assert abs(lg.item() - lo.item()) / abs(lo.item()) < 2e-3, (it, lg.item(), lo.item())
+        # step 0 is a forward parity check (measured 0 .. 1e-7); from then on the two trajectories amplify their rounding differences: five
+        # arithmetic variants of this library (split / fp32-MFMA plans, stem / 16-channel / head kernel forms) sit 0.9e-4 .. 5e-4 from the oracle
+        # at step 1 and 0.95e-3 .. 2.3e-3 at step 2 -- each other's distance as much as the oracle's
+        bar = (1e-5, 2e-3, 5e-3)[it]
+        assert abs(lg.item() - lo.item()) / abs(lo.item()) < bar, (it, lg.item(), lo.item())
         po_ = np.array([p.double().norm().item() for p in om.parameters()])
         pg_ = np.array([p.double().norm().item() for p in hm.parameters()])
         if it == 0:
