@@ -44,6 +44,7 @@ rocprofv3 --kernel-trace --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE --output-f
 cd $R
 python tools/rocpd_stats.py $(find $O/kt -name "*.db" | head -1) --steady > $O/kernel_stats.txt
 python tools/rocpd_stats.py $(find $O/kt -name "*.db" | head -1) --steady --timeline > $O/timeline.txt
+python tools/exclusive_time.py $(find $O/kt -name "*.db" | head -1) 12 > $O/exclusive_time.txt
 python tools/rocpd_stats.py $(find $O/kt1 -name "*.db" | head -1) --steady > $O/kernel_stats_single_stream.txt
 python tools/rocpd_stats.py $(find $O/kt1f -name "*.db" | head -1) --steady > $O/kernel_stats_fp32_mfma_single_stream.txt
 python tools/rocpd_stats.py $(find $O/kt116 -name "*.db" | head -1) --steady > $O/kernel_stats_bf16_storage_single_stream.txt
