@@ -407,6 +407,8 @@ PRE_FWD = [
     (2, 256, 256, 3, 1, 1, 29, 50),
     (2, 512, 512, 3, 1, 1, 15, 25),   # layer4
     (2, 64, 128, 3, 2, 1, 113, 200),  # stride 2: wide patch
+    (2, 128, 256, 3, 2, 1, 57, 100),  # layer3.0.conv1 / layer4.0.conv1: the stride-2 layers the default plan routes here
+    (16, 256, 512, 3, 2, 1, 29, 50),
     (2, 640, 512, 1, 1, 0, 15, 25),   # conv_fusion
     (2, 32, 32, 3, 1, 1, 120, 200),   # decoder.layer3 conv2
     (3, 32, 48, 3, 1, 1, 9, 7),       # tiny / ragged
