@@ -279,7 +279,7 @@ static int ew_grid2(int64_t n) {
     const int64_t cap = (int64_t)num_cus() * 16;
     return (int)(g > cap ? cap : (g < 1 ? 1 : g));
 }
-constexpr int SM_BLOCKS = 64;  // blocks per sample in the smoothness passes
+constexpr int SM_BLOCKS = 256;  // blocks per sample in the smoothness passes (64 left the b = 8 passes of config 4 at two blocks per CU: smooth_main 157 us)
 
 }  // namespace rd
 using namespace rd;

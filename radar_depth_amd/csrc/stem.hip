@@ -455,6 +455,65 @@ __global__ __launch_bounds__(256) void stem_dgrad_channel_kernel(const T* __rest
     }
 }
 
+// Tiled form for the 16-channel depth stem (round 4; the only caller: stage 2's dense-depth channel, once per multistage step, alone on the
+// chain between the two stages' backward passes -- 175 us for 46 MB with the kernel above, whose every pixel walks up to 16 x 16 global
+// loads).  A workgroup stages the 12 x 20 pixel patch of dout behind a 16 x 32 pixel tile of dx in LDS; wave = parity class (h & 1, w & 1) of
+// the pixels it computes, so its taps (3 or 4 kernel rows x 3 or 4 columns) are the same for all of them and its weights live in registers;
+// lane = (pixel column, channel quad), summed over the quads with two DPP exchanges.
+template <typename T>
+__global__ __launch_bounds__(256) void stem_dgrad_channel16_kernel(const T* __restrict__ dout, const float* __restrict__ wp, int N, int H, int W,
+                                                                   int Ho, int Wo, int Cin, int ci, int tiles_h, int tiles_w,
+                                                                   float* __restrict__ dx) {
+    constexpr int Cout = 16, TH = 16, TW = 32, PR = 12, PC = 20;
+    __shared__ float4 s_d[PR * PC * 4];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, q = lane & 3, pl = lane >> 2;
+    const int per_img = tiles_h * tiles_w;
+    const int n = blockIdx.x / per_img, trem = blockIdx.x - n * per_img;
+    const int h0 = (trem / tiles_w) * TH, w0 = (trem % tiles_w) * TW;
+    const int oh0 = (h0 - 3) >> 1, ow0 = (w0 - 3) >> 1;          // first dout row / column any pixel of the tile reads (may be negative)
+    const T* src = dout + (size_t)n * Ho * Wo * Cout;
+    for (int e = tid; e < PR * PC * 4; e += 256) {
+        const int px = e >> 2, qq = e & 3;
+        const int r = px / PC, c = px - r * PC;
+        const int oh = oh0 + r, ow = ow0 + c;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (oh >= 0 && oh < Ho && ow >= 0 && ow < Wo) v = ld4(src + ((size_t)oh * Wo + ow) * Cout + 4 * qq);
+        s_d[e] = v;
+    }
+    const int ph = wave >> 1, pw = wave & 1;
+    const int kh0 = (ph + 3) & 1, kw0 = (pw + 3) & 1;             // taps of matching parity: kh0, kh0 + 2, ... < 7
+    float4 wr[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int kh = kh0 + 2 * i, kw = kw0 + 2 * j;
+            wr[i][j] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (kh < 7 && kw < 7) wr[i][j] = *reinterpret_cast<const float4*>(wp + ((size_t)(kh * 7 + kw) * Cin + ci) * Cout + 4 * q);
+        }
+    rd_sync();
+    const int w = w0 + 2 * pl + pw;
+#pragma unroll
+    for (int a = 0; a < TH / 2; ++a) {
+        const int h = h0 + 2 * a + ph;
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int r = ((h + 3 - (kh0 + 2 * i)) >> 1) - oh0;      // (taps with kh >= 7 have zero weights; their row index is clamped)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int c = ((w + 3 - (kw0 + 2 * j)) >> 1) - ow0;
+                const float4 dv = s_d[((r < 0 ? 0 : r) * PC + (c < 0 ? 0 : c)) * 4 + q];
+                const float4 wt = wr[i][j];
+                s = fmaf(dv.x, wt.x, s); s = fmaf(dv.y, wt.y, s); s = fmaf(dv.z, wt.z, s); s = fmaf(dv.w, wt.w, s);
+            }
+        }
+        s += dpp_xor1(s);
+        s += dpp_xor2(s);
+        if (q == 0 && h < H && w < W) dx[((size_t)n * H + h) * W + w] = s;
+    }
+}
+
 static int stem_fill(StemArgs& a, const float* const* planes, const int64_t* strides, int Cin, int N, int H, int W, int Cout) {
     RD_CHECK_ARG(planes && strides && Cin >= 1 && Cin <= 3 && N > 0 && H > 6 && W > 6, "stem: bad arguments");
     RD_CHECK_ARG(Cout == 64 || Cout == 16 || Cout == 32, "stem: Cout=%d unsupported", Cout);
@@ -588,6 +647,14 @@ static int stem_dgrad_channel_T(const T* dout, const float* w_packed, int32_t N,
     const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
     int64_t g = cdiv64((int64_t)N * H * W, 256);
     if (g > (int64_t)num_cus() * 16) g = (int64_t)num_cus() * 16;
+    static const bool tiled = !(getenv("RD_STEM_DGRAD_TILED") && atoi(getenv("RD_STEM_DGRAD_TILED")) == 0);
+    const int tiles_h = cdiv(H, 16), tiles_w = cdiv(W, 32);
+    if (tiled && Cout == 16 && (int64_t)N * tiles_h * tiles_w < (1ll << 31)) {
+        hipLaunchKernelGGL(stem_dgrad_channel16_kernel<T>, dim3(N * tiles_h * tiles_w), dim3(256), 0, static_cast<hipStream_t>(stream), dout,
+                           w_packed, N, H, W, Ho, Wo, Cin, ci, tiles_h, tiles_w, dx);
+        RD_CHECK_LAUNCH("stem_dgrad_channel16_kernel");
+        return RD_OK;
+    }
     hipLaunchKernelGGL(stem_dgrad_channel_kernel<T>, dim3((int)g), dim3(256), 0, static_cast<hipStream_t>(stream), dout, w_packed, N,
                        H, W, Ho, Wo, Cin, ci, Cout, dx);
     RD_CHECK_LAUNCH("stem_dgrad_channel_kernel");

@@ -91,3 +91,26 @@ def test_stem_forward_split(cfg):
     assert res["split"][0] < 2.0 * res["fp32"][0] + 1e-7
     s_, f_ = res["split"][1].sum(0).double(), res["fp32"][1].sum(0).double()
     assert ((s_ - f_).abs().max() / f_.abs().max()).item() < 1e-5
+
+
+@pytest.mark.parametrize("cfg", [(2, 2, 16, 97, 161, 1), (8, 2, 16, 450, 800, 1), (1, 2, 16, 15, 63, 0), (2, 2, 16, 64, 64, 1), (2, 3, 64, 33, 47, 2)])
+def test_stem_dgrad_channel(cfg):
+    """rd_stem_dgrad_channel (the gradient w.r.t. ONE input plane of the 7x7 / stride-2 stem: stage 2's dense-depth channel,
+    multistage_model.py:75) against torch autograd: the LDS-tiled 16-channel form (parity-class waves) and the generic kernel (Cout = 64)."""
+    from radar_depth_amd._lib import check, current_stream, lib, ptr
+    L = lib()
+    n, cin, cout, h, w, ci = cfg
+    g = torch.Generator().manual_seed(9)
+    x = torch.randn(n, cin, h, w, generator=g, dtype=torch.float64, requires_grad=True)
+    wt = torch.randn(cout, cin, 7, 7, generator=g, dtype=torch.float64) * 0.1
+    y = F.conv2d(x, wt, stride=2, padding=3)
+    go = torch.randn(y.shape, generator=g, dtype=torch.float64)
+    y.backward(go)
+    ref = x.grad[:, ci]
+    dout = go.permute(0, 2, 3, 1).contiguous().float().cuda()
+    wp = wt.permute(2, 3, 1, 0).reshape(49, cin, cout).contiguous().float().cuda()
+    dx = torch.full((n, h, w), float("nan"), device="cuda")
+    check(L.rd_stem_dgrad_channel(ptr(dout), ptr(wp), n, h, w, cin, ci, cout, ptr(dx), current_stream()), "rd_stem_dgrad_channel")
+    torch.cuda.synchronize()
+    assert not torch.isnan(dx).any()
+    assert ((dx.cpu().double() - ref).abs().max() / ref.abs().max()).item() < 2e-6, cfg
