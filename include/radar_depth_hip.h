@@ -157,6 +157,12 @@ int rd_gconv_split_pre(const RdConvDesc* d, const void* in_pieces, int64_t in_pi
                        const float* bias, int32_t act, int32_t act_cols, const float* addend, int32_t ld_add, float* stat_partial, void* stream);
 int rd_gconv_split_pre_stat_tiles(const RdConvDesc* d);
 int rd_gconv_split_pre_plan_info(const RdConvDesc* d, int32_t* out);
+/* diagnostics / tests (host only, no GPU needed): the slot map of the split kernels -- which tile pixel each lane of an A fragment
+ * reads.  The map places the 16 lanes of every ds_read_b128 pass on 16 different 16-byte LDS slots (csrc/gconv_split.hip,
+ * gs_slot_pixel; tests/test_slot_map.py checks it against the lane groups of MI355X_MICROARCH.md).  pre != 0: the pre-split plan.
+ * out[0..3] = slots per tile (BM), tile rows, tile columns, LDS row pitch of the patch in pixels; slots[m] = (r << 16) | c of the
+ * tile pixel in slot m, -1 for an empty slot; n_slots >= BM. */
+int rd_gconv_split_slot_map(const RdConvDesc* d, int32_t pre, int32_t phase, int32_t* out, int32_t* slots, int32_t n_slots);
 /* diagnostics: with RD_GCONV_SPLIT_TRACE=1 (an MFMA wave) / =2 (a staging wave) every workgroup records cycle-counter stamps around
  * the barrier of its first 30 tap groups (64 slots per workgroup); copies the last traced launch to the host (tools/trace_gconv_split.py) */
 int rd_gconv_split_trace_read(unsigned long long* host, int n_wg);
