@@ -32,6 +32,7 @@
 #include <string>
 #include <type_traits>
 #include <unordered_map>
+#include <vector>
 
 #include "common.h"
 
@@ -72,11 +73,10 @@ struct GsArgs {
     int dbg;                      // diagnostics (RD_GCONV_SPLIT_DEBUG, ablations for tools/ablate_gconv_split.py; results are then garbage):
                                   // 4 no weight copies, 8 no patch copies / staging, 16 no epilogue; 1 no MFMAs, 2 no fragment reads
                                   // (the last two as template instantiations of gconv_sp2_kernel<2,2> only)
-    // slot map (gs_slot_pixel): LDS row pitch of the patch in pixels, per phase (patch width + 0..3 pad columns), and the number of
-    // tile pixels per residue class (r * pitch + c) mod 16, four bytes per word; natural != 0: row-major slots (diagnostics)
+    // slot map (gs_slot_pixel, computed by the host once per plan): LDS row pitch of the patch in pixels per phase (patch width + 0..3
+    // pad columns) and the table [phase][BM]: (r << 16) | c of the tile pixel slot m holds, -(1 + residue of the lane) for an empty slot
     int ppitch[RD_MAX_PHASES];
-    unsigned nres[RD_MAX_PHASES][4];
-    int natural;
+    const int* slots;
 };
 
 // ---- which tile pixel a lane of an A fragment reads: the slot map
@@ -90,12 +90,14 @@ struct GsArgs {
 // tile (M tile g / 2, lane set g % 2) holds, in the lane that stands for residue k, the pixel of rank g among the tile's pixels with
 // (r * pitch + c) mod 16 == k, in row-major order.  Residue classes with more pixels than the tile has passes (the host picks the
 // row pitch that minimises them) overflow into the slots classes with fewer pixels leave free, in a fixed order.  Both the patch
-// address table and the output pixel table are filled from this map, so nothing else in the kernels depends on the order.
-__host__ __device__ __forceinline__ int gs_nres(const unsigned (&w)[4], int k) { return (int)((w[k >> 2] >> ((k & 3) * 8)) & 255u); }
+// address table and the output pixel table are filled from this map, so nothing else in the kernels depends on the order.  The map is
+// a function of the plan alone: the host computes it once per plan (computed in the kernel prologue it cost ~1 % of a launch) and the
+// workgroups read it from a small device table.
+static inline int gs_nres(const unsigned (&w)[4], int k) { return (int)((w[k >> 2] >> ((k & 3) * 8)) & 255u); }
 
 // slot m of a tile of TH x TW pixels (full tile: edge tiles use the same map and mask) -> (r, c); false: the slot is empty (rho =
 // the residue its lane stands for, for a harmless default address)
-__host__ __device__ __forceinline__ bool gs_slot_pixel(int m, int TH, int TW, int pitch, int G, const unsigned (&nres)[4], bool natural, int& r, int& c, int& rho) {
+static inline bool gs_slot_pixel(int m, int TH, int TW, int pitch, int G, const unsigned (&nres)[4], bool natural, int& r, int& c, int& rho) {
     if (natural) {
         r = m / TW; c = m - r * TW; rho = 0;
         return r < TH;
@@ -115,11 +117,9 @@ __host__ __device__ __forceinline__ bool gs_slot_pixel(int m, int TH, int TW, in
     if (!have) {
         // f-th empty slot in (residue, pass) order <- f-th overflow pixel in (residue, rank) order
         int f = g - gs_nres(nres, k);
-#pragma unroll
         for (int q = 0; q < 16; ++q)
             if (q < k) f += gs_nres(nres, q) < G ? G - gs_nres(nres, q) : 0;
         int acc = 0;
-#pragma unroll
         for (int q = 0; q < 16; ++q) {
             const int ov = gs_nres(nres, q) > G ? gs_nres(nres, q) - G : 0;
             if (!have && f < acc + ov) { cls = q; rank = G + f - acc; have = true; }
@@ -237,8 +237,9 @@ __global__ __launch_bounds__(512) void gconv_split_kernel(const GsArgs a) {
     const int pplane = a.pplane;
 
     for (int m = tid; m < BM; m += 512) {
-        int r, c, rho;
-        const bool have = gs_slot_pixel(m, a.TH, a.TW, PWP, BM / 16, a.nres[ph], a.natural != 0, r, c, rho);
+        const int sv = a.slots[ph * BM + m];
+        const bool have = sv >= 0;
+        const int r = sv >> 16, c = sv & 0xffff, rho = -1 - sv;
         const bool ok = have && (r < th_n) && (c < tw_n);
         s_opix[m] = ok ? ((n * D.Ho + (r0 + r) * OS + P.out_off_h) * D.Wo + (c0 + c) * OS + P.out_off_w) : -1;
         // (masked pixels of an edge tile keep their own patch address -- staged or not, their accumulator rows are never stored;
@@ -909,8 +910,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void g
     const int pplane = a.pplane;
 
     for (int m = tid; m < BM; m += 256) {
-        int r, c, rho;
-        const bool have = gs_slot_pixel(m, a.TH, a.TW, PWP, BM / 16, a.nres[ph], a.natural != 0, r, c, rho);
+        const int sv = a.slots[ph * BM + m];
+        const bool have = sv >= 0;
+        const int r = sv >> 16, c = sv & 0xffff, rho = -1 - sv;
         const bool ok = have && (r < th_n) && (c < tw_n);
         s_opix[m] = ok ? ((n * D.Ho + (r0 + r) * OS + P.out_off_h) * D.Wo + (c0 + c) * OS + P.out_off_w) : -1;
         // (masked pixels of an edge tile keep their own patch address -- staged or not, their accumulator rows are never stored;
@@ -1518,6 +1520,39 @@ static int gs_plan_query(const RdConvDesc* d, GsPlan& pl, RdConvDesc& dd, bool p
     return e.ok;
 }
 
+// slot table of a plan on the current device, [phase][BM] ints (GsArgs::slots); built and uploaded at the first launch of the plan
+// (one synchronous 1.5-6 KB copy: the training / inference plans run one un-captured step before any graph capture).  Tables are
+// never freed (a few KB per distinct descriptor); RD_GCONV_SPLIT_NATURAL=1 (diagnostics, read once): the round-4 row-major map.
+static const int* gs_slot_table(const RdConvDesc* d, bool pre, const GsPlan& pl) {
+    static std::mutex mu;
+    static std::unordered_map<std::string, int*> tables;
+    static const bool natural = getenv("RD_GCONV_SPLIT_NATURAL") && atoi(getenv("RD_GCONV_SPLIT_NATURAL"));
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return nullptr;
+    unsigned ep;
+    { std::lock_guard<std::mutex> lk(g_gs_mu); ep = g_gs_epoch; }
+    std::string key(reinterpret_cast<const char*>(d), sizeof(RdConvDesc));
+    key.push_back(pre ? 'P' : 'R');
+    key.append(reinterpret_cast<const char*>(&dev), sizeof(dev));
+    key.append(reinterpret_cast<const char*>(&ep), sizeof(ep));
+    std::lock_guard<std::mutex> lk(mu);
+    auto it = tables.find(key);
+    if (it != tables.end()) return it->second;
+    const int BM = 4 * pl.MT * 32;
+    std::vector<int> host((size_t)RD_MAX_PHASES * BM, -1);
+    for (int i = 0; i < d->n_phases; ++i)
+        for (int m = 0; m < BM; ++m) {
+            int r, c, rho;
+            const bool have = gs_slot_pixel(m, pl.TH, pl.TW, pl.ppitch[i], BM / 16, pl.nres[i], natural, r, c, rho);
+            host[(size_t)i * BM + m] = have ? ((r << 16) | c) : -1 - rho;
+        }
+    int* devp = nullptr;
+    if (hipMalloc(&devp, host.size() * sizeof(int)) != hipSuccess) return nullptr;
+    if (hipMemcpy(devp, host.data(), host.size() * sizeof(int), hipMemcpyHostToDevice) != hipSuccess) { (void)hipFree(devp); return nullptr; }
+    tables.emplace(std::move(key), devp);
+    return devp;
+}
+
 }  // namespace rd
 
 using namespace rd;
@@ -1611,14 +1646,9 @@ static int gs_launch(const RdConvDesc* d, const float* in, const void* in_pieces
         const int PW_ = pl.ppitch[i];
         for (int t = 0; t < p.n_taps; ++t) a.tapoff[i][t] = ((p.dh[t] - p.dh_min) * PW_ + (p.dw[t] - p.dw_min)) * (pre ? 16 : GS_PSB);
     }
-    for (int i = 0; i < RD_MAX_PHASES; ++i) {
-        a.ppitch[i] = pl.ppitch[i];
-        for (int w = 0; w < 4; ++w) a.nres[i][w] = pl.nres[i][w];
-    }
-    {
-        static const char* nat = getenv("RD_GCONV_SPLIT_NATURAL");      // diagnostics: row-major slots (the round-4 map) at the same pitch
-        a.natural = nat && atoi(nat) ? 1 : 0;
-    }
+    for (int i = 0; i < RD_MAX_PHASES; ++i) a.ppitch[i] = pl.ppitch[i];
+    a.slots = gs_slot_table(d, pre, pl);
+    if (!a.slots) { set_error("gconv_split: cannot allocate the slot table of the plan"); return RD_ELAUNCH; }
     const int grid = d->N * pl.tiles_total * pl.n_cotiles;
     hipStream_t s = static_cast<hipStream_t>(stream);
     a.trace = nullptr;

@@ -68,6 +68,17 @@ class Act:
         return self.t[..., self.c0:self.c0 + self.C]
 
 
+def _strided_zero_check(t, dd):
+    """-> callable: True while the pixels of the NHWC buffer t that the strided input-gradient descriptor dd never writes are still zero."""
+    def chk():
+        m = torch.zeros(t.shape[1], t.shape[2], dtype=torch.bool, device=t.device)
+        for i in range(dd.n_phases):
+            ph = dd.phase[i]
+            m[ph.out_off_h::dd.out_stride, ph.out_off_w::dd.out_stride][:ph.lh, :ph.lw] = True
+        return bool((t[:, ~m] == 0).all().item())
+    return chk
+
+
 def _p(t):
     return C.c_void_p(0 if t is None else t.data_ptr())
 
@@ -149,7 +160,11 @@ class LateFusionPlan:
         # RD_FUSE_BN_BWD=0 (diagnostics): every BatchNorm backward runs its own reduce pass, as in round 2
         self.fuse_bn_bwd = os.environ.get("RD_FUSE_BN_BWD", "1") == "1"
         self.bnb_out = None
+        self.persistent_zero_checks = []   # callables: the never-written pixels of the persistent buffers still hold zeros (tests)
         self._build()
+        if self.persistent and not self.dry_run:
+            # the build-time zeros were laid down on torch's current stream; the plan may first run on any stream: order them here
+            torch.cuda.current_stream().synchronize()
 
     def close(self):
         """Destroy the plan's hipEvents (its buffers are torch tensors and go with the object).  Called when the LAST holder lets go
@@ -468,6 +483,7 @@ class LateFusionPlan:
                 # chain of the backward, 8 us each alone and a kernel boundary beside the other streams' work)
                 dx.t.zero_()
                 self.persistent.append(dx.t)
+                self.persistent_zero_checks.append(_strided_zero_check(dx.t, dd))
             else:
                 self.op(self.bwd, name + ".zero", self.L.rd_fill, dx.ptr, C.c_int64(dx.t.numel() * dx.t.element_size() // 4), C.c_float(0.0),
                         self.stream)
@@ -1163,35 +1179,65 @@ class LateFusionPlan:
 
 
 class ModulePlan(LateFusionPlan):
-    """ONE BasicBlock (models.py:75-112) or UpProjModule (models.py:181-209) run through the very op builders the network
-    plan uses (_block / _upproj and their backward), on a stand-alone NHWC input: layer-level forward + backward parity
-    against the reference-generated fixtures (tests/golden/upproj_module.npz, basic_block.npz) at kernel-level tolerance,
-    between "one kernel" and "the whole network".  owner: an ArenaOwner nn.Module holding `mod` (gradient arena)."""
+    """ONE BasicBlock (models.py:75-112), UpProjModule (models.py:181-209) or whole UpProj decoder (models.py:210-216: four modules in a
+    row) run through the very op builders the network plan uses (_block / _upproj and their backward), on a stand-alone NHWC input.
+    It backs the stand-alone `forward` of those modules (radar_depth_amd/model/models.py: the reference's sub-modules are callable on
+    their own) and the layer-level parity tests against the reference-generated fixtures (tests/golden/upproj_module.npz,
+    basic_block.npz).  owner: the ArenaOwner nn.Module whose gradient arena holds `mod`'s parameters (the module itself when it is
+    called stand-alone).  train=False: eval-mode forward only (BatchNorm folded into the convolutions from the running statistics)."""
 
-    def __init__(self, owner, mod, kind, batch, height, width, cin, bf16=False):
-        assert kind in ("block", "upproj")
+    def __init__(self, owner, mod, kind, batch, height, width, cin, bf16=False, train=True, split=False):
+        assert kind in ("block", "upproj", "decoder")
         self._mod, self._kind, self._cin = mod, kind, cin
         owner._ensure_arenas()      # parameters move into the flat arena BEFORE any op captures their addresses
-        super().__init__(owner, batch, height, width, train=True, bf16=bf16)
+        super().__init__(owner, batch, height, width, train=train, bf16=bf16, split=split)
 
     def _build(self):
         self.x = self.act(self.N, self.H, self.W, self._cin)
-        build, back = (self._upproj, self._upproj_bwd) if self._kind == "upproj" else (self._block, self._block_bwd)
-        self.y, ctx = build("m", self._mod, self.x)
+        if self._kind == "decoder":
+            mods = [("layer%d" % i, getattr(self._mod, "layer%d" % i)) for i in (1, 2, 3, 4)]
+            build, back = self._upproj, self._upproj_bwd
+        else:
+            mods = [("m", self._mod)]
+            build, back = (self._upproj, self._upproj_bwd) if self._kind == "upproj" else (self._block, self._block_bwd)
+        z, ctxs = self.x, []
+        for name, mod in mods:
+            z, ctx = build(name, mod, z)
+            ctxs.append(ctx)
+        self.y = z
         self._finish_pack_jobs()
+        if not self.train:
+            return
         self.dy = self.act(self.y.N, self.y.H, self.y.W, self.y.C)
-        self.dx = back(ctx, self.dy)
+        g = self.dy
+        for ctx in reversed(ctxs):
+            g = back(ctx, g)
+        self.dx = g
         self._flush_reduces()
         self.edge(self.bwd, "join1", 1, 0)
         self.edge(self.bwd, "join2", 2, 0)
 
-    def run(self, x_nchw, dy_nchw):
-        """x [N,C,H,W], dy [N,C',H',W'] CUDA fp32 -> (y, dx) as NCHW tensors; parameter gradients land in the owner's arena."""
+    def forward_nchw(self, x_nchw):
+        """x [N,C,H,W] CUDA fp32 -> y [N,C',H',W'] (a fresh NCHW tensor); no host synchronisation."""
+        if tuple(x_nchw.shape) != (self.N, self._cin, self.H, self.W):
+            raise ValueError("plan built for [%d,%d,%d,%d], got %s" % (self.N, self._cin, self.H, self.W, tuple(x_nchw.shape)))
         self.set_stream()
+        self.generation += 1
         self.x.t.copy_(x_nchw.permute(0, 2, 3, 1))
         self.run_list("prep")
         self.run_list("fwd")
+        return self.y.view().permute(0, 3, 1, 2).contiguous()
+
+    def backward_nchw(self, dy_nchw):
+        """dy [N,C',H',W'] -> dx [N,C,H,W]; parameter gradients land in the owner's gradient arena."""
+        self.set_stream()
         self.dy.t.copy_(dy_nchw.permute(0, 2, 3, 1))
         self.run_list("bwd")
+        return self.dx.view().permute(0, 3, 1, 2).contiguous()
+
+    def run(self, x_nchw, dy_nchw):
+        """x [N,C,H,W], dy [N,C',H',W'] CUDA fp32 -> (y, dx) as NCHW tensors; parameter gradients land in the owner's arena."""
+        y = self.forward_nchw(x_nchw)
+        dx = self.backward_nchw(dy_nchw)
         torch.cuda.synchronize()
-        return self.y.view().permute(0, 3, 1, 2).contiguous(), self.dx.view().permute(0, 3, 1, 2).contiguous()
+        return y, dx

@@ -38,13 +38,24 @@ class _PlanOnly(nn.Module):
                            "(call the ResNet_latefusion / ResNet_multistage module)" % type(self).__name__)
 
 
-class Unpool(_PlanOnly):
-    """Zero-stuffing x2 upsample (models.py:13-27).  Holds no tensor: the HIP path folds it into the following
-    5x5 convolution (four-phase zero-skipping form), so there is nothing to move with .cuda()/.to()."""
+class Unpool(nn.Module):
+    """Zero-stuffing x2 upsample (models.py:13-27).  Holds no tensor: inside a network the HIP path folds it into the following
+    5x5 convolution (four-phase zero-skipping form), so there is nothing to move with .cuda()/.to().  Called on its own it is pure
+    data movement -- the input lands on every stride-th pixel of a zero buffer (what the reference's conv_transpose2d with a one-hot
+    kernel computes) -- with no arithmetic and therefore no kernel of its own; autograd differentiates the strided copy."""
 
     def __init__(self, num_channels, stride=2):
         super().__init__()
         self.num_channels, self.stride = num_channels, stride
+
+    def forward(self, x):
+        if not x.is_cuda:
+            raise RuntimeError("radar_depth_amd modules run on MI355X only (HIP kernels); got a %s tensor" % x.device.type)
+        assert x.dim() == 4 and x.shape[1] == self.num_channels
+        s = self.stride
+        out = x.new_zeros(x.shape[0], x.shape[1], x.shape[2] * s, x.shape[3] * s)
+        out[:, :, ::s, ::s] = x
+        return out
 
 
 def weights_init(m):
@@ -74,74 +85,6 @@ def weights_init_kaiming(m):
 
 def weights_init_kaiming_leaky(m):
     _kaiming(m, "leaky_relu")
-
-
-class BasicBlock(_PlanOnly):
-    expansion = 1
-
-    def __init__(self, inplanes, planes, stride=1, downsample=None, groups=1, base_width=64, dilation=1, norm_layer=None):
-        super().__init__()
-        if dilation > 1:
-            raise NotImplementedError("Dilation > 1 not supported in BasicBlock")
-        self.conv1 = _conv(inplanes, planes, 3, stride)
-        self.bn1 = nn.BatchNorm2d(planes)
-        self.relu = nn.ReLU(inplace=True)
-        self.conv2 = _conv(planes, planes, 3)
-        self.bn2 = nn.BatchNorm2d(planes)
-        self.downsample = downsample
-        self.stride = stride
-
-
-def _make_layer(inplanes, planes, blocks, stride, init=None):
-    down = None
-    if stride != 1 or inplanes != planes:
-        down = nn.Sequential(_conv(inplanes, planes, 1, stride, pad=0), nn.BatchNorm2d(planes))
-    seq = nn.Sequential(BasicBlock(inplanes, planes, stride, down), *[BasicBlock(planes, planes) for _ in range(1, blocks)])
-    if init is not None:
-        for mod in seq.modules():
-            init(mod)
-    return seq
-
-
-class Decoder(_PlanOnly):
-    names = ["deconv2", "deconv3", "upconv", "upproj"]
-
-    def __init__(self):
-        super().__init__()
-        self.layer1 = self.layer2 = self.layer3 = self.layer4 = None
-
-
-class UpProj(Decoder):
-    class UpProjModule(_PlanOnly):
-        def __init__(self, in_channels):
-            super().__init__()
-            half = in_channels // 2
-            self.unpool = Unpool(in_channels)
-            self.upper_branch = nn.Sequential(OrderedDict([
-                ("conv1", _conv(in_channels, half, 5)),
-                ("batchnorm1", nn.BatchNorm2d(half)),
-                ("relu", nn.ReLU()),
-                ("conv2", _conv(half, half, 3)),
-                ("batchnorm2", nn.BatchNorm2d(half)),
-            ]))
-            self.bottom_branch = nn.Sequential(OrderedDict([
-                ("conv", _conv(in_channels, half, 5)),
-                ("batchnorm", nn.BatchNorm2d(half)),
-            ]))
-            self.relu = nn.ReLU()
-
-    def __init__(self, in_channels):
-        super().__init__()
-        self.layer1 = self.UpProjModule(in_channels)
-        self.layer2 = self.UpProjModule(in_channels // 2)
-        self.layer3 = self.UpProjModule(in_channels // 4)
-        self.layer4 = self.UpProjModule(in_channels // 8)
-
-
-def choose_decoder(decoder, in_channels):
-    if decoder == "upproj":
-        return UpProj(in_channels)
-    assert False, "invalid option for decoder: {}".format(decoder)
 
 
 PLAN_CACHE_SIZE = int(os.environ.get("RD_PLAN_CACHE", "3"))
@@ -206,6 +149,130 @@ class ArenaOwner:
 
     def _grad_view(self, param):
         return self._arena_root()._ensure_arenas()["gviews"][id(param)]
+
+
+class _ModuleFunction(torch.autograd.Function):
+    """Bridges a ModulePlan (one sub-module run stand-alone) into torch.autograd, like _PlanFunction does for a network."""
+
+    @staticmethod
+    def forward(ctx, plan, x, *params):
+        ctx.plan, ctx.params = plan, params
+        out = plan.forward_nchw(x)
+        ctx.generation = plan.generation
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        plan = ctx.plan
+        if plan.generation != ctx.generation:
+            raise RuntimeError("this module ran another forward since the one being differentiated: its saved activations are static "
+                               "buffers, so call backward() before the next training-mode forward of the same input shape")
+        dx = plan.backward_nchw(gout.contiguous().float())
+        return (None, dx) + tuple(plan.m._grad_view(p) for p in ctx.params)
+
+
+class _StandaloneForward:
+    """Mixin of the contract's sub-modules (BasicBlock, UpProj.UpProjModule, UpProj): inside a network they are parameter containers
+    whose arithmetic runs in the parent's plan; called on their own -- the reference's are ordinary callable nn.Modules,
+    models.py:96-112,199-216 -- they build (and cache per input shape / mode) a one-module plan from the same op builders
+    (engine.ModulePlan) and run it: differentiable in training mode (batch statistics, running statistics updated), folded-BN
+    inference in eval mode.  The module becomes the root of its own parameter arena for that; a parent network that runs afterwards
+    notices and re-homes its parameters (ArenaOwner._ensure_arenas)."""
+    _plan_kind = None
+
+    def forward(self, x):
+        from ..engine import ModulePlan
+        if not x.is_cuda:
+            raise RuntimeError("radar_depth_amd modules run on MI355X only (HIP kernels); got a %s tensor" % x.device.type)
+        assert x.dim() == 4
+        x = x.contiguous().float()
+        st = self._ensure_arenas()
+        train = bool(self.training)
+        key = (tuple(x.shape), train, st["version"])
+        plans = self.__dict__.setdefault("_plans", {})
+        if key not in plans:
+            for k in [k for k in plans if k[2] != st["version"]] + list(plans)[:max(0, len(plans) + 1 - PLAN_CACHE_SIZE)]:
+                plans.pop(k, None)
+            plans[key] = ModulePlan(self, self, self._plan_kind, x.shape[0], x.shape[2], x.shape[3], x.shape[1], train=train)
+        else:
+            plans[key] = plans.pop(key)
+        plan = plans[key]
+        if train and torch.is_grad_enabled():
+            return _ModuleFunction.apply(plan, x, *st["params"])
+        return plan.forward_nchw(x)
+
+
+class BasicBlock(_StandaloneForward, ArenaOwner, _PlanOnly):
+    expansion = 1
+    _plan_kind = "block"
+
+    def __init__(self, inplanes, planes, stride=1, downsample=None, groups=1, base_width=64, dilation=1, norm_layer=None):
+        super().__init__()
+        if dilation > 1:
+            raise NotImplementedError("Dilation > 1 not supported in BasicBlock")
+        self.conv1 = _conv(inplanes, planes, 3, stride)
+        self.bn1 = nn.BatchNorm2d(planes)
+        self.relu = nn.ReLU(inplace=True)
+        self.conv2 = _conv(planes, planes, 3)
+        self.bn2 = nn.BatchNorm2d(planes)
+        self.downsample = downsample
+        self.stride = stride
+
+
+def _make_layer(inplanes, planes, blocks, stride, init=None):
+    down = None
+    if stride != 1 or inplanes != planes:
+        down = nn.Sequential(_conv(inplanes, planes, 1, stride, pad=0), nn.BatchNorm2d(planes))
+    seq = nn.Sequential(BasicBlock(inplanes, planes, stride, down), *[BasicBlock(planes, planes) for _ in range(1, blocks)])
+    if init is not None:
+        for mod in seq.modules():
+            init(mod)
+    return seq
+
+
+class Decoder(_PlanOnly):
+    names = ["deconv2", "deconv3", "upconv", "upproj"]
+
+    def __init__(self):
+        super().__init__()
+        self.layer1 = self.layer2 = self.layer3 = self.layer4 = None
+
+
+class UpProj(_StandaloneForward, ArenaOwner, Decoder):
+    _plan_kind = "decoder"
+
+    class UpProjModule(_StandaloneForward, ArenaOwner, _PlanOnly):
+        _plan_kind = "upproj"
+
+        def __init__(self, in_channels):
+            super().__init__()
+            half = in_channels // 2
+            self.unpool = Unpool(in_channels)
+            self.upper_branch = nn.Sequential(OrderedDict([
+                ("conv1", _conv(in_channels, half, 5)),
+                ("batchnorm1", nn.BatchNorm2d(half)),
+                ("relu", nn.ReLU()),
+                ("conv2", _conv(half, half, 3)),
+                ("batchnorm2", nn.BatchNorm2d(half)),
+            ]))
+            self.bottom_branch = nn.Sequential(OrderedDict([
+                ("conv", _conv(in_channels, half, 5)),
+                ("batchnorm", nn.BatchNorm2d(half)),
+            ]))
+            self.relu = nn.ReLU()
+
+    def __init__(self, in_channels):
+        super().__init__()
+        self.layer1 = self.UpProjModule(in_channels)
+        self.layer2 = self.UpProjModule(in_channels // 2)
+        self.layer3 = self.UpProjModule(in_channels // 4)
+        self.layer4 = self.UpProjModule(in_channels // 8)
+
+
+def choose_decoder(decoder, in_channels):
+    if decoder == "upproj":
+        return UpProj(in_channels)
+    assert False, "invalid option for decoder: {}".format(decoder)
 
 
 class ResNet_latefusion(ArenaOwner, nn.Module):

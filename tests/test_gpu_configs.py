@@ -366,47 +366,42 @@ class _Holder:
     pass
 
 
-def _module_plan(mod, kind, n, h, w, cin):
-    from radar_depth_amd.engine import ModulePlan
-    from radar_depth_amd.model.models import ArenaOwner
-
-    class Single(ArenaOwner, torch.nn.Module):
-        def __init__(self, inner):
-            super().__init__()
-            self.mod = inner
-    owner = Single(mod).cuda()
-    return owner, ModulePlan(owner, owner.mod, kind, n, h, w, cin)
+def _call(mod, x_np, gy_np):
+    """module(x); y.backward(gy) -- the sub-module called on its own, as the reference's can be."""
+    mod = mod.cuda().train()
+    x = torch.tensor(x_np).cuda().requires_grad_(True)
+    y = mod(x)
+    y.backward(torch.tensor(gy_np).cuda())
+    torch.cuda.synchronize()
+    return y, x.grad
 
 
 def test_upproj_module_fwd_bwd_vs_golden():
-    """One UpProjModule(32) (models.py:181-209: unpool -> 5x5 ‖ 5x5 -> BN/ReLU -> 3x3 -> BN -> add -> ReLU) through the plan's own
-    builders -- 4-phase zero-skipping conv, fused BN statistics, joined BN backward, 25-tap dgrad, per-phase wgrad -- against the
-    reference's module output, input gradient and all 9 parameter gradients.  Tolerance 1e-4 of each tensor's max (the
-    kernels are exact-fp32 fmaf chains; differences are summation order)."""
+    """One UpProjModule(32) (models.py:181-209: unpool -> 5x5 ‖ 5x5 -> BN/ReLU -> 3x3 -> BN -> add -> ReLU) called STAND-ALONE
+    (module(x); y.backward(gy): a one-module plan built from the network plan's own builders -- 4-phase zero-skipping conv, fused BN
+    statistics, joined BN backward, 25-tap dgrad, per-phase wgrad) against the reference's module output, input gradient and all 9
+    parameter gradients.  Tolerance 1e-4 of each tensor's max (the kernels are exact-fp32 fmaf chains; differences are summation order)."""
     from radar_depth_amd.model.models import UpProj
     from radar_depth_amd.synthetic import procedural_fill_
     want = np.load(os.path.join(GOLD, "upproj_module.npz"))
     mod = UpProj.UpProjModule(32)
     procedural_fill_(mod)
-    n, c, h, w = want["x"].shape
-    owner, plan = _module_plan(mod, "upproj", n, h, w, c)
-    y, dx = plan.run(torch.tensor(want["x"]).cuda(), torch.tensor(want["gy"]).cuda())
+    y, dx = _call(mod, want["x"], want["gy"])
     assert rel(_t(y), want["y"]) < 1e-4
     assert rel(_t(dx), want["gx"]) < 1e-4
     checked = 0
-    for name, p in owner.mod.named_parameters():
-        assert rel(_t(owner._grad_view(p)), want["grad/" + name]) < 1e-4, name
+    for name, p in mod.named_parameters():
+        assert rel(_t(p.grad), want["grad/" + name]) < 1e-4, name
         checked += 1
     assert checked == 9
 
 
 @pytest.mark.parametrize("tag,cin,cout,stride", [("id", 32, 32, 1), ("ds", 32, 64, 2), ("id16", 16, 16, 1)])
 def test_basic_block_fwd_bwd_vs_golden(tag, cin, cout, stride):
-    """The reference's own BasicBlock (models.py:75-112), identity-residual and stride-2 + 1x1-downsample forms, through the
-    plan's builders: output, input gradient (residual + conv paths summed in the dgrad epilogue) and every parameter gradient
-    vs vectors generated from the reference; 1e-4 of each tensor's max.  id16 is the depth encoder's layer1 block
-    (BasicBlock(16, 16), models.py:567) on a 19x37 map: the 16x16x4-MFMA kernels (conv16.hip forward / dgrad with the residual
-    addend, wgrad16.hip) with their BatchNorm joins behind a reference-generated pin."""
+    """The reference's own BasicBlock (models.py:75-112), identity-residual and stride-2 + 1x1-downsample forms, called stand-alone:
+    output, input gradient (residual + conv paths summed in the dgrad epilogue) and every parameter gradient vs vectors generated from
+    the reference; 1e-4 of each tensor's max.  id16 is the depth encoder's layer1 block (BasicBlock(16, 16), models.py:567) on a
+    19x37 map: the 16-channel kernels with their BatchNorm joins behind a reference-generated pin."""
     from radar_depth_amd.model.models import BasicBlock, _conv
     from radar_depth_amd.synthetic import procedural_fill_
     want = np.load(os.path.join(GOLD, "basic_block16.npz" if tag == "id16" else "basic_block.npz"))
@@ -415,13 +410,65 @@ def test_basic_block_fwd_bwd_vs_golden(tag, cin, cout, stride):
         down = torch.nn.Sequential(_conv(cin, cout, 1, stride, pad=0), torch.nn.BatchNorm2d(cout))
     mod = BasicBlock(cin, cout, stride, down)
     procedural_fill_(mod)
-    n, c, h, w = want[tag + "/x"].shape
-    owner, plan = _module_plan(mod, "block", n, h, w, c)
-    y, dx = plan.run(torch.tensor(want[tag + "/x"]).cuda(), torch.tensor(want[tag + "/gy"]).cuda())
+    y, dx = _call(mod, want[tag + "/x"], want[tag + "/gy"])
     assert rel(_t(y), want[tag + "/y"]) < 1e-4
     assert rel(_t(dx), want[tag + "/gx"]) < 1e-4
-    for name, p in owner.mod.named_parameters():
-        assert rel(_t(owner._grad_view(p)), want[tag + "/grad/" + name]) < 1e-4, name
+    for name, p in mod.named_parameters():
+        assert rel(_t(p.grad), want[tag + "/grad/" + name]) < 1e-4, name
+
+
+def test_submodules_standalone_vs_oracle():
+    """The other stand-alone forms of the contract's sub-modules against the CPU oracle's modules with the same parameters:
+    the whole UpProj decoder (models.py:210-216, four modules in a row) forward + backward in training mode, a BasicBlock and an
+    UpProjModule in EVAL mode (running statistics, BatchNorm folded into the convolutions), Unpool (models.py:13-27) with its
+    gradient; and a training-mode forward of a sub-module must update its BatchNorm running statistics like the oracle's."""
+    from oracle import models as om
+    from radar_depth_amd.model import models as hm
+    from radar_depth_amd.synthetic import procedural_fill_
+    torch.manual_seed(3)
+    # decoder, training mode
+    dec, odec = hm.UpProj(64), om.UpProj(64)
+    procedural_fill_(dec)
+    procedural_fill_(odec)
+    x = torch.randn(2, 64, 5, 7)
+    gy = torch.randn(2, 4, 80, 112)
+    xo = x.clone().requires_grad_(True)
+    yo = odec.train()(xo)
+    yo.backward(gy)
+    y, dx = _call(dec, x.numpy(), gy.numpy())
+    assert rel(_t(y), _t(yo)) < 1e-4 and rel(_t(dx), _t(xo.grad)) < 2e-4
+    for (n, p), (_, q) in zip(dec.named_parameters(), odec.named_parameters()):
+        assert rel(_t(p.grad), _t(q.grad)) < 2e-4, n
+    for k in ("layer1.upper_branch.batchnorm1.running_mean", "layer4.bottom_branch.batchnorm.running_var"):
+        assert rel(_t(dec.state_dict()[k]), _t(odec.state_dict()[k])) < 1e-4, k
+    # eval mode: BasicBlock (stride 2 + downsample) and UpProjModule, after the statistics moved
+    down = torch.nn.Sequential(hm._conv(32, 64, 1, 2, pad=0), torch.nn.BatchNorm2d(64))
+    odown = torch.nn.Sequential(om._conv(32, 64, 1, 2, pad=0), torch.nn.BatchNorm2d(64))
+    for mod, omod, shape in ((hm.BasicBlock(32, 64, 2, down), om.BasicBlock(32, 64, 2, odown), (2, 32, 11, 13)),
+                             (hm.UpProj.UpProjModule(32), om.UpProj.UpProjModule(32), (2, 32, 7, 9))):
+        procedural_fill_(mod)
+        procedural_fill_(omod)
+        for bn, obn in zip([m for m in mod.modules() if isinstance(m, torch.nn.BatchNorm2d)], [m for m in omod.modules() if isinstance(m, torch.nn.BatchNorm2d)]):
+            rm, rv = torch.randn(bn.num_features) * 0.1, torch.rand(bn.num_features) + 0.5
+            for b_ in (bn, obn):
+                b_.running_mean.copy_(rm)
+                b_.running_var.copy_(rv)
+        xe = torch.randn(*shape)
+        with torch.no_grad():
+            ye = mod.cuda().eval()(xe.cuda())
+            yoe = omod.eval()(xe)
+        assert rel(_t(ye), _t(yoe)) < 1e-4, type(mod).__name__
+    # Unpool
+    up, oup = hm.Unpool(8), om.Unpool(8)
+    xu = torch.randn(2, 8, 5, 6)
+    xg = xu.clone().cuda().requires_grad_(True)
+    yu = up(xg)
+    gu = torch.randn_like(yu)
+    yu.backward(gu)
+    xog = xu.clone().requires_grad_(True)
+    you = oup(xog)
+    you.backward(gu.cpu())
+    assert torch.equal(yu.detach().cpu(), you.detach()) and torch.equal(xg.grad.cpu(), xog.grad)
 
 
 # ------------------------------------------------------------------------------------------------ robustness (ADVICE r1)
