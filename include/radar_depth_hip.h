@@ -118,6 +118,15 @@ int rd_gconv_bf16(const RdConvDesc* d, const float* in, const void* w_packed_bf1
 int rd_gconv_bf16_stat_tiles(const RdConvDesc* d);
 /* diagnostics: out[0..7] = MT, NT, pipelined*1000 + CKP, TH, TW, patch pixels, lds_bytes, workgroups */
 int rd_gconv_bf16_plan_info(const RdConvDesc* d, int32_t* out);
+/* storage-typed forms: with dtype = RD_DTYPE_BF16 the unit-stride-input descriptors of 4..9 taps per phase (3x3 forward / input
+ * gradient, the UpProj forward) run on the persistent pipelined kernel of csrc/gconv_bf16p.hip, whose tiling -- hence the number of
+ * statistics rows rd_gconv_bf16_t writes -- differs from rd_gconv_bf16's: size the statistics buffer with this query when the
+ * tensors are bf16.  plan_info_t: out[2] >= 2000 marks that kernel. */
+int rd_gconv_bf16_stat_tiles_t(int32_t dtype, const RdConvDesc* d);
+int rd_gconv_bf16_plan_info_t(int32_t dtype, const RdConvDesc* d, int32_t* out);
+/* tests / sweeps: on != 0 makes the persistent kernel serve every shape it can run (also those a planner rule leaves to rd_gconv_bf16's
+ * kernel because they measured slower); returns the previous setting.  Do not toggle between sizing buffers on a plan and launching. */
+int rd_gconv_bf16p_plan_all(int32_t on);
 /* diagnostics: with RD_GCONV_BF16_TRACE=1 every workgroup records cycle-counter stamps at its phase boundaries (32 slots per
  * workgroup: count, stamps); copies the last traced launch to the host (tools/trace_gconv_bf16.py) */
 int rd_gconv_bf16_trace_read(unsigned long long* host, int n_wg);

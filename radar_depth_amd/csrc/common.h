@@ -59,6 +59,14 @@ int launch_stem16_fwd(int io16, const float* const* planes, const int64_t* strid
 int launch_conv16(const RdConvDesc& d, const float* in, const float* w_packed, float* out, const float* addend, int ld_add,
                   float* stat, hipStream_t s);
 
+// gconv_bf16p.hip: the persistent bf16-storage convolution (dispatched from rd_gconv_bf16_t for the descriptors it serves)
+int gconv_bf16p_supported(const RdConvDesc* d);
+int gconv_bf16p_plan_all(int on);
+int gconv_bf16p_stat_tiles(const RdConvDesc* d);
+int gconv_bf16p_plan_info(const RdConvDesc* d, int32_t* out);
+int launch_gconv_bf16p(const RdConvDesc* d, const void* in, const void* w_packed_bf16, void* out, const float* bias, int32_t act, int32_t act_cols,
+                       const void* addend, int32_t ld_add, float* stat_partial, hipStream_t s);
+
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 

@@ -632,10 +632,31 @@ extern "C" int rd_gconv_bf16_stat_tiles(const RdConvDesc* d) {
     return d->N * pl.tiles_total;
 }
 
+// storage-typed forms of the two queries: with bf16 tensors the descriptor may be served by gconv_bf16p.hip, whose tiling differs
+extern "C" int rd_gconv_bf16_stat_tiles_t(int32_t dtype, const RdConvDesc* d) {
+    if (dtype == RD_DTYPE_BF16 && gconv_bf16p_supported(d) == 1) return gconv_bf16p_stat_tiles(d);
+    return rd_gconv_bf16_stat_tiles(d);
+}
+
+extern "C" int rd_gconv_bf16p_plan_all(int32_t on) { return gconv_bf16p_plan_all(on); }
+
+extern "C" int rd_gconv_bf16_plan_info_t(int32_t dtype, const RdConvDesc* d, int32_t* out) {
+    if (dtype == RD_DTYPE_BF16 && gconv_bf16p_supported(d) == 1) {
+        const int rc = gconv_bf16p_plan_info(d, out);
+        if (rc == RD_OK) out[2] += 2000;          // (marks the persistent kernel in the plan strings of the tools)
+        return rc;
+    }
+    return rd_gconv_bf16_plan_info(d, out);
+}
+
 static int gconv_bf16_impl(bool io16, const RdConvDesc* d, const void* in, const void* w_packed_bf16, void* out, const float* bias,
                            int32_t act, int32_t act_cols, const void* addend, int32_t ld_add, float* stat_partial, void* stream) {
     RD_CHECK_ARG(in && w_packed_bf16 && out, "gconv_bf16: null tensor");
     RD_CHECK_ARG(!io16 || (d && d->ldi % 8 == 0), "gconv_bf16: bf16 storage needs the input channel stride to be a multiple of 8");
+    // bf16 storage, unit-stride input, 4..9 taps per phase: the persistent pipelined kernel (gconv_bf16p.hip; its statistics tiling is
+    // its own: rd_gconv_bf16_stat_tiles_t)
+    if (io16 && gconv_bf16p_supported(d) == 1)
+        return launch_gconv_bf16p(d, in, w_packed_bf16, out, bias, act, act_cols, addend, ld_add, stat_partial, static_cast<hipStream_t>(stream));
     GconvBfArgs a;
     GconvBfPlan pl;
     int rc = bf_plan_query(d, pl, a.d);

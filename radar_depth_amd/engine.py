@@ -346,8 +346,11 @@ class LateFusionPlan:
             self.pack_jobs.append((w, wd, o, i, kh * kw, cin, off, cout, 1, None, 3 if sp_d else quad))
         if not sp_f:
             self._tune(d)
-        tiles = (self.L.rd_gconv_split_pre_stat_tiles if pre_f else self.L.rd_gconv_split_stat_tiles if sp_f else
-                 self.L.rd_gconv_bf16_stat_tiles if self.bf16 else self.L.rd_gconv_stat_tiles_ws)(C.byref(d))
+        if self.bf16 and not sp_f:
+            tiles = self.L.rd_gconv_bf16_stat_tiles_t(self.dt, C.byref(d))      # (bf16 storage: the persistent kernel's own tiling)
+        else:
+            tiles = (self.L.rd_gconv_split_pre_stat_tiles if pre_f else self.L.rd_gconv_split_stat_tiles if sp_f else
+                     self.L.rd_gconv_stat_tiles_ws)(C.byref(d))
         if tiles < 0:
             check(tiles, "rd_gconv_stat_tiles(%s)" % name)
         stat = self.buf(tiles, 2, cout) if self.train else None

@@ -60,7 +60,7 @@ def test_gconv_bf16_storage_forward_dgrad(cfg):
     xs = _nhwc16(x)
     wp = ops.pack_weights_bf16(wt.cuda())
     out = torch.full((n, d.Ho, d.Wo, co), float("nan"), dtype=torch.bfloat16, device="cuda")
-    stat = torch.full((L.rd_gconv_bf16_stat_tiles(C.byref(d)), 2, co), float("nan"), device="cuda")
+    stat = torch.full((L.rd_gconv_bf16_stat_tiles_t(BF16, C.byref(d)), 2, co), float("nan"), device="cuda")
     check(L.rd_gconv_bf16_t(BF16, C.byref(d), ptr(xs), ptr(wp), ptr(out), None, 0, 0, None, 0, ptr(stat), current_stream()), "gconv_bf16_t")
     torch.cuda.synchronize()
     got = out.permute(0, 3, 1, 2)
@@ -83,6 +83,79 @@ def test_gconv_bf16_storage_forward_dgrad(cfg):
         gys = _nhwc16(gy)
         check(L.rd_gconv_bf16_t(BF16, C.byref(dd), ptr(gys), ptr(wd), ptr(dx), None, 0, 0, ptr(adds), ci if adds is not None else 0, None,
                                 current_stream()), "gconv_bf16_t dgrad")
+        torch.cuda.synchronize()
+        assert _ulp_err(dx.permute(0, 3, 1, 2), dref) <= 1.01
+
+
+@pytest.mark.parametrize("grid_cap", [0, 1, 5])
+@pytest.mark.parametrize("cfg", [(2, 64, 64, 23, 31, "conv"), (3, 32, 32, 57, 100, "conv"), (1, 128, 64, 29, 50, "conv"), (2, 64, 96, 13, 29, "conv"),
+                                 (1, 256, 256, 15, 25, "conv"), (2, 64, 64, 9, 13, "upproj"), (1, 32, 32, 30, 50, "upproj"), (2, 128, 128, 15, 25, "upproj"),
+                                 (2, 64, 64, 3, 5, "conv")])
+def test_gconv_bf16p_persistent_kernel(cfg, grid_cap, monkeypatch):
+    """csrc/gconv_bf16p.hip (the persistent pipelined kernel rd_gconv_bf16_t dispatches bf16 tensors with a unit-stride input and 4..9
+    taps per phase to): 3x3 forward with BatchNorm partial sums, its input gradient with a residual addend, and the four-phase UpProj
+    forward, against fp64 convolutions of the same bf16 operands: every output within one bf16 ulp, statistics within 1e-4.
+    grid_cap 1 / 5: the whole tile list walked by one / five workgroups (the cross-tile pipeline: ring slots, prefetch across the
+    tile boundary, scratch reuse); 0: the launch's own grid.  Ragged tiles, edge tiles and images smaller than a tile included."""
+    from radar_depth_amd import convdesc as cd, ops
+    from radar_depth_amd._lib import check, current_stream, lib, ptr
+    n, ci, co, h, w, kind = cfg
+    L = lib()
+    prev = L.rd_gconv_bf16p_plan_all(1)
+    try:
+        _bf16p_case(cfg, grid_cap, monkeypatch)
+    finally:
+        L.rd_gconv_bf16p_plan_all(prev)
+
+
+def _bf16p_case(cfg, grid_cap, monkeypatch):
+    from radar_depth_amd import convdesc as cd, ops
+    from radar_depth_amd._lib import check, current_stream, lib, ptr
+    n, ci, co, h, w, kind = cfg
+    L = lib()
+    if grid_cap:
+        monkeypatch.setenv("RD_GCONV_BF16P_GRID", str(grid_cap))
+    else:
+        monkeypatch.delenv("RD_GCONV_BF16P_GRID", raising=False)
+    g = torch.Generator().manual_seed(sum(cfg[:5]) + grid_cap)
+    x = _bf(torch.randn(n, ci, h, w, generator=g))
+    if kind == "upproj":
+        wt = torch.randn(co, ci, 5, 5, generator=g) * (2.0 / (9 * ci)) ** 0.5
+        up = torch.zeros(n, ci, 2 * h, 2 * w)
+        up[:, :, ::2, ::2] = x
+        ref = F.conv2d(up.double(), _bf(wt).double(), None, 1, 2)
+        d = cd.upproj_fwd(n, h, w, ci, co)
+    else:
+        wt = torch.randn(co, ci, 3, 3, generator=g) * (2.0 / (9 * ci)) ** 0.5
+        ref = F.conv2d(x.double(), _bf(wt).double(), None, 1, 1)
+        d = cd.conv_fwd(n, h, w, ci, co, 3, 1, 1)
+    info = (C.c_int32 * 8)()
+    check(L.rd_gconv_bf16_plan_info_t(BF16, C.byref(d), info), "plan_info_t")
+    assert info[2] >= 2000, "this shape must be served by the persistent kernel"
+    xs = _nhwc16(x)
+    wp = ops.pack_weights_bf16(wt.cuda())
+    out = torch.full((n, d.Ho, d.Wo, co), float("nan"), dtype=torch.bfloat16, device="cuda")
+    stat = torch.full((L.rd_gconv_bf16_stat_tiles_t(BF16, C.byref(d)), 2, co), float("nan"), device="cuda")
+    for _ in range(2):          # (twice: the second launch must not depend on what the first left in the LDS / the slot table cache)
+        check(L.rd_gconv_bf16_t(BF16, C.byref(d), ptr(xs), ptr(wp), ptr(out), None, 0, 0, None, 0, ptr(stat), current_stream()), "gconv_bf16_t")
+    torch.cuda.synchronize()
+    got = out.permute(0, 3, 1, 2)
+    assert not torch.isnan(got.float()).any()
+    assert _ulp_err(got, ref) <= 1.01, _ulp_err(got, ref)
+    s_ = stat.double().sum(0).cpu()
+    assert ((s_[0] - ref.sum((0, 2, 3))).abs().max() / (ref ** 2).sum((0, 2, 3)).sqrt().max()).item() < 1e-4
+    assert ((s_[1] - (ref ** 2).sum((0, 2, 3))).abs().max() / (ref ** 2).sum((0, 2, 3)).max()).item() < 1e-4
+    if kind == "conv":
+        gy = _bf(torch.randn(ref.shape, generator=g))
+        add = _bf(torch.randn(n, ci, h, w, generator=g))
+        dref = torch.nn.grad.conv2d_input((n, ci, h, w), _bf(wt).double(), gy.double(), 1, 1) + add.double()
+        dd, _ = cd.conv_dgrad(n, h, w, ci, co, 3, 1, 1)
+        check(L.rd_gconv_bf16_plan_info_t(BF16, C.byref(dd), info), "plan_info_t")
+        assert info[2] >= 2000
+        dx = torch.full((n, h, w, ci), float("nan"), dtype=torch.bfloat16, device="cuda")
+        wd = ops.pack_weights_bf16(wt.cuda(), transpose=True)
+        adds, gys = _nhwc16(add), _nhwc16(gy)
+        check(L.rd_gconv_bf16_t(BF16, C.byref(dd), ptr(gys), ptr(wd), ptr(dx), None, 0, 0, ptr(adds), ci, None, current_stream()), "gconv_bf16_t dgrad")
         torch.cuda.synchronize()
         assert _ulp_err(dx.permute(0, 3, 1, 2), dref) <= 1.01
 

@@ -427,11 +427,11 @@ def test_submodules_standalone_vs_oracle():
     from radar_depth_amd.synthetic import procedural_fill_
     torch.manual_seed(3)
     # decoder, training mode
-    dec, odec = hm.UpProj(64), om.UpProj(64)
+    dec, odec = hm.UpProj(256), om.UpProj(256)          # (the networks' decoder: modules of 256 / 128 / 64 / 32 input channels)
     procedural_fill_(dec)
     procedural_fill_(odec)
-    x = torch.randn(2, 64, 5, 7)
-    gy = torch.randn(2, 4, 80, 112)
+    x = torch.randn(2, 256, 5, 7)
+    gy = torch.randn(2, 16, 80, 112)
     xo = x.clone().requires_grad_(True)
     yo = odec.train()(xo)
     yo.backward(gy)

