@@ -495,6 +495,9 @@ def main():
                                   "all other kernels fp32 (v_mfma_f32_32x32x2_f32 / VALU)" % (kinds0.count("gconv_split") + kinds0.count("gconv_split_pre"), kinds0.count("wgrad_split") + kinds0.count("wgrad_split_pre")))
     elif not bf16:
         out["config"]["arith"] = "fp32 everywhere: every convolution on v_mfma_f32_32x32x2_f32 (the alternate plan of the default line)"
+    # short arithmetic tag at the top level (the metric string is BASELINE.json's, the arithmetic must still be visible in one glance)
+    out["arith"] = ("fp32 via 3 x bf16 split, 6 MFMA terms, fp32 accumulate" if split else "bf16 storage + bf16 MFMA" if args.storage == "bf16"
+                    else "bf16 MFMA operands, fp32 tensors" if bf16 else "fp32 MFMA")
     per_gpu = out["value"] / world
     if rank == 0 and not args.no_roofline:
         agg, fam = instrumented_pass(ts)

@@ -75,11 +75,10 @@ __global__ __launch_bounds__(256) void poison_lds_kernel(unsigned* sink, int wor
     if (sink && lds_words[(threadIdx.x * 97) % words] == 0u) sink[0] = 1;      // keep the stores alive
 }
 extern "C" int rd_debug_poison_lds(void* stream) {
-    static bool attr_set = false;
+    static std::atomic<unsigned long long> attr_set{0};
     const int bytes = 160 * 1024 - 1024;
-    if (!attr_set) {
+    if (rd::attr_once(attr_set)) {
         RD_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(poison_lds_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
-        attr_set = true;
     }
     hipLaunchKernelGGL(poison_lds_kernel, dim3(rd::num_cus() * 4), dim3(256), bytes, static_cast<hipStream_t>(stream), (unsigned*)nullptr, bytes / 4);
     RD_CHECK_LAUNCH("poison_lds_kernel");

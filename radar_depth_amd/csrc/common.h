@@ -2,6 +2,8 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+
+#include <atomic>
 #include <stdio.h>
 #include <string.h>
 
@@ -36,6 +38,15 @@ void set_error(const char* fmt, ...);
             return RD_ELAUNCH;                                                    \
         }                                                                         \
     } while (0)
+
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) is per DEVICE: a launcher keeps one bit per device of the process (a
+// process-wide bool left a second device's kernels without the attribute).  True exactly once per (flag, current device); thread-safe.
+static inline bool attr_once(std::atomic<unsigned long long>& mask) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return true;
+    const unsigned long long bit = 1ull << (dev & 63);
+    return (mask.fetch_or(bit) & bit) == 0;
+}
 
 static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 static inline int64_t cdiv64(int64_t a, int64_t b) { return (a + b - 1) / b; }

@@ -558,11 +558,10 @@ static bool plan_gconv_bf16(const RdConvDesc& d, GconvBfPlan& best) {
 
 template <int MT, int NT, bool PIPE, bool IO16>
 static int launch_bf(const GconvBfArgs& a, int grid, size_t lds, hipStream_t s) {
-    static bool attr_set = false;
+    static std::atomic<unsigned long long> attr_set{0};
     auto k = gconv_bf16_kernel<MT, NT, PIPE, IO16>;
-    if (!attr_set) {
+    if (attr_once(attr_set)) {
         RD_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        attr_set = true;
     }
     hipLaunchKernelGGL(k, dim3(grid), dim3(256), lds, s, a);
     RD_CHECK_LAUNCH("gconv_bf16_kernel");

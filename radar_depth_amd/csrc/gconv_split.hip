@@ -1350,11 +1350,10 @@ static bool plan_sp2(const RdConvDesc& d, GsPlan& best) {
 
 template <int MT, int NT, int DBG = 0>
 static int launch_sp2(const GsArgs& a, int grid, size_t lds, hipStream_t s) {
-    static bool attr_set = false;
+    static std::atomic<unsigned long long> attr_set{0};
     auto k = gconv_sp2_kernel<MT, NT, DBG>;
-    if (!attr_set) {
+    if (attr_once(attr_set)) {
         RD_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
-        attr_set = true;
     }
     hipLaunchKernelGGL(k, dim3(grid), dim3(256), lds, s, a);
     RD_CHECK_LAUNCH("gconv_sp2_kernel");
@@ -1363,11 +1362,10 @@ static int launch_sp2(const GsArgs& a, int grid, size_t lds, hipStream_t s) {
 
 template <int MT, int NT, bool PDB, bool PRE>
 static int launch_gs(const GsArgs& a, int grid, size_t lds, hipStream_t s) {
-    static bool attr_set = false;
+    static std::atomic<unsigned long long> attr_set{0};
     auto k = gconv_split_kernel<MT, NT, PDB, PRE>;
-    if (!attr_set) {
+    if (attr_once(attr_set)) {
         RD_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        attr_set = true;
     }
     hipLaunchKernelGGL(k, dim3(grid), dim3(512), lds, s, a);
     RD_CHECK_LAUNCH("gconv_split_kernel");

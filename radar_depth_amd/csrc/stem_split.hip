@@ -313,10 +313,9 @@ extern "C" int rd_stem_fwd_split(const float* const* planes, const int64_t* stri
     const size_t lds = ((size_t)2 * 3 * SS_PPL + (size_t)3 * 2 * ksteps * NT * 32 * 8) * 2 + (size_t)4 * 2 * NT * 32 * sizeof(float);
     hipStream_t s = static_cast<hipStream_t>(stream);
     auto launch = [&](auto k) -> int {
-        static bool attr_done = false;      // (one flag per instantiation of this generic lambda)
-        if (!attr_done) {
+        static std::atomic<unsigned long long> attr_done{0};      // (one flag per instantiation of this generic lambda)
+        if (attr_once(attr_done)) {
             RD_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-            attr_done = true;
         }
         hipLaunchKernelGGL(k, dim3(grid), dim3(512), lds, s, a);
         return RD_OK;

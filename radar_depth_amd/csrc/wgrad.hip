@@ -760,11 +760,10 @@ static inline bool tile_is_tiled(const WgradPlan* tile) { return tile != nullptr
 
 template <int RH, int RW>
 static int launch_strip(const WgradPlan& pl, const WgradArgs& a, int grid, hipStream_t s) {
-    static bool attr_set = false;
+    static std::atomic<unsigned long long> attr_set{0};
     auto k = wgrad_strip_kernel<RH, RW>;
-    if (!attr_set) {
+    if (attr_once(attr_set)) {
         RD_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        attr_set = true;
     }
     hipLaunchKernelGGL(k, dim3(grid), dim3(256), pl.lds, s, a, pl.sa);
     RD_CHECK_LAUNCH("wgrad_strip_kernel");
@@ -773,11 +772,10 @@ static int launch_strip(const WgradPlan& pl, const WgradArgs& a, int grid, hipSt
 
 template <int TG, int MF, bool LA, bool SHB, int PITCH = 0, int RW = 3>
 static int launch_wgrad(const WgradArgs& a, int grid, size_t lds, hipStream_t s) {
-    static bool attr_set = false;
+    static std::atomic<unsigned long long> attr_set{0};
     auto k = wgrad_kernel<TG, MF, LA, SHB, PITCH, RW>;
-    if (!attr_set) {
+    if (attr_once(attr_set)) {
         RD_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        attr_set = true;
     }
     hipLaunchKernelGGL(k, dim3(grid), dim3(256), lds, s, a);
     RD_CHECK_LAUNCH("wgrad_kernel");

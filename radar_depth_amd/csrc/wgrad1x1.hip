@@ -194,11 +194,10 @@ void wgrad1x1_splits(const RdConvDesc& d, int& n_splits, long long& pix_per_spli
 template <int TI, int TO>
 static int launch_w1(const Wgrad1x1Args& a, hipStream_t s) {
     constexpr size_t lds = (size_t)2 * (2 * TI * 32 + 2 * TO * 32) * W1_PC * sizeof(float);
-    static bool attr = false;
+    static std::atomic<unsigned long long> attr{0};
     auto k = wgrad1x1_kernel<TI, TO>;
-    if (!attr) {
+    if (attr_once(attr)) {
         RD_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr = true;
     }
     hipLaunchKernelGGL(k, dim3(a.n_cib * a.n_cob * a.n_splits), dim3(256), lds, s, a);
     RD_CHECK_LAUNCH("wgrad1x1_kernel");

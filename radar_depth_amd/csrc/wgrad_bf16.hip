@@ -459,11 +459,10 @@ static int wgrad_bf16_impl(bool io16, const RdConvDesc* d, const void* in, const
 #define RD_WB(FULL_, NK_) RD_WB2(FULL_, NK_, false) RD_WB2(FULL_, NK_, true)
 #define RD_WB2(FULL_, NK_, IO_)                                                                                                 \
     if (full == FULL_ && nk == NK_ && io16 == IO_) {                                                                            \
-        static bool attr_set = false;                                                                                           \
+        static std::atomic<unsigned long long> attr_set{0};                                                                                           \
         auto k = wgrad_bf16_kernel<FULL_, NK_, IO_>;                                                                            \
-        if (!attr_set) {                                                                                                        \
+        if (attr_once(attr_set)) {                                                                                                        \
             RD_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); \
-            attr_set = true;                                                                                                    \
         }                                                                                                                       \
         hipLaunchKernelGGL(k, grid, dim3(512), pl.lds_bytes, st, a);                                                            \
         RD_CHECK_LAUNCH("wgrad_bf16_kernel");                                                                                   \

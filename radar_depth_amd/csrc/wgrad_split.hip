@@ -432,11 +432,10 @@ static WsPlan ws_plan(const RdConvDesc& d) {
 
 template <int TR, int TC, typename G, bool PRE>
 static int launch_ws(const WsArgs& a, int grid, hipStream_t s) {
-    static bool attr_set = false;
+    static std::atomic<unsigned long long> attr_set{0};
     auto k = wgrad_split_kernel<TR, TC, G, PRE>;
-    if (!attr_set) {
+    if (attr_once(attr_set)) {
         RD_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        attr_set = true;
     }
     hipLaunchKernelGGL(k, dim3(grid), dim3(512), 2 * (PRE ? G::BUF_P : G::BUF), s, a);
     RD_CHECK_LAUNCH("wgrad_split_kernel");

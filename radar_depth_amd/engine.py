@@ -235,10 +235,19 @@ class LateFusionPlan:
         for lo, hi in covered:
             if lo <= pos < hi:
                 pos = hi
-        if pos < a.c0 + a.C and not ent.get("standalone_%d_%d" % (a.c0, a.C)):
-            ent["standalone_%d_%d" % (a.c0, a.C)] = True
+        key = "standalone_%d_%d" % (a.c0, a.C)
+        here = self.streams.index(self._s)
+        if pos < a.c0 + a.C and key not in ent:
+            ent[key] = (here, id(lst))
             ent["prod"].append((C.c_void_p(0), a.c0, a.C))
             self.op(lst, "split_pieces@%x+%d" % (a.t.data_ptr(), a.c0), self.L.rd_split_pieces, a.ptr, a.ld, C.c_int64(m), a.C, ptr_, ent["plane"], self.stream)
+        elif key in ent and ent[key][0] != here:
+            # a later consumer of the same stand-alone planes on ANOTHER stream: order it behind the stream the split pass was issued on
+            # (the shipped models have no such consumer; a new one must not race the pass)
+            if ent[key][1] != id(lst):
+                raise NotImplementedError("piece planes of %x are produced by a stand-alone pass in another op list than their consumer on stream %d"
+                                          % (a.t.data_ptr(), here))
+            self.edge(lst, "split_pieces_join@%x+%d" % (a.t.data_ptr(), a.c0), ent[key][0], here)
         return ptr_, ent["plane"]
 
     def _pre_ok(self, a):

@@ -106,6 +106,12 @@ def _evict_plans(cache, version, room_for=1):
         if sys.getrefcount(plan) <= 2:
             for pl in ([plan.p1, plan.p2] if hasattr(plan, "p1") else [plan]):
                 if hasattr(pl, "close"):
+                    # the plan's side streams are not known to torch's caching allocator: nothing of the plan may still be running
+                    # when its ~11 GB go back to the allocator and the next plan zeroes / uploads into the same blocks
+                    for st in (getattr(pl, "_side", None) or []):
+                        st.synchronize()
+                    if not getattr(pl, "dry_run", True):
+                        torch.cuda.current_stream().synchronize()
                     pl.close()
                     pl.keep = []
 

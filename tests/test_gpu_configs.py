@@ -296,8 +296,10 @@ def test_config5_multistage_bf16_step_vs_emulated_oracle(geom):
 
 
 # ------------------------------------------------------------------------------------------------ plain multistage
-def test_plain_multistage_step_vs_oracle():
-    """--arch resnet18_multistage (main.py:431-438): loss = d1 + d2, no uncertainty weights, no smoothness term."""
+@pytest.mark.parametrize("operands", ["fp32", "split"])
+def test_plain_multistage_step_vs_oracle(operands):
+    """--arch resnet18_multistage (main.py:431-438): loss = d1 + d2, no uncertainty weights, no smoothness term.  Both plans of the fused
+    step; the fp32-MFMA plan keeps the tighter third-step bar it had before the split plan became the default."""
     from oracle import train as otrain
     from radar_depth_amd.main import HipTrainStep
     from radar_depth_amd.synthetic import make_batch
@@ -306,7 +308,7 @@ def test_plain_multistage_step_vs_oracle():
     assert hw_ is None and ow is None and "w_stage1" not in dict(hm.named_parameters())
     opt = torch.optim.SGD(om.parameters(), 0.01, momentum=0.9, weight_decay=1e-4)
     crit = otrain.make_criterion(args.arch)
-    ts = HipTrainStep(hm, b, h, w, lr=0.01, momentum=0.9, weight_decay=1e-4, loss_weights=None)
+    ts = HipTrainStep(hm, b, h, w, lr=0.01, momentum=0.9, weight_decay=1e-4, loss_weights=None, operands=operands)
     for it in range(3):
         x, t = make_batch(b, h, w, 700 + it, ref_pixels=h * w)
         lo, po, ex = otrain.train_step(args.arch, om, crit, opt, x, t, None)
@@ -315,7 +317,8 @@ def test_plain_multistage_step_vs_oracle():
         # step 0 is a forward parity check (measured 0 .. 1e-7); from then on the two trajectories amplify their rounding differences: five
         # arithmetic variants of this library (split / fp32-MFMA plans, stem / 16-channel / head kernel forms) sit 0.9e-4 .. 5e-4 from the oracle
         # at step 1 and 0.95e-3 .. 2.3e-3 at step 2 -- each other's distance as much as the oracle's
-        bar = (1e-5, 2e-3, 5e-3)[it]
+        bar = ((1e-5, 2e-3, 2.5e-3) if operands == "fp32" else (1e-5, 2e-3, 5e-3))[it]
+        print("plain multistage [%s] step %d: loss rel err %.3e (bar %.1e)" % (operands, it, abs(lg.item() - lo.item()) / abs(lo.item()), bar))
         assert abs(lg.item() - lo.item()) / abs(lo.item()) < bar, (it, lg.item(), lo.item())
         po_ = np.array([p.double().norm().item() for p in om.parameters()])
         pg_ = np.array([p.double().norm().item() for p in hm.parameters()])

@@ -22,7 +22,9 @@ from radar_depth_amd.synthetic import make_batch  # noqa: E402
 
 def main(argv=None):
     argv = list(sys.argv[1:] if argv is None else argv)
-    extra = {"--steps-per-epoch": 5, "--height": 450, "--width": 800, "--output": "/tmp/radar_depth_run", "--storage": "fp32"}
+    # --operands split|fp32|bf16: the convolution arithmetic of the fused step (default "split": what bench.py measures; "fp32": every
+    # convolution on the fp32 MFMA, the arithmetic of the eager autograd path)
+    extra = {"--steps-per-epoch": 5, "--height": 450, "--width": 800, "--output": "/tmp/radar_depth_run", "--storage": "fp32", "--operands": "split"}
     for key in list(extra):                      # options of this script, stripped before the reference's parser sees argv
         if key in argv:
             i = argv.index(key)
@@ -38,6 +40,7 @@ def main(argv=None):
     best.set_to_worst()
     step = HipTrainStep(model, args.batch_size, h, w, lr=args.lr, momentum=args.momentum, weight_decay=args.weight_decay,
                         loss_weights=loss_weights, criterion=args.criterion, storage=extra["--storage"],
+                        operands=None if extra["--storage"] == "bf16" else extra["--operands"],
                         autotune=os.environ.get("RD_AUTOTUNE", "1") == "1")     # main.py:11,47 (cudnn.benchmark = True): time the plans once
     if args.resume:                              # main.py:235-266
         ck = utils.load_checkpoint(args.resume)
