@@ -16,7 +16,7 @@ OBJ = os.path.join(CSRC, "build")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libradardepth_hip.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"] + os.environ.get("RD_EXTRA_FLAGS", "").split()      # (build-time experiments: RD_EXTRA_FLAGS="-DRD_MMA_ORDER=1" python -m radar_depth_amd.build --force)
 # every object keeps hipcc's per-kernel register / spill / scratch report next to it (<source>.resource.txt): the ISA audit
 # (tools/audit_resources.py, tests/test_abi_host.py) reads those instead of recompiling
 RES_FLAG = "-Rpass-analysis=kernel-resource-usage"

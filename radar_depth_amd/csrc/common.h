@@ -9,6 +9,30 @@
 
 #include "../../include/radar_depth_hip.h"
 
+// The six kept terms of one accumulator, back to back.  Default order: smallest first.  RD_MMA_ORDER=1 (build-time experiment, round 5):
+// an order in which consecutive MFMAs share an operand (three operand changes each instead of five): fewer toggling input latches of the
+// matrix pipe -- the kernels are power-limited.
+#ifndef RD_MMA_ORDER
+#define RD_MMA_ORDER 0
+#endif
+#if RD_MMA_ORDER == 1
+#define RD_SPLIT_TERMS(c, a0, a1, a2, b0, b1, b2)                           \
+    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, b0, c, 0, 0, 0);        \
+    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b0, c, 0, 0, 0);        \
+    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b1, c, 0, 0, 0);        \
+    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b1, c, 0, 0, 0);        \
+    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b2, c, 0, 0, 0);        \
+    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b0, c, 0, 0, 0);
+#else
+#define RD_SPLIT_TERMS(c, a0, a1, a2, b0, b1, b2)                           \
+    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b2, c, 0, 0, 0);        \
+    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b1, c, 0, 0, 0);        \
+    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, b0, c, 0, 0, 0);        \
+    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b1, c, 0, 0, 0);        \
+    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b0, c, 0, 0, 0);        \
+    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b0, c, 0, 0, 0);
+#endif
+
 namespace rd {
 
 void set_error(const char* fmt, ...);

@@ -514,12 +514,7 @@ __global__ __launch_bounds__(512) void gconv_split_kernel(const GsArgs a) {
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt) {
                     f32x16 c = acc[mt][nt];
-                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[0][mt], B[2][nt], c, 0, 0, 0);
-                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[1][mt], B[1][nt], c, 0, 0, 0);
-                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[2][mt], B[0][nt], c, 0, 0, 0);
-                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[0][mt], B[1][nt], c, 0, 0, 0);
-                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[1][mt], B[0][nt], c, 0, 0, 0);
-                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[0][mt], B[0][nt], c, 0, 0, 0);
+                    RD_SPLIT_TERMS(c, A[0][mt], A[1][mt], A[2][mt], B[0][nt], B[1][nt], B[2][nt])
                     acc[mt][nt] = c;
                 }
         };
@@ -565,12 +560,7 @@ __global__ __launch_bounds__(512) void gconv_split_kernel(const GsArgs a) {
 #pragma unroll
                         for (int nt = 0; nt < NT; ++nt) {
                             f32x16 c = acc[mt][nt];
-                            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[0][mt], Bc[2][nt], c, 0, 0, 0);
-                            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[1][mt], Bc[1][nt], c, 0, 0, 0);
-                            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[2][mt], Bc[0][nt], c, 0, 0, 0);
-                            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[0][mt], Bc[1][nt], c, 0, 0, 0);
-                            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[1][mt], Bc[0][nt], c, 0, 0, 0);
-                            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[0][mt], Bc[0][nt], c, 0, 0, 0);
+                            RD_SPLIT_TERMS(c, A[0][mt], A[1][mt], A[2][mt], Bc[0][nt], Bc[1][nt], Bc[2][nt])
                             acc[mt][nt] = c;
                             __builtin_amdgcn_sched_barrier(0);
                             if (nt == 0) {
@@ -968,12 +958,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void g
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) {
                 f32x16 c = acc[mt][nt];
-                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[0][mt], B[2][nt], c, 0, 0, 0);
-                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[1][mt], B[1][nt], c, 0, 0, 0);
-                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[2][mt], B[0][nt], c, 0, 0, 0);
-                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[0][mt], B[1][nt], c, 0, 0, 0);
-                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[1][mt], B[0][nt], c, 0, 0, 0);
-                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[0][mt], B[0][nt], c, 0, 0, 0);
+                RD_SPLIT_TERMS(c, A[0][mt], A[1][mt], A[2][mt], B[0][nt], B[1][nt], B[2][nt])
                 acc[mt][nt] = c;
             }
     };

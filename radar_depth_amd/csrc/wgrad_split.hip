@@ -336,12 +336,7 @@ __global__ __launch_bounds__(512) void wgrad_split_kernel(const WsArgs a) {
                 }
                 __builtin_amdgcn_sched_barrier(0);
                 f32x16 c = acc[t];
-                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[s_ & 1][0], B[rk & 1][2], c, 0, 0, 0);
-                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[s_ & 1][1], B[rk & 1][1], c, 0, 0, 0);
-                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[s_ & 1][2], B[rk & 1][0], c, 0, 0, 0);
-                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[s_ & 1][0], B[rk & 1][1], c, 0, 0, 0);
-                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[s_ & 1][1], B[rk & 1][0], c, 0, 0, 0);
-                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[s_ & 1][0], B[rk & 1][0], c, 0, 0, 0);
+                RD_SPLIT_TERMS(c, A[s_ & 1][0], A[s_ & 1][1], A[s_ & 1][2], B[rk & 1][0], B[rk & 1][1], B[rk & 1][2])
                 acc[t] = c;
                 __builtin_amdgcn_sched_barrier(0);
             }
