@@ -1,10 +1,13 @@
 # end-of-round collection ON THE GPU BOX (started by tools/gpu_collect.sh, which refuses a dirty tree and passes the commit in RD_HEAD):
 # full GPU test suite; kernel traces + counter passes of the default bench command line (the split plan) and of its alternates; every
 # bench line; per-layer tables; workgroup traces / ablations of the split kernels; stress; resource audit.  Output: gpurun_out/$RD_ROUND/
-R=$GRAFT_REPO_ROOT; RD_ROUND=${RD_ROUND:-r04}; export RD_ROUND; export RD_HEAD=${RD_HEAD:-$(cat $R/.collect_head 2>/dev/null || echo unknown)}
+R=$GRAFT_REPO_ROOT; RD_ROUND=${RD_ROUND:-r05}; export RD_ROUND; export RD_HEAD=${RD_HEAD:-$(cat $R/.collect_head 2>/dev/null || echo unknown)}
 O=$R/gpurun_out/$RD_ROUND; mkdir -p $O; cd $R
 echo "collecting $RD_ROUND at $RD_HEAD"
-timeout 1500 python -m pytest tests -m gpu -q > $O/pytest.txt 2>&1; grep -E "passed|failed|error" $O/pytest.txt | tail -3
+timeout 1800 python -m pytest tests -m gpu -q -s > $O/pytest.txt 2>&1; grep -E "passed|failed|error" $O/pytest.txt | tail -3
+# the margins the parity tests print: worst / median errors per plan, fp64-anchored gradients, the three-step trajectory
+{ echo "# collected at git $RD_HEAD: margins printed by pytest -m gpu -s (tests/test_gpu_margins.py, tests/test_gpu_configs.py)"; grep -aE "fp64-anchored|three steps|gradient norms|config4 grad|plain multistage" $O/pytest.txt | sed 's/^[.sF]*//'; } > $O/parity_margins.txt
+{ echo "# collected at git $RD_HEAD: python tools/diag_fp64.py (b=2 97x161) and 2 129 193"; python tools/diag_fp64.py 2>&1 | grep -v amdgpu.ids; python tools/diag_fp64.py 2 129 193 2>&1 | grep -v amdgpu.ids | tail -4; } > $O/diag_fp64.txt
 # ---- bench lines (JSON, one per file)
 python bench.py 2>/dev/null | tail -1 > $O/bench_c2.json
 python bench.py --operands fp32 --no-cpu-baseline 2>/dev/null | tail -1 > $O/bench_c2_fp32_mfma.json
@@ -17,6 +20,23 @@ RD_FORCE_DP=1 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --ma
 python tools/bench_ops.py > $O/bench_ops_per_layer.txt 2>/dev/null
 python tools/bench_split_pre.py 2>&1 | grep -v amdgpu.ids > $O/bench_split_pre.txt
 python tools/bench_wgrad_split.py 2>&1 | grep -v amdgpu.ids > $O/bench_wgrad_split.txt
+# round 5: slot-map A/B in one job (RD_GCONV_SPLIT_NATURAL=1: the round-4 row-major slots), bf16-storage per-layer A/B, ablations of the
+# persistent bf16-storage kernel, fill-rate / zero-fill microbenchmarks, host issue time
+{ echo "# collected at git $RD_HEAD: slot map A/B, one box, one job"; python tools/bench_split_pre.py 2>&1 | grep TOTAL | sed 's/^/slot map    : /'; RD_GCONV_SPLIT_NATURAL=1 python tools/bench_split_pre.py 2>&1 | grep TOTAL | sed 's/^/row-major   : /';
+  for i in 1 2; do python bench.py --no-cpu-baseline --no-alt --no-roofline 2>/dev/null | tail -1 | python -c "import json,sys;d=json.loads(sys.stdin.read());print('slot map    : %.1f samples/s %.3f ms' % (d['value'], d['ms_per_step']))";
+  RD_GCONV_SPLIT_NATURAL=1 python bench.py --no-cpu-baseline --no-alt --no-roofline 2>/dev/null | tail -1 | python -c "import json,sys;d=json.loads(sys.stdin.read());print('row-major   : %.1f samples/s %.3f ms' % (d['value'], d['ms_per_step']))"; done; } > $O/slot_map_ab.txt 2>&1
+python tools/bench_bf16_storage_ops.py 2>&1 | grep -v amdgpu.ids > $O/bf16_storage_ops_new.txt
+RD_GCONV_BF16P=0 python tools/bench_bf16_storage_ops.py 2>&1 | grep -v amdgpu.ids > $O/bf16_storage_ops_old.txt
+RD_GCONV_BF16P=all python tools/ablate_bf16p.py 2>&1 | grep -v amdgpu.ids > $O/ablate_bf16p.txt
+{ /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -o /tmp/fill_rate tools/micro/fill_rate.hip 2>/dev/null && /tmp/fill_rate; } > $O/fill_rate.txt 2>&1
+{ /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -o /tmp/buf_lds_oob tools/micro/buf_lds_oob.hip 2>/dev/null && /tmp/buf_lds_oob; } > $O/buf_lds_oob.txt 2>&1
+# host issue time: plain launches vs hipGraph replay of the SPLIT plan, configs 2 and 4, and config 4 through the data-parallel code path
+{ echo "# collected at git $RD_HEAD: bench.py host_issue_ms_per_step; plain launches (default) vs --graph (hipGraph replay), split plan; dp1 = RD_FORCE_DP=1 under torchrun, one rank"
+  for cfg in 2 4; do for g in "" "--graph"; do
+    python bench.py --config $cfg $g --no-cpu-baseline --no-alt --no-roofline 2>/dev/null | tail -1 | python -c "import json,sys;d=json.loads(sys.stdin.read());print('config $cfg %-8s: %8.1f samples/s  step %.3f ms  host issue %.3f ms' % ('$g' or 'plain', d['value'], d['ms_per_step'], d.get('host_issue_ms_per_step') or float('nan')))"
+  done; done
+  RD_FORCE_DP=1 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29519 bench.py --gpus 1 --config 4 --no-cpu-baseline --no-alt --no-roofline 2>/dev/null | grep '^{' | tail -1 | python -c "import json,sys;d=json.loads(sys.stdin.read());print('config 4 dp1     : %8.1f samples/s  step %.3f ms  host issue %.3f ms' % (d['value'], d['ms_per_step'], d.get('host_issue_ms_per_step') or float('nan')))"
+} > $O/host_time.txt 2>&1
 python tools/bench_bn.py fp32 2>/dev/null | grep "ch " | cut -c1-330 > $O/bench_bn.txt
 for r in 1 2; do RD_GCONV_SPLIT_TRACE=$r python tools/trace_gconv_split.py 2>&1 | grep -v amdgpu.ids; done > $O/trace_gconv_split.txt
 RD_GCONV_SPLIT_TRACE=1 python tools/trace_gconv_split.py --pre 2>&1 | grep -v amdgpu.ids > $O/trace_gconv_sp2.txt
