@@ -539,6 +539,10 @@ def main():
                                    note="bf16 MFMA FLOPs issued (6 per algorithmic fp32 FLOP) against the dense bf16 peak, i.e. algorithmic fp32 FLOPs "
                                         "against 2500/6 = 416.7 TFLOP/s; random-data sustained rate of this device is ~1850 TFLOP/s "
                                         "(tools/micro/mfma_agpr.hip: the clock drops to 1.85 GHz)",
+                                   # what the device SUSTAINS on a pure v_mfma_f32_32x32x16_bf16 stream with random operands (the clock falls to
+                                   # 1.73-1.85 GHz under that load: tools/micro/mfma_bf16_peak.hip, profiles/r03_mfma_bf16_peak.txt); `frac` above stays
+                                   # priced against the nominal dense peak
+                                   sustained_bf16_peak=1750.0, frac_of_sustained=round(achieved / 1750.0, 4),
                                    fp32_equivalent_tflops=round(flops / (ms * 1e-3) / 1e12, 1), fp32_equivalent_peak=round(2500.0 / 6, 1),
                                    fp32_mfma_peak=PEAK_FP32_TFLOPS, frac_of_fp32_mfma_peak=round(flops / (ms * 1e-3) / 1e12 / PEAK_FP32_TFLOPS, 4),
                                    step_frac_of_split_bound=round(step_flops * args.steps / dt / 1e12 / (2500.0 / 6), 4),

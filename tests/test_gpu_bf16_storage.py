@@ -136,7 +136,9 @@ def _bf16p_case(cfg, grid_cap, monkeypatch):
     wp = ops.pack_weights_bf16(wt.cuda())
     out = torch.full((n, d.Ho, d.Wo, co), float("nan"), dtype=torch.bfloat16, device="cuda")
     stat = torch.full((L.rd_gconv_bf16_stat_tiles_t(BF16, C.byref(d)), 2, co), float("nan"), device="cuda")
-    for _ in range(2):          # (twice: the second launch must not depend on what the first left in the LDS / the slot table cache)
+    for rep in range(2):        # (twice: the second launch must not depend on what the first left in the LDS / the slot table cache;
+        if rep == 1:            #  and with every CU's LDS NaN-filled first: masked slots, unstaged patch rows and ring slots are never consumed)
+            check(L.rd_debug_poison_lds(current_stream()), "poison_lds")
         check(L.rd_gconv_bf16_t(BF16, C.byref(d), ptr(xs), ptr(wp), ptr(out), None, 0, 0, None, 0, ptr(stat), current_stream()), "gconv_bf16_t")
     torch.cuda.synchronize()
     got = out.permute(0, 3, 1, 2)
@@ -155,6 +157,7 @@ def _bf16p_case(cfg, grid_cap, monkeypatch):
         dx = torch.full((n, h, w, ci), float("nan"), dtype=torch.bfloat16, device="cuda")
         wd = ops.pack_weights_bf16(wt.cuda(), transpose=True)
         adds, gys = _nhwc16(add), _nhwc16(gy)
+        check(L.rd_debug_poison_lds(current_stream()), "poison_lds")
         check(L.rd_gconv_bf16_t(BF16, C.byref(dd), ptr(gys), ptr(wd), ptr(dx), None, 0, 0, ptr(adds), ci, None, current_stream()), "gconv_bf16_t dgrad")
         torch.cuda.synchronize()
         assert _ulp_err(dx.permute(0, 3, 1, 2), dref) <= 1.01
