@@ -13,10 +13,9 @@
 //
 //   * persistent workgroups: 2 per CU (4 waves, <= 80 KB of LDS, <= 256 registers), each walks the tile list job = wg, wg + G, ...
 //     The copies of the NEXT stage -- also across the tile boundary: the next tile's first stage is requested before the current
-//     tile's last MFMAs and lands under them and the epilogue -- are issued right behind the barrier that frees their ring slot, one
-//     stage (36 MFMAs per wave on the 3x3 layers) ahead; every second workgroup of a CU starts half a tile late so that one's
-//     epilogue falls into the other's MFMA phase for the whole launch (a start offset is lost at once when workgroups are not
-//     persistent: the next pair is dispatched together again).
+//     tile's last MFMAs and lands under them and the epilogue -- are issued right behind the barrier that frees their ring slot: the
+//     weights (L2 hits) one stage (36 MFMAs per wave on the 3x3 layers) ahead, the patch (HBM) two stages ahead; every second
+//     workgroup of a CU starts half a tile late (measured: the start offset changes nothing, profiles/r05_ablate_bf16p.txt).
 //   * stage = one 16-channel chunk of the patch x all taps of the phase: weights [tap][2][BN] x 16 B copied with global_load_lds from
 //     the packed operand (already in this layout), patch rows copied with buffer_load_dwordx4 ... lds straight from the bf16 NHWC
 //     tensor: one instruction per patch row (lanes 0-31: channels 0-7 of 32 columns, lanes 32-63: channels 8-15), out-of-image
@@ -25,7 +24,7 @@
 //   * LDS patch image [row][unit][32 columns] x 16 B with a row pitch of 64 + p slots (p = 0..15 chosen by the planner): a tap is a
 //     wave-uniform offset (dh rows + dw slots), and the slot map of gconv_split.hip (slot_map.h) places the 16 lanes of every
 //     ds_read_b128 pass on 16 different slots mod 16 -- the pad p is what balances the residue classes r * pitch + c of a tile
-//     whose width is not a multiple of 16.  Two ring slots each for weights and patch; one raw s_barrier per stage.
+//     whose width is not a multiple of 16.  Two ring slots for the weights, three for the patch; one raw s_barrier per stage.
 #include <math.h>
 #include <stdlib.h>
 
