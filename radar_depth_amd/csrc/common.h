@@ -102,6 +102,13 @@ int gconv_bf16p_plan_info(const RdConvDesc* d, int32_t* out);
 int launch_gconv_bf16p(const RdConvDesc* d, const void* in, const void* w_packed_bf16, void* out, const float* bias, int32_t act, int32_t act_cols,
                        const void* addend, int32_t ld_add, float* stat_partial, hipStream_t s);
 
+// gemm1_split.hip: one-tap descriptors of rd_gconv_split
+int gemm1_split_supported(const RdConvDesc* d);
+int gemm1_split_stat_tiles(const RdConvDesc* d);
+int gemm1_split_plan_info(const RdConvDesc* d, int32_t* out);
+int launch_gemm1_split(const RdConvDesc* d, const float* in, const void* w_split, int64_t piece_elems, float* out, const float* bias, int32_t act,
+                       int32_t act_cols, const float* addend, int32_t ld_add, float* stat_partial, hipStream_t s);
+
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 

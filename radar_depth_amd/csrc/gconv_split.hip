@@ -1490,14 +1490,18 @@ extern "C" int rd_gconv_split_plan_all(int on) {
     return prev;
 }
 
+// (one-tap descriptors -- 1x1 convolutions and their input gradients -- go to gemm1_split.hip's channel-grouped kernel: same operands,
+//  same arithmetic, same epilogue; the three queries below and rd_gconv_split answer for whichever kernel serves the descriptor)
 extern "C" int rd_gconv_split_supported(const RdConvDesc* d) {
     GsPlan pl; RdConvDesc dd;
+    if (gemm1_split_supported(d)) return 1;
     return gs_plan_query(d, pl, dd);
 }
 
 // diagnostics: out[0..7] = MT, NT, TH, TW, PP, LDS bytes, workgroups, tap groups of the largest phase
 extern "C" int rd_gconv_split_plan_info(const RdConvDesc* d, int32_t* out) {
     GsPlan pl; RdConvDesc dd;
+    if (out && gemm1_split_supported(d)) return gemm1_split_plan_info(d, out);        // (out[7] = 1000 marks the 1x1 kernel)
     if (!out || gs_plan_query(d, pl, dd) != 1) return RD_EINVAL;
     const int v[8] = {pl.MT, pl.NT, pl.TH, pl.TW, pl.PP, (int)pl.lds_bytes, d->N * pl.tiles_total * pl.n_cotiles, (pl.taps_max + GS_TPS - 1) / GS_TPS + 100 * pl.pdb};
     for (int i = 0; i < 8; ++i) out[i] = v[i];
@@ -1521,6 +1525,7 @@ extern "C" int rd_gconv_split_slot_map(const RdConvDesc* d, int32_t pre, int32_t
 
 extern "C" int rd_gconv_split_stat_tiles(const RdConvDesc* d) {
     GsPlan pl; RdConvDesc dd;
+    if (gemm1_split_supported(d)) return gemm1_split_stat_tiles(d);
     if (gs_plan_query(d, pl, dd) != 1) return RD_EINVAL;
     return d->N * pl.tiles_total;
 }
@@ -1529,6 +1534,8 @@ static int gs_launch(const RdConvDesc* d, const float* in, const void* in_pieces
                      float* out, const float* bias, int32_t act, int32_t act_cols, const float* addend, int32_t ld_add, float* stat_partial, void* stream) {
     const bool pre = in_pieces != nullptr;
     RD_CHECK_ARG(d && (in || in_pieces) && w_split && out, "gconv_split: null argument");
+    if (!pre && gemm1_split_supported(d))
+        return launch_gemm1_split(d, in, w_split, piece_elems, out, bias, act, act_cols, addend, ld_add, stat_partial, static_cast<hipStream_t>(stream));
     GsArgs a;
     GsPlan pl;
     if (gs_plan_query(d, pl, a.d, pre) != 1) { set_error("gconv_split: descriptor not supported (rd_gconv_split_supported)"); return RD_EINVAL; }
