@@ -6,7 +6,8 @@ import ctypes as C
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "lib", "libradardepth_hip.so")
+# (RD_LIB_PATH: another build of the same ABI -- A/B runs of two kernel versions in one GPU job, tools/ab_lib.sh)
+LIB_PATH = os.environ.get("RD_LIB_PATH") or os.path.join(HERE, "lib", "libradardepth_hip.so")
 
 RD_MAX_TAPS = 25
 RD_MAX_PHASES = 4

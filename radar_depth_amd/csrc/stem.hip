@@ -23,6 +23,7 @@ struct StemArgs {
     int Cin, N, H, W, Ho, Wo, Cout, tiles_h, tiles_w;
     int total_tiles, tiles_per_split;  // wgrad
     int debug;            // ablation bits (RD_STEM_DEBUG): 1 stage only the first tile's patch, 2 skip the MFMA walk, 4 skip the stores
+                          // (weight gradient, RD_STEM_WGRAD_DEBUG: 1 stage dout once per workgroup, 2 skip the MFMA walk)
 };
 
 constexpr int ST_TW = 32;
@@ -338,7 +339,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void s
                 for (int u = 0; u < UPW; ++u)
                     if (tid + u * 256 < PLANE) s_patch[ci * PLANE + tid + u * 256] = vnext[ci][u];
             }
-        for (int base = tid; base < NPIX * (BN / 4); base += 256 * U) {
+        for (int base = tid; base < NPIX * (BN / 4) && !((a.debug & 1) && tile > tile_begin); base += 256 * U) {   // (ablation: 1 = stage dout once)
             float4 v[U];
 #pragma unroll
             for (int u = 0; u < U; ++u) {
@@ -359,7 +360,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void s
         rd_sync();
         if (tile + 1 < tile_end) fetch_patch(tile + 1, vnext);          // in flight during the pixel walk
         // pixel walk (two pixels per MFMA), pipelined like the forward K walk; NPIX/2/4 = 16 steps per wave (even)
-        {
+        if (!(a.debug & 2)) {
             float a0[MTK], b0[NT], a1[MTK], b1[NT];
 #define RD_SW_LOAD(AV, BV, Q)                                                                    \
             {                                                                                        \
@@ -605,7 +606,7 @@ static int stem_wgrad_impl(int io16, const float* const* planes, const int64_t* 
     if (rc != RD_OK) return rc;
     RD_CHECK_ARG(dout && grad_oihw && ws, "stem_wgrad: null tensor");
     a.w = nullptr; a.out = nullptr; a.stat = nullptr; a.dout = dout;
-    a.debug = 0;
+    { static const char* dbg = getenv("RD_STEM_WGRAD_DEBUG"); a.debug = dbg ? atoi(dbg) : 0; }     // ablation bits (tools/bench_stem.py)
     a.tiles_h = cdiv(a.Ho, 4); a.tiles_w = cdiv(a.Wo, ST_TW);
     a.total_tiles = N * a.tiles_h * a.tiles_w;
     const int splits = stem_wgrad_splits(a.total_tiles);

@@ -136,6 +136,7 @@ class LateFusionPlan:
         self.stream_mask = int(os.environ.get("RD_STREAM_MASK", "3"))
         self.fwd, self.bwd = [], []
         self.prep = []
+        self.probes = []       # (name, stream index, torch timing event): RD_TAIL_EVENTS=1
         self.evalcoef_jobs = []   # (C, bn, scale ptr, shift ptr) of the folded BatchNorms of an inference plan
         self.pack_jobs = []    # (src, dst, O, I, T, ldc, off, rows_total, transpose, scale, quad): packed in ONE launch per forward
         self.taps = {}         # name -> Act of intermediate tensors (tests / debugging)
@@ -275,6 +276,16 @@ class LateFusionPlan:
             check(self.L.rd_event_create(C.byref(ev)), "rd_event_create")
         self.events.append(ev)
         return ev
+
+    def probe(self, lst, name, k):
+        """RD_TAIL_EVENTS=1 (tools/tail_probe.py): a timing event on stream k at this point of the op list -- where the chains of the three
+        streams really are at a fork / join of an un-profiled step (under rocprofv3 the host falls behind and reorders the streams)."""
+        if self.dry_run or os.environ.get("RD_TAIL_EVENTS") != "1":
+            return
+        ev = torch.cuda.Event(enable_timing=True)
+        ev.record()                       # (materialises the hipEvent_t)
+        self.probes.append((name, k, ev))
+        self.op(lst, "probe." + name, self.L.rd_event_record, C.c_void_p(ev.cuda_event), self.streams[k])
 
     def edge(self, lst, name, src, dst):
         """Make stream `dst` wait for everything enqueued so far on stream `src` (fork or join)."""
@@ -775,8 +786,12 @@ class LateFusionPlan:
         # (g and x are in registers there): no separate reduce pass over the two largest tensors of the network
         tiles = self.L.rd_bnact_maxpool_bwd_tiles(N, ctx["Hc"], ctx["Wc"], cout)
         red = self.buf(tiles, 3, cout)
+        two_pass = os.environ.get("RD_STEM_BWD_TWO_PASS", "0") == "1"
+        # (The apply pass folded into the weight gradient's staging loop -- nobody else reads the RGB stem's BatchNorm input gradient --
+        #  was built and dropped: bit-identical, 214 + 328 us -> 517 us alone, level in the step: the fp32 weight-gradient kernel has no
+        #  registers left to keep a second operand's loads in flight.  profiles/r05_stem_tail.txt)
         dx = self.act(raw.N, raw.H, raw.W, cout)
-        if os.environ.get("RD_STEM_BWD_TWO_PASS", "0") == "1":
+        if two_pass:
             # opt-in: the full-resolution gradient g is never materialised -- the first pass takes the sums only, the second repeats
             # the (quarter-size) gather and stores the BatchNorm input gradient directly.  0.6 GB/step less HBM traffic, bit-identical
             # results, but no faster: fp32 760.2 / 759.5 vs 762.6 / 758.0 samples/s, bf16 storage 1 % slower (1798 vs 1818), round 3
@@ -917,6 +932,7 @@ class LateFusionPlan:
             dep_planes = [t.data_ptr() for t in self.depth_planes]
             dep_strides = [hw] * len(dep_planes)
         # encoders: RGB on the main stream, the (small-channel, low-occupancy) depth encoder concurrently on stream 1
+        self.probe(self.fwd, "fwd_begin", 0)
         self.edge(self.fwd, "fork_depth", 0, 1)
         a, self.c_stem_rgb = self._stem("conv1", rgb_planes, rgb_strides, m.conv1, m.bn1, ACT_RELU, "maxpool")
         with self.on(1):
@@ -952,6 +968,8 @@ class LateFusionPlan:
                     last = li == 3 and bi == len(layer) - 1
                     xd, ctx = self._block("%s.%d" % (lname, bi), blk, xd, out=self.cat.chan(c_rgb, c_dep) if last else None)
                     self.blocks_d.append(ctx)
+        self.probe(self.fwd, "fwd_rgb_encoder_end", 0)
+        self.probe(self.fwd, "fwd_depth_encoder_end", 1)
         self.edge(self.fwd, "join_depth", 1, 0)
         # fusion 1x1 convs (no activation, models.py:652-657)
         if not self.train:
@@ -1052,6 +1070,9 @@ class LateFusionPlan:
         def end_segment(prefixes, last=False):
             evs = []
             self._flush_reduces()
+            if last:
+                for q in (0, 1, 2):
+                    self.probe(self.bwd, "bwd_end_stream%d" % q, q)
             if last or self.segment_joins:
                 self.edge(self.bwd, "join1", 1, 0)
                 self.edge(self.bwd, "join2", 2, 0)
@@ -1087,6 +1108,7 @@ class LateFusionPlan:
         self.conv_bwd(self.c_fus, drf, dx=dcat)
         end_segment(("conv_fusion", "bn_fusion", "conv2", "bn2", "decoder", "conv3"))
 
+        self.probe(self.bwd, "bwd_encoders_begin", 0)
         c_rgb = self.blocks_rgb[-1]["y"].C
         g = dcat.chan(0, c_rgb)
         gd = dcat.chan(c_rgb, dcat.C - c_rgb)
@@ -1095,17 +1117,29 @@ class LateFusionPlan:
             self.dx_dense = self.dense_grad_dst if self.dense_grad_dst is not None else self.buf(N, self.H, self.W)
             dense = (1, self.dx_dense)
         # blocks come in pairs per ResNet stage: indices (6,7)=layer4, (4,5)=layer3, (2,3)=layer2, (0,1)=layer1
+        # The depth chain needs the main stream once: for dcat (the fusion layer's input gradient).  Where the segments end in joins
+        # (hipGraph capture, torch.distributed's all_reduce) every segment forks it again; without joins a second fork would only make
+        # depth layer3 wait for RGB layer4 and depth layer2 / layer1 / stem for RGB layer3 -- the depth chain then trails the RGB chain
+        # at the end of the step with the chip to itself (RD_DEPTH_FORK_ONCE=0 restores the per-stage forks).
+        fork_once = not self.segment_joins and os.environ.get("RD_DEPTH_FORK_ONCE", "1") == "1"
         for stage in (3, 2):
-            self.edge(self.bwd, "fork_depth", 0, 1)
+            if stage == 3 or not fork_once:
+                self.edge(self.bwd, "fork_depth", 0, 1)
             for ctx in reversed(self.blocks_rgb[2 * stage:2 * stage + 2]):
                 g = self._block_bwd(ctx, g)
             with self.on(1):
                 for ctx in reversed(self.blocks_d[2 * stage:2 * stage + 2]):
                     gd = self._block_bwd(ctx, gd)
             end_segment(("layer%d" % (stage + 1), "layer%d_depth" % (stage + 1)))
-        self.edge(self.bwd, "fork_depth", 0, 1)
+        self.probe(self.bwd, "bwd_rgb_layer3_end", 0)
+        self.probe(self.bwd, "bwd_depth_layer3_end", 1)
+        if not fork_once:
+            self.edge(self.bwd, "fork_depth", 0, 1)
         for ctx in reversed(self.blocks_rgb[0:4]):
             g = self._block_bwd(ctx, g)
+        # (Making the depth chain's last blocks wait for the RGB chain to reach its stem -- to run them beside the stem's two HBM-bound
+        #  passes instead of beside the MFMA-bound layers -- costs 1-3.5 %: that chain is ~0.8 ms of dependent small launches and then
+        #  trails the step.  profiles/r05_stem_tail.txt)
         self._stem_bwd(self.c_stem_rgb, g)
         with self.on(1):
             for ctx in reversed(self.blocks_d[0:4]):
@@ -1167,7 +1201,9 @@ class LateFusionPlan:
             self.streams[1].value = self.streams[2].value = cur
             return
         if self._side is None:
-            self._side = [torch.cuda.Stream(device=self.dev), torch.cuda.Stream(device=self.dev)]
+            # (default priorities: raising a stream's priority measured 17-29 % slower in round 1; RD_SIDE_PRIO="p1,p2" for experiments)
+            pr = [int(v) for v in os.environ.get("RD_SIDE_PRIO", "0,0").split(",")]
+            self._side = [torch.cuda.Stream(device=self.dev, priority=pr[0]), torch.cuda.Stream(device=self.dev, priority=pr[1])]
         self.streams[1].value = self._side[0].cuda_stream
         self.streams[2].value = self._side[1].cuda_stream
 

@@ -119,7 +119,7 @@ def test_bn_forward_backward(M, Cc, act, res):
         assert _rel(Gt.cpu(), x2.grad) < 1e-6
 
 
-@pytest.mark.parametrize("N,H,W,Cc,act", [(2, 49, 81, 64, 1), (2, 50, 80, 16, 2), (1, 7, 9, 16, 2)])
+@pytest.mark.parametrize("N,H,W,Cc,act", [(2, 49, 81, 64, 1), (2, 50, 80, 16, 2), (1, 7, 9, 16, 2), (3, 8, 9, 16, 1), (1, 9, 8, 64, 2), (2, 1, 5, 16, 1)])
 def test_bnact_maxpool(N, H, W, Cc, act):
     from radar_depth_amd._lib import check, current_stream, lib, ptr
     L = lib()

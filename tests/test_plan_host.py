@@ -195,9 +195,11 @@ def test_segment_events_replace_joins():
     assert [len(e) for e in pj.segment_events] == [0, 0, 0, 0]
     assert [len(e) for e in pe.segment_events] == [2, 2, 2, 0]
     names = lambda plan: [n for n, _, _ in plan.bwd]
-    strip = lambda ns: [n for n in ns if not n.startswith(("join", "segment_end"))]
+    strip = lambda ns: [n for n in ns if not n.startswith(("join", "segment_end", "fork_depth"))]
     assert strip(names(pj)) == strip(names(pe))
     assert names(pj).count("join1.record") == 4 and names(pe).count("join1.record") == 1
+    # without joins the depth chain is forked from the main stream ONCE (it needs the fusion layer's input gradient and nothing else)
+    assert names(pj).count("fork_depth.record") == 3 and names(pe).count("fork_depth.record") == 1
     assert [s[2] for s in pj.bwd_segments] == [s[2] for s in pe.bwd_segments]
 
 

@@ -25,3 +25,26 @@ for cin, cout, first in ((3, 64, 0), (1, 16, 3)):
     dout = torch.randn(N, Ho, Wo, cout, device="cuda")
     t = timeit(lambda: check(L.rd_stem_wgrad(planes, strides, cin, N, H, W, ptr(dout), cout, ptr(gw), ptr(ws), current_stream()), "stem_wgrad"))
     print("stem wgrad %d->%d: %7.1f us  %5.1f TF (%4.1f%% of fp32 peak)" % (cin, cout, t * 1e6, gf / t / 1e3, 100 * gf / t / 1e3 / 157.3))
+    # BatchNorm-backward apply pass of the stem (the kernel in front of the weight gradient at the end of the step)
+    M = N * Ho * Wo
+    raw = torch.randn(N, Ho, Wo, cout, device="cuda")
+    gamma = torch.rand(cout, device="cuda") + 0.5
+    mean = raw.mean((0, 1, 2)); invstd = 1.0 / torch.sqrt(raw.var((0, 1, 2), unbiased=False) + 1e-5)
+    tiles = L.rd_bn_bwd_tiles(C.c_int64(M), cout)
+    red = torch.zeros(tiles, 3, cout, device="cuda")
+    check(L.rd_bn_bwd_reduce_t(0, ptr(dout), cout, None, 0, ptr(raw), cout, ptr(mean), None, 0, None, None, 0, C.c_int64(M), cout, 0, ptr(red), current_stream()), "reduce")
+    dg, db, coef, dx = torch.zeros(cout, device="cuda"), torch.zeros(cout, device="cuda"), torch.zeros(3 * cout, device="cuda"), torch.empty_like(raw)
+    ta = timeit(lambda: check(L.rd_bn_bwd_apply_t(0, ptr(dout), cout, ptr(raw), cout, ptr(red), tiles, 1, ptr(gamma), ptr(mean), ptr(invstd), ptr(dg), ptr(db), ptr(coef), ptr(dx), cout, C.c_int64(M), cout, current_stream()), "apply"))
+    print("stem %d->%d: BatchNorm-backward apply %7.1f us, weight gradient %7.1f us" % (cin, cout, ta * 1e6, t * 1e6))
+    # pooling + activation backward with the BatchNorm-backward sums (the first kernel of the stem's backward)
+    Hp, Wp = (Ho - 1) // 2 + 1, (Wo - 1) // 2 + 1
+    sc, sh = torch.rand(cout, device="cuda") + 0.5, torch.randn(cout, device="cuda") * 0.3
+    pooled = torch.empty(N, Hp, Wp, cout, device="cuda"); idx = torch.empty(N, Hp, Wp, cout, dtype=torch.uint8, device="cuda")
+    check(L.rd_bnact_maxpool_fwd(ptr(raw), ptr(sc), ptr(sh), 1, N, Ho, Wo, cout, ptr(pooled), cout, ptr(idx), current_stream()), "pool")
+    dyp = torch.randn(N, Hp, Wp, cout, device="cuda")
+    tl = L.rd_bnact_maxpool_bwd_tiles(N, Ho, Wo, cout)
+    redp = torch.zeros(tl, 3, cout, device="cuda")
+    tp = timeit(lambda: check(L.rd_bnact_maxpool_bwd_stats(ptr(dyp), cout, ptr(idx), ptr(raw), ptr(sc), ptr(sh), 1, N, Ho, Wo, cout, ptr(dx), ptr(mean), ptr(redp), current_stream()), "poolb"))
+    tfw = timeit(lambda: check(L.rd_bnact_maxpool_fwd(ptr(raw), ptr(sc), ptr(sh), 1, N, Ho, Wo, cout, ptr(pooled), cout, ptr(idx), current_stream()), "pool"))
+    mb = (raw.numel() * 8 + pooled.numel() * 5) / 1e6
+    print("stem %d->%d: pool + act backward with sums %7.1f us (%.0f MB, %.2f TB/s); forward %7.1f us" % (cin, cout, tp * 1e6, mb, mb / tp / 1e6, tfw * 1e6))
