@@ -786,15 +786,17 @@ class LateFusionPlan:
         # (g and x are in registers there): no separate reduce pass over the two largest tensors of the network
         tiles = self.L.rd_bnact_maxpool_bwd_tiles(N, ctx["Hc"], ctx["Wc"], cout)
         red = self.buf(tiles, 3, cout)
-        two_pass = os.environ.get("RD_STEM_BWD_TWO_PASS", "0") == "1"
+        # two passes over the pooled gradient (sums, then the BatchNorm input gradient stored directly: the full-resolution g is never
+        # materialised): level on fp32 tensors, +0.6 % on bf16 storage since the 2 x 2 gather (1877 vs 1866 and 278.1 vs 276.0 samples/s,
+        # configs 3 / 5, one job; profiles/r05_stem_tail.txt)
+        two_pass = os.environ.get("RD_STEM_BWD_TWO_PASS", "1" if self.storage == "bf16" else "0") == "1"
         # (The apply pass folded into the weight gradient's staging loop -- nobody else reads the RGB stem's BatchNorm input gradient --
         #  was built and dropped: bit-identical, 214 + 328 us -> 517 us alone, level in the step: the fp32 weight-gradient kernel has no
         #  registers left to keep a second operand's loads in flight.  profiles/r05_stem_tail.txt)
         dx = self.act(raw.N, raw.H, raw.W, cout)
         if two_pass:
-            # opt-in: the full-resolution gradient g is never materialised -- the first pass takes the sums only, the second repeats
-            # the (quarter-size) gather and stores the BatchNorm input gradient directly.  0.6 GB/step less HBM traffic, bit-identical
-            # results, but no faster: fp32 760.2 / 759.5 vs 762.6 / 758.0 samples/s, bf16 storage 1 % slower (1798 vs 1818), round 3
+            # the first pass takes the sums only, the second repeats the (quarter-size) gather and stores the BatchNorm input gradient
+            # directly.  0.6 GB/step less HBM traffic on fp32 tensors, bit-identical results
             self.op(self.bwd, ctx["name"] + ".pool_bwd", self.L.rd_bnact_maxpool_bwd_stats_t, self.dt, dpooled.ptr, dpooled.ld, _p(ctx["idx"]), raw.ptr,
                     _p(co["scale"]), _p(co["shift"]), ctx["act"], N, ctx["Hc"], ctx["Wc"], cout, C.c_void_p(0), _p(co["mean"]), _p(red), self.stream)
             bn = co["bn"]
