@@ -316,6 +316,15 @@ int rd_conv16_split(const RdConvDesc* d, const float* in, const float* w_packed,
 int64_t rd_stem_wgrad_workspace_floats(int32_t N, int32_t H, int32_t W, int32_t Cin, int32_t Cout);
 int rd_stem_wgrad(const float* const* planes, const int64_t* strides, int32_t Cin, int32_t N, int32_t H,
                   int32_t W, const float* dout, int32_t Cout, float* grad_oihw, float* ws, void* stream);
+/* The same weight gradient on the bf16 matrix cores -- the split plans' (and the bf16-storage plans') form: the input planes and an
+ * fp32 dout are split into three bf16 pieces while they are staged, six v_mfma_f32_32x32x16_bf16 per product, fp32 accumulation
+ * (rd_gconv_split's arithmetic; a bf16 dout is its own single piece).  rd_stem_wgrad_t's contract: dtype is the element type of dout,
+ * grad_oihw [Cout,Cin,7,7] is overwritten, ws needs rd_stem_wgrad_workspace_floats floats.  rd_stem_wgrad_split_supported: 1 for the
+ * stems of the path (3 -> 64, 1 -> 16, 2 -> 16).  As close to an fp64 gradient as the fp32-MFMA kernel (tests/test_gpu_stem.py).
+ * (reference: loss.backward() through models.py:627-631 conv1 / conv1_depth, main.py:440) */
+int rd_stem_wgrad_split_supported(int32_t Cin, int32_t Cout);
+int rd_stem_wgrad_split_t(int32_t dtype, const float* const* planes, const int64_t* strides, int32_t Cin, int32_t N, int32_t H,
+                          int32_t W, const void* dout, int32_t Cout, float* grad_oihw, float* ws, void* stream);
 /* input gradient w.r.t. ONE input channel `ci` of the stem (stage-2 dense-depth channel,
  * multistage_model.py:75 -- the stage-1 prediction is not detached).  dx is [N,H,W] (overwritten). */
 int rd_stem_dgrad_channel(const float* dout, const float* w_packed, int32_t N, int32_t H, int32_t W,

@@ -1,0 +1,398 @@
+// fp32 weight gradient of the 7x7 / stride-2 stems on the bf16 matrix cores (models.py:539,559,633,643; the step's last kernel):
+//     dW[k = (kh, kw, c)][co] = sum over output pixels (n, oh, ow) of  in[n, c, 2 oh + kh - 3, 2 ow + kw - 3] * dout[n, oh, ow, co]
+// with both operands split into three bf16 pieces while they are staged and every product rebuilt from six v_mfma_f32_32x32x16_bf16
+// (gconv_split.hip's arithmetic and error analysis; a bf16-storage dout is its own single piece: three MFMAs).  The fp32 kernel
+// (stem.hip: v_mfma_f32_32x32x2_f32, 292 of its 328 us at b = 16 are the MFMA walk) sits alone at the end of the step.
+//
+// The reduction index is the PIXEL, and the bf16 MFMA wants eight consecutive pixels per lane for a fixed row:
+//   * dout is pixel-major in HBM and in LDS ([piece][32-channel tile][pixel][32 channels], 64 bytes per pixel) and its fragments are
+//     transposing reads (ds_read_b64_tr_b16), exactly wgrad_split.hip's;
+//   * the input row of a lane is a stride-2 walk over an image row: column 2 ow + kw - 3.  The halo patch is therefore staged
+//     de-interleaved by column parity -- [piece][plane c][patch row][parity][40] bf16, patch column x = 2 (ow - c0) + kw + 1 lives in
+//     parity plane x & 1 at index x >> 1 -- so that eight consecutive output pixels are eight consecutive elements, starting at
+//     element 8 q + sh with sh = (kw + 1) >> 1 in 0..3.  gfx950 serves a ds_read_b128 at such a 2-byte-aligned address correctly but at
+//     1/8 to 1/12 of the aligned rate (tools/micro/lds_unaligned.hip: 48-64 LDS clocks per read against 4-8; the first version of this
+//     kernel was LDS-bound on them, 285 us).  A fragment is therefore five 4-byte-aligned dwords from element 8 q + 2 (sh >> 1) on and
+//     four v_alignbit_b32 by 16 (sh & 1) bits: per-lane constants.  No im2col image, no gather in the walk.
+//
+//   workgroup : 8 waves, one per CU.  Waves 4-7 stage tile i + 1 (patch: 4-byte loads, split, 2-byte stores; dout: 8-channel units,
+//               split, 16-byte stores) into the other LDS buffer; one barrier per tile.  Waves 0-3 walk tile i: the tile's eight
+//               16-pixel reduction steps are dealt to them two each (split-K inside the workgroup), every wave holds the whole
+//               160 x 64 accumulator block (MTK x NT tiles of 32 x 32) and the four are summed through LDS at the end.
+//   pixel tile: 4 rows x 32 columns of one image.
+//   split-K   : contiguous tile ranges per workgroup, slabs [split][k][Cout] with k = (kh * 7 + kw) * Cin + c -- stem.hip's layout,
+//               reduced by the same deterministic slab reduction.
+#include <math.h>
+#include <stdlib.h>
+
+#include "common.h"
+
+namespace rd {
+
+int launch_slab_reduce(const float* slabs, int n_splits, int64_t E, float* tmp, float* grad_oihw, int S, int Cin, int Cout,
+                       int O, int I, int co_off, int accumulate, hipStream_t s);   // wgrad.hip
+
+typedef __bf16 swbf16x8 __attribute__((ext_vector_type(8)));
+typedef short sws16x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int swu32x4 __attribute__((ext_vector_type(4)));
+typedef float swf32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 swbf16x2 __attribute__((ext_vector_type(2)));
+
+constexpr int SW_R = 4, SW_TW = 32, SW_PIX = SW_R * SW_TW;       // 128 output pixels per tile, eight reduction steps
+constexpr int SW_PR = 2 * SW_R + 5;                              // 13 patch rows
+constexpr int SW_PC = 72;                                        // staged patch columns x = 0 .. 71 (read: 1 .. 70)
+constexpr int SW_PITCH = 40;                                     // elements per (row, parity) line (36 used)
+constexpr int SW_PPLANE = ((3 * SW_PR * 2 * SW_PITCH * 2 + 255) / 256) * 256;   // bytes of one piece of the patch (three input planes)
+constexpr int SW_XBYTES = 3 * SW_PPLANE;
+constexpr int SW_YPLANE = SW_PIX * 64;                           // bytes of one [pixel][32 channels] bf16 plane of dout
+constexpr unsigned SW_OOB = 0x80000000u;
+
+struct StemWsArgs {
+    const float* plane[3];
+    long long stride[3];        // elements between consecutive images of each input plane
+    const void* dout;           // NHWC [N,Ho,Wo,Cout], fp32 or (io16) bf16
+    float* slabs;
+    int Cin, N, H, W, Ho, Wo, Cout, tiles_h, tiles_w, total_tiles, tiles_per_split;
+    int dbg;                    // ablation bits (RD_STEM_WGRAD_SPLIT_DEBUG; results garbage): 1 no MFMA walk, 2 no staging after the first tile
+};
+
+__device__ __forceinline__ unsigned sw_cvt_pk(float a, float b) {
+    swf32x2 v;
+    v[0] = a; v[1] = b;
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, swbf16x2));
+}
+// three bf16 pieces of eight fp32 values, a pair at a time (gconv_split.hip)
+__device__ __forceinline__ void sw_split8(const float4 v0, const float4 v1, swu32x4& w0, swu32x4& w1, swu32x4& w2) {
+    const float x[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        float a = x[2 * i], b = x[2 * i + 1];
+        const unsigned u0 = sw_cvt_pk(a, b);
+        a -= __uint_as_float(u0 << 16);
+        b -= __uint_as_float(u0 & 0xffff0000u);
+        const unsigned u1 = sw_cvt_pk(a, b);
+        a -= __uint_as_float(u1 << 16);
+        b -= __uint_as_float(u1 & 0xffff0000u);
+        w0[i] = u0;
+        w1[i] = u1;
+        w2[i] = sw_cvt_pk(a, b);
+    }
+}
+// eight consecutive pixels of one dout channel: two transposing reads of four pixels each (64 bytes per pixel)
+__device__ __forceinline__ swbf16x8 sw_frag_tr(unsigned addr) {
+    typedef __attribute__((address_space(3))) sws16x4* lp;
+    const sws16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(reinterpret_cast<lp>(addr));
+    const sws16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(reinterpret_cast<lp>(addr + 4 * 64));
+    typedef short s16x8 __attribute__((ext_vector_type(8)));
+    s16x8 r;
+    r[0] = lo[0]; r[1] = lo[1]; r[2] = lo[2]; r[3] = lo[3];
+    r[4] = hi[0]; r[5] = hi[1]; r[6] = hi[2]; r[7] = hi[3];
+    return __builtin_bit_cast(swbf16x8, r);
+}
+// eight consecutive elements of a parity line from a 2-byte-aligned position: addr is the 4-byte-aligned address of the dword that holds
+// the first one, sh16 = 16 if it is that dword's upper half
+__device__ __forceinline__ swbf16x8 sw_frag_row(unsigned addr, unsigned sh16) {
+    typedef __attribute__((address_space(3))) const unsigned* lp;
+    const lp q = reinterpret_cast<lp>(addr);
+    const unsigned e0 = q[0], e1 = q[1], e2 = q[2], e3 = q[3], e4 = q[4];
+    swu32x4 v;
+    v[0] = __builtin_amdgcn_alignbit(e1, e0, sh16);
+    v[1] = __builtin_amdgcn_alignbit(e2, e1, sh16);
+    v[2] = __builtin_amdgcn_alignbit(e3, e2, sh16);
+    v[3] = __builtin_amdgcn_alignbit(e4, e3, sh16);
+    return __builtin_bit_cast(swbf16x8, v);
+}
+
+// MTK = ceil(49 Cin / 32) row tiles, NT = 32-channel tiles of dout, B16: dout is bf16 (one piece)
+template <int MTK, int NT, bool B16>
+__global__ __launch_bounds__(512) void stem_wgrad_split_kernel(const StemWsArgs a) {
+    constexpr int YBYTES = 3 * NT * SW_YPLANE;          // (B16 plans use the first piece only)
+    constexpr int BUF = SW_XBYTES + YBYTES;
+    constexpr int NPB = B16 ? 1 : 3;
+    constexpr int CIN = MTK == 5 ? 3 : MTK == 4 ? 2 : 1;      // (49 Cin rows in MTK tiles of 32)
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const bool loader = wave >= 4;
+    const unsigned lds0 = (unsigned)(size_t)smem;
+    constexpr int K = 49 * CIN;
+
+    const int split = xcd_remap(blockIdx.x, gridDim.x);
+    const int tile_begin = split * a.tiles_per_split;
+    const int tile_end = min(tile_begin + a.tiles_per_split, a.total_tiles);
+    const int ntiles = tile_end - tile_begin;
+    const int tiles_img = a.tiles_h * a.tiles_w;
+
+    f32x16 acc[MTK][NT];      // (zeroed in the compute branch only)
+
+    if (loader) {
+        // ------------------------------------------------------------------------------------------ staging waves
+        const int lt = tid - 256;
+        // patch slots of this thread: element e = lt + 256 q of a plane's [13][72] patch
+        constexpr int UPB = (SW_PR * SW_PC + 255) / 256;      // 4
+        int prx[UPB], pdst[UPB];
+#pragma unroll
+        for (int q = 0; q < UPB; ++q) {
+            const int e = lt + q * 256;
+            const int pr = e / SW_PC, x = e - pr * SW_PC;
+            const bool in = e < SW_PR * SW_PC;
+            prx[q] = ((in ? pr : 30000) << 16) | x;
+            pdst[q] = in ? ((pr * 2 + (x & 1)) * SW_PITCH + (x >> 1)) * 2 : 36 * 2;      // (slots past the patch: a padding element of line 0)
+        }
+        // dout units of this thread: unit u = lt + 256 j = (co tile t, pixel, 8-channel quarter q)
+        constexpr int YU = NT * SW_PIX * 4;
+        constexpr int UPY = YU / 256;                         // 2 NT
+        int ypx[UPY], ych[UPY], ydst[UPY];
+#pragma unroll
+        for (int j = 0; j < UPY; ++j) {
+            const int u = lt + 256 * j;
+            const int t = u / (SW_PIX * 4), rem = u - t * (SW_PIX * 4);
+            ypx[j] = rem >> 2;
+            ych[j] = t * 32 + (rem & 3) * 8;
+            ydst[j] = SW_XBYTES + t * SW_YPLANE + rem * 16;
+        }
+        const unsigned yimg = (unsigned)(a.Ho * a.Wo * a.Cout) * (B16 ? 2u : 4u);
+        float pf[3][UPB];
+        float4 y0[UPY], y1[UPY];
+        auto fetch = [&](int tile) {
+            const int n = tile / tiles_img, tr = tile - n * tiles_img;
+            const int r0 = (tr / a.tiles_w) * SW_R, c0 = (tr % a.tiles_w) * SW_TW;
+            const int ih0 = 2 * r0 - 3, iw0 = 2 * c0 - 4;          // patch row 0 / patch column x = 0
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                if (c < CIN) {
+                    const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc(
+                        const_cast<float*>(a.plane[c] + (size_t)n * a.stride[c]), 0, (unsigned)(a.H * a.W) * 4u, 0x00020000);
+#pragma unroll
+                    for (int q = 0; q < UPB; ++q) {
+                        const int ih = ih0 + (prx[q] >> 16), iw = iw0 + (prx[q] & 0xffff);
+                        const unsigned off = (ih >= 0 && ih < a.H && iw >= 0 && iw < a.W) ? (unsigned)(ih * a.W + iw) * 4u : SW_OOB;
+                        pf[c][q] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, (int)off, 0, 0));
+                    }
+                }
+            }
+            const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc(
+                const_cast<char*>(static_cast<const char*>(a.dout)) + (size_t)n * a.Ho * a.Wo * a.Cout * (B16 ? 2 : 4), 0, yimg, 0x00020000);
+#pragma unroll
+            for (int j = 0; j < UPY; ++j) {
+                const int oh = r0 + (ypx[j] >> 5), ow = c0 + (ypx[j] & 31);
+                const bool ok = oh < a.Ho && ow < a.Wo && ych[j] < a.Cout;
+                if (B16) {
+                    const unsigned off = ok ? (unsigned)(((oh * a.Wo + ow) * a.Cout + ych[j]) * 2) : SW_OOB;
+                    y0[j] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(ry, (int)off, 0, 0));
+                } else {
+                    const unsigned off = ok ? (unsigned)(((oh * a.Wo + ow) * a.Cout + ych[j]) * 4) : SW_OOB;
+                    y0[j] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(ry, (int)off, 0, 0));
+                    y1[j] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(ry, (int)off + 16, 0, 0));
+                }
+            }
+        };
+        auto split_put = [&](int buf) {
+            const unsigned base = lds0 + buf * BUF;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                if (c < CIN) {
+#pragma unroll
+                    for (int q = 0; q < UPB; ++q) {
+                        float f = pf[c][q];
+                        const __bf16 p0 = (__bf16)f;
+                        f -= (float)p0;
+                        const __bf16 p1 = (__bf16)f;
+                        f -= (float)p1;
+                        const __bf16 p2 = (__bf16)f;
+                        const unsigned ad = base + c * (SW_PR * 2 * SW_PITCH * 2) + pdst[q];
+                        asm volatile("ds_write_b16 %0, %1" ::"v"(ad), "v"((unsigned)__builtin_bit_cast(unsigned short, p0)) : "memory");
+                        asm volatile("ds_write_b16 %0, %1 offset:%2" ::"v"(ad), "v"((unsigned)__builtin_bit_cast(unsigned short, p1)), "n"(SW_PPLANE) : "memory");
+                        asm volatile("ds_write_b16 %0, %1 offset:%2" ::"v"(ad), "v"((unsigned)__builtin_bit_cast(unsigned short, p2)), "n"(2 * SW_PPLANE) : "memory");
+                    }
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < UPY; ++j) {
+                const unsigned ad = base + ydst[j];
+                if (B16) {
+                    asm volatile("ds_write_b128 %0, %1" ::"v"(ad), "v"(__builtin_bit_cast(swu32x4, y0[j])) : "memory");
+                } else {
+                    swu32x4 w0, w1, w2;
+                    sw_split8(y0[j], y1[j], w0, w1, w2);
+                    asm volatile("ds_write_b128 %0, %1" ::"v"(ad), "v"(w0) : "memory");
+                    asm volatile("ds_write_b128 %0, %1" ::"v"(ad + NT * SW_YPLANE), "v"(w1) : "memory");
+                    asm volatile("ds_write_b128 %0, %1" ::"v"(ad + 2 * NT * SW_YPLANE), "v"(w2) : "memory");
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        };
+        // tile i lives in buffer i & 1.  Iteration i: barrier B(i) (tile i published, buffer (i + 1) & 1 free); split and store tile
+        // i + 1 (fetched during iteration i - 1), then fetch tile i + 2: its loads have the whole walk of tile i + 1 to land
+        if (ntiles > 0) {
+            fetch(tile_begin);
+            split_put(0);
+            if (ntiles > 1) fetch(tile_begin + 1);
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        for (int i = 0; i < ntiles; ++i) {
+            rd_sync();                            // B(i)
+            if (i + 1 < ntiles && !(a.dbg & 2)) split_put((i + 1) & 1);
+            if (i + 2 < ntiles && !(a.dbg & 2)) fetch(tile_begin + i + 2);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        }
+        rd_sync();                                // matches the compute waves' final barrier
+    } else {
+        // ------------------------------------------------------------------------------------------ compute waves
+#pragma unroll
+        for (int mt = 0; mt < MTK; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) acc[mt][nt][i] = 0.f;
+        const int l31 = lane & 31, g = lane >> 5;
+        // lane part of a patch fragment address: row m = mt * 32 + l31 = (kh * 7 + kw) * Cin + c; rows past K read row 0 (never stored)
+        unsigned arow[MTK], ash[MTK];
+#pragma unroll
+        for (int mt = 0; mt < MTK; ++mt) {
+            int m = mt * 32 + l31;
+            if (m >= K) m = 0;
+            const int t = m / CIN, c = m - t * CIN, kh = t / 7, kw = t - kh * 7;
+            const int sh = (kw + 1) >> 1;
+            arow[mt] = lds0 + (unsigned)(((c * SW_PR + kh) * 2 + ((kw + 1) & 1)) * SW_PITCH + 2 * (sh >> 1) + 8 * g) * 2u;
+            ash[mt] = 16u * (sh & 1);
+        }
+        // lane part of a dout fragment address (wgrad_split.hip): pixel row (lane & 15) / 4 of the group's four, 8-byte chunk lane & 3,
+        // second 16 channels for lanes 16..31 of each half, pixels 8.. for the upper half wave
+        const unsigned yb = lds0 + SW_XBYTES + (unsigned)(((lane & 15) >> 2) + g * 8) * 64u + (lane & 3) * 8u + ((lane >> 4) & 1) * 32u;
+        for (int i = 0; i < ntiles; ++i) {
+            rd_sync();                            // B(i)
+            if (a.dbg & 1) continue;
+            const unsigned bo = (i & 1) * BUF;
+            // this wave's two reduction steps of the tile: ks = wave and wave + 4, step ks = (row ks >> 1, column half ks & 1)
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int ks = wave + 4 * h;
+                const int rl = ks >> 1, s = ks & 1;
+                const unsigned xo = bo + (unsigned)(4 * rl * SW_PITCH + 16 * s) * 2u;
+                const unsigned yo = bo + (unsigned)(rl * 32 + 16 * s) * 64u;
+                swbf16x8 B[NT][NPB];
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                    for (int p = 0; p < NPB; ++p) B[nt][p] = sw_frag_tr(yb + yo + nt * SW_YPLANE + p * NT * SW_YPLANE);
+                swbf16x8 A[2][3];
+#pragma unroll
+                for (int p = 0; p < 3; ++p) A[0][p] = sw_frag_row(arow[0] + xo + p * SW_PPLANE, ash[0]);
+#pragma unroll
+                for (int mt = 0; mt < MTK; ++mt) {
+                    // the next row tile's fragments are read in front of this one's MFMAs and the order is pinned (wgrad_split.hip)
+                    if (mt + 1 < MTK) {
+#pragma unroll
+                        for (int p = 0; p < 3; ++p) A[(mt + 1) & 1][p] = sw_frag_row(arow[mt + 1] + xo + p * SW_PPLANE, ash[mt + 1]);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt) {
+                        f32x16 c = acc[mt][nt];
+                        if (B16) {
+                            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[mt & 1][2], B[nt][0], c, 0, 0, 0);
+                            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[mt & 1][1], B[nt][0], c, 0, 0, 0);
+                            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[mt & 1][0], B[nt][0], c, 0, 0, 0);
+                        } else {
+                            RD_SPLIT_TERMS(c, A[mt & 1][0], A[mt & 1][1], A[mt & 1][2], B[nt][0], B[nt][NPB > 1 ? 1 : 0], B[nt][NPB > 2 ? 2 : 0])
+                        }
+                        acc[mt][nt] = c;
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+        }
+        rd_sync();
+    }
+    // ---- the four compute waves' partial blocks summed through LDS, one accumulator tile at a time (every wave takes part in the
+    // barriers); slab [k][Cout] of this split (zeros when the split has no tiles)
+    float* red = smem;      // [4][16][64]
+    float* slab = a.slabs + (size_t)split * K * a.Cout;
+    const int l31 = lane & 31, hh = lane >> 5;
+#pragma unroll
+    for (int mt = 0; mt < MTK; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            rd_sync();
+            if (!loader) {
+#pragma unroll
+                for (int i = 0; i < 16; ++i) red[(wave * 16 + i) * 64 + lane] = acc[mt][nt][i];
+            }
+            rd_sync();
+            if (!loader) {
+#pragma unroll
+                for (int ii = 0; ii < 4; ++ii) {
+                    const int i = ii * 4 + wave;
+                    const float v = red[(0 * 16 + i) * 64 + lane] + red[(1 * 16 + i) * 64 + lane] + red[(2 * 16 + i) * 64 + lane] +
+                                    red[(3 * 16 + i) * 64 + lane];
+                    const int k = mt * 32 + (i & 3) + 8 * (i >> 2) + 4 * hh;
+                    const int co = nt * 32 + l31;
+                    if (k < K && co < a.Cout) slab[(size_t)k * a.Cout + co] = v;
+                }
+            }
+        }
+}
+
+}  // namespace rd
+using namespace rd;
+
+extern "C" int64_t rd_stem_wgrad_workspace_floats(int32_t N, int32_t H, int32_t W, int32_t Cin, int32_t Cout);     // stem.hip: an upper bound for this kernel's splits too
+
+extern "C" int rd_stem_wgrad_split_supported(int32_t Cin, int32_t Cout) {
+    static const char* off = getenv("RD_STEM_WGRAD_SPLIT");      // RD_STEM_WGRAD_SPLIT=0: diagnostics
+    if (off && atoi(off) == 0) return 0;
+    return ((Cin == 3 && Cout == 64) || (Cin >= 1 && Cin <= 2 && Cout == 16)) ? 1 : 0;
+}
+
+// Same contract as rd_stem_wgrad_t (weight gradient OIHW, overwritten; ws of rd_stem_wgrad_workspace_floats floats).
+extern "C" int rd_stem_wgrad_split_t(int32_t dtype, const float* const* planes, const int64_t* strides, int32_t Cin, int32_t N, int32_t H,
+                                     int32_t W, const void* dout, int32_t Cout, float* grad_oihw, float* ws, void* stream) {
+    RD_CHECK_ARG(dtype == RD_DTYPE_F32 || dtype == RD_DTYPE_BF16, "stem_wgrad_split_t: bad dtype %d", dtype);
+    RD_CHECK_ARG(planes && strides && dout && grad_oihw && ws && N > 0 && H > 0 && W > 0, "stem_wgrad_split: null tensor / empty shape");
+    RD_CHECK_ARG(rd_stem_wgrad_split_supported(Cin, Cout) == 1 && cdiv(49 * Cin, 32) == (Cin == 3 ? 5 : Cin == 2 ? 4 : 2), "stem_wgrad_split: unsupported shape Cin=%d Cout=%d", Cin, Cout);
+    RD_CHECK_ARG((int64_t)H * W * 4 < (int64_t)SW_OOB && (int64_t)((H - 1) / 2 + 1) * ((W - 1) / 2 + 1) * Cout * 4 < (int64_t)SW_OOB,
+                 "stem_wgrad_split: an image exceeds the 2 GB buffer-addressing range");
+    StemWsArgs a;
+    for (int c = 0; c < 3; ++c) {
+        a.plane[c] = c < Cin ? planes[c] : nullptr;
+        a.stride[c] = c < Cin ? strides[c] : 0;
+        RD_CHECK_ARG(c >= Cin || planes[c] != nullptr, "stem_wgrad_split: null input plane %d", c);
+    }
+    a.dout = dout; a.slabs = ws;
+    a.Cin = Cin; a.N = N; a.H = H; a.W = W; a.Cout = Cout;
+    a.Ho = (H - 1) / 2 + 1; a.Wo = (W - 1) / 2 + 1;
+    a.tiles_h = cdiv(a.Ho, SW_R); a.tiles_w = cdiv(a.Wo, SW_TW);
+    a.total_tiles = N * a.tiles_h * a.tiles_w;
+    { static const char* dbg = getenv("RD_STEM_WGRAD_SPLIT_DEBUG"); a.dbg = dbg ? atoi(dbg) : 0; }
+    // one workgroup per CU, at least two tiles per split (the first tile's staging is exposed); never more splits than stem.hip's
+    // kernel would use (the workspace is sized for those)
+    int ns = num_cus();
+    const int max_ns = cdiv(a.total_tiles, 2);
+    if (ns > max_ns) ns = max_ns < 1 ? 1 : max_ns;
+    a.tiles_per_split = cdiv(a.total_tiles, ns);
+    const int n_splits = cdiv(a.total_tiles, a.tiles_per_split);
+    const int K = 49 * Cin;
+    const int64_t E = (int64_t)K * Cout;
+    RD_CHECK_ARG((int64_t)(n_splits + (n_splits < 16 ? n_splits : 16)) * E <= rd_stem_wgrad_workspace_floats(N, H, W, Cin, Cout),
+                 "stem_wgrad_split: workspace smaller than this kernel's %d splits need", n_splits);
+    const int MTK = cdiv(K, 32), NT = Cout > 32 ? 2 : 1;
+    const bool b16 = dtype == RD_DTYPE_BF16;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const size_t lds = 2 * ((size_t)SW_XBYTES + 3 * (size_t)NT * SW_YPLANE);
+#define RD_SWS(M_, N_, B_)                                                                                           \
+    if (MTK == M_ && NT == N_ && b16 == B_) {                                                                        \
+        static std::atomic<unsigned long long> attr_set{0};       /* (one flag set per instantiation) */             \
+        if (attr_once(attr_set))                                                                                     \
+            RD_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(stem_wgrad_split_kernel<M_, N_, B_>),     \
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                 \
+        hipLaunchKernelGGL((stem_wgrad_split_kernel<M_, N_, B_>), dim3(n_splits), dim3(512), lds, s, a);             \
+        RD_CHECK_LAUNCH("stem_wgrad_split_kernel");                                                                  \
+    } else
+    RD_SWS(5, 2, false) RD_SWS(5, 2, true) RD_SWS(2, 1, false) RD_SWS(2, 1, true) RD_SWS(4, 1, false) RD_SWS(4, 1, true) {
+        set_error("stem_wgrad_split: no instantiation for Cin=%d Cout=%d", Cin, Cout);
+        return RD_EINVAL;
+    }
+#undef RD_SWS
+    return launch_slab_reduce(ws, n_splits, E, ws + (int64_t)n_splits * E, grad_oihw, 49, Cin, Cout, Cout, Cin, 0, 0, s);
+}

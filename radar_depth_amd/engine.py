@@ -815,7 +815,11 @@ class LateFusionPlan:
         wst = 2 if cur == 0 else cur
         self.edge(self.bwd, ctx["name"] + ".fork_wgrad", cur, wst)
         with self.on(wst):
-            self.op(self.bwd, ctx["name"] + ".wgrad", self.L.rd_stem_wgrad_t, self.dt, ctx["pl"], ctx["st"], cin, N, H, W, dx.ptr, cout,
+            # split and bf16-storage plans: the stem weight gradients on the bf16 matrix cores too (csrc/stem_wgrad_split.hip: three-piece
+            # operands, fp32 arithmetic; the RGB one is the last kernel of the step, alone on the chip)
+            f_wg = (self.L.rd_stem_wgrad_split_t if (self.split or self.storage == "bf16") and
+                    self.L.rd_stem_wgrad_split_supported(cin, cout) == 1 else self.L.rd_stem_wgrad_t)
+            self.op(self.bwd, ctx["name"] + ".wgrad", f_wg, self.dt, ctx["pl"], ctx["st"], cin, N, H, W, dx.ptr, cout,
                     _p(self.grad_of(ctx["conv"].weight)), _p(ws), self.stream)
         if dgrad_channel is not None:
             ci, dst = dgrad_channel

@@ -114,3 +114,48 @@ def test_stem_dgrad_channel(cfg):
     torch.cuda.synchronize()
     assert not torch.isnan(dx).any()
     assert ((dx.cpu().double() - ref).abs().max() / ref.abs().max()).item() < 2e-6, cfg
+
+
+@pytest.mark.parametrize("cfg", [
+    (2, 3, 64, 97, 161, 0),       # RGB stem, ragged tiles in both directions
+    (2, 1, 16, 97, 161, 0),       # depth stem
+    (2, 2, 16, 64, 64, 0),        # stage 2 of the multistage net: two depth planes
+    (16, 3, 64, 450, 800, 0),     # BASELINE config 2's own launch (one workgroup per CU, ~46 tiles each)
+    (1, 3, 64, 15, 63, 0),        # a single ragged tile row, fewer tiles than CUs
+    (3, 3, 64, 9, 11, 0),         # tiles smaller than the 4 x 32 block
+    (2, 3, 64, 97, 161, 1),       # bf16 storage: dout is its own single piece
+    (2, 1, 16, 97, 161, 1),
+    (8, 3, 64, 450, 800, 1),
+])
+def test_stem_wgrad_split(cfg):
+    """rd_stem_wgrad_split_t (csrc/stem_wgrad_split.hip: three-piece operands on v_mfma_f32_32x32x16_bf16, fp32 accumulation) against an
+    fp64 weight gradient: as close as the fp32-MFMA kernel rd_stem_wgrad_t (bar: 1.5x its error + a floor), inputs spanning 2^-12 .. 2^12 in
+    magnitude, every element of the gradient written (NaN-filled target and workspace)."""
+    from radar_depth_amd._lib import check, current_stream, lib, ptr
+    L = lib()
+    n, cin, cout, h, w, dt = cfg
+    assert L.rd_stem_wgrad_split_supported(cin, cout) == 1
+    tdt = torch.bfloat16 if dt else torch.float32
+    gen = torch.Generator().manual_seed(17)
+    mag = torch.exp2(torch.randint(-12, 13, (n, cin + 1, 1, 1), generator=gen).float())
+    x = (torch.randn(n, cin + 1, h, w, generator=gen) * mag).cuda()       # the stem reads planes 1.. of a wider NCHW tensor (strided images)
+    ho, wo = (h - 1) // 2 + 1, (w - 1) // 2 + 1
+    dout = (torch.randn(n, ho, wo, cout, generator=gen) * torch.exp2(torch.randint(-6, 7, (1, 1, 1, cout), generator=gen).float())).to(tdt).cuda()
+    hw = h * w
+    planes = (C.c_void_p * 3)(*[x.data_ptr() + 4 * hw * (1 + c) if c < cin else None for c in range(3)])
+    strides = (C.c_int64 * 3)(*[(cin + 1) * hw if c < cin else 0 for c in range(3)])
+    L.rd_stem_wgrad_workspace_floats.restype = C.c_int64
+    nws = int(L.rd_stem_wgrad_workspace_floats(n, h, w, cin, cout))
+    want = torch.nn.grad.conv2d_weight(x[:, 1:].double(), (cout, cin, 7, 7), dout.double().permute(0, 3, 1, 2).contiguous(), stride=2, padding=3).cpu()
+    err = {}
+    for name, fn in (("fp32", L.rd_stem_wgrad_t), ("split", L.rd_stem_wgrad_split_t)):
+        ws = torch.full((nws,), float("nan"), device="cuda")
+        gw = torch.full((cout, cin, 7, 7), float("nan"), device="cuda")
+        check(fn(dt, planes, strides, cin, n, h, w, ptr(dout), cout, ptr(gw), ptr(ws), current_stream()), name)
+        torch.cuda.synchronize()
+        got = gw.cpu().double()
+        assert not torch.isnan(got).any(), (cfg, name)
+        err[name] = ((got - want).abs().max() / want.abs().max()).item()
+    print("stem wgrad %s: fp32-MFMA %.2e, split %.2e of the gradient's max" % (cfg, err["fp32"], err["split"]))
+    assert err["split"] < 1.5 * err["fp32"] + 2e-7, (cfg, err)
+    assert err["split"] < 2e-5, (cfg, err)

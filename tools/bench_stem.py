@@ -25,6 +25,11 @@ for cin, cout, first in ((3, 64, 0), (1, 16, 3)):
     dout = torch.randn(N, Ho, Wo, cout, device="cuda")
     t = timeit(lambda: check(L.rd_stem_wgrad(planes, strides, cin, N, H, W, ptr(dout), cout, ptr(gw), ptr(ws), current_stream()), "stem_wgrad"))
     print("stem wgrad %d->%d: %7.1f us  %5.1f TF (%4.1f%% of fp32 peak)" % (cin, cout, t * 1e6, gf / t / 1e3, 100 * gf / t / 1e3 / 157.3))
+    ts_ = timeit(lambda: check(L.rd_stem_wgrad_split_t(0, planes, strides, cin, N, H, W, ptr(dout), cout, ptr(gw), ptr(ws), current_stream()), "stem_wgrad_split"))
+    d16 = dout.to(torch.bfloat16)
+    tb_ = timeit(lambda: check(L.rd_stem_wgrad_split_t(1, planes, strides, cin, N, H, W, ptr(d16), cout, ptr(gw), ptr(ws), current_stream()), "stem_wgrad_split"))
+    t16 = timeit(lambda: check(L.rd_stem_wgrad_t(1, planes, strides, cin, N, H, W, ptr(d16), cout, ptr(gw), ptr(ws), current_stream()), "stem_wgrad"))
+    print("stem wgrad %d->%d on the bf16 matrix cores (three-piece operands): %7.1f us  %5.1f TF fp32-equivalent; bf16 dout: %7.1f us (fp32-MFMA kernel: %7.1f us)" % (cin, cout, ts_ * 1e6, gf / ts_ / 1e3, tb_ * 1e6, t16 * 1e6))
     # BatchNorm-backward apply pass of the stem (the kernel in front of the weight gradient at the end of the step)
     M = N * Ho * Wo
     raw = torch.randn(N, Ho, Wo, cout, device="cuda")
