@@ -53,7 +53,8 @@ struct StemWsArgs {
     const void* dout;           // NHWC [N,Ho,Wo,Cout], fp32 or (io16) bf16
     float* slabs;
     int Cin, N, H, W, Ho, Wo, Cout, tiles_h, tiles_w, total_tiles, tiles_per_split;
-    int dbg;                    // ablation bits (RD_STEM_WGRAD_SPLIT_DEBUG; results garbage): 1 no MFMA walk, 2 no staging after the first tile
+    int dbg;                    // ablation bits (RD_STEM_WGRAD_SPLIT_DEBUG; results garbage): 1 no MFMA walk, 2 no staging after the first tile,
+                                // 4 staging without the split arithmetic, 8 without its LDS stores, 16 without its global loads
 };
 
 __device__ __forceinline__ unsigned sw_cvt_pk(float a, float b) {
@@ -89,17 +90,19 @@ __device__ __forceinline__ swbf16x8 sw_frag_tr(unsigned addr) {
     r[4] = hi[0]; r[5] = hi[1]; r[6] = hi[2]; r[7] = hi[3];
     return __builtin_bit_cast(swbf16x8, r);
 }
-// eight consecutive elements of a parity line from a 2-byte-aligned position: addr is the 4-byte-aligned address of the dword that holds
-// the first one, sh16 = 16 if it is that dword's upper half
-__device__ __forceinline__ swbf16x8 sw_frag_row(unsigned addr, unsigned sh16) {
+// eight consecutive elements of a parity line from a 2-byte-aligned position, in two halves so that the MFMAs of the previous row tile
+// sit between the reads and the first use of their data: sw_row_load fetches the five dwords from the 4-byte-aligned address of the
+// dword that holds the first element, sw_row_finish shifts them by sh16 = 16 bits if that element is the dword's upper half
+__device__ __forceinline__ void sw_row_load(unsigned addr, unsigned (&e)[5]) {
     typedef __attribute__((address_space(3))) const unsigned* lp;
     const lp q = reinterpret_cast<lp>(addr);
-    const unsigned e0 = q[0], e1 = q[1], e2 = q[2], e3 = q[3], e4 = q[4];
+#pragma unroll
+    for (int i = 0; i < 5; ++i) e[i] = q[i];
+}
+__device__ __forceinline__ swbf16x8 sw_row_finish(const unsigned (&e)[5], unsigned sh16) {
     swu32x4 v;
-    v[0] = __builtin_amdgcn_alignbit(e1, e0, sh16);
-    v[1] = __builtin_amdgcn_alignbit(e2, e1, sh16);
-    v[2] = __builtin_amdgcn_alignbit(e3, e2, sh16);
-    v[3] = __builtin_amdgcn_alignbit(e4, e3, sh16);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) v[i] = __builtin_amdgcn_alignbit(e[i + 1], e[i], sh16);
     return __builtin_bit_cast(swbf16x8, v);
 }
 
@@ -128,17 +131,13 @@ __global__ __launch_bounds__(512) void stem_wgrad_split_kernel(const StemWsArgs 
     if (loader) {
         // ------------------------------------------------------------------------------------------ staging waves
         const int lt = tid - 256;
-        // patch slots of this thread: element e = lt + 256 q of a plane's [13][72] patch
-        constexpr int UPB = (SW_PR * SW_PC + 255) / 256;      // 4
-        int prx[UPB], pdst[UPB];
-#pragma unroll
-        for (int q = 0; q < UPB; ++q) {
-            const int e = lt + q * 256;
-            const int pr = e / SW_PC, x = e - pr * SW_PC;
-            const bool in = e < SW_PR * SW_PC;
-            prx[q] = ((in ? pr : 30000) << 16) | x;
-            pdst[q] = in ? ((pr * 2 + (x & 1)) * SW_PITCH + (x >> 1)) * 2 : 36 * 2;      // (slots past the patch: a padding element of line 0)
-        }
+        // patch slot of this thread: four consecutive columns x0 .. x0 + 3 (x0 = 4 (lt % 18)) of patch row lt / 18 -- ONE 16-byte load per
+        // plane; (x0, x0 + 2) are neighbours of the even-column line, (x0 + 1, x0 + 3) of the odd one: a dword store each per piece
+        // (2-byte stores of single elements: twice the LDS instructions, and two lanes per dword)
+        constexpr int XG = SW_PC / 4;                          // 18 groups per row
+        const bool pin = lt < SW_PR * XG;
+        const int ppr = pin ? lt / XG : 0, px0 = pin ? 4 * (lt - (lt / XG) * XG) : 0;
+        const unsigned pdst = pin ? (unsigned)((ppr * 2) * SW_PITCH + (px0 >> 1)) * 2u : 36u * 2u;      // (idle threads: padding elements of line 0)
         // dout units of this thread: unit u = lt + 256 j = (co tile t, pixel, 8-channel quarter q)
         constexpr int YU = NT * SW_PIX * 4;
         constexpr int UPY = YU / 256;                         // 2 NT
@@ -152,23 +151,27 @@ __global__ __launch_bounds__(512) void stem_wgrad_split_kernel(const StemWsArgs 
             ydst[j] = SW_XBYTES + t * SW_YPLANE + rem * 16;
         }
         const unsigned yimg = (unsigned)(a.Ho * a.Wo * a.Cout) * (B16 ? 2u : 4u);
-        float pf[3][UPB];
-        float4 y0[UPY], y1[UPY];
-        auto fetch = [&](int tile) {
+        // two register sets: the loads of tile i + 2 are issued BEFORE tile i + 1 is split and stored, so that they have a whole iteration in
+        // flight (with one set, issued behind the split, the next iteration's split waited for them: 195 us, 142 us without the loads)
+        struct Regs { float4 pf[3]; int pnval; float4 y0[UPY], y1[UPY]; };
+        Regs ra, rb;
+        ra.pnval = rb.pnval = 4;
+        auto fetch = [&](int tile, Regs& rg) {
+            float4 (&pf)[3] = rg.pf; int& pnval = rg.pnval; float4 (&y0)[UPY] = rg.y0; float4 (&y1)[UPY] = rg.y1;
+            if (a.dbg & 16) return;
             const int n = tile / tiles_img, tr = tile - n * tiles_img;
             const int r0 = (tr / a.tiles_w) * SW_R, c0 = (tr % a.tiles_w) * SW_TW;
             const int ih0 = 2 * r0 - 3, iw0 = 2 * c0 - 4;          // patch row 0 / patch column x = 0
+            const int ih = ih0 + ppr, iw = iw0 + px0;          // (iw0 and x0 are multiples of 4 columns apart from -4: a group is never split by the left edge)
+            const int nval = a.W - iw;                         // columns of the group inside the image
+            pnval = nval;                                      // (the mask is applied when the values are split: nothing here may wait for a load)
+            const unsigned poff = (pin && ih >= 0 && ih < a.H && iw >= 0 && nval > 0) ? (unsigned)(ih * a.W + iw) * 4u : SW_OOB;
 #pragma unroll
             for (int c = 0; c < 3; ++c) {
                 if (c < CIN) {
                     const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc(
                         const_cast<float*>(a.plane[c] + (size_t)n * a.stride[c]), 0, (unsigned)(a.H * a.W) * 4u, 0x00020000);
-#pragma unroll
-                    for (int q = 0; q < UPB; ++q) {
-                        const int ih = ih0 + (prx[q] >> 16), iw = iw0 + (prx[q] & 0xffff);
-                        const unsigned off = (ih >= 0 && ih < a.H && iw >= 0 && iw < a.W) ? (unsigned)(ih * a.W + iw) * 4u : SW_OOB;
-                        pf[c][q] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, (int)off, 0, 0));
-                    }
+                    pf[c] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)poff, 0, 0));
                 }
             }
             const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc(
@@ -187,23 +190,29 @@ __global__ __launch_bounds__(512) void stem_wgrad_split_kernel(const StemWsArgs 
                 }
             }
         };
-        auto split_put = [&](int buf) {
+        auto split_put = [&](int buf, Regs& rg) {
+            float4 (&pf)[3] = rg.pf; const int pnval = rg.pnval; float4 (&y0)[UPY] = rg.y0; float4 (&y1)[UPY] = rg.y1;
             const unsigned base = lds0 + buf * BUF;
 #pragma unroll
             for (int c = 0; c < 3; ++c) {
                 if (c < CIN) {
+                    // (columns past the right edge are the next row's first ones, or past the image: zero them)
+                    float e0 = pf[c].x, e2 = pnval > 2 ? pf[c].z : 0.f, o0 = pnval > 1 ? pf[c].y : 0.f, o2 = pnval > 3 ? pf[c].w : 0.f;
+                    const unsigned ad = base + c * (SW_PR * 2 * SW_PITCH * 2) + pdst;
 #pragma unroll
-                    for (int q = 0; q < UPB; ++q) {
-                        float f = pf[c][q];
-                        const __bf16 p0 = (__bf16)f;
-                        f -= (float)p0;
-                        const __bf16 p1 = (__bf16)f;
-                        f -= (float)p1;
-                        const __bf16 p2 = (__bf16)f;
-                        const unsigned ad = base + c * (SW_PR * 2 * SW_PITCH * 2) + pdst[q];
-                        asm volatile("ds_write_b16 %0, %1" ::"v"(ad), "v"((unsigned)__builtin_bit_cast(unsigned short, p0)) : "memory");
-                        asm volatile("ds_write_b16 %0, %1 offset:%2" ::"v"(ad), "v"((unsigned)__builtin_bit_cast(unsigned short, p1)), "n"(SW_PPLANE) : "memory");
-                        asm volatile("ds_write_b16 %0, %1 offset:%2" ::"v"(ad), "v"((unsigned)__builtin_bit_cast(unsigned short, p2)), "n"(2 * SW_PPLANE) : "memory");
+                    for (int pc = 0; pc < 3; ++pc) {
+                        unsigned ue, uo;
+                        if (a.dbg & 4) { ue = __float_as_uint(e0); uo = __float_as_uint(o0); }
+                        else {
+                            ue = sw_cvt_pk(e0, e2); uo = sw_cvt_pk(o0, o2);
+                            e0 -= __uint_as_float(ue << 16); e2 -= __uint_as_float(ue & 0xffff0000u);
+                            o0 -= __uint_as_float(uo << 16); o2 -= __uint_as_float(uo & 0xffff0000u);
+                        }
+                        typedef __attribute__((address_space(3))) unsigned* lp;
+                        if (!(a.dbg & 8)) {
+                            *reinterpret_cast<lp>(ad + pc * SW_PPLANE) = ue;
+                            *reinterpret_cast<lp>(ad + pc * SW_PPLANE + SW_PITCH * 2) = uo;
+                        }
                     }
                 }
             }
@@ -214,26 +223,35 @@ __global__ __launch_bounds__(512) void stem_wgrad_split_kernel(const StemWsArgs 
                     asm volatile("ds_write_b128 %0, %1" ::"v"(ad), "v"(__builtin_bit_cast(swu32x4, y0[j])) : "memory");
                 } else {
                     swu32x4 w0, w1, w2;
-                    sw_split8(y0[j], y1[j], w0, w1, w2);
-                    asm volatile("ds_write_b128 %0, %1" ::"v"(ad), "v"(w0) : "memory");
-                    asm volatile("ds_write_b128 %0, %1" ::"v"(ad + NT * SW_YPLANE), "v"(w1) : "memory");
-                    asm volatile("ds_write_b128 %0, %1" ::"v"(ad + 2 * NT * SW_YPLANE), "v"(w2) : "memory");
+                    if (a.dbg & 4) { w0 = __builtin_bit_cast(swu32x4, y0[j]); w1 = __builtin_bit_cast(swu32x4, y1[j]); w2 = w0; }
+                    else sw_split8(y0[j], y1[j], w0, w1, w2);
+                    if (!(a.dbg & 8)) {
+                        asm volatile("ds_write_b128 %0, %1" ::"v"(ad), "v"(w0) : "memory");
+                        asm volatile("ds_write_b128 %0, %1" ::"v"(ad + NT * SW_YPLANE), "v"(w1) : "memory");
+                        asm volatile("ds_write_b128 %0, %1" ::"v"(ad + 2 * NT * SW_YPLANE), "v"(w2) : "memory");
+                    }
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
         };
-        // tile i lives in buffer i & 1.  Iteration i: barrier B(i) (tile i published, buffer (i + 1) & 1 free); split and store tile
-        // i + 1 (fetched during iteration i - 1), then fetch tile i + 2: its loads have the whole walk of tile i + 1 to land
+        // tile i of this workgroup lives in buffer i & 1 and, while in registers, in set A for even i, set B for odd i.  Iteration i: barrier
+        // B(i) (tile i published, buffer (i + 1) & 1 free); fetch tile i + 2; split and store tile i + 1 (fetched during iteration i - 1)
+        const bool nostage = a.dbg & 2;
         if (ntiles > 0) {
-            fetch(tile_begin);
-            split_put(0);
-            if (ntiles > 1) fetch(tile_begin + 1);
+            fetch(tile_begin, ra);
+            if (ntiles > 1) fetch(tile_begin + 1, rb);
+            split_put(0, ra);
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        for (int i = 0; i < ntiles; ++i) {
-            rd_sync();                            // B(i)
-            if (i + 1 < ntiles && !(a.dbg & 2)) split_put((i + 1) & 1);
-            if (i + 2 < ntiles && !(a.dbg & 2)) fetch(tile_begin + i + 2);
+        for (int i = 0; i < ntiles; i += 2) {
+            rd_sync();                            // B(i), i even: tile i + 1 is in set B, set A is free
+            if (i + 2 < ntiles && !nostage) fetch(tile_begin + i + 2, ra);
+            if (i + 1 < ntiles && !nostage) split_put(1, rb);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            if (i + 1 >= ntiles) break;
+            rd_sync();                            // B(i + 1): tile i + 2 is in set A, set B is free
+            if (i + 3 < ntiles && !nostage) fetch(tile_begin + i + 3, rb);
+            if (i + 2 < ntiles && !nostage) split_put(0, ra);
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         }
         rd_sync();                                // matches the compute waves' final barrier
@@ -265,39 +283,54 @@ __global__ __launch_bounds__(512) void stem_wgrad_split_kernel(const StemWsArgs 
             if (a.dbg & 1) continue;
             const unsigned bo = (i & 1) * BUF;
             // this wave's two reduction steps of the tile: ks = wave and wave + 4, step ks = (row ks >> 1, column half ks & 1)
+            unsigned xo[2], yo[2];
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
                 const int ks = wave + 4 * h;
                 const int rl = ks >> 1, s = ks & 1;
-                const unsigned xo = bo + (unsigned)(4 * rl * SW_PITCH + 16 * s) * 2u;
-                const unsigned yo = bo + (unsigned)(rl * 32 + 16 * s) * 64u;
+                xo[h] = bo + (unsigned)(4 * rl * SW_PITCH + 16 * s) * 2u;
+                yo[h] = bo + (unsigned)(rl * 32 + 16 * s) * 64u;
+            }
+            unsigned R[3][5];
+            swbf16x8 A[3];
+#pragma unroll
+            for (int p = 0; p < 3; ++p) sw_row_load(arow[0] + xo[0] + p * SW_PPLANE, R[p]);
+#pragma unroll
+            for (int p = 0; p < 3; ++p) A[p] = sw_row_finish(R[p], ash[0]);
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
                 swbf16x8 B[NT][NPB];
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
-                    for (int p = 0; p < NPB; ++p) B[nt][p] = sw_frag_tr(yb + yo + nt * SW_YPLANE + p * NT * SW_YPLANE);
-                swbf16x8 A[2][3];
-#pragma unroll
-                for (int p = 0; p < 3; ++p) A[0][p] = sw_frag_row(arow[0] + xo + p * SW_PPLANE, ash[0]);
+                    for (int p = 0; p < NPB; ++p) B[nt][p] = sw_frag_tr(yb + yo[h] + nt * SW_YPLANE + p * NT * SW_YPLANE);
 #pragma unroll
                 for (int mt = 0; mt < MTK; ++mt) {
-                    // the next row tile's fragments are read in front of this one's MFMAs and the order is pinned (wgrad_split.hip)
-                    if (mt + 1 < MTK) {
+                    // the next row tile's dwords (the first one of the second step included) are requested in front of this one's MFMAs and
+                    // shifted into place behind them; the order is pinned (left alone the compiler hoists the reads of a whole step)
+                    const bool more = mt + 1 < MTK || h == 0;
+                    const int nmt = mt + 1 < MTK ? mt + 1 : 0, nh = mt + 1 < MTK ? h : 1;
+                    if (more) {
 #pragma unroll
-                        for (int p = 0; p < 3; ++p) A[(mt + 1) & 1][p] = sw_frag_row(arow[mt + 1] + xo + p * SW_PPLANE, ash[mt + 1]);
+                        for (int p = 0; p < 3; ++p) sw_row_load(arow[nmt] + xo[nh] + p * SW_PPLANE, R[p]);
                     }
                     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                     for (int nt = 0; nt < NT; ++nt) {
                         f32x16 c = acc[mt][nt];
                         if (B16) {
-                            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[mt & 1][2], B[nt][0], c, 0, 0, 0);
-                            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[mt & 1][1], B[nt][0], c, 0, 0, 0);
-                            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[mt & 1][0], B[nt][0], c, 0, 0, 0);
+                            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[2], B[nt][0], c, 0, 0, 0);
+                            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[1], B[nt][0], c, 0, 0, 0);
+                            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[0], B[nt][0], c, 0, 0, 0);
                         } else {
-                            RD_SPLIT_TERMS(c, A[mt & 1][0], A[mt & 1][1], A[mt & 1][2], B[nt][0], B[nt][NPB > 1 ? 1 : 0], B[nt][NPB > 2 ? 2 : 0])
+                            RD_SPLIT_TERMS(c, A[0], A[1], A[2], B[nt][0], B[nt][NPB > 1 ? 1 : 0], B[nt][NPB > 2 ? 2 : 0])
                         }
                         acc[mt][nt] = c;
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (more) {
+#pragma unroll
+                        for (int p = 0; p < 3; ++p) A[p] = sw_row_finish(R[p], ash[nmt]);
                     }
                     __builtin_amdgcn_sched_barrier(0);
                 }
