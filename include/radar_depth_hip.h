@@ -325,6 +325,15 @@ int rd_stem_wgrad(const float* const* planes, const int64_t* strides, int32_t Ci
 int rd_stem_wgrad_split_supported(int32_t Cin, int32_t Cout);
 int rd_stem_wgrad_split_t(int32_t dtype, const float* const* planes, const int64_t* strides, int32_t Cin, int32_t N, int32_t H,
                           int32_t W, const void* dout, int32_t Cout, float* grad_oihw, float* ws, void* stream);
+/* The same with the stem BatchNorm's backward apply pass folded into its staging waves -- for a stem nobody asks an input gradient of
+ * (the RGB stem; the depth stem outside the multistage network's second stage), whose BatchNorm input gradient only this kernel would
+ * read.  g: gradient at the BatchNorm OUTPUT [N,Ho,Wo,Cout] (what rd_bnact_maxpool_bwd_stats_t stores); x: the stem's raw output;
+ * red_partial / n_tiles: that call's partial sums; coef_ws: 3*Cout floats.  Equivalent to rd_bn_bwd_apply_t(g, x, ..., which = 1, dx)
+ * followed by rd_stem_wgrad_split_t(dx): same dgamma / dbeta, same weight-gradient bits, no dx tensor (3 -> 64 and 1 -> 16 stems). */
+int rd_stem_wgrad_split_bn_t(int32_t dtype, const float* const* planes, const int64_t* strides, int32_t Cin, int32_t N, int32_t H,
+                             int32_t W, const void* g, const void* x, const float* red_partial, int32_t n_tiles, const float* gamma,
+                             const float* mean, const float* invstd, float* dgamma, float* dbeta, float* coef_ws, int32_t Cout,
+                             float* grad_oihw, float* ws, void* stream);
 /* input gradient w.r.t. ONE input channel `ci` of the stem (stage-2 dense-depth channel,
  * multistage_model.py:75 -- the stage-1 prediction is not detached).  dx is [N,H,W] (overwritten). */
 int rd_stem_dgrad_channel(const float* dout, const float* w_packed, int32_t N, int32_t H, int32_t W,

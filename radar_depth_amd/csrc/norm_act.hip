@@ -658,6 +658,17 @@ extern "C" int rd_bn_bwd_reduce_x_t(int32_t dtype, const void* dy, int32_t lddy,
     return RD_EINVAL;
 }
 
+namespace rd {
+// (for rd_stem_wgrad_split_bn_t, csrc/stem_wgrad_split.hip: the coefficient kernel without the apply pass)
+int launch_bn_bwd_coeffs(const float* red_partial, int n_tiles, int C, int which, double count, const float* gamma, const float* invstd,
+                         float* dgamma, float* dbeta, float* coef_ws, hipStream_t s) {
+    hipLaunchKernelGGL(bn_bwd_coeffs_kernel, dim3(C), dim3(256), 0, s, red_partial, n_tiles, C, which, count, gamma, invstd, dgamma, dbeta,
+                       coef_ws);
+    RD_CHECK_LAUNCH("bn_bwd_coeffs_kernel");
+    return RD_OK;
+}
+}  // namespace rd
+
 template <typename T>
 static int rd_bn_bwd_apply_T(const T* g, int32_t ldg, const T* x, int32_t ldx, const float* red_partial, int32_t n_tiles, int32_t which, const float* gamma, const float* mean, const float* invstd, float* dgamma, float* dbeta, float* coef_ws, T* dx, int32_t lddx, int64_t M, int32_t C, void* stream,
                              void* pieces = nullptr, int64_t piece_elems = 0) {

@@ -62,7 +62,7 @@ const std::unordered_map<std::string, Entry>& registry() {
         RD_ENTRY(rd_wgrad), RD_ENTRY(rd_wgrad_reduce), RD_ENTRY(rd_wgrad_reduce_batched),
         RD_ENTRY(rd_wgrad_bf16_t), RD_ENTRY(rd_wgrad_bf16), RD_ENTRY(rd_wgrad_bf16_reduce), RD_ENTRY(rd_wgrad_split), RD_ENTRY(rd_wgrad_split_reduce),
         RD_ENTRY(rd_pack_weights_batched), RD_ENTRY(rd_fill),
-        RD_ENTRY(rd_stem_fwd_t), RD_ENTRY(rd_stem_fwd_bf16_t), RD_ENTRY(rd_stem_fwd_split), RD_ENTRY(rd_conv16_split), RD_ENTRY(rd_stem_wgrad_t), RD_ENTRY(rd_stem_wgrad_split_t), RD_ENTRY(rd_stem_dgrad_channel_t),
+        RD_ENTRY(rd_stem_fwd_t), RD_ENTRY(rd_stem_fwd_bf16_t), RD_ENTRY(rd_stem_fwd_split), RD_ENTRY(rd_conv16_split), RD_ENTRY(rd_stem_wgrad_t), RD_ENTRY(rd_stem_wgrad_split_t), RD_ENTRY(rd_stem_wgrad_split_bn_t), RD_ENTRY(rd_stem_dgrad_channel_t),
         RD_ENTRY(rd_bn_finalize), RD_ENTRY(rd_bn_eval_coeffs), RD_ENTRY(rd_bn_eval_coeffs_batched), RD_ENTRY(rd_bn_act_t),
         RD_ENTRY(rd_bn_bwd_reduce_t), RD_ENTRY(rd_bn_bwd_reduce_x_t), RD_ENTRY(rd_bn_bwd_reduce_x2_t),
         RD_ENTRY(rd_bn_bwd_apply_t), RD_ENTRY(rd_bn_bwd_apply_x_t), RD_ENTRY(rd_bn_bwd_apply_x2_t),

@@ -53,6 +53,13 @@ struct StemWsArgs {
     const void* dout;           // NHWC [N,Ho,Wo,Cout], fp32 or (io16) bf16
     float* slabs;
     int Cin, N, H, W, Ho, Wo, Cout, tiles_h, tiles_w, total_tiles, tiles_per_split;
+    // BNF (rd_stem_wgrad_split_bn_t): dout is the gradient g at the stem BatchNorm's OUTPUT, bn_x the BatchNorm input (the stem's raw
+    // output), and the staged operand is that BatchNorm's input gradient A*g + B*(x - mean) + K per channel (bn_coef = [3][Cout] as
+    // bn_bwd_coeffs_kernel writes it) -- bn_bwd_dx_kernel's expression, term for term; a bf16-storage plan rounds it to bf16 as that
+    // kernel's store would
+    const void* bn_x;
+    const float* bn_coef;
+    const float* bn_mean;
     int dbg;                    // ablation bits (RD_STEM_WGRAD_SPLIT_DEBUG; results garbage): 1 no MFMA walk, 2 no staging after the first tile,
                                 // 4 staging without the split arithmetic, 8 without its LDS stores, 16 without its global loads
 };
@@ -106,8 +113,9 @@ __device__ __forceinline__ swbf16x8 sw_row_finish(const unsigned (&e)[5], unsign
     return __builtin_bit_cast(swbf16x8, v);
 }
 
-// MTK = ceil(49 Cin / 32) row tiles, NT = 32-channel tiles of dout, B16: dout is bf16 (one piece)
-template <int MTK, int NT, bool B16>
+// MTK = ceil(49 Cin / 32) row tiles, NT = 32-channel tiles of dout, B16: dout is bf16 (one piece), BNF: dout is formed from (g, x,
+// coefficients) by the staging waves
+template <int MTK, int NT, bool B16, bool BNF = false>
 __global__ __launch_bounds__(512) void stem_wgrad_split_kernel(const StemWsArgs a) {
     constexpr int YBYTES = 3 * NT * SW_YPLANE;          // (B16 plans use the first piece only)
     constexpr int BUF = SW_XBYTES + YBYTES;
@@ -138,24 +146,39 @@ __global__ __launch_bounds__(512) void stem_wgrad_split_kernel(const StemWsArgs 
         const bool pin = lt < SW_PR * XG;
         const int ppr = pin ? lt / XG : 0, px0 = pin ? 4 * (lt - (lt / XG) * XG) : 0;
         const unsigned pdst = pin ? (unsigned)((ppr * 2) * SW_PITCH + (px0 >> 1)) * 2u : 36u * 2u;      // (idle threads: padding elements of line 0)
-        // dout units of this thread: unit u = lt + 256 j = (co tile t, pixel, 8-channel quarter q)
-        constexpr int YU = NT * SW_PIX * 4;
-        constexpr int UPY = YU / 256;                         // 2 NT
-        int ypx[UPY], ych[UPY], ydst[UPY];
+        // dout units of this thread: 8-channel group q8 = lt % (4 NT) of pixels lt / (4 NT) + (256 / (4 NT)) j -- one channel group per thread
+        // (a wave's load covers whole 128- / 256-byte pixel rows; with BNF one set of coefficients per thread)
+        constexpr int UQ = 4 * NT;                            // 8-channel units per pixel
+        constexpr int UPY = SW_PIX * UQ / 256;                // 2 NT
+        const int yq8 = lt % UQ;
+        const int ych0 = yq8 * 8;
+        int ypx[UPY], ydst[UPY];
 #pragma unroll
         for (int j = 0; j < UPY; ++j) {
-            const int u = lt + 256 * j;
-            const int t = u / (SW_PIX * 4), rem = u - t * (SW_PIX * 4);
-            ypx[j] = rem >> 2;
-            ych[j] = t * 32 + (rem & 3) * 8;
-            ydst[j] = SW_XBYTES + t * SW_YPLANE + rem * 16;
+            ypx[j] = lt / UQ + (256 / UQ) * j;
+            ydst[j] = SW_XBYTES + (yq8 >> 2) * SW_YPLANE + (ypx[j] * 4 + (yq8 & 3)) * 16;
         }
         const unsigned yimg = (unsigned)(a.Ho * a.Wo * a.Cout) * (B16 ? 2u : 4u);
         // two register sets: the loads of tile i + 2 are issued BEFORE tile i + 1 is split and stored, so that they have a whole iteration in
         // flight (with one set, issued behind the split, the next iteration's split waited for them: 195 us, 142 us without the loads)
-        struct Regs { float4 pf[3]; int pnval; float4 y0[UPY], y1[UPY]; };
+        struct Regs { float4 pf[3]; int pnval; float4 y0[UPY], y1[UPY]; float4 x0[BNF ? UPY : 1], x1[BNF ? UPY : 1]; unsigned ok; };
         Regs ra, rb;
         ra.pnval = rb.pnval = 4;
+        ra.ok = rb.ok = 0;
+        // (BNF) a thread's units all cover the same eight channels: their coefficients are kept in registers (the compute waves set the
+        // kernel's register budget; these waves have room)
+        float cfA[8], cfB[8], cfK[8], cfM[8];
+        if constexpr (BNF) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const int ch = ych0 + k;
+                const bool in = ch < a.Cout;
+                cfA[k] = in ? a.bn_coef[ch] : 0.f;
+                cfB[k] = in ? a.bn_coef[a.Cout + ch] : 0.f;
+                cfK[k] = in ? a.bn_coef[2 * a.Cout + ch] : 0.f;
+                cfM[k] = in ? a.bn_mean[ch] : 0.f;
+            }
+        }
         auto fetch = [&](int tile, Regs& rg) {
             float4 (&pf)[3] = rg.pf; int& pnval = rg.pnval; float4 (&y0)[UPY] = rg.y0; float4 (&y1)[UPY] = rg.y1;
             if (a.dbg & 16) return;
@@ -176,19 +199,29 @@ __global__ __launch_bounds__(512) void stem_wgrad_split_kernel(const StemWsArgs 
             }
             const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc(
                 const_cast<char*>(static_cast<const char*>(a.dout)) + (size_t)n * a.Ho * a.Wo * a.Cout * (B16 ? 2 : 4), 0, yimg, 0x00020000);
+            const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(
+                const_cast<char*>(static_cast<const char*>(BNF ? a.bn_x : a.dout)) + (size_t)n * a.Ho * a.Wo * a.Cout * (B16 ? 2 : 4), 0, yimg, 0x00020000);
+            unsigned okm = 0;
 #pragma unroll
             for (int j = 0; j < UPY; ++j) {
                 const int oh = r0 + (ypx[j] >> 5), ow = c0 + (ypx[j] & 31);
-                const bool ok = oh < a.Ho && ow < a.Wo && ych[j] < a.Cout;
+                const bool ok = oh < a.Ho && ow < a.Wo && ych0 < a.Cout;
+                okm |= ok ? 1u << j : 0u;
                 if (B16) {
-                    const unsigned off = ok ? (unsigned)(((oh * a.Wo + ow) * a.Cout + ych[j]) * 2) : SW_OOB;
+                    const unsigned off = ok ? (unsigned)(((oh * a.Wo + ow) * a.Cout + ych0) * 2) : SW_OOB;
                     y0[j] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(ry, (int)off, 0, 0));
+                    if constexpr (BNF) rg.x0[j] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rx, (int)off, 0, 0));
                 } else {
-                    const unsigned off = ok ? (unsigned)(((oh * a.Wo + ow) * a.Cout + ych[j]) * 4) : SW_OOB;
+                    const unsigned off = ok ? (unsigned)(((oh * a.Wo + ow) * a.Cout + ych0) * 4) : SW_OOB;
                     y0[j] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(ry, (int)off, 0, 0));
                     y1[j] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(ry, (int)off + 16, 0, 0));
+                    if constexpr (BNF) {
+                        rg.x0[j] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rx, (int)off, 0, 0));
+                        rg.x1[j] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rx, (int)off + 16, 0, 0));
+                    }
                 }
             }
+            rg.ok = okm;
         };
         auto split_put = [&](int buf, Regs& rg) {
             float4 (&pf)[3] = rg.pf; const int pnval = rg.pnval; float4 (&y0)[UPY] = rg.y0; float4 (&y1)[UPY] = rg.y1;
@@ -213,6 +246,41 @@ __global__ __launch_bounds__(512) void stem_wgrad_split_kernel(const StemWsArgs 
                             *reinterpret_cast<lp>(ad + pc * SW_PPLANE) = ue;
                             *reinterpret_cast<lp>(ad + pc * SW_PPLANE + SW_PITCH * 2) = uo;
                         }
+                    }
+                }
+            }
+            if constexpr (BNF) {
+                // the BatchNorm input gradient of the unit's eight channels, in place (units outside the tile / the channel range stay zero)
+#pragma unroll
+                for (int j = 0; j < UPY; ++j) {
+                    float g8[8], x8[8];
+                    if (B16) {
+                        const swu32x4 gu = __builtin_bit_cast(swu32x4, y0[j]), xu = __builtin_bit_cast(swu32x4, rg.x0[j]);
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) {
+                            g8[2 * k] = __uint_as_float(gu[k] << 16); g8[2 * k + 1] = __uint_as_float(gu[k] & 0xffff0000u);
+                            x8[2 * k] = __uint_as_float(xu[k] << 16); x8[2 * k + 1] = __uint_as_float(xu[k] & 0xffff0000u);
+                        }
+                    } else {
+                        g8[0] = y0[j].x; g8[1] = y0[j].y; g8[2] = y0[j].z; g8[3] = y0[j].w; g8[4] = y1[j].x; g8[5] = y1[j].y; g8[6] = y1[j].z; g8[7] = y1[j].w;
+                        x8[0] = rg.x0[j].x; x8[1] = rg.x0[j].y; x8[2] = rg.x0[j].z; x8[3] = rg.x0[j].w;
+                        x8[4] = rg.x1[j].x; x8[5] = rg.x1[j].y; x8[6] = rg.x1[j].z; x8[7] = rg.x1[j].w;
+                    }
+                    const bool ok = (rg.ok >> j) & 1u;
+                    float d8[8];
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) {
+                        const float d = fmaf(cfA[k], g8[k], fmaf(cfB[k], x8[k] - cfM[k], cfK[k]));
+                        d8[k] = ok ? d : 0.f;
+                    }
+                    if (B16) {
+                        swu32x4 w;
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) w[k] = sw_cvt_pk(d8[2 * k], d8[2 * k + 1]);      // (round to nearest even: the separate pass's store)
+                        y0[j] = __builtin_bit_cast(float4, w);
+                    } else {
+                        y0[j] = make_float4(d8[0], d8[1], d8[2], d8[3]);
+                        y1[j] = make_float4(d8[4], d8[5], d8[6], d8[7]);
                     }
                 }
             }
@@ -378,9 +446,14 @@ extern "C" int rd_stem_wgrad_split_supported(int32_t Cin, int32_t Cout) {
     return ((Cin == 3 && Cout == 64) || (Cin >= 1 && Cin <= 2 && Cout == 16)) ? 1 : 0;
 }
 
-// Same contract as rd_stem_wgrad_t (weight gradient OIHW, overwritten; ws of rd_stem_wgrad_workspace_floats floats).
-extern "C" int rd_stem_wgrad_split_t(int32_t dtype, const float* const* planes, const int64_t* strides, int32_t Cin, int32_t N, int32_t H,
-                                     int32_t W, const void* dout, int32_t Cout, float* grad_oihw, float* ws, void* stream) {
+namespace rd {
+int launch_bn_bwd_coeffs(const float* red_partial, int n_tiles, int C, int which, double count, const float* gamma, const float* invstd,
+                         float* dgamma, float* dbeta, float* coef_ws, hipStream_t s);     // norm_act.hip
+}
+
+static int stem_wgrad_split_impl(int32_t dtype, const float* const* planes, const int64_t* strides, int32_t Cin, int32_t N, int32_t H,
+                                 int32_t W, const void* dout, int32_t Cout, float* grad_oihw, float* ws, void* stream, const void* bn_x,
+                                 const float* bn_coef, const float* bn_mean) {
     RD_CHECK_ARG(dtype == RD_DTYPE_F32 || dtype == RD_DTYPE_BF16, "stem_wgrad_split_t: bad dtype %d", dtype);
     RD_CHECK_ARG(planes && strides && dout && grad_oihw && ws && N > 0 && H > 0 && W > 0, "stem_wgrad_split: null tensor / empty shape");
     RD_CHECK_ARG(rd_stem_wgrad_split_supported(Cin, Cout) == 1 && cdiv(49 * Cin, 32) == (Cin == 3 ? 5 : Cin == 2 ? 4 : 2), "stem_wgrad_split: unsupported shape Cin=%d Cout=%d", Cin, Cout);
@@ -393,6 +466,7 @@ extern "C" int rd_stem_wgrad_split_t(int32_t dtype, const float* const* planes, 
         RD_CHECK_ARG(c >= Cin || planes[c] != nullptr, "stem_wgrad_split: null input plane %d", c);
     }
     a.dout = dout; a.slabs = ws;
+    a.bn_x = bn_x; a.bn_coef = bn_coef; a.bn_mean = bn_mean;
     a.Cin = Cin; a.N = N; a.H = H; a.W = W; a.Cout = Cout;
     a.Ho = (H - 1) / 2 + 1; a.Wo = (W - 1) / 2 + 1;
     a.tiles_h = cdiv(a.Ho, SW_R); a.tiles_w = cdiv(a.Wo, SW_TW);
@@ -413,19 +487,46 @@ extern "C" int rd_stem_wgrad_split_t(int32_t dtype, const float* const* planes, 
     const bool b16 = dtype == RD_DTYPE_BF16;
     hipStream_t s = static_cast<hipStream_t>(stream);
     const size_t lds = 2 * ((size_t)SW_XBYTES + 3 * (size_t)NT * SW_YPLANE);
-#define RD_SWS(M_, N_, B_)                                                                                           \
-    if (MTK == M_ && NT == N_ && b16 == B_) {                                                                        \
+    const bool bnf = bn_x != nullptr;
+#define RD_SWS(M_, N_, B_, F_)                                                                                       \
+    if (MTK == M_ && NT == N_ && b16 == B_ && bnf == F_) {                                                           \
         static std::atomic<unsigned long long> attr_set{0};       /* (one flag set per instantiation) */             \
         if (attr_once(attr_set))                                                                                     \
-            RD_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(stem_wgrad_split_kernel<M_, N_, B_>),     \
+            RD_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(stem_wgrad_split_kernel<M_, N_, B_, F_>), \
                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                 \
-        hipLaunchKernelGGL((stem_wgrad_split_kernel<M_, N_, B_>), dim3(n_splits), dim3(512), lds, s, a);             \
+        hipLaunchKernelGGL((stem_wgrad_split_kernel<M_, N_, B_, F_>), dim3(n_splits), dim3(512), lds, s, a);         \
         RD_CHECK_LAUNCH("stem_wgrad_split_kernel");                                                                  \
     } else
-    RD_SWS(5, 2, false) RD_SWS(5, 2, true) RD_SWS(2, 1, false) RD_SWS(2, 1, true) RD_SWS(4, 1, false) RD_SWS(4, 1, true) {
-        set_error("stem_wgrad_split: no instantiation for Cin=%d Cout=%d", Cin, Cout);
+    RD_SWS(5, 2, false, false) RD_SWS(5, 2, true, false) RD_SWS(2, 1, false, false) RD_SWS(2, 1, true, false) RD_SWS(4, 1, false, false)
+    RD_SWS(4, 1, true, false) RD_SWS(5, 2, false, true) RD_SWS(5, 2, true, true) RD_SWS(2, 1, false, true) RD_SWS(2, 1, true, true) {
+        set_error("stem_wgrad_split: no instantiation for Cin=%d Cout=%d%s", Cin, Cout, bnf ? " with the BatchNorm apply pass folded in" : "");
         return RD_EINVAL;
     }
 #undef RD_SWS
     return launch_slab_reduce(ws, n_splits, E, ws + (int64_t)n_splits * E, grad_oihw, 49, Cin, Cout, Cout, Cin, 0, 0, s);
+}
+
+// Same contract as rd_stem_wgrad_t (weight gradient OIHW, overwritten; ws of rd_stem_wgrad_workspace_floats floats).
+extern "C" int rd_stem_wgrad_split_t(int32_t dtype, const float* const* planes, const int64_t* strides, int32_t Cin, int32_t N, int32_t H,
+                                     int32_t W, const void* dout, int32_t Cout, float* grad_oihw, float* ws, void* stream) {
+    return stem_wgrad_split_impl(dtype, planes, strides, Cin, N, H, W, dout, Cout, grad_oihw, ws, stream, nullptr, nullptr, nullptr);
+}
+
+// The same with the stem BatchNorm's backward apply pass folded into the staging waves -- for a stem nobody asks an input gradient of
+// (the RGB stem; the depth stem outside the multistage network's second stage), whose BatchNorm input gradient only this kernel would
+// read: a read of g and x and a write of dx (1.1 GB at b = 16, the last kernel of the main chain) disappear.  g: gradient at the
+// BatchNorm OUTPUT (what rd_bnact_maxpool_bwd_stats_t stores); x: the stem's raw output; red_partial / n_tiles: that call's sums;
+// coef_ws: 3 * Cout floats.  Equivalent to rd_bn_bwd_apply_t(g, x, ..., which = 1, dx) + rd_stem_wgrad_split_t(dx): same dgamma / dbeta,
+// same weight-gradient bits (tests/test_gpu_stem.py).  Shapes: 3 -> 64 and 1 -> 16.
+extern "C" int rd_stem_wgrad_split_bn_t(int32_t dtype, const float* const* planes, const int64_t* strides, int32_t Cin, int32_t N, int32_t H,
+                                        int32_t W, const void* g, const void* x, const float* red_partial, int32_t n_tiles,
+                                        const float* gamma, const float* mean, const float* invstd, float* dgamma, float* dbeta,
+                                        float* coef_ws, int32_t Cout, float* grad_oihw, float* ws, void* stream) {
+    RD_CHECK_ARG(g && x && red_partial && gamma && mean && invstd && coef_ws && n_tiles > 0, "stem_wgrad_split_bn_t: null argument");
+    RD_CHECK_ARG(Cin != 2, "stem_wgrad_split_bn_t: the two-plane stem needs its BatchNorm input gradient (rd_stem_dgrad_channel)");
+    const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
+    int rc = launch_bn_bwd_coeffs(red_partial, n_tiles, Cout, 1, (double)N * Ho * Wo, gamma, invstd, dgamma, dbeta, coef_ws,
+                                  static_cast<hipStream_t>(stream));
+    if (rc != RD_OK) return rc;
+    return stem_wgrad_split_impl(dtype, planes, strides, Cin, N, H, W, g, Cout, grad_oihw, ws, stream, x, coef_ws, mean);
 }

@@ -786,14 +786,19 @@ class LateFusionPlan:
         # (g and x are in registers there): no separate reduce pass over the two largest tensors of the network
         tiles = self.L.rd_bnact_maxpool_bwd_tiles(N, ctx["Hc"], ctx["Wc"], cout)
         red = self.buf(tiles, 3, cout)
-        # two passes over the pooled gradient (sums, then the BatchNorm input gradient stored directly: the full-resolution g is never
-        # materialised): level on fp32 tensors, +0.6 % on bf16 storage since the 2 x 2 gather (1877 vs 1866 and 278.1 vs 276.0 samples/s,
-        # configs 3 / 5, one job; profiles/r05_stem_tail.txt)
-        two_pass = os.environ.get("RD_STEM_BWD_TWO_PASS", "1" if self.storage == "bf16" else "0") == "1"
-        # (The apply pass folded into the weight gradient's staging loop -- nobody else reads the RGB stem's BatchNorm input gradient --
-        #  was built and dropped: bit-identical, 214 + 328 us -> 517 us alone, level in the step: the fp32 weight-gradient kernel has no
-        #  registers left to keep a second operand's loads in flight.  profiles/r05_stem_tail.txt)
-        dx = self.act(raw.N, raw.H, raw.W, cout)
+        # Nobody but the weight gradient reads this BatchNorm's input gradient unless an input gradient is asked of the stem: on the plans
+        # whose stem weight gradient runs on the bf16 matrix cores the apply pass (a read of g and raw and a write of dx -- 1.1 GB for the
+        # RGB stem at b = 16 -- as the last kernel of the main chain) is folded into that kernel's staging waves (rd_stem_wgrad_split_bn_t:
+        # same bits, tests/test_gpu_stem.py; RD_STEM_WGRAD_BN=0 restores the separate pass).  (Folded into the fp32-MFMA kernel it was
+        # level: no registers left there to keep a second operand's loads in flight.  profiles/r05_stem_tail.txt)
+        wg_split = (self.split or self.storage == "bf16") and self.L.rd_stem_wgrad_split_supported(cin, cout) == 1
+        can_fuse = wg_split and dgrad_channel is None and cin != 2 and os.environ.get("RD_STEM_WGRAD_BN", "1") == "1"
+        # where the apply pass stays: two passes over the pooled gradient (sums, then the BatchNorm input gradient stored directly; the
+        # full-resolution g is never materialised) -- level on fp32 tensors, +0.6 % on bf16 storage since the 2 x 2 gather (1877 vs 1866
+        # and 278.1 vs 276.0 samples/s, configs 3 / 5, one job; profiles/r05_stem_tail.txt)
+        two_pass = os.environ.get("RD_STEM_BWD_TWO_PASS", "1" if self.storage == "bf16" and not can_fuse else "0") == "1"
+        fuse_apply = can_fuse and not two_pass
+        dx = None if fuse_apply else self.act(raw.N, raw.H, raw.W, cout)
         if two_pass:
             # the first pass takes the sums only, the second repeats the (quarter-size) gather and stores the BatchNorm input gradient
             # directly.  0.6 GB/step less HBM traffic on fp32 tensors, bit-identical results
@@ -808,7 +813,8 @@ class LateFusionPlan:
             g = self.act(N, ctx["Hc"], ctx["Wc"], cout)
             self.op(self.bwd, ctx["name"] + ".pool_bwd", self.L.rd_bnact_maxpool_bwd_stats_t, self.dt, dpooled.ptr, dpooled.ld, _p(ctx["idx"]), raw.ptr,
                     _p(co["scale"]), _p(co["shift"]), ctx["act"], N, ctx["Hc"], ctx["Wc"], cout, g.ptr, _p(co["mean"]), _p(red), self.stream)
-            self._bn_apply(ctx["name"] + ".bn.bn1", g, raw, red, tiles, 1, co, dx)
+            if not fuse_apply:
+                self._bn_apply(ctx["name"] + ".bn.bn1", g, raw, red, tiles, 1, co, dx)
         nws = self.L.rd_stem_wgrad_workspace_floats(N, H, W, cin, cout)
         ws = self.buf(int(nws))
         cur = self.streams.index(self._s) if self._s in self.streams else 0
@@ -817,10 +823,17 @@ class LateFusionPlan:
         with self.on(wst):
             # split and bf16-storage plans: the stem weight gradients on the bf16 matrix cores too (csrc/stem_wgrad_split.hip: three-piece
             # operands, fp32 arithmetic; the RGB one is the last kernel of the step, alone on the chip)
-            f_wg = (self.L.rd_stem_wgrad_split_t if (self.split or self.storage == "bf16") and
-                    self.L.rd_stem_wgrad_split_supported(cin, cout) == 1 else self.L.rd_stem_wgrad_t)
-            self.op(self.bwd, ctx["name"] + ".wgrad", f_wg, self.dt, ctx["pl"], ctx["st"], cin, N, H, W, dx.ptr, cout,
-                    _p(self.grad_of(ctx["conv"].weight)), _p(ws), self.stream)
+            if fuse_apply:
+                bn = co["bn"]
+                coef = self.buf(3 * cout)
+                # (the op keeps the apply pass's name: it is this BatchNorm's one gradient writer)
+                self.op(self.bwd, ctx["name"] + ".bn.bn1.bwd_apply", self.L.rd_stem_wgrad_split_bn_t, self.dt, ctx["pl"], ctx["st"], cin, N, H, W,
+                        g.ptr, raw.ptr, _p(red), tiles, _p(bn.weight), _p(co["mean"]), _p(co["invstd"]), _p(self.grad_of(bn.weight)),
+                        _p(self.grad_of(bn.bias)), _p(coef), cout, _p(self.grad_of(ctx["conv"].weight)), _p(ws), self.stream)
+            else:
+                f_wg = self.L.rd_stem_wgrad_split_t if wg_split else self.L.rd_stem_wgrad_t
+                self.op(self.bwd, ctx["name"] + ".wgrad", f_wg, self.dt, ctx["pl"], ctx["st"], cin, N, H, W, dx.ptr, cout,
+                        _p(self.grad_of(ctx["conv"].weight)), _p(ws), self.stream)
         if dgrad_channel is not None:
             ci, dst = dgrad_channel
             self.op(self.bwd, ctx["name"] + ".dgrad_ch", self.L.rd_stem_dgrad_channel_t, self.dt, dx.ptr, _p(ctx["wp"]), N, H, W, cin, ci, cout,

@@ -159,3 +159,59 @@ def test_stem_wgrad_split(cfg):
     print("stem wgrad %s: fp32-MFMA %.2e, split %.2e of the gradient's max" % (cfg, err["fp32"], err["split"]))
     assert err["split"] < 1.5 * err["fp32"] + 2e-7, (cfg, err)
     assert err["split"] < 2e-5, (cfg, err)
+
+
+@pytest.mark.parametrize("cfg", [
+    (2, 3, 64, 97, 161, 0),       # RGB stem, ragged tiles
+    (2, 1, 16, 97, 161, 0),       # depth stem (one 16-channel half of a 32-channel tile)
+    (4, 3, 64, 225, 400, 0),      # several tiles per workgroup
+    (1, 3, 64, 9, 11, 0),
+    (2, 3, 64, 97, 161, 1),       # bf16 storage: the operand is the bf16-rounded value the separate pass would have stored
+    (2, 1, 16, 97, 161, 1),
+])
+def test_stem_wgrad_split_bn_same_bits_as_two_passes(cfg):
+    """rd_stem_wgrad_split_bn_t (the stem BatchNorm's backward apply pass folded into the staging waves of the split weight gradient) against
+    rd_bn_bwd_apply_t + rd_stem_wgrad_split_t on the same tensors: bit-identical weight gradient, dgamma, dbeta (same expression, same
+    order of operations, same pieces)."""
+    from radar_depth_amd._lib import check, current_stream, lib, ptr
+    L = lib()
+    n, cin, cout, h, w, dt = cfg
+    tdt = torch.bfloat16 if dt else torch.float32
+    gen = torch.Generator().manual_seed(11)
+    x_in = torch.randn(n, cin, h, w, generator=gen).cuda()
+    ho, wo = (h - 1) // 2 + 1, (w - 1) // 2 + 1
+    m = n * ho * wo
+    raw = (torch.randn(n, ho, wo, cout, generator=gen) * 1.5 + 0.3).to(tdt).cuda()
+    g = (torch.randn(n, ho, wo, cout, generator=gen) * (torch.rand(n, ho, wo, cout, generator=gen) < 0.3)).to(tdt).cuda()   # pooled gradients are sparse
+    gamma = (torch.rand(cout, generator=gen) + 0.5).cuda()
+    x32 = raw.float()
+    mean = x32.mean((0, 1, 2))
+    invstd = 1.0 / torch.sqrt(x32.var((0, 1, 2), unbiased=False) + 1e-5)
+    tiles = L.rd_bn_bwd_tiles(C.c_int64(m), cout)
+    red = torch.zeros(tiles, 3, cout, device="cuda")
+    check(L.rd_bn_bwd_reduce_t(dt, ptr(g), cout, None, 0, ptr(raw), cout, ptr(mean), None, 0, None, None, 0, C.c_int64(m), cout, 0, ptr(red),
+                               current_stream()), "rd_bn_bwd_reduce_t")
+    hw = h * w
+    planes = (C.c_void_p * 3)(*[x_in.data_ptr() + 4 * hw * c if c < cin else None for c in range(3)])
+    strides = (C.c_int64 * 3)(*[cin * hw if c < cin else 0 for c in range(3)])
+    L.rd_stem_wgrad_workspace_floats.restype = C.c_int64
+    nws = L.rd_stem_wgrad_workspace_floats(n, h, w, cin, cout)
+    res = []
+    for fused in (0, 1):
+        ws = torch.full((int(nws),), float("nan"), device="cuda")
+        dg, db = torch.zeros(cout, device="cuda"), torch.zeros(cout, device="cuda")
+        coef = torch.zeros(3 * cout, device="cuda")
+        gw = torch.full((cout, cin, 7, 7), float("nan"), device="cuda")
+        if fused:
+            check(L.rd_stem_wgrad_split_bn_t(dt, planes, strides, cin, n, h, w, ptr(g), ptr(raw), ptr(red), tiles, ptr(gamma), ptr(mean), ptr(invstd),
+                                             ptr(dg), ptr(db), ptr(coef), cout, ptr(gw), ptr(ws), current_stream()), "rd_stem_wgrad_split_bn_t")
+        else:
+            dx = torch.empty_like(raw)
+            check(L.rd_bn_bwd_apply_t(dt, ptr(g), cout, ptr(raw), cout, ptr(red), tiles, 1, ptr(gamma), ptr(mean), ptr(invstd), ptr(dg), ptr(db),
+                                      ptr(coef), ptr(dx), cout, C.c_int64(m), cout, current_stream()), "rd_bn_bwd_apply_t")
+            check(L.rd_stem_wgrad_split_t(dt, planes, strides, cin, n, h, w, ptr(dx), cout, ptr(gw), ptr(ws), current_stream()), "rd_stem_wgrad_split_t")
+        torch.cuda.synchronize()
+        res.append((gw.cpu(), dg.cpu(), db.cpu()))
+    for a_, b_ in zip(res[0], res[1]):
+        assert not torch.isnan(b_).any()
+        assert torch.equal(a_, b_), cfg

@@ -40,7 +40,12 @@ for cin, cout, first in ((3, 64, 0), (1, 16, 3)):
     check(L.rd_bn_bwd_reduce_t(0, ptr(dout), cout, None, 0, ptr(raw), cout, ptr(mean), None, 0, None, None, 0, C.c_int64(M), cout, 0, ptr(red), current_stream()), "reduce")
     dg, db, coef, dx = torch.zeros(cout, device="cuda"), torch.zeros(cout, device="cuda"), torch.zeros(3 * cout, device="cuda"), torch.empty_like(raw)
     ta = timeit(lambda: check(L.rd_bn_bwd_apply_t(0, ptr(dout), cout, ptr(raw), cout, ptr(red), tiles, 1, ptr(gamma), ptr(mean), ptr(invstd), ptr(dg), ptr(db), ptr(coef), ptr(dx), cout, C.c_int64(M), cout, current_stream()), "apply"))
-    print("stem %d->%d: BatchNorm-backward apply %7.1f us, weight gradient %7.1f us" % (cin, cout, ta * 1e6, t * 1e6))
+    tf = timeit(lambda: check(L.rd_stem_wgrad_split_bn_t(0, planes, strides, cin, N, H, W, ptr(dout), ptr(raw), ptr(red), tiles, ptr(gamma), ptr(mean), ptr(invstd), ptr(dg), ptr(db), ptr(coef), cout, ptr(gw), ptr(ws), current_stream()), "fused"))
+    r16, t16r = raw.to(torch.bfloat16), None
+    dx16 = torch.empty_like(r16)
+    ta16 = timeit(lambda: check(L.rd_bn_bwd_apply_t(1, ptr(d16), cout, ptr(r16), cout, ptr(red), tiles, 1, ptr(gamma), ptr(mean), ptr(invstd), ptr(dg), ptr(db), ptr(coef), ptr(dx16), cout, C.c_int64(M), cout, current_stream()), "apply"))
+    tf16 = timeit(lambda: check(L.rd_stem_wgrad_split_bn_t(1, planes, strides, cin, N, H, W, ptr(d16), ptr(r16), ptr(red), tiles, ptr(gamma), ptr(mean), ptr(invstd), ptr(dg), ptr(db), ptr(coef), cout, ptr(gw), ptr(ws), current_stream()), "fused"))
+    print("stem %d->%d: BatchNorm-backward apply %7.1f us + split weight gradient %7.1f us; folded into one launch %7.1f us | bf16 storage: %7.1f + %7.1f us; folded %7.1f us" % (cin, cout, ta * 1e6, ts_ * 1e6, tf * 1e6, ta16 * 1e6, tb_ * 1e6, tf16 * 1e6))
     # pooling + activation backward with the BatchNorm-backward sums (the first kernel of the stem's backward)
     Hp, Wp = (Ho - 1) // 2 + 1, (Wo - 1) // 2 + 1
     sc, sh = torch.rand(cout, device="cuda") + 0.5, torch.randn(cout, device="cuda") * 0.3
