@@ -38,6 +38,13 @@ RD_GCONV_BF16P=all python tools/ablate_bf16p.py 2>&1 | grep -v amdgpu.ids > $O/a
   RD_FORCE_DP=1 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29519 bench.py --gpus 1 --config 4 --no-cpu-baseline --no-alt --no-roofline 2>/dev/null | grep '^{' | tail -1 | python -c "import json,sys;d=json.loads(sys.stdin.read());print('config 4 dp1     : %8.1f samples/s  step %.3f ms  host issue %.3f ms' % (d['value'], d['ms_per_step'], d.get('host_issue_ms_per_step') or float('nan')))"
 } > $O/host_time.txt 2>&1
 python tools/bench_bn.py fp32 2>/dev/null | grep "ch " | cut -c1-330 > $O/bench_bn.txt
+# round 5 (second half): the stems' kernels alone (split weight gradient, folded apply pass, 2 x 2 pooling gather), ablations of the split stem
+# weight gradient, un-profiled stream probes of configs 2 / 3 / 4, the unaligned-LDS-read microbenchmark
+{ echo "# collected at git $RD_HEAD: python tools/bench_stem.py (b = 16, 450 x 800; kernels alone)"; python tools/bench_stem.py 2>&1 | grep -v amdgpu.ids
+  for d in 1 2; do echo "# RD_STEM_WGRAD_SPLIT_DEBUG=$d (1: no MFMA walk, 2: no staging after the first tile)"; RD_STEM_WGRAD_SPLIT_DEBUG=$d python tools/bench_stem.py 2>&1 | grep "on the bf16"; done; } > $O/bench_stem.txt
+{ echo "# collected at git $RD_HEAD: python tools/tail_probe.py <config> 12 (RD_TAIL_EVENTS=1: timing events recorded from the op list of an UN-PROFILED step)"
+  for c in 2 3 4; do echo "## config $c"; python tools/tail_probe.py $c 12 2>&1 | grep -v "amdgpu.ids\|Info"; done; } > $O/tail_probe.txt
+{ /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -o /tmp/lds_unaligned tools/micro/lds_unaligned.hip 2>/dev/null && /tmp/lds_unaligned; } > $O/lds_unaligned.txt 2>&1
 for r in 1 2; do RD_GCONV_SPLIT_TRACE=$r python tools/trace_gconv_split.py 2>&1 | grep -v amdgpu.ids; done > $O/trace_gconv_split.txt
 RD_GCONV_SPLIT_TRACE=1 python tools/trace_gconv_split.py --pre 2>&1 | grep -v amdgpu.ids > $O/trace_gconv_sp2.txt
 for r in 1 2; do RD_GCONV_SP2=0 RD_GCONV_SPLIT_TRACE=$r python tools/trace_gconv_split.py --pre 2>&1 | grep -v amdgpu.ids; done > $O/trace_gconv_split_pre8.txt
@@ -65,6 +72,7 @@ cd $R
 python tools/rocpd_stats.py $(find $O/kt -name "*.db" | head -1) --steady > $O/kernel_stats.txt
 python tools/rocpd_stats.py $(find $O/kt -name "*.db" | head -1) --steady --timeline > $O/timeline.txt
 python tools/exclusive_time.py $(find $O/kt -name "*.db" | head -1) 12 > $O/exclusive_time.txt
+{ echo "# collected at git $RD_HEAD: python tools/step_trace.py (one step of the multi-stream kernel trace, per queue; under the profiler the host falls behind -- see tail_probe.txt for the un-profiled stream ends)"; python tools/step_trace.py $(find $O/kt -name "*.db" | head -1); } > $O/step_trace.txt
 python tools/rocpd_stats.py $(find $O/kt1 -name "*.db" | head -1) --steady > $O/kernel_stats_single_stream.txt
 python tools/rocpd_stats.py $(find $O/kt1f -name "*.db" | head -1) --steady > $O/kernel_stats_fp32_mfma_single_stream.txt
 python tools/rocpd_stats.py $(find $O/kt116 -name "*.db" | head -1) --steady > $O/kernel_stats_bf16_storage_single_stream.txt
