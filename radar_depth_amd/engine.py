@@ -956,6 +956,11 @@ class LateFusionPlan:
         a, self.c_stem_rgb = self._stem("conv1", rgb_planes, rgb_strides, m.conv1, m.bn1, ACT_RELU, "maxpool")
         with self.on(1):
             d_, self.c_stem_d = self._stem("conv1_depth", dep_planes, dep_strides, m.conv1_depth, m.bn1_depth, ACT_LEAKY02, "maxpool_depth")
+        # the stems read the network input through small HOST arrays of plane pointers / image strides (the ops hold the arrays' addresses):
+        # a caller may point them at its own [N,C,H,W] batch instead of copying it into x_in (bind_input; main.HipTrainStep does)
+        self.x_bind = [(self.c_stem_rgb["pl"], self.c_stem_rgb["st"], 0, 3)]
+        if self.depth_planes is None:
+            self.x_bind.append((self.c_stem_d["pl"], self.c_stem_d["st"], 3, ndep))
         # The weight pack of everything but the stems runs on the (then idle) weight-gradient stream beside the stems and their pooling
         # (_finish_pack_jobs): at the head of the step nothing else could overlap its ~0.2 ms.  Both encoder chains pick it up here.
         self.pack_overlap = self.train and self.multi_stream and os.environ.get("RD_PACK_OVERLAP", "1") == "1"
@@ -1225,6 +1230,15 @@ class LateFusionPlan:
             self._side = [torch.cuda.Stream(device=self.dev, priority=pr[0]), torch.cuda.Stream(device=self.dev, priority=pr[1])]
         self.streams[1].value = self._side[0].cuda_stream
         self.streams[2].value = self._side[1].cuda_stream
+
+    def bind_input(self, base_ptr, channels):
+        """Point the stems' input planes at an fp32 [N,channels,H,W] tensor at base_ptr (contiguous; channels >= the planes the network reads).
+        bind_input(self.x_in.data_ptr(), self.x_in.shape[1]) restores the plan's own buffer."""
+        hw = self.H * self.W
+        for pl, st, c0, n in self.x_bind:
+            for c in range(n):
+                pl[c] = base_ptr + 4 * hw * (c0 + c)
+                st[c] = channels * hw
 
     def run_forward(self, x=None):
         """x: [N,>=4,H,W] fp32 CUDA tensor (copied into the plan's static input buffer) or None if already there."""

@@ -1,0 +1,55 @@
+"""The fused step reads the caller's batch in place (HipTrainStep._bind_batch: the stems' plane tables and the ops that take the input /
+target pointer are re-pointed at contiguous fp32 tensors of the plan's shapes) -- same bits as with the copies into the plan's static
+buffers, across steps with different batches (re-binding), for both networks of the path, and with a fallback for anything else."""
+import types
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _run(arch, zero_copy, monkeypatch, odd_input=False):
+    from radar_depth_amd import main as hmain
+    from radar_depth_amd.main import HipTrainStep
+    from radar_depth_amd.synthetic import make_batch, procedural_fill_
+    monkeypatch.setenv("RD_ZERO_COPY_INPUT", "1" if zero_copy else "0")
+    b, h, w = 2, 97, 161
+    args = types.SimpleNamespace(arch=arch, decoder="upproj", modality="rgbd", pretrained=False)
+    torch.manual_seed(0)
+    made = hmain.create_model(args, [h, w])
+    m, lw = made if isinstance(made, tuple) else (made, None)
+    procedural_fill_(m)
+    m = m.cuda().train()
+    ts = HipTrainStep(m, b, h, w, lr=0.01, momentum=0.9, weight_decay=1e-4, loss_weights=lw)
+    losses = []
+    keep = []
+    for k in range(3):
+        x, t = make_batch(b, h, w, 100 + k)
+        x, t = x.cuda(), t.cuda()
+        if odd_input and k == 1:
+            x = torch.cat([x, x[:, :1]], 1)[:, :4]            # a non-contiguous view: must take the copy path
+            assert not x.is_contiguous()
+        keep += [x, t]
+        loss, _ = ts.step(x, t)
+        losses.append(loss.clone())
+    torch.cuda.synchronize()
+    bound = ts._bound
+    return [v.item() for v in losses], [p.detach().clone() for p in m.parameters()], bound, keep, ts
+
+
+@pytest.mark.parametrize("arch", ["resnet18_latefusion", "resnet18_multistage_uncertainty_fixs"])
+def test_step_reads_the_callers_batch_in_place(arch, monkeypatch):
+    l0, p0, b0, _, ts0 = _run(arch, False, monkeypatch)
+    l1, p1, b1, keep, ts1 = _run(arch, True, monkeypatch)
+    assert b0 == [ts0.plan.x_in.data_ptr(), ts0.target.data_ptr()]              # copies: the ops point at the static buffers
+    assert b1 == [keep[-2].data_ptr(), keep[-1].data_ptr()]                     # in place: at the last batch
+    assert l0 == l1, (l0, l1)
+    assert all(torch.equal(a, b) for a, b in zip(p0, p1))
+
+
+def test_noncontiguous_batch_takes_the_copy(monkeypatch):
+    l0, p0, _, _, _ = _run("resnet18_latefusion", False, monkeypatch)
+    l1, p1, b1, _, ts1 = _run("resnet18_latefusion", True, monkeypatch, odd_input=True)
+    assert l0 == l1
+    assert all(torch.equal(a, b) for a, b in zip(p0, p1))
