@@ -488,10 +488,10 @@ def main():
     if split:
         kinds0 = [k for pl in ts.plans for k, _ in pl.meta.values()]
         out["config"]["arith"] = ("fp32 tensors and fp32 results; the convolutions the library has a split plan for (%d forward / input-gradient and %d "
-                                  "weight-gradient launches per step) compute every fp32 product on the bf16 matrix cores from three bf16 pieces per "
+                                  "weight-gradient launches per step, plus the RGB stem's forward and both stems' weight gradients) compute every fp32 product on the bf16 matrix cores from three bf16 pieces per "
                                   "operand (x = x0 + x1 + x2 exactly), six v_mfma_f32_32x32x16_bf16 terms per product (the three dropped terms are below "
                                   "2^-24 of it), fp32 accumulation; error vs fp64 at the level of the fp32 MFMA kernels, pinned against the CPU oracle at "
-                                  "this batch size at the fp32 bars (tests/test_gpu_configs.py, tests/test_gpu_gconv_split.py, tests/test_gpu_wgrad_split.py); "
+                                  "this batch size at the fp32 bars (tests/test_gpu_configs.py, tests/test_gpu_gconv_split.py, tests/test_gpu_wgrad_split.py, tests/test_gpu_stem.py); "
                                   "all other kernels fp32 (v_mfma_f32_32x32x2_f32 / VALU)" % (kinds0.count("gconv_split") + kinds0.count("gconv_split_pre"), kinds0.count("wgrad_split") + kinds0.count("wgrad_split_pre")))
     elif not bf16:
         out["config"]["arith"] = "fp32 everywhere: every convolution on v_mfma_f32_32x32x2_f32 (the alternate plan of the default line)"
