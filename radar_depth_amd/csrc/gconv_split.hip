@@ -1376,15 +1376,19 @@ static bool gs_shape_ok(const RdConvDesc* d, bool sp2 = false) {
         //   * one-tap layers (0.4-0.8x: a chunk is 36 MFMAs, nothing to hide the staging behind);
         //   * fewer than 64 channels on a side (0.8-1.0x on the 32-channel decoder layers: the 32-wide output tile halves the reuse
         //     of every staged patch);
-        //   * stride-2 convolutions in either direction (0.75-0.95x forward: the patch holds four times the pixels a tap touches;
-        //     0.9x for their zero-filled input gradients); the UpProj input gradient (stride-2 input, four phases) gains 1.1-1.4x
+        //   * (the UpProj input gradient -- stride-2 input, four phases -- gains 1.1-1.4x; stride-2 3x3: see below)
         int taps_max = 0;
         for (int i = 0; i < d->n_phases; ++i) taps_max = taps_max > d->phase[i].n_taps ? taps_max : d->phase[i].n_taps;
         if (taps_max < 4) return false;
         // (gconv_sp2_kernel has 32-wide output tiles at two workgroups per CU: the 32-channel decoder / depth-encoder layers pay there)
         if (!sp2 && (d->Cin < 64 || d->Cout < 64)) return false;
-        if (d->in_stride == 2 && taps_max <= 9) return false;       // stride-2 forward (the UpProj input gradient has 25 taps)
-        if (d->out_stride == 2 && taps_max <= 4) return false;      // stride-2 input gradient (phases of 1 / 2 / 2 / 4 taps)
+        // stride-2 3x3 in either direction: only on pre-split operands (gconv_sp2: 1.28-1.56x forward, 1.05-1.25x for the zero-filled input
+        // gradients against the fp32 kernel; the producers' extra piece planes leave +0.9 % on the step, round 5 -- in round 4, with the 1x1
+        // layers still on the fp32 kernel, it was level); split while staging it is 0.75-0.95x: the patch holds four times the pixels a tap
+        // touches.  RD_GCONV_S2_PRE=0 / 1 (A/B): fp32 kernels / forward only
+        static const int s2pre = getenv("RD_GCONV_S2_PRE") ? atoi(getenv("RD_GCONV_S2_PRE")) : 2;      // 0: fp32 kernels, 1: forward only, 2: + input gradient
+        if (d->in_stride == 2 && taps_max <= 9 && !(sp2 && s2pre >= 1)) return false;
+        if (d->out_stride == 2 && taps_max <= 4 && !(sp2 && s2pre >= 2)) return false;      // stride-2 input gradient (phases of 1 / 2 / 2 / 4 taps)
     }
     if ((int64_t)d->Hi * d->Wi * d->ldi * 4 >= (int64_t)GS_OOB) return false;
     for (int i = 0; i < d->n_phases; ++i) {
