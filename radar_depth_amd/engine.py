@@ -961,6 +961,7 @@ class LateFusionPlan:
         self.x_bind = [(self.c_stem_rgb["pl"], self.c_stem_rgb["st"], 0, 3)]
         if self.depth_planes is None:
             self.x_bind.append((self.c_stem_d["pl"], self.c_stem_d["st"], 3, ndep))
+        self._x_bound = xp           # base pointer the stems' plane tables point at (bind_input)
         # The weight pack of everything but the stems runs on the (then idle) weight-gradient stream beside the stems and their pooling
         # (_finish_pack_jobs): at the head of the step nothing else could overlap its ~0.2 ms.  Both encoder chains pick it up here.
         self.pack_overlap = self.train and self.multi_stream and os.environ.get("RD_PACK_OVERLAP", "1") == "1"
@@ -1239,11 +1240,19 @@ class LateFusionPlan:
             for c in range(n):
                 pl[c] = base_ptr + 4 * hw * (c0 + c)
                 st[c] = channels * hw
+        self._x_bound = base_ptr
+
+    def bind_own_input(self):
+        """The plan's own entry points (run_forward and the stand-alone module plans) read x_in: undo a caller's bind_input (a fused step and
+        the eager forward may share one cached plan)."""
+        if getattr(self, "_x_bound", self.x_in.data_ptr()) != self.x_in.data_ptr():
+            self.bind_input(self.x_in.data_ptr(), self.x_in.shape[1])
 
     def run_forward(self, x=None):
         """x: [N,>=4,H,W] fp32 CUDA tensor (copied into the plan's static input buffer) or None if already there."""
         self.set_stream()
         self.generation += 1
+        self.bind_own_input()
         if x is not None and self.x_source is None:
             if tuple(x.shape[:1]) + tuple(x.shape[2:]) != (self.N, self.H, self.W):
                 raise ValueError("plan built for [%d,*,%d,%d], got %s" % (self.N, self.H, self.W, tuple(x.shape)))

@@ -433,10 +433,10 @@ class HipTrainStep:
             for i, k, a, which in self._bind_sites:
                 a.value = want[which]                                             # (the Python-loop diagnostics path reads the argument objects)
                 check(self.L.rd_optable_set_word(self._table.h, i, k, C.c_uint64(want[which])), "rd_optable_set_word")
-            if want[0] != self._bound[0]:
-                for pl in self.plans:
-                    pl.bind_input(want[0], p.x_in.shape[1])
             self._bound = want
+        for pl in self.plans:                                   # (plan state, shared with the eager forward of a cached plan: checked every step)
+            if pl._x_bound != want[0]:
+                pl.bind_input(want[0], p.x_in.shape[1])
 
     def synchronize_comm(self):
         """Block the host until this step's own communicator (comm="rccl": a second RCCL communicator on a private stream next to

@@ -53,3 +53,33 @@ def test_noncontiguous_batch_takes_the_copy(monkeypatch):
     l1, p1, b1, _, ts1 = _run("resnet18_latefusion", True, monkeypatch, odd_input=True)
     assert l0 == l1
     assert all(torch.equal(a, b) for a, b in zip(p0, p1))
+
+
+def test_eager_forward_after_an_in_place_step_reads_its_own_input(monkeypatch):
+    """A fused step with operands="fp32" and the eager nn.Module forward share one cached plan: after a step that pointed the stems at the
+    caller's batch, the eager forward must read ITS input (run_forward re-binds the plan's own buffer), and the next step re-binds again."""
+    from radar_depth_amd.main import HipTrainStep
+    from radar_depth_amd.model.models import ResNet_latefusion
+    from radar_depth_amd.synthetic import make_batch, procedural_fill_
+    monkeypatch.setenv("RD_ZERO_COPY_INPUT", "1")
+    b, h, w = 2, 97, 161
+    torch.manual_seed(0)
+    m = ResNet_latefusion(18, "upproj", [h, w], 4, False)
+    procedural_fill_(m)
+    m = m.cuda().train()
+    xa, ta = [v.cuda() for v in make_batch(b, h, w, 1)]
+    xb, tb = [v.cuda() for v in make_batch(b, h, w, 2)]
+    with torch.no_grad():
+        want_b = m(xb).clone()                         # eager forward (training-mode statistics), before any step
+    ts = HipTrainStep(m, b, h, w, lr=0.0, momentum=0.0, weight_decay=0.0, operands="fp32")     # lr = 0: the parameters stay put
+    # (BatchNorm running statistics move, the training-mode forward does not read them)
+    l1, _ = ts.step(xa, ta)
+    l1 = l1.item()
+    assert ts.plan._x_bound == xa.data_ptr()
+    with torch.no_grad():
+        got_b = m(xb).clone()
+    torch.cuda.synchronize()
+    assert torch.equal(got_b, want_b)
+    l2, _ = ts.step(xa, ta)
+    torch.cuda.synchronize()
+    assert ts.plan._x_bound == xa.data_ptr() and l2.item() == l1
