@@ -318,3 +318,20 @@ def test_split_plan_routes_supported_convolutions():
     fns = collections.Counter(f.__name__ if hasattr(f, "__name__") else str(f) for _, f, _ in plan.fwd + plan.bwd)
     assert fns["rd_gconv_split"] == kinds["gconv_split"]
     assert fns["rd_wgrad_split"] == kinds["wgrad_split"] and fns["rd_wgrad_split_reduce"] >= kinds["wgrad_split"]
+
+
+def test_bind_input_repoints_the_stem_plane_tables():
+    """LateFusionPlan.bind_input (what the fused step uses to read the caller's batch in place): the stems' host-side plane tables follow
+    the given base pointer and channel count -- RGB planes 0..2, the depth plane 3 -- and bind_own_input restores the plan's buffer."""
+    from radar_depth_amd.engine import LateFusionPlan
+    m = _model(64, 96)
+    plan = LateFusionPlan(m, 2, 64, 96, train=True, dry_run=True)
+    hw, base0 = 64 * 96, plan.x_in.data_ptr()
+    (pl_rgb, st_rgb, c0, n), (pl_d, st_d, c0d, nd) = plan.x_bind
+    assert (c0, n, c0d, nd) == (0, 3, 3, 1)
+    assert [pl_rgb[c] for c in range(3)] == [base0 + 4 * hw * c for c in range(3)] and pl_d[0] == base0 + 4 * hw * 3
+    plan.bind_input(1 << 40, 6)                          # a [N,6,H,W] batch somewhere else
+    assert [pl_rgb[c] for c in range(3)] == [(1 << 40) + 4 * hw * c for c in range(3)] and pl_d[0] == (1 << 40) + 4 * hw * 3
+    assert list(st_rgb)[:3] == [6 * hw] * 3 and st_d[0] == 6 * hw and plan._x_bound == 1 << 40
+    plan.bind_own_input()
+    assert pl_rgb[0] == base0 and st_rgb[0] == plan.x_in.shape[1] * hw and plan._x_bound == base0
