@@ -214,6 +214,157 @@ def cpu_baseline(arch, batch, height, width):
                       % (arch, height, width, "; ".join(plan_txt), batch, res[batch][2], nt, ncpu, cpu)}
 
 
+def eager_loop(model, x, t, warmup, steps, lr=0.01, momentum=0.9, weight_decay=1e-4):
+    """EXACTLY the reference's loop body (main.py:440-445) through the drop-in surface -- `pred = model(input); loss = criterion(pred,
+    target); optimizer.zero_grad(); loss.backward(); optimizer.step()` with torch.optim.SGD -- timed like the fused step.  This is what
+    a maintainer gets who only swaps the three imports of INTEGRATION.md section 1."""
+    from radar_depth_amd.evaluation.criteria_new import MaskedL1Loss
+    model.train()
+    crit = MaskedL1Loss()
+    opt = torch.optim.SGD(model.parameters(), lr, momentum=momentum, weight_decay=weight_decay)
+    loss = None
+
+    def one():
+        pred = model(x)
+        loss = crit(pred, t)
+        opt.zero_grad()
+        loss.backward()
+        opt.step()
+        return loss
+    for _ in range(warmup):
+        loss = one()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    host = 0.0
+    for _ in range(steps):
+        h0 = time.perf_counter()
+        loss = one()
+        host += time.perf_counter() - h0
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    return dt, float(loss.item()), host
+
+
+class PowerReader:
+    """Average socket power over a window, from whatever the box exposes (amdsmi python binding, hwmon sysfs, rocm-smi); None when
+    nothing is readable.  Sampled from a thread during the clock pass -- never inside the timed region."""
+
+    def __init__(self, device_index=0):
+        import glob
+        self.kind, self._h, self._path = None, None, None
+        try:
+            import amdsmi
+            amdsmi.amdsmi_init()
+            hs = amdsmi.amdsmi_get_processor_handles()
+            self._amdsmi, self._h = amdsmi, hs[min(device_index, len(hs) - 1)]
+            if self._read_amdsmi() is not None:
+                self.kind = "amdsmi"
+        except Exception:                                   # noqa: BLE001
+            self._h = None
+        if self.kind is None:
+            for pat in ("/sys/class/drm/card*/device/hwmon/hwmon*/power1_average", "/sys/class/drm/card*/device/hwmon/hwmon*/power1_input"):
+                for f in sorted(glob.glob(pat)):
+                    try:
+                        if float(open(f).read()) > 0:
+                            self.kind, self._path = "sysfs:" + f, f
+                            break
+                    except (OSError, ValueError):
+                        pass
+                if self.kind:
+                    break
+        self.samples = []
+        self._stop = None
+
+    def _read_amdsmi(self):
+        try:
+            info = self._amdsmi.amdsmi_get_power_info(self._h)
+            for key in ("current_socket_power", "average_socket_power", "socket_power"):
+                v = info.get(key)
+                if isinstance(v, (int, float)) and v > 0:
+                    return float(v)
+        except Exception:                                   # noqa: BLE001
+            pass
+        return None
+
+    def read(self):
+        if self.kind == "amdsmi":
+            return self._read_amdsmi()
+        if self._path:
+            try:
+                return float(open(self._path).read()) / 1e6      # microwatts
+            except (OSError, ValueError):
+                return None
+        return None
+
+    def start(self, period=0.01):
+        import threading
+        if self.kind is None:
+            return
+        self._stop = threading.Event()
+
+        def loop():
+            while not self._stop.is_set():
+                v = self.read()
+                if v is not None:
+                    self.samples.append(v)
+                self._stop.wait(period)
+        self._thr = threading.Thread(target=loop, daemon=True)
+        self._thr.start()
+
+    def stop(self):
+        if self._stop is not None:
+            self._stop.set()
+            self._thr.join()
+        if not self.samples:
+            return None
+        return {"source": self.kind, "avg_w": round(sum(self.samples) / len(self.samples), 1), "max_w": round(max(self.samples), 1), "samples": len(self.samples)}
+
+
+def clock_pass(L, step_fn, steps, ms_per_step, main_stream):
+    """Effective shader clock WHILE the steps execute: rd_clock_probe windows of 1 ms back to back on a stream of
+    their own for the duration of `steps` more steps issued right behind them (an extra pass OUTSIDE the timed region), eight one-wave
+    workgroups each (one per XCD); two marker probes on the steps' stream delimit the steps on the device's real-time counter, only
+    windows inside them are kept.  Returns MHz statistics and the average socket power over the same pass."""
+    nblk, win_us = 8, 1000
+    n_win = int(steps * ms_per_step * 1.25) + 4
+    buf = torch.zeros((n_win + 2) * nblk * 4, dtype=torch.int64, device="cuda")
+    base = buf.data_ptr()
+    probe = torch.cuda.Stream()
+    ps = C.c_void_p(probe.cuda_stream)
+    torch.cuda.synchronize()
+    for _ in range(3):
+        step_fn()                                            # the device is at its in-step clock when the windows start
+    power = PowerReader(torch.cuda.current_device())
+    power.start()
+    assert L.rd_clock_probe(C.c_void_p(base + n_win * nblk * 32), 1, 1, main_stream()) == 0            # start marker (behind the 3 steps)
+    probe.wait_stream(torch.cuda.current_stream())
+    for k in range(n_win):
+        assert L.rd_clock_probe(C.c_void_p(base + k * nblk * 32), nblk, win_us, ps) == 0
+    for _ in range(steps):
+        step_fn()
+    assert L.rd_clock_probe(C.c_void_p(base + (n_win + 1) * nblk * 32), 1, 1, main_stream()) == 0      # end marker
+    torch.cuda.synchronize()
+    pw = power.stop()
+    v = buf.cpu().view(-1, nblk, 4)
+    t_begin, t_end = int(v[n_win, 0, 3]), int(v[n_win + 1, 0, 3])
+    mhz, per_xcd = [], {}
+    for k in range(n_win):
+        for b in range(nblk):
+            clk, ticks, xcc, r0 = (int(q) for q in v[k, b])
+            if ticks > 0 and r0 >= t_begin and r0 + ticks <= t_end:
+                f = 100.0 * clk / ticks
+                mhz.append(f)
+                per_xcd.setdefault(xcc & 0xf, []).append(f)
+    if not mhz:
+        return None, pw
+    mhz.sort()
+    return {"mean": round(sum(mhz) / len(mhz), 1), "min": round(mhz[0], 1), "p10": round(mhz[len(mhz) // 10], 1), "median": round(mhz[len(mhz) // 2], 1),
+            "max": round(mhz[-1], 1), "windows": len(mhz), "window_us": win_us,
+            "per_xcd_mean": {str(k): round(sum(a) / len(a), 1) for k, a in sorted(per_xcd.items())},
+            "how": "rd_clock_probe: s_memtime / s_memrealtime over 1-ms windows on a side stream, one wave per XCD, concurrent with %d "
+                   "steps of an extra pass outside the timed region; windows inside the steps only" % steps}, pw
+
+
 # BASELINE.json configs (index as in the file): (arch, per-GPU batch, height, width, storage)
 CONFIGS = {
     2: ("resnet18_latefusion", 16, 450, 800, "fp32"),
@@ -304,6 +455,37 @@ def dry_run(args, world, rank):
         raise SystemExit("dry run: the bucketed exchange did not produce the all-rank sum over the whole arena")
 
 
+def eager_block(model, x, t, args, operands, fused_value=None):
+    model.operands = operands
+    dt, final_loss, host = eager_loop(model, x, t, args.warmup, args.steps)
+    v = args.batch * args.steps / dt
+    blk = {"operands": operands, "value": round(v, 2), "unit": "samples/s", "ms_per_step": round(1e3 * dt / args.steps, 3),
+           "host_issue_ms_per_step": round(1e3 * host / args.steps, 3), "steps": args.steps, "warmup": args.warmup, "final_loss": round(final_loss, 5),
+           "loop": "pred = model(x); loss = MaskedL1Loss()(pred, target); optimizer.zero_grad(); loss.backward(); optimizer.step() -- "
+                   "radar_depth_amd drop-in modules + torch.optim.SGD(lr .01, momentum .9, wd 1e-4): the reference's main.py:440-445 verbatim"}
+    if fused_value:
+        blk["frac_of_fused_step"] = round(v / fused_value, 4)
+    return blk
+
+
+def eager_main(args, ts, model, x, t):
+    """`--mode eager`: the line's value IS the reference's loop body through the drop-in modules (no HipTrainStep anywhere)."""
+    blk = eager_block(model, x, t, args, args.operands)
+    out = {"metric": METRIC, "value": blk["value"], "unit": "samples/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
+           "ms_per_step": blk["ms_per_step"], "host_issue_ms_per_step": blk["host_issue_ms_per_step"], "higher_is_better": True, "scaling": "weak",
+           "vs_baseline": None, "dtype": "f32", "data": "synthetic", "mode": "eager",
+           "config": {"workload": "%s --decoder upproj --modality rgbd, b=%d/GPU %dx%d fp32, full step through the nn.Module surface: %s"
+                                  % (args.arch, args.batch, args.height, args.width, blk["loop"]),
+                      "baseline_config": args.config, "global_batch": args.batch, "parallelism": "single", "final_loss": blk["final_loss"],
+                      "rd_env": {k: v for k, v in sorted(os.environ.items()) if k.startswith("RD_")}},
+           "arith": "fp32 via 3 x bf16 split, 6 MFMA terms, fp32 accumulate" if args.operands == "split" else "fp32 MFMA"}
+    if (args.batch, args.height, args.width) != (16, 450, 800):
+        out["metric"] = "training samples/sec, %s b=%d %dx%d rgbd" % (args.arch, args.batch, args.height, args.width)
+    if not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(args.arch, args.batch, args.height, args.width)
+    print(json.dumps(out), flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -342,6 +524,12 @@ def main():
     ap.add_argument("--comm", default="rccl", choices=["rccl", "torch"],
                     help="gradient exchange for --gpus > 1: rccl = the C ABI's own communicator (rd_allreduce_bucket on a communication "
                          "stream, event-chained per backward segment); torch = torch.distributed.all_reduce (cross-check)")
+    ap.add_argument("--mode", default="fused", choices=["fused", "eager"],
+                    help="fused (default): HipTrainStep, the whole step as one rd_optable_run call.  eager: `value` is the reference's own loop "
+                         "body through the drop-in modules -- pred = model(x); loss = criterion(pred, target); optimizer.zero_grad(); "
+                         "loss.backward(); optimizer.step() with torch.optim.SGD (main.py:440-445); latefusion / fp32 storage only.  The default "
+                         "line carries the same measurement as its `alt_eager` block")
+    ap.add_argument("--no-clock", action="store_true", help="skip the in-step shader clock / socket power pass (roofline.shader_clock_mhz)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--dry-run", action="store_true",
@@ -400,11 +588,16 @@ def main():
                         [args.height, args.width])
     model, loss_weights = made if isinstance(made, tuple) else (made, None)
     model = model.cuda()
-    ts = HipTrainStep(model, args.batch, args.height, args.width, lr=0.01, momentum=0.9, weight_decay=1e-4,
-                      loss_weights=loss_weights, use_graph=args.graph, operands=args.operands,
-                      comm=comm_used if comm_used != "none" else "auto", storage=args.storage, autotune=bool(args.autotune))
+    if args.mode == "eager" and (world > 1 or args.arch != "resnet18_latefusion" or args.storage != "fp32" or args.operands not in ("split", "fp32")):
+        raise SystemExit("bench.py --mode eager: the reference's loop body main.py:440-445 (latefusion, fp32 storage, split or fp32 operands, one GPU)")
+    ts = None if args.mode == "eager" else HipTrainStep(
+        model, args.batch, args.height, args.width, lr=0.01, momentum=0.9, weight_decay=1e-4,
+        loss_weights=loss_weights, use_graph=args.graph, operands=args.operands,
+        comm=comm_used if comm_used != "none" else "auto", storage=args.storage, autotune=bool(args.autotune))
     x, t = make_batch(args.batch, args.height, args.width, 1234 + 1000 * rank)
     x, t = x.cuda(), t.cuda()
+    if args.mode == "eager":
+        return eager_main(args, ts, model, x, t)
 
     def sync():
         # drain this rank's own work first: the step's all-reduces (own communicator, communication stream) are then complete
@@ -573,6 +766,22 @@ def main():
             by_kernel = {k: [round(v[0], 3), v[1], round(v[3] / (v[0] * 1e-3) / 1e9, 0)] for k, v in sorted(agg.items(), key=lambda kv: -kv[1][0])}
         out["roofline"]["eager_ms_by_family"] = {k: round(v, 3) for k, v in sorted(fam.items(), key=lambda kv: -kv[1])}
         out["roofline"]["eager_ms_by_kernel"] = by_kernel
+        if not args.no_clock and world == 1:
+            # the clock the chip runs at INSIDE the step and the socket power over the same pass: what turns "the bf16
+            # matrix plan is power-limited" from an inference into a measurement, and what makes lines of different boxes comparable
+            try:
+                with torch.cuda.stream(ts.side):
+                    mhz, pw = clock_pass(ts.L, lambda: ts.step(x, t), args.steps, 1e3 * dt / args.steps, lambda: C.c_void_p(ts.side.cuda_stream))
+                out["roofline"]["shader_clock_mhz"] = mhz
+                out["roofline"]["socket_power_w"] = pw
+                if mhz and "sustained_bf16_peak" in out["roofline"]:
+                    # dense bf16 MFMA rate at the MEASURED in-step clock (2500 TFLOP/s is the figure at the 2400 MHz boost clock)
+                    sus = 2500.0 * mhz["mean"] / 2400.0
+                    out["roofline"]["sustained_bf16_peak"] = round(sus, 1)
+                    out["roofline"]["sustained_bf16_peak_source"] = "2500 TFLOP/s x measured in-step shader clock (mean %.0f MHz) / 2400 MHz" % mhz["mean"]
+                    out["roofline"]["frac_of_sustained"] = round(out["roofline"]["achieved"] / sus, 4)
+            except Exception as e:                          # noqa: BLE001 -- diagnostics never take the metric down
+                out["roofline"]["shader_clock_mhz"] = {"error": "%s: %s" % (type(e).__name__, e)}
     if (rank == 0 and world == 1 and args.operands == "split" and args.storage == "fp32" and not args.no_alt and not args.graph
             and not args.no_roofline and not args.no_cpu_baseline and os.environ.get("RD_FORCE_DP") != "1"):
         # the same workload once more on the plain fp32-MFMA plan (every convolution on v_mfma_f32_32x32x2_f32), timed the same way in
@@ -592,7 +801,15 @@ def main():
                 loss2, _ = ts2.step(x, t)
             torch.cuda.synchronize()
             adt = time.perf_counter() - a0
+            mhz2, pw2 = (None, None)
+            if not args.no_clock:
+                try:
+                    with torch.cuda.stream(ts2.side):
+                        mhz2, pw2 = clock_pass(ts2.L, lambda: ts2.step(x, t), args.steps, 1e3 * adt / args.steps, lambda: C.c_void_p(ts2.side.cuda_stream))
+                except Exception as e:                      # noqa: BLE001
+                    mhz2 = {"error": "%s: %s" % (type(e).__name__, e)}
             out["alt_fp32_mfma"] = {"operands": "fp32", "value": round(args.batch * args.steps / adt, 2), "unit": "samples/s", "ms_per_step": round(1e3 * adt / args.steps, 3),
+                                    "shader_clock_mhz": mhz2, "socket_power_w": pw2,
                                     "steps": args.steps, "warmup": args.warmup, "final_loss": round(float(loss2.item()), 5),
                                     "step_frac_of_bound": round(args.batch * args.steps / adt / bnd["fp32"], 4),
                                     "note": "same workload, same process, every convolution on the fp32 MFMA (v_mfma_f32_32x32x2_f32; rounds 1-3's headline "
@@ -600,6 +817,14 @@ def main():
             ts2.close()
         except Exception as e:      # the alternative line must never take the metric down with it
             out["alt_fp32_mfma"] = {"error": "%s: %s" % (type(e).__name__, e)}
+    if (rank == 0 and world == 1 and args.arch == "resnet18_latefusion" and args.storage == "fp32" and args.operands in ("split", "fp32")
+            and not args.no_alt and not args.graph and not args.no_roofline and os.environ.get("RD_FORCE_DP") != "1"):
+        # the drop-in route of INTEGRATION.md section 1, measured: the reference's loop body verbatim on the same model
+        try:
+            ts.close()
+            out["alt_eager"] = eager_block(model, x, t, args, args.operands, fused_value=out["value"])
+        except Exception as e:                              # noqa: BLE001
+            out["alt_eager"] = {"error": "%s: %s" % (type(e).__name__, e)}
     if world > 1:
         torch.distributed.barrier()
     # communicator teardown BEFORE the result line, and C stdio flushed around it: RCCL writes its version banner through C

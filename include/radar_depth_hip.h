@@ -494,6 +494,13 @@ int rd_stage_frames(const uint8_t* rgb_hwc, const int16_t* lidar, const int16_t*
 int rd_nchw_to_nhwc(const float* src, float* dst, int32_t N, int32_t C, int32_t H, int32_t W, void* stream);
 int rd_nhwc_to_nchw(const float* src, float* dst, int32_t N, int32_t C, int32_t H, int32_t W, void* stream);
 
+/* Diagnostics (bench.py `roofline.shader_clock_mhz`): n_blocks (<= 64) one-wave workgroups each sleep for duration_us and write
+ * out[4 * block + 0..3] = { shader clocks elapsed (s_memtime), 10-ns ticks elapsed (s_memrealtime), XCC_ID, start tick }:
+ * clocks / ticks * 100 = the effective shader clock in MHz of that workgroup's XCD over the window.  Meant to run on a stream of
+ * its own beside the training step (the sleeping wave takes no issue slots).  `out`: device memory, 32 * n_blocks bytes.
+ * No counterpart in the reference (measurement only). */
+int rd_clock_probe(unsigned long long* out, int32_t n_blocks, int32_t duration_us, void* stream);
+
 /* Fork/join between the caller's streams (the plan runs the depth encoder and the weight-gradient chains on side streams);
  * record/wait pairs are captured as graph edges when the main stream is being captured. */
 int rd_event_create(void** event);

@@ -77,9 +77,7 @@ __global__ __launch_bounds__(256) void poison_lds_kernel(unsigned* sink, int wor
 extern "C" int rd_debug_poison_lds(void* stream) {
     static std::atomic<unsigned long long> attr_set{0};
     const int bytes = 160 * 1024 - 1024;
-    if (rd::attr_once(attr_set)) {
-        RD_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(poison_lds_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
-    }
+    RD_SET_ATTR_ONCE(attr_set, hipFuncSetAttribute(reinterpret_cast<const void*>(poison_lds_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
     hipLaunchKernelGGL(poison_lds_kernel, dim3(rd::num_cus() * 4), dim3(256), bytes, static_cast<hipStream_t>(stream), (unsigned*)nullptr, bytes / 4);
     RD_CHECK_LAUNCH("poison_lds_kernel");
     return RD_OK;

@@ -4,6 +4,7 @@
 #include <stdint.h>
 
 #include <atomic>
+#include <mutex>
 #include <stdio.h>
 #include <string.h>
 
@@ -64,13 +65,38 @@ void set_error(const char* fmt, ...);
     } while (0)
 
 // hipFuncSetAttribute(MaxDynamicSharedMemorySize) is per DEVICE: a launcher keeps one bit per device of the process (a
-// process-wide bool left a second device's kernels without the attribute).  True exactly once per (flag, current device); thread-safe.
-static inline bool attr_once(std::atomic<unsigned long long>& mask) {
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess) return true;
-    const unsigned long long bit = 1ull << (dev & 63);
-    return (mask.fetch_or(bit) & bit) == 0;
-}
+// process-wide bool left a second device's kernels without the attribute).  The bit is set only AFTER the attribute call has
+// returned hipSuccess, and the call runs under a mutex (with the bit set first, a second host thread could launch with
+// > 64 KB of dynamic LDS before the attribute was applied, and one failed call was never retried).  A failing hipGetDevice leaves
+// nothing cached: the attribute is simply set again by the next launch.
+struct AttrOnce {
+    std::atomic<unsigned long long>& mask;
+    unsigned long long bit = 0;
+    bool first = false;
+    std::unique_lock<std::mutex> lock;
+    static std::mutex& mu() { static std::mutex m; return m; }
+    explicit AttrOnce(std::atomic<unsigned long long>& m) : mask(m) {
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess) { first = true; return; }
+        bit = 1ull << (dev & 63);
+        if (mask.load(std::memory_order_acquire) & bit) return;
+        lock = std::unique_lock<std::mutex>(mu());
+        first = (mask.load(std::memory_order_acquire) & bit) == 0;
+    }
+    void done() { if (bit) mask.fetch_or(bit, std::memory_order_release); }
+};
+#define RD_SET_ATTR_ONCE(mask_, ...)                                                       \
+    do {                                                                                   \
+        rd::AttrOnce once__(mask_);                                                        \
+        if (once__.first) {                                                                \
+            hipError_t e__ = (__VA_ARGS__);                                                \
+            if (e__ != hipSuccess) {                                                       \
+                rd::set_error("%s: %s", #__VA_ARGS__, hipGetErrorString(e__));             \
+                return RD_ELAUNCH;                                                         \
+            }                                                                              \
+            once__.done();                                                                 \
+        }                                                                                  \
+    } while (0)
 
 static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 static inline int64_t cdiv64(int64_t a, int64_t b) { return (a + b - 1) / b; }

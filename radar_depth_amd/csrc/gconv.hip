@@ -873,9 +873,7 @@ template <int MT, int NT, int WM, int WN, int CKW, bool SWZ, bool PIPE, bool GRP
 static int launch_cfg(const GconvArgs& a, int grid, size_t lds, hipStream_t s) {
     static std::atomic<unsigned long long> attr_set{0};
     auto k = gconv_kernel<MT, NT, WM, WN, CKW, SWZ, PIPE, GRP, BNB>;
-    if (attr_once(attr_set)) {
-        RD_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    }
+    RD_SET_ATTR_ONCE(attr_set, hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     hipLaunchKernelGGL(k, dim3(grid), dim3(256), lds, s, a);
     RD_CHECK_LAUNCH("gconv_kernel");
     return RD_OK;

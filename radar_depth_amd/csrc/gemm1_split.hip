@@ -382,7 +382,7 @@ template <int MT, int NT>
 static int launch_g1(const G1Args& a, int grid, size_t lds, hipStream_t s) {
     static std::atomic<unsigned long long> attr_set{0};
     auto k = gemm1_split_kernel<MT, NT>;
-    if (attr_once(attr_set)) RD_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
+    RD_SET_ATTR_ONCE(attr_set, hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
     hipLaunchKernelGGL(k, dim3(grid), dim3(256), lds, s, a);
     RD_CHECK_LAUNCH("gemm1_split_kernel");
     return RD_OK;

@@ -426,7 +426,7 @@ __global__ __launch_bounds__(256) void bnact_maxpool_bwd_kernel(const T* __restr
     extern __shared__ float sm[];
     const int Q = C >> 2;
     const int lq = quad_log2(Q);
-    const int64_t total = (int64_t)N * Ho * Wo * Q;          // Ho == ceil(H/2), Wo == ceil(W/2)
+    const int64_t total = (int64_t)N * Ho * Wo * Q;          // Ho == ceil(H/2), Wo == ceil(W/2): the launchers pass (H + 2 - 3) / 2 + 1, which is that
     float4 acc[3] = {make_float4(0, 0, 0, 0), make_float4(0, 0, 0, 0), make_float4(0, 0, 0, 0)};
     const float4 mu = (part || coef) ? *reinterpret_cast<const float4*>(mean + (threadIdx.x % Q) * 4) : make_float4(0, 0, 0, 0);
     float4 cA = make_float4(0, 0, 0, 0), cB = cA, cK = cA;
@@ -808,7 +808,7 @@ template <typename T>
 static int rd_bnact_maxpool_bwd_T(const T* dy, int32_t lddy, const uint8_t* idx, const T* x, const float* scale, const float* shift, int32_t act, int32_t N, int32_t H, int32_t W, int32_t C, T* g, void* stream) {
     RD_CHECK_ARG(dy && idx && x && scale && shift && g && C % 4 == 0 && lddy % 4 == 0, "bnact_maxpool_bwd: bad arguments");
     const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
-    hipLaunchKernelGGL((bnact_maxpool_bwd_kernel<T>), dim3(ew_grid((int64_t)N * H * W * (C / 4))), dim3(256), 0,
+    hipLaunchKernelGGL((bnact_maxpool_bwd_kernel<T>), dim3(ew_grid((int64_t)N * Ho * Wo * (C / 4))), dim3(256), 0,
                        static_cast<hipStream_t>(stream), dy, lddy, idx, x, scale, shift, act, N, H, W, C, Ho, Wo, g,
                        (const float*)nullptr, (float*)nullptr, (const float*)nullptr);
     RD_CHECK_LAUNCH("bnact_maxpool_bwd_kernel");
@@ -827,8 +827,11 @@ extern "C" int rd_bnact_maxpool_bwd_t(int32_t dtype, const void* dy, int32_t ldd
 
 // Same, and the stem BatchNorm's backward sums in the same pass: red_partial [rd_bnact_maxpool_bwd_tiles(...)][3][C]
 // (slot 0 = sum g, slot 1 = sum g*(x - mean)), consumed by rd_bn_bwd_apply(which = 1).
+// (the kernel's work item is one 2 x 2 block of positions x one channel quad: N * ceil(H/2) * ceil(W/2) * C/4 of them -- grid and tile
+//  count are sized from THAT everywhere, ADVICE r5: sized from N*H*W*C/4, small shapes launched up to 4x the blocks, all writing zero rows)
 extern "C" int rd_bnact_maxpool_bwd_tiles(int32_t N, int32_t H, int32_t W, int32_t C) {
-    return ew_grid((int64_t)N * H * W * (C / 4));
+    const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
+    return ew_grid((int64_t)N * Ho * Wo * (C / 4));
 }
 template <typename T>
 static int rd_bnact_maxpool_bwd_stats_T(const T* dy, int32_t lddy, const uint8_t* idx, const T* x, const float* scale, const float* shift, int32_t act, int32_t N, int32_t H, int32_t W, int32_t C, T* g, const float* mean, float* red_partial, void* stream) {
@@ -837,7 +840,7 @@ static int rd_bnact_maxpool_bwd_stats_T(const T* dy, int32_t lddy, const uint8_t
     RD_CHECK_ARG(C >= 4 && 256 % (C / 4) == 0, "bnact_maxpool_bwd_stats: C/4 = %d must divide 256", C / 4);
     const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
     const int Q = C / 4, RL = 256 / Q;
-    hipLaunchKernelGGL((bnact_maxpool_bwd_kernel<T>), dim3(ew_grid((int64_t)N * H * W * (C / 4))), dim3(256),
+    hipLaunchKernelGGL((bnact_maxpool_bwd_kernel<T>), dim3(ew_grid((int64_t)N * Ho * Wo * (C / 4))), dim3(256),
                        (size_t)RL * 3 * C * sizeof(float), static_cast<hipStream_t>(stream), dy, lddy, idx, x, scale, shift, act, N, H,
                        W, C, Ho, Wo, g, mean, red_partial, (const float*)nullptr);
     RD_CHECK_LAUNCH("bnact_maxpool_bwd_kernel");
@@ -870,7 +873,7 @@ static int rd_bnact_maxpool_bwd_apply_T(const T* dy, int32_t lddy, const uint8_t
     hipLaunchKernelGGL(bn_bwd_coeffs_kernel, dim3(C), dim3(256), 0, s, red_partial, n_tiles, C, 1, (double)((int64_t)N * H * W), gamma, invstd,
                        dgamma, dbeta, coef_ws);
     RD_CHECK_LAUNCH("bn_bwd_coeffs_kernel");
-    hipLaunchKernelGGL((bnact_maxpool_bwd_kernel<T>), dim3(ew_grid((int64_t)N * H * W * (C / 4))), dim3(256), 0, s, dy, lddy, idx, x, scale,
+    hipLaunchKernelGGL((bnact_maxpool_bwd_kernel<T>), dim3(ew_grid((int64_t)N * Ho * Wo * (C / 4))), dim3(256), 0, s, dy, lddy, idx, x, scale,
                        shift, act, N, H, W, C, Ho, Wo, dx, mean, (float*)nullptr, (const float*)coef_ws);
     RD_CHECK_LAUNCH("bnact_maxpool_bwd_kernel");
     return RD_OK;

@@ -566,11 +566,9 @@ static int stem_fwd_impl(int io16, const float* const* planes, const int64_t* st
     const int Kq = Kp + 4;
     const size_t lds = ((size_t)((Kq + 3) & ~3) + (size_t)Kq * BN + (size_t)Cin * 21 * ST_PW + (size_t)8 * BN) * 4;
     hipStream_t s = static_cast<hipStream_t>(stream);
-    static std::atomic<unsigned long long> attr{0};
-    if (attr_once(attr)) {
-        RD_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(stem_fwd_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
-        RD_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(stem_fwd_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
-    }
+    static std::atomic<unsigned long long> attr{0}, attr1{0};
+    RD_SET_ATTR_ONCE(attr, hipFuncSetAttribute(reinterpret_cast<const void*>(stem_fwd_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
+    RD_SET_ATTR_ONCE(attr1, hipFuncSetAttribute(reinterpret_cast<const void*>(stem_fwd_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
     if (NT == 2) hipLaunchKernelGGL(stem_fwd_kernel<2>, dim3(grid), dim3(256), lds, s, a);
     else hipLaunchKernelGGL(stem_fwd_kernel<1>, dim3(grid), dim3(256), lds, s, a);
     RD_CHECK_LAUNCH("stem_fwd_kernel");

@@ -314,9 +314,7 @@ extern "C" int rd_stem_fwd_split(const float* const* planes, const int64_t* stri
     hipStream_t s = static_cast<hipStream_t>(stream);
     auto launch = [&](auto k) -> int {
         static std::atomic<unsigned long long> attr_done{0};      // (one flag per instantiation of this generic lambda)
-        if (attr_once(attr_done)) {
-            RD_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        }
+        RD_SET_ATTR_ONCE(attr_done, hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         hipLaunchKernelGGL(k, dim3(grid), dim3(512), lds, s, a);
         return RD_OK;
     };

@@ -491,9 +491,7 @@ static int stem_wgrad_split_impl(int32_t dtype, const float* const* planes, cons
 #define RD_SWS(M_, N_, B_, F_)                                                                                       \
     if (MTK == M_ && NT == N_ && b16 == B_ && bnf == F_) {                                                           \
         static std::atomic<unsigned long long> attr_set{0};       /* (one flag set per instantiation) */             \
-        if (attr_once(attr_set))                                                                                     \
-            RD_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(stem_wgrad_split_kernel<M_, N_, B_, F_>), \
-                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                 \
+        RD_SET_ATTR_ONCE(attr_set, hipFuncSetAttribute(reinterpret_cast<const void*>(stem_wgrad_split_kernel<M_, N_, B_, F_>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                 \
         hipLaunchKernelGGL((stem_wgrad_split_kernel<M_, N_, B_, F_>), dim3(n_splits), dim3(512), lds, s, a);         \
         RD_CHECK_LAUNCH("stem_wgrad_split_kernel");                                                                  \
     } else

@@ -762,9 +762,7 @@ template <int RH, int RW>
 static int launch_strip(const WgradPlan& pl, const WgradArgs& a, int grid, hipStream_t s) {
     static std::atomic<unsigned long long> attr_set{0};
     auto k = wgrad_strip_kernel<RH, RW>;
-    if (attr_once(attr_set)) {
-        RD_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    }
+    RD_SET_ATTR_ONCE(attr_set, hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     hipLaunchKernelGGL(k, dim3(grid), dim3(256), pl.lds, s, a, pl.sa);
     RD_CHECK_LAUNCH("wgrad_strip_kernel");
     return RD_OK;
@@ -774,9 +772,7 @@ template <int TG, int MF, bool LA, bool SHB, int PITCH = 0, int RW = 3>
 static int launch_wgrad(const WgradArgs& a, int grid, size_t lds, hipStream_t s) {
     static std::atomic<unsigned long long> attr_set{0};
     auto k = wgrad_kernel<TG, MF, LA, SHB, PITCH, RW>;
-    if (attr_once(attr_set)) {
-        RD_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    }
+    RD_SET_ATTR_ONCE(attr_set, hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     hipLaunchKernelGGL(k, dim3(grid), dim3(256), lds, s, a);
     RD_CHECK_LAUNCH("wgrad_kernel");
     return RD_OK;

@@ -196,9 +196,7 @@ static int launch_w1(const Wgrad1x1Args& a, hipStream_t s) {
     constexpr size_t lds = (size_t)2 * (2 * TI * 32 + 2 * TO * 32) * W1_PC * sizeof(float);
     static std::atomic<unsigned long long> attr{0};
     auto k = wgrad1x1_kernel<TI, TO>;
-    if (attr_once(attr)) {
-        RD_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    }
+    RD_SET_ATTR_ONCE(attr, hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(k, dim3(a.n_cib * a.n_cob * a.n_splits), dim3(256), lds, s, a);
     RD_CHECK_LAUNCH("wgrad1x1_kernel");
     return RD_OK;

@@ -461,9 +461,7 @@ static int wgrad_bf16_impl(bool io16, const RdConvDesc* d, const void* in, const
     if (full == FULL_ && nk == NK_ && io16 == IO_) {                                                                            \
         static std::atomic<unsigned long long> attr_set{0};                                                                                           \
         auto k = wgrad_bf16_kernel<FULL_, NK_, IO_>;                                                                            \
-        if (attr_once(attr_set)) {                                                                                                        \
-            RD_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); \
-        }                                                                                                                       \
+        RD_SET_ATTR_ONCE(attr_set, hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));                                                                                                                       \
         hipLaunchKernelGGL(k, grid, dim3(512), pl.lds_bytes, st, a);                                                            \
         RD_CHECK_LAUNCH("wgrad_bf16_kernel");                                                                                   \
         return RD_OK;                                                                                                           \

@@ -429,9 +429,7 @@ template <int TR, int TC, typename G, bool PRE>
 static int launch_ws(const WsArgs& a, int grid, hipStream_t s) {
     static std::atomic<unsigned long long> attr_set{0};
     auto k = wgrad_split_kernel<TR, TC, G, PRE>;
-    if (attr_once(attr_set)) {
-        RD_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    }
+    RD_SET_ATTR_ONCE(attr_set, hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     hipLaunchKernelGGL(k, dim3(grid), dim3(512), 2 * (PRE ? G::BUF_P : G::BUF), s, a);
     RD_CHECK_LAUNCH("wgrad_split_kernel");
     return RD_OK;

@@ -170,8 +170,11 @@ class HipTrainStep:
             self.plans = [model._plan(batch, height, width, True, bf16=operands == "bf16", storage=storage, segment_joins=joins,
                                       autotune=autotune, split=operands == "split")]
         self.plan = self.plans[0]
+        from .model.models import ArenaOwner, hold_plan
+        self._held = hold_plan(self.mp if self.multistage else self.plan)      # released by close(): the plan cache never closes it under this step
         self.st = model._ensure_arenas()
         self._arena_version = self.st["version"]
+        self._rehomes = ArenaOwner.REHOMES[0]
         dev = self.plan.dev
         self.batch, self.height, self.width = batch, height, width
         self.lr, self.momentum, self.wd = lr, momentum, weight_decay
@@ -456,6 +459,10 @@ class HipTrainStep:
         for ev in evs or []:
             if ev.value:
                 self.L.rd_event_destroy(ev)
+        held, self._held = getattr(self, "_held", None), None
+        if held is not None:
+            from .model.models import release_plan
+            release_plan(held)
 
     def __del__(self):
         try:
@@ -487,9 +494,13 @@ class HipTrainStep:
                              "last batch or use drop_last=True)" % (want_in + (tuple(inputs.shape),)))
         if tuple(target.shape) != want_t:
             raise ValueError("HipTrainStep was built for target %s, got %s" % (want_t, tuple(target.shape)))
-        st = self.st                    # cheap per-step check (no module traversal): first / last parameter still view the arena
-        if (self.model._arena_root().__dict__.get("_arena_state") is not st or st["params"][0].data_ptr() != st["ptrs"][0]
-                or st["params"][-1].data_ptr() != st["ptrs"][-1]):
+        st = self.st                    # cheap per-step check (no module traversal): first / last parameter still view the arena;
+        from .model.models import ArenaOwner      # EVERY parameter whenever any module anywhere (re)built an arena since the last step
+        moved = st["params"][0].data_ptr() != st["ptrs"][0] or st["params"][-1].data_ptr() != st["ptrs"][-1]
+        if not moved and self._rehomes != ArenaOwner.REHOMES[0]:
+            moved = any(q.data_ptr() != a for q, a in zip(st["params"], st["ptrs"]))
+            self._rehomes = ArenaOwner.REHOMES[0]
+        if self.model._arena_root().__dict__.get("_arena_state") is not st or moved:
             raise RuntimeError("the model's parameter arena was rebuilt after this HipTrainStep was created (model.to() / "
                                "reassigned parameter .data): build a new HipTrainStep")
         for pl in self.plans:
@@ -550,6 +561,8 @@ class HipInference:
         else:
             self.mp = None
             self.plans = [model._plan(batch, height, width, False, bf16=bf16, storage=storage)]
+        from .model.models import hold_plan
+        self._held = hold_plan(self.mp if self.multistage else self.plans[0], self)     # (released when this object is collected)
         self.use_graph = use_graph
         self.graph = None
         self.calls = 0

@@ -90,30 +90,65 @@ def weights_init_kaiming_leaky(m):
 PLAN_CACHE_SIZE = int(os.environ.get("RD_PLAN_CACHE", "3"))
 
 
+def eager_operands(module):
+    """Arithmetic of the convolutions when a module is CALLED (`pred = model(x)`, the reference's main.py:440) rather than stepped by
+    HipTrainStep: "split" (default since round 6 -- fp32 arithmetic on the bf16 matrix cores, the plan the headline is measured on) or
+    "fp32" (every convolution on the fp32 MFMA).  Per module: `model.operands = "fp32"` (looked up on the arena root, so it can be
+    set on the network and holds for its sub-modules); process-wide default: RD_EAGER_OPERANDS."""
+    root = module._arena_root() if hasattr(module, "_arena_root") else module
+    mode = getattr(module, "operands", None) or getattr(root, "operands", None) or os.environ.get("RD_EAGER_OPERANDS", "split")
+    if mode not in ("split", "fp32"):
+        raise ValueError("operands must be 'split' or 'fp32', got %r" % (mode,))
+    return mode
+
+
+def _close_plan(plan):
+    """Free a plan's ~11 GB and its hipEvents NOW (instead of whenever the garbage collector gets to an object that sits in a reference
+    cycle).  The plan's side streams are not known to torch's caching allocator: nothing of the plan may still be running when its
+    buffers go back to the allocator and the next plan zeroes / uploads into the same blocks."""
+    for pl in ([plan.p1, plan.p2] if hasattr(plan, "p1") else [plan]):
+        if hasattr(pl, "close"):
+            for st in (getattr(pl, "_side", None) or []):
+                st.synchronize()
+            if not getattr(pl, "dry_run", True):
+                torch.cuda.current_stream().synchronize()
+            pl.close()
+            pl.keep = []
+
+
+def hold_plan(plan, holder=None):
+    """Explicit holder count of a cached plan (a LateFusionPlan or a MultistagePlan): a HipTrainStep / HipInference holds its plan from
+    construction to close(), an autograd node from its forward until the node is collected (`holder`: the object whose lifetime is the
+    hold -- released by a finalizer).  A plan the cache has evicted is closed by its LAST holder's release, never under a live one
+    (ADVICE r4 / VERDICT r5 #13: this replaces a sys.getrefcount() test)."""
+    plan.__dict__["holders"] = plan.__dict__.get("holders", 0) + 1
+    if holder is not None:
+        weakref.finalize(holder, release_plan, plan)
+    return plan
+
+
+def release_plan(plan):
+    n = plan.__dict__.get("holders", 0) - 1
+    plan.__dict__["holders"] = max(n, 0)
+    if n <= 0 and plan.__dict__.get("evicted"):
+        try:
+            _close_plan(plan)
+        except Exception:                 # (interpreter shutdown: the runtime may already be gone)
+            pass
+
+
 def _evict_plans(cache, version, room_for=1):
     """A plan owns every activation / gradient / workspace buffer of one (batch, size, mode) key -- about 11 GB at b=16
     450x800 training.  The cache is a small LRU (the steady batch, a ragged last batch, validate()'s batch 1): plans of a
-    rebuilt parameter arena go first, then the least recently used.  Eviction only drops the CACHE's reference: a HipTrainStep /
-    HipInference / autograd node fetched its plan once and keeps using it, so the plan's HBM and hipEvents go when its last holder
-    does (LateFusionPlan.__del__), never under a live step."""
-    import sys
+    rebuilt parameter arena go first, then the least recently used.  An evicted plan nobody holds (hold_plan) is closed at once --
+    ragged last batches plus validate() at 900x1600 could otherwise briefly keep more than PLAN_CACHE_SIZE plans alive; one that a
+    HipTrainStep / HipInference / autograd node still holds goes with its last holder (release_plan)."""
     stale = [k for k in cache if k[4] != version]
     for k in stale + [k for k in cache if k not in stale][:max(0, len(cache) - len(stale) + room_for - PLAN_CACHE_SIZE)]:
         plan = cache.pop(k)
-        # nobody but the cache held it (this frame's name + getrefcount's argument = 2): free its ~11 GB and its hipEvents NOW instead of
-        # whenever the garbage collector gets to a plan that sits in a reference cycle -- ragged last batches plus validate() at
-        # 900x1600 could otherwise briefly hold more than PLAN_CACHE_SIZE plans
-        if sys.getrefcount(plan) <= 2:
-            for pl in ([plan.p1, plan.p2] if hasattr(plan, "p1") else [plan]):
-                if hasattr(pl, "close"):
-                    # the plan's side streams are not known to torch's caching allocator: nothing of the plan may still be running
-                    # when its ~11 GB go back to the allocator and the next plan zeroes / uploads into the same blocks (ADVICE r4)
-                    for st in (getattr(pl, "_side", None) or []):
-                        st.synchronize()
-                    if not getattr(pl, "dry_run", True):
-                        torch.cuda.current_stream().synchronize()
-                    pl.close()
-                    pl.keep = []
+        plan.__dict__["evicted"] = True
+        if plan.__dict__.get("holders", 0) <= 0:
+            _close_plan(plan)
 
 
 # ------------------------------------------------------------------------------------------------
@@ -122,6 +157,16 @@ class ArenaOwner:
     gradient and momentum arenas.  Parameters remain ordinary nn.Parameters (views into the arena), so
     state_dict / load_state_dict / external optimizers work unchanged, while the HIP SGD kernel and the RCCL
     gradient all-reduce see one contiguous buffer each."""
+
+    REHOMES = [0]      # bumped whenever ANY root (re)builds its arenas: a HipTrainStep re-checks every parameter pointer when it moved
+
+    def _adopt_arena_children(self):
+        """The network is the arena owner of every ArenaOwner below it (BasicBlock, UpProj, UpProjModule; the stages of the multistage
+        net): a stand-alone call of a child -- model.layer1[0](x), model.decoder(x) -- then runs on the parent's arenas instead of
+        re-homing the child's parameters into an arena of its own behind a live HipTrainStep's back."""
+        for mod in self.modules():
+            if mod is not self and isinstance(mod, ArenaOwner) and "_arena_owner_ref" not in mod.__dict__:
+                mod.__dict__["_arena_owner_ref"] = weakref.ref(self)
 
     def _arena_root(self):
         ref = getattr(self, "_arena_owner_ref", None)
@@ -151,6 +196,7 @@ class ArenaOwner:
         st = dict(arena=arena, grads=grads, mom=mom, gviews=gviews, ptrs=[p.data_ptr() for p in params], params=params,
                   version=(root.__dict__.get("_arena_state") or {}).get("version", 0) + 1, total=total)
         root.__dict__["_arena_state"] = st
+        ArenaOwner.REHOMES[0] += 1
         return st
 
     def _grad_view(self, param):
@@ -192,19 +238,20 @@ class _StandaloneForward:
             raise RuntimeError("radar_depth_amd modules run on MI355X only (HIP kernels); got a %s tensor" % x.device.type)
         assert x.dim() == 4
         x = x.contiguous().float()
-        st = self._ensure_arenas()
+        st = self._ensure_arenas()          # (the arenas of the network this module belongs to, or its own when it was built alone)
         train = bool(self.training)
-        key = (tuple(x.shape), train, st["version"])
-        plans = self.__dict__.setdefault("_plans", {})
+        split = train and eager_operands(self) == "split"      # (eval plans fold BatchNorm into fp32 weights: the fp32 kernels)
+        key = (tuple(x.shape), train, st["version"], split)
+        plans = self.__dict__.setdefault("_module_plans", {})
         if key not in plans:
             for k in [k for k in plans if k[2] != st["version"]] + list(plans)[:max(0, len(plans) + 1 - PLAN_CACHE_SIZE)]:
                 plans.pop(k, None)
-            plans[key] = ModulePlan(self, self, self._plan_kind, x.shape[0], x.shape[2], x.shape[3], x.shape[1], train=train)
+            plans[key] = ModulePlan(self, self, self._plan_kind, x.shape[0], x.shape[2], x.shape[3], x.shape[1], train=train, split=split)
         else:
             plans[key] = plans.pop(key)
         plan = plans[key]
         if train and torch.is_grad_enabled():
-            return _ModuleFunction.apply(plan, x, *st["params"])
+            return _ModuleFunction.apply(plan, x, *list(self.parameters()))
         return plan.forward_nchw(x)
 
 
@@ -330,6 +377,7 @@ class ResNet_latefusion(ArenaOwner, nn.Module):
         self.decoder.apply(weights_init)
         self.conv3.apply(weights_init)
         self.__dict__["_plans"] = {}
+        self._adopt_arena_children()
 
     # the reference takes the encoder from torchvision.models.resnet18(pretrained=True) (models.py:526,546-551); there is
     # no torchvision / network here, so ImageNet weights come from a local torchvision-format state_dict instead.
@@ -366,7 +414,8 @@ class ResNet_latefusion(ArenaOwner, nn.Module):
             raise RuntimeError("radar_depth_amd modules run on MI355X only (HIP kernels); got a %s tensor" % x.device.type)
         assert x.dim() == 4 and x.shape[1] >= 4
         x = x.contiguous().float()
-        plan = self._plan(x.shape[0], x.shape[2], x.shape[3], self.training)
+        # (eval plans fold BatchNorm into the packed fp32 weights and run the fp32 kernels; training plans follow eager_operands())
+        plan = self._plan(x.shape[0], x.shape[2], x.shape[3], self.training, split=self.training and eager_operands(self) == "split")
         if self.training and torch.is_grad_enabled():
             return _PlanFunction.apply(plan, x, *self._arena_root()._ensure_arenas()["params"])
         return plan.run_forward(x).clone()
@@ -377,7 +426,7 @@ class _PlanFunction(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, plan, x, *params):
-        ctx.plan = plan
+        ctx.plan = hold_plan(plan, ctx)          # (held until this node is collected: the cache never closes a plan under it)
         ctx.n_params = len(params)
         ctx.params = params
         out = plan.run_forward(x).clone()

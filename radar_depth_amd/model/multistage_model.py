@@ -74,6 +74,7 @@ class ResNet_multistage(ArenaOwner, nn.Module):
             self.stage1.load_state_dict(weights)
             self.stage2.load_state_dict(self.filter_state_dict(weights, self.stage2.state_dict()), strict=False)
         self.__dict__["_ms_plans"] = {}
+        self._adopt_arena_children()
 
     @staticmethod
     def filter_state_dict(pretrain_dict, target_dict):
@@ -108,7 +109,8 @@ class ResNet_multistage(ArenaOwner, nn.Module):
             raise RuntimeError("radar_depth_amd modules run on MI355X only (HIP kernels); got a %s tensor" % x.device.type)
         assert x.dim() == 4 and x.shape[1] >= 4
         x = x.contiguous().float()
-        mp = self._plans(x.shape[0], x.shape[2], x.shape[3], self.training)
+        from .models import eager_operands
+        mp = self._plans(x.shape[0], x.shape[2], x.shape[3], self.training, split=self.training and eager_operands(self) == "split")
         if self.training and torch.is_grad_enabled():
             params = [p for p in self._ensure_arenas()["params"]]
             d1, d2 = _MultistageFunction.apply(mp, x, *params)
@@ -160,7 +162,8 @@ class MultistagePlan:
 class _MultistageFunction(torch.autograd.Function):
     @staticmethod
     def forward(ctx, mp, x, *params):
-        ctx.mp, ctx.params = mp, params
+        from .models import hold_plan
+        ctx.mp, ctx.params = hold_plan(mp, ctx), params
         mp.run_forward(x)
         ctx.generation = (mp.p1.generation, mp.p2.generation)
         return mp.p1.pred.clone(), mp.p2.pred.clone()

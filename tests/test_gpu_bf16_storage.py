@@ -268,7 +268,7 @@ def _pair(arch, h, w):
     return args, hm.cuda().train(), hw_, om.train(), ow
 
 
-@pytest.mark.parametrize("arch", ["resnet18_latefusion", "resnet18_multistage_uncertainty_fixs"])
+@pytest.mark.parametrize("arch", ["resnet18_latefusion", pytest.param("resnet18_multistage_uncertainty_fixs", marks=pytest.mark.slow)])
 def test_bf16_storage_train_step_vs_emulated_oracle(arch):
     """One training step with bf16 storage against the oracle with the same rounding points (tests/bf16_emulation.py).
     The quantised network is CHAOTIC at the level of individual pixels: tests/test_conditioning.py measures that a 1e-7 relative
@@ -405,7 +405,7 @@ def test_config3_per_gpu_workload_b16_450x800_bf16_storage():
     assert all(torch.isfinite(p).all() for p in hm.parameters())
 
 
-@pytest.mark.parametrize("b", [2, 8])
+@pytest.mark.parametrize("b", [2, pytest.param(8, marks=pytest.mark.slow)])
 def test_config5_geometry_multistage_900x1600_bf16_storage(b):
     """BASELINE configs[4]'s network and geometry (multistage_uncertainty_fixs, 900x1600) under bf16 storage, at b=2 and at the
     configuration's own per-GPU batch b=8 (what `bench.py --config 5` runs): the four loss terms of the fused step against the
@@ -432,6 +432,7 @@ def test_config5_geometry_multistage_900x1600_bf16_storage(b):
     assert all(torch.isfinite(p).all() for p in hm.parameters())
 
 
+@pytest.mark.slow
 def test_bf16_storage_loss_trajectory_vs_fp32_oracle_450x800():
     """A bf16 check whose expectation does NOT pass through tests/bf16_emulation.py: three SGD steps of resnet18_latefusion at
     450x800 (b=2) under bf16 storage against the plain fp32 CPU oracle (pinned to the reference by the golden vectors) taking

@@ -272,6 +272,7 @@ def test_split_step_is_bitwise_reproducible():
         assert torch.equal(p1, p2)
 
 
+@pytest.mark.slow
 def test_multistage_split_step_matches_oracle():
     """HipTrainStep(operands="split") on resnet18_multistage_uncertainty_fixs (two stages, uncertainty-weighted losses, SGD incl. w_stage1/2)
     against the CPU oracle at the fp32 plan's tolerances (tests/test_gpu_model.py::test_multistage_fused_step_matches_oracle)."""

@@ -53,11 +53,15 @@ def build(h, w):
     return m.cuda()
 
 
-def run_case(npz, batch, h, w, seed, sub, dense_small, fwd_tol=1e-3):
+def run_case(npz, batch, h, w, seed, sub, dense_small, fwd_tol=1e-3, operands="split"):
+    """The reference's loop body (main.py:440-445) through the drop-in surface: pred = model(x); loss = criterion(pred, t);
+    optimizer.zero_grad(); loss.backward(); optimizer.step() -- on the module's eager plan, `operands` = its arithmetic
+    (model.operands: "split", the default since round 6, or "fp32")."""
     from radar_depth_amd.evaluation.criteria_new import MaskedL1Loss
     from radar_depth_amd.synthetic import make_batch
     want = np.load(os.path.join(GOLD, npz))
     m = build(h, w)
+    m.operands = operands
     ref_px = h * w if dense_small else 450 * 800
     x, t = make_batch(batch, h, w, seed, ref_pixels=ref_px)
     x, t = x.cuda(), t.cuda()
@@ -70,7 +74,8 @@ def run_case(npz, batch, h, w, seed, sub, dense_small, fwd_tol=1e-3):
     m.train()
     opt = torch.optim.SGD(m.parameters(), 0.01, momentum=0.9, weight_decay=1e-4)
     y = m(x)
-    plan = m._plan(batch, h, w, True)
+    plan = m._plan(batch, h, w, True, split=operands == "split")
+    assert plan.generation == 1 and plan.split == (operands == "split")      # the plan the call above ran on, not a fresh one
     torch.cuda.synchronize()
     # per-module statistics: localises any divergence to a layer
     worst = ("", 0.0)
@@ -123,12 +128,35 @@ def run_case(npz, batch, h, w, seed, sub, dense_small, fwd_tol=1e-3):
     return m
 
 
-def test_latefusion_small_vs_golden():
-    run_case("latefusion_small.npz", 2, 97, 161, 4321, 1, True)
+@pytest.mark.parametrize("operands", ["split", "fp32"])
+def test_latefusion_small_vs_golden(operands):
+    run_case("latefusion_small.npz", 2, 97, 161, 4321, 1, True, operands=operands)
 
 
-def test_latefusion_full_vs_golden():
-    run_case("latefusion_full.npz", 2, 450, 800, 1234, 8, False)
+@pytest.mark.parametrize("operands", ["split", "fp32"])
+def test_latefusion_full_vs_golden(operands):
+    run_case("latefusion_full.npz", 2, 450, 800, 1234, 8, False, operands=operands)
+
+
+def test_eager_default_is_the_split_plan(monkeypatch):
+    """`pred = model(x)` runs the plan the headline is measured on unless told otherwise (model.operands / RD_EAGER_OPERANDS)."""
+    from radar_depth_amd.model import models
+    m = build(64, 96)
+    assert models.eager_operands(m) == "split" and models.eager_operands(m.layer1[0]) == "split"
+    m.operands = "fp32"
+    assert models.eager_operands(m) == "fp32" and models.eager_operands(m.layer1[0]) == "fp32"      # sub-modules follow their network
+    del m.operands
+    monkeypatch.setenv("RD_EAGER_OPERANDS", "fp32")
+    assert models.eager_operands(m) == "fp32"
+    monkeypatch.delenv("RD_EAGER_OPERANDS")
+    x = torch.rand(1, 4, 64, 96, device="cuda")
+    m.train()
+    m(x)
+    plans = list(m.__dict__["_plans"].values())
+    assert len(plans) == 1 and plans[0].split
+    m.operands = "bogus"
+    with pytest.raises(ValueError):
+        m(x)
 
 
 def test_fused_step_matches_oracle():
@@ -218,6 +246,7 @@ def test_multistage_vs_golden():
     assert np.abs(pn - want["param_norms1"]).max() / want["param_norms1"].max() < 1e-4
 
 
+@pytest.mark.slow
 def test_multistage_fused_step_matches_oracle():
     """HipTrainStep on resnet18_multistage_uncertainty_fixs (fused losses, stage coupling, SGD incl. w_stage1/2) vs the oracle."""
     import types

@@ -164,7 +164,7 @@ def test_plan_cache_is_a_small_lru():
             self.close()
     cap = models.PLAN_CACHE_SIZE
     cache = {}
-    held = FakePlan(0)                                   # what a HipTrainStep does: fetch once, keep using
+    held = models.hold_plan(FakePlan(0))                 # what a HipTrainStep does: fetch once, hold, keep using
     cache[(0, 450, 800, True, 1, None, False, "fp32", True)] = held
     for i in range(1, cap + 2):
         models._evict_plans(cache, version=1)
@@ -177,9 +177,20 @@ def test_plan_cache_is_a_small_lru():
     models._evict_plans(cache, version=2)
     gc.collect()
     assert not cache and sorted(closed) == list(range(1, cap + 2))
-    del held
+    assert 0 not in closed and held.__dict__["evicted"] and held.__dict__["holders"] == 1
+    models.release_plan(held)                            # HipTrainStep.close(): the LAST holder of an evicted plan closes it -- by count,
+    assert 0 in closed                                   # not by sys.getrefcount (another name bound to the plan changes nothing)
+    # an autograd node holds through a finalizer on the node object
+    class Node:
+        pass
+    node, p9 = Node(), FakePlan(9)
+    models.hold_plan(p9, node)
+    cache[(9, 1, 1, True, 2, None)] = p9
+    models._evict_plans(cache, version=3)
+    assert 9 not in closed
+    del node
     gc.collect()
-    assert 0 in closed
+    assert 9 in closed
 
 
 def test_segment_events_replace_joins():
