@@ -494,6 +494,24 @@ int rd_stage_frames(const uint8_t* rgb_hwc, const int16_t* lidar, const int16_t*
 int rd_nchw_to_nhwc(const float* src, float* dst, int32_t N, int32_t C, int32_t H, int32_t W, void* stream);
 int rd_nhwc_to_nchw(const float* src, float* dst, int32_t N, int32_t C, int32_t H, int32_t W, void* stream);
 
+/* ---------------------------------------------------------------------------------------
+ * Winograd F(2x2, 3x3) form of the 3x3 / stride-1 / pad-1 convolutions with >= 64 channels a side, on the split-bf16 pipeline
+ * (csrc/wino_split.hip): 16 instead of 36 products per 2x2 output tile, each product rebuilt from six bf16 MFMA terms like
+ * rd_gconv_split.  Replaces F.conv2d / its input gradient for the BasicBlock and UpProj conv2 layers
+ * (/root/reference/model/models.py:96-112,203-206; cuDNN's own Winograd under cudnn.benchmark, /root/reference/main.py:11,47).
+ *   rd_wino_pack      : U = G g G^T of an OIHW [O][I][3][3] tensor (fp64, rounded once to fp32, three bf16 pieces) in the kernel's
+ *                       copy layout; flip = 1 packs the input-gradient operand (channels transposed, taps rotated by 180 degrees).
+ *                       u_packed: rd_wino_packed_bytes(O, I, flip) bytes.
+ *   rd_wino_conv3x3   : out[N,H,W,Cout (stride ldo)] = conv3x3(in[N,H,W,Cin (stride ldi)]) (+ addend); stat_partial (may be NULL):
+ *                       [rd_wino_stat_tiles(N,H,W)][2][Cout] per-tile sum / sum of squares of the stored values, the BatchNorm
+ *                       statistics contract of rd_gconv.  fp32 NHWC tensors; Cin % 16 == 0, Cout % 64 == 0, both >= 64. */
+int64_t rd_wino_packed_bytes(int32_t O, int32_t I, int32_t flip);
+int rd_wino_pack(const float* w_oihw, int32_t O, int32_t I, int32_t flip, void* u_packed, void* stream);
+int rd_wino_supported(int32_t H, int32_t W, int32_t Cin, int32_t Cout, int32_t ldi, int32_t ldo);
+int rd_wino_stat_tiles(int32_t N, int32_t H, int32_t W);
+int rd_wino_conv3x3(const float* in, int32_t N, int32_t H, int32_t W, int32_t Cin, int32_t ldi, const void* u_packed, float* out,
+                    int32_t Cout, int32_t ldo, const float* addend, int32_t ld_add, float* stat_partial, void* stream);
+
 /* Diagnostics (bench.py `roofline.shader_clock_mhz`): n_blocks (<= 64) one-wave workgroups each sleep for duration_us and write
  * out[4 * block + 0..3] = { shader clocks elapsed (s_memtime), 10-ns ticks elapsed (s_memrealtime), XCC_ID, start tick }:
  * clocks / ticks * 100 = the effective shader clock in MHz of that workgroup's XCD over the window.  Meant to run on a stream of

@@ -1,0 +1,430 @@
+// Winograd F(2x2, 3x3) on the split-bf16 matrix pipeline (round 6): the 3x3 / stride-1 / pad-1 convolutions with
+// >= 64 channels a side (forward, and the input gradient = the same kernel on 180-degree-rotated, transposed weights) with 16 instead of
+// 36 multiplications per 2x2 output tile and (ci, co) pair -- 2.25x fewer of the v_mfma_f32_32x32x16_bf16 instructions the device is
+// power-limited on.  It is what cuDNN runs for the reference's fp32 3x3 layers under cudnn.benchmark = True
+// (/root/reference/main.py:11,47; layers: /root/reference/model/models.py:96-112).
+//
+//   Y = A^T [ sum_ci (G g G^T) (.) (B^T d B) ] A          d: 4x4 input patch, g: 3x3 filter, Y: 2x2 outputs
+//
+//   * B^T d B in fp32 VALU (adds only) by the staging waves, straight from global memory (NHWC: a lane owns one tile and two input
+//     channels -- sixteen 8-byte loads per 16-channel chunk), then split into three bf16 pieces exactly as gconv_split.hip splits its
+//     patch (x = x0 + x1 + x2 bitwise) and stored as the A operand of sixteen independent GEMMs [32 tiles x 16 ci] x [16 ci x 64 co];
+//   * G g G^T once per step by rd_wino_pack (fp64, rounded once to fp32, three pieces), laid out so that the B image of a phase is
+//     one linear 48 KB global_load_lds copy;
+//   * six MFMA terms per product, fp32 accumulation: gconv_split.hip's arithmetic (RD_SPLIT_TERMS);
+//   * A^T m A in the epilogue: rows inside the wave that owns a column of the 4x4 position grid, columns across the four MFMA waves
+//     through LDS; BatchNorm partial sums, residual addend and the NHWC store from there.
+//
+//   workgroup : 8 waves, ONE per CU (144 KB of LDS).  Waves 0-3 own the accumulators -- wave w holds column j = w of the 4x4 position
+//               grid, all four rows i, for 32 tiles x 64 output channels: 4 x 2 tiles of 32 x 32 = 128 accumulator registers -- and do
+//               nothing but fragment reads and MFMAs; waves 4-7 stage.
+//   phase     : half a 16-channel chunk's positions (rows i = 2 hf, 2 hf + 1): A 24 KB + B 48 KB, two buffers; one barrier per phase.
+//               The staging waves transform a chunk when its loads have landed (in the chunk's second phase), write the first half's
+//               pieces at once and keep the second half's sixteen values in registers for the next phase.
+//   tile block: 4 x 8 Winograd tiles = 8 x 16 output pixels; odd sizes (113, 57, 29, 15) by masking the last tile row / column.
+#include <stdlib.h>
+
+#include <type_traits>
+
+#include "common.h"
+
+namespace rd {
+
+typedef __bf16 wbf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned int wu32x4 __attribute__((ext_vector_type(4)));
+typedef float wf32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 wbf16x2 __attribute__((ext_vector_type(2)));
+
+constexpr int WN_TBH = 4, WN_TBW = 8;              // tiles per block
+constexpr int WN_T = WN_TBH * WN_TBW;              // 32 tiles = one MFMA M tile
+constexpr int WN_CB = 64;                          // output channels per workgroup
+constexpr int WN_AH = 8 * 3 * 2 * 512;             // A image of a phase: [pos 8][piece 3][k half 2][tile 32] x 16 B
+constexpr int WN_BH = 8 * 3 * 2 * 1024;            // B image of a phase: [pos 8][piece 3][k half 2][co 64] x 16 B
+constexpr int WN_BUF = WN_AH + WN_BH;              // 73,728 B
+constexpr int WN_ZP = 68;                          // floats per (tile) row of the epilogue's exchange buffer (64 + 4: 16-byte aligned rows)
+constexpr unsigned WN_OOB = 0x80000000u;
+
+struct WinoArgs {
+    const float* in;
+    const unsigned short* u;      // rd_wino_pack's operand: [cot][phase][WN_BH bytes]
+    float* out;
+    const float* addend;
+    float* stat;
+    int N, H, W, Cin, Cout, ldi, ldo, ld_add;
+    int tiles_h, tiles_w, bh, bw, n_cot;
+    int dbg;                      // diagnostics (RD_WINO_DEBUG; results are then garbage): 1 no MFMAs, 2 no A staging, 4 no B copies, 8 no epilogue
+};
+
+__device__ __forceinline__ unsigned wn_cvt_pk(float a, float b) {
+    wf32x2 v;
+    v[0] = a;
+    v[1] = b;
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, wbf16x2));
+}
+
+__global__ __launch_bounds__(512) void wino_split_kernel(const WinoArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char wsm[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const bool loader = wave >= 4;
+    const int l31 = lane & 31, hh = lane >> 5;
+
+    const int vid = xcd_remap(blockIdx.x, gridDim.x);
+    const int cot = vid % a.n_cot;
+    const int pt = vid / a.n_cot;
+    const int nb_img = a.bh * a.bw;
+    const int n = pt / nb_img;
+    const int rem = pt - n * nb_img;
+    const int by = rem / a.bw, bx = rem - by * a.bw;
+    const int nchunks = a.Cin >> 4;
+    const int nphases = 2 * nchunks;
+
+    f32x16 acc[4][2];
+
+    if (loader) {
+        // ---------------------------------------------------------------------------------------------- staging waves
+        const int sw = wave - 4;
+        const int ltid = tid - 256;
+        const int tl = (sw & 1) * 16 + (lane >> 2);      // tile of this lane
+        const int q4 = lane & 3, kh = sw >> 1;           // channel pair q4 of k half kh: channels kh * 8 + q4 * 2, + 1 of the chunk
+        const int ty = by * WN_TBH + (tl >> 3), tx = bx * WN_TBW + (tl & 7);
+        const int iy0 = 2 * ty - 1, ix0 = 2 * tx - 1;
+        unsigned off[16];
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const int iy = iy0 + r, ix = ix0 + c;
+                const bool ok = iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;
+                off[r * 4 + c] = ok ? (unsigned)(((iy * a.W + ix) * a.ldi + kh * 8 + q4 * 2) * 4) : WN_OOB;
+            }
+        const char* in_n = reinterpret_cast<const char*>(a.in) + (size_t)n * a.H * a.W * a.ldi * 4;
+        const unsigned img_bytes = (unsigned)(a.H * a.W * a.ldi) * 4u;
+        const unsigned a_dst = (unsigned)(kh * 512 + tl * 16 + q4 * 4);       // inside one (position, piece) plane pair of an A image
+        const char* u_wg = reinterpret_cast<const char*>(a.u) + (size_t)cot * nphases * WN_BH;
+
+        wf32x2 raw[16];
+        auto fetch = [&](int c) {
+            const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(in_n + c * 64), 0, img_bytes - c * 64, 0x00020000);
+#pragma unroll
+            for (int p = 0; p < 16; ++p) raw[p] = __builtin_bit_cast(wf32x2, __builtin_amdgcn_raw_buffer_load_b64(r, (int)off[p], 0, 0));
+        };
+        auto issue_b = [&](int ph) {
+            if (a.dbg & 4) return;
+            const char* src = u_wg + (size_t)ph * WN_BH;
+            char* dst = wsm + (ph & 1) * WN_BUF + WN_AH;
+#pragma unroll
+            for (int k = 0; k < WN_BH / (256 * 16); ++k)
+                glds16(reinterpret_cast<const float*>(src + (k * 256 + ltid) * 16), reinterpret_cast<float*>(dst + (k * 256 + sw * 64) * 16));
+        };
+        // split the two channels' values of position p8 (of the phase's eight) into three packed pieces and store them
+        auto put = [&](char* abuf, int p8, wf32x2 v) {
+            float x = v[0], y = v[1];
+            const unsigned u0 = wn_cvt_pk(x, y);
+            x -= __uint_as_float(u0 << 16);
+            y -= __uint_as_float(u0 & 0xffff0000u);
+            const unsigned u1 = wn_cvt_pk(x, y);
+            x -= __uint_as_float(u1 << 16);
+            y -= __uint_as_float(u1 & 0xffff0000u);
+            const unsigned u2 = wn_cvt_pk(x, y);
+            const unsigned ad = (unsigned)(size_t)abuf + a_dst + p8 * (3 * 1024);
+            asm volatile("ds_write_b32 %0, %1" ::"v"(ad), "v"(u0) : "memory");
+            asm volatile("ds_write_b32 %0, %1 offset:1024" ::"v"(ad), "v"(u1) : "memory");
+            asm volatile("ds_write_b32 %0, %1 offset:2048" ::"v"(ad), "v"(u2) : "memory");
+        };
+        wf32x2 vhi[8];      // positions of rows i = 2, 3 of the chunk whose first half was written last
+        // B^T d B of the fetched chunk: rows i = 0, 1 stored into abuf, rows 2, 3 kept in vhi
+        auto transform = [&](char* abuf) {
+            wf32x2 t[4][4];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                t[0][c] = raw[0 * 4 + c] - raw[2 * 4 + c];
+                t[1][c] = raw[1 * 4 + c] + raw[2 * 4 + c];
+                t[2][c] = raw[2 * 4 + c] - raw[1 * 4 + c];
+                t[3][c] = raw[1 * 4 + c] - raw[3 * 4 + c];
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const wf32x2 v0 = t[i][0] - t[i][2], v1 = t[i][1] + t[i][2], v2 = t[i][2] - t[i][1], v3 = t[i][1] - t[i][3];
+                if (i < 2) {
+                    if (!(a.dbg & 2)) {
+                        put(abuf, i * 4 + 0, v0);
+                        put(abuf, i * 4 + 1, v1);
+                        put(abuf, i * 4 + 2, v2);
+                        put(abuf, i * 4 + 3, v3);
+                    }
+                } else {
+                    vhi[(i - 2) * 4 + 0] = v0;
+                    vhi[(i - 2) * 4 + 1] = v1;
+                    vhi[(i - 2) * 4 + 2] = v2;
+                    vhi[(i - 2) * 4 + 3] = v3;
+                }
+            }
+        };
+        // prologue: chunk 0's first half + the weights of phase 0
+        issue_b(0);
+        fetch(0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        transform(wsm);
+        glds_wait();
+        __builtin_amdgcn_s_barrier();
+        for (int c = 0; c < nchunks; ++c) {
+            // phase (c, 0): the compute waves read buffer 0; buffer 1 <- rows 2, 3 of chunk c + the weights of phase 2c + 1; the next chunk's loads go out
+            issue_b(2 * c + 1);
+            if (c + 1 < nchunks) fetch(c + 1);
+            if (!(a.dbg & 2)) {
+#pragma unroll
+                for (int p = 0; p < 8; ++p) put(wsm + WN_BUF, p, vhi[p]);
+            }
+            // (the weight copies must have landed at the barrier; the 16 patch loads issued behind them need not)
+            if (c + 1 < nchunks) asm volatile("s_waitcnt vmcnt(16) lgkmcnt(0)" ::: "memory");
+            else glds_wait();
+            __builtin_amdgcn_s_barrier();
+            // phase (c, 1): the compute waves read buffer 1; buffer 0 <- rows 0, 1 of chunk c + 1 + the weights of phase 2c + 2
+            if (c + 1 < nchunks) {
+                issue_b(2 * c + 2);
+                asm volatile("s_waitcnt vmcnt(12)" ::: "memory");      // the patch loads (older than the 12 weight copies just issued) are in
+                transform(wsm);
+            }
+            glds_wait();
+            __builtin_amdgcn_s_barrier();
+        }
+    } else {
+        // ---------------------------------------------------------------------------------------------- compute waves
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+                for (int k = 0; k < 16; ++k) acc[i][nb][k] = 0.f;
+        const int a_off = hh * 512 + l31 * 16;
+        const int b_off = WN_AH + hh * 1024 + l31 * 16;
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        auto phase = [&](const char* base, auto hf_) {
+            constexpr int hf = decltype(hf_)::value;
+            wbf16x8 A[2][3], B[2][3][2];
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                const int p8 = wave + 4 * s;
+#pragma unroll
+                for (int p = 0; p < 3; ++p) {
+                    A[s][p] = *reinterpret_cast<const wbf16x8*>(base + a_off + (p8 * 3 + p) * 1024);
+#pragma unroll
+                    for (int nb = 0; nb < 2; ++nb) B[s][p][nb] = *reinterpret_cast<const wbf16x8*>(base + b_off + (p8 * 3 + p) * 2048 + nb * 512);
+                }
+            }
+            if (!(a.dbg & 1)) {
+#pragma unroll
+                for (int s = 0; s < 2; ++s)
+#pragma unroll
+                    for (int nb = 0; nb < 2; ++nb) {
+                        f32x16 c = acc[2 * hf + s][nb];
+                        RD_SPLIT_TERMS(c, A[s][0], A[s][1], A[s][2], B[s][0][nb], B[s][1][nb], B[s][2][nb])
+                        acc[2 * hf + s][nb] = c;
+                    }
+            }
+        };
+        for (int c = 0; c < nchunks; ++c) {
+            phase(wsm, std::integral_constant<int, 0>{});
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            phase(wsm + WN_BUF, std::integral_constant<int, 1>{});
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+        }
+    }
+    if (a.dbg & 8) return;
+
+    // ---- epilogue.  Rows of A^T m A inside the wave (Z_r = sum_i A^T[r][i] m_i, the wave's column j), columns across the waves:
+    // Z goes to LDS as [j][r][tile][co], every thread then combines the four j of (tile, r, four channels): Y_r0 = Z0 + Z1 + Z2,
+    // Y_r1 = Z1 - Z2 - Z3 -- two horizontally adjacent output pixels, 16-byte stores.
+    float* zb = reinterpret_cast<float*>(wsm);
+    if (!loader) {
+#pragma unroll
+        for (int nb = 0; nb < 2; ++nb) {
+            const f32x16 z0 = acc[0][nb] + acc[1][nb] + acc[2][nb];
+            const f32x16 z1 = acc[1][nb] - acc[2][nb] - acc[3][nb];
+#pragma unroll
+            for (int k = 0; k < 16; ++k) {
+                const int m = 8 * (k >> 2) + 4 * hh + (k & 3);
+                zb[((wave * 2 + 0) * WN_T + m) * WN_ZP + nb * 32 + l31] = z0[k];
+                zb[((wave * 2 + 1) * WN_T + m) * WN_ZP + nb * 32 + l31] = z1[k];
+            }
+        }
+    }
+    rd_sync();
+    const int c4 = tid & 15;                 // channel quad of this thread (both of its items)
+    const int co = cot * WN_CB + c4 * 4;
+    float4 ssum = make_float4(0.f, 0.f, 0.f, 0.f), ssq = ssum;
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+        const int rt = (tid >> 4) + 32 * it;   // 0..63 = tile * 2 + r
+        const int m = rt >> 1, r = rt & 1;
+        float4 z[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) z[j] = *reinterpret_cast<const float4*>(zb + ((j * 2 + r) * WN_T + m) * WN_ZP + c4 * 4);
+        float4 y0 = make_float4(z[0].x + z[1].x + z[2].x, z[0].y + z[1].y + z[2].y, z[0].z + z[1].z + z[2].z, z[0].w + z[1].w + z[2].w);
+        float4 y1 = make_float4(z[1].x - z[2].x - z[3].x, z[1].y - z[2].y - z[3].y, z[1].z - z[2].z - z[3].z, z[1].w - z[2].w - z[3].w);
+        const int oy = 2 * (by * WN_TBH + (m >> 3)) + r, ox = 2 * (bx * WN_TBW + (m & 7));
+        const bool okr = oy < a.H && co < a.Cout;
+        const bool ok0 = okr && ox < a.W, ok1 = okr && ox + 1 < a.W;
+        const size_t pix = ((size_t)n * a.H + oy) * a.W + ox;
+        if (a.addend) {
+            if (ok0) { const float4 v = ld4(a.addend + pix * a.ld_add + co); y0.x += v.x; y0.y += v.y; y0.z += v.z; y0.w += v.w; }
+            if (ok1) { const float4 v = ld4(a.addend + (pix + 1) * a.ld_add + co); y1.x += v.x; y1.y += v.y; y1.z += v.z; y1.w += v.w; }
+        }
+        if (ok0) {
+            st4(a.out + pix * a.ldo + co, y0);
+            ssum.x += y0.x; ssum.y += y0.y; ssum.z += y0.z; ssum.w += y0.w;
+            ssq.x += y0.x * y0.x; ssq.y += y0.y * y0.y; ssq.z += y0.z * y0.z; ssq.w += y0.w * y0.w;
+        }
+        if (ok1) {
+            st4(a.out + (pix + 1) * a.ldo + co, y1);
+            ssum.x += y1.x; ssum.y += y1.y; ssum.z += y1.z; ssum.w += y1.w;
+            ssq.x += y1.x * y1.x; ssq.y += y1.y * y1.y; ssq.z += y1.z * y1.z; ssq.w += y1.w * y1.w;
+        }
+    }
+    if (a.stat) {
+        // BatchNorm partial sums of this workgroup's 128 pixels x 64 channels: [pt][2][Cout] like the other convolution kernels
+        rd_sync();                                     // (every thread is done reading the exchange buffer)
+        float* red = reinterpret_cast<float*>(wsm);    // [32 thread rows][2][64]
+        const int row = tid >> 4;
+        *reinterpret_cast<float4*>(red + (row * 2 + 0) * 64 + c4 * 4) = ssum;
+        *reinterpret_cast<float4*>(red + (row * 2 + 1) * 64 + c4 * 4) = ssq;
+        rd_sync();
+        if (tid < 128) {
+            const int which = tid >> 6, j = tid & 63;
+            float s = 0.f;
+#pragma unroll 8
+            for (int rw = 0; rw < 32; ++rw) s += red[(rw * 2 + which) * 64 + j];
+            if (cot * WN_CB + j < a.Cout) a.stat[((size_t)pt * 2 + which) * a.Cout + cot * WN_CB + j] = s;
+        }
+    }
+}
+
+// U = G g G^T of every (reduction channel, output channel) pair in fp64, rounded once to fp32, split into three bf16 pieces, in the
+// layout the kernel copies linearly: [cot][phase = 2 * chunk + half][pos 8][piece 3][k half 2][co 64][8 reduction channels].
+// flip = 0: forward (reduction = the I of OIHW, output = O); flip = 1: input gradient (reduction = O, output = I, taps rotated by 180 degrees).
+__global__ __launch_bounds__(256) void wino_pack_kernel(const float* __restrict__ w, int O, int I, int flip, unsigned short* __restrict__ u) {
+    const int R = flip ? O : I, Q = flip ? I : O;
+    const int r8n = R >> 3;
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= Q * r8n) return;
+    const int q = e / r8n, r8 = e - q * r8n;
+    const int nph = 2 * (R >> 4);
+    const int cot = q >> 6, ql = q & 63;
+    const int chunk = r8 >> 1, kh8 = r8 & 1;
+    unsigned short pc[16][3][8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const int r = r8 * 8 + k;
+        const float* g = flip ? w + ((size_t)r * I + q) * 9 : w + ((size_t)q * I + r) * 9;
+        double gg[3][3];
+#pragma unroll
+        for (int y = 0; y < 3; ++y)
+#pragma unroll
+            for (int x = 0; x < 3; ++x) gg[y][x] = flip ? (double)g[(2 - y) * 3 + (2 - x)] : (double)g[y * 3 + x];
+        double t[4][3];
+#pragma unroll
+        for (int x = 0; x < 3; ++x) {
+            t[0][x] = gg[0][x];
+            t[1][x] = 0.5 * (gg[0][x] + gg[1][x] + gg[2][x]);
+            t[2][x] = 0.5 * (gg[0][x] - gg[1][x] + gg[2][x]);
+            t[3][x] = gg[2][x];
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const double uu[4] = {t[i][0], 0.5 * (t[i][0] + t[i][1] + t[i][2]), 0.5 * (t[i][0] - t[i][1] + t[i][2]), t[i][2]};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                float f = (float)uu[j];
+                const __bf16 p0 = (__bf16)f;
+                f -= (float)p0;
+                const __bf16 p1 = (__bf16)f;
+                f -= (float)p1;
+                const __bf16 p2 = (__bf16)f;
+                pc[i * 4 + j][0][k] = __builtin_bit_cast(unsigned short, p0);
+                pc[i * 4 + j][1][k] = __builtin_bit_cast(unsigned short, p1);
+                pc[i * 4 + j][2][k] = __builtin_bit_cast(unsigned short, p2);
+            }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int p = 0; p < 3; ++p) {
+                const int ph = 2 * chunk + (i >> 1), p8 = (i & 1) * 4 + j;
+                const size_t o = ((size_t)cot * nph + ph) * WN_BH + ((p8 * 3 + p) * 2 + kh8) * 1024 + ql * 16;
+                uint4 v;
+                v.x = pc[i * 4 + j][p][0] | ((unsigned)pc[i * 4 + j][p][1] << 16);
+                v.y = pc[i * 4 + j][p][2] | ((unsigned)pc[i * 4 + j][p][3] << 16);
+                v.z = pc[i * 4 + j][p][4] | ((unsigned)pc[i * 4 + j][p][5] << 16);
+                v.w = pc[i * 4 + j][p][6] | ((unsigned)pc[i * 4 + j][p][7] << 16);
+                *reinterpret_cast<uint4*>(reinterpret_cast<char*>(u) + o) = v;
+            }
+}
+
+static bool wino_shape_ok(int H, int W, int Cin, int Cout, int ldi, int ldo) {
+    return H >= 2 && W >= 2 && Cin >= 64 && Cin % 16 == 0 && Cout >= 64 && Cout % 64 == 0 && ldi % 4 == 0 && ldo % 4 == 0 &&
+           (long long)H * W * ldi * 4 < 0x7fffffffll;
+}
+}  // namespace rd
+
+// bytes of the packed operand for an O x I x 3 x 3 weight tensor (flip as in rd_wino_pack)
+extern "C" int64_t rd_wino_packed_bytes(int32_t O, int32_t I, int32_t flip) {
+    const int R = flip ? O : I, Q = flip ? I : O;
+    return (int64_t)((Q + 63) / 64) * (2 * (R / 16)) * rd::WN_BH;
+}
+
+extern "C" int rd_wino_pack(const float* w_oihw, int32_t O, int32_t I, int32_t flip, void* u_packed, void* stream) {
+    RD_CHECK_ARG(w_oihw && u_packed && O > 0 && I > 0, "rd_wino_pack: bad arguments");
+    const int R = flip ? O : I, Q = flip ? I : O;
+    RD_CHECK_ARG(R % 16 == 0 && Q % 64 == 0, "rd_wino_pack: reduction channels %d %% 16, output channels %d %% 64", R, Q);
+    const int n = Q * (R / 8);
+    hipLaunchKernelGGL(rd::wino_pack_kernel, dim3((n + 255) / 256), dim3(256), 0, static_cast<hipStream_t>(stream), w_oihw, O, I, flip,
+                       static_cast<unsigned short*>(u_packed));
+    RD_CHECK_LAUNCH("wino_pack_kernel");
+    return RD_OK;
+}
+
+extern "C" int rd_wino_supported(int32_t H, int32_t W, int32_t Cin, int32_t Cout, int32_t ldi, int32_t ldo) {
+    return rd::wino_shape_ok(H, W, Cin, Cout, ldi, ldo) ? 1 : 0;
+}
+
+// rows of the [tiles][2][Cout] BatchNorm partial-sum buffer rd_wino_conv3x3 writes
+extern "C" int rd_wino_stat_tiles(int32_t N, int32_t H, int32_t W) {
+    const int th = (H + 1) / 2, tw = (W + 1) / 2;
+    return N * ((th + rd::WN_TBH - 1) / rd::WN_TBH) * ((tw + rd::WN_TBW - 1) / rd::WN_TBW);
+}
+
+extern "C" int rd_wino_conv3x3(const float* in, int32_t N, int32_t H, int32_t W, int32_t Cin, int32_t ldi, const void* u_packed, float* out,
+                               int32_t Cout, int32_t ldo, const float* addend, int32_t ld_add, float* stat_partial, void* stream) {
+    using namespace rd;
+    RD_CHECK_ARG(in && u_packed && out && N > 0, "rd_wino_conv3x3: bad arguments");
+    RD_CHECK_ARG(wino_shape_ok(H, W, Cin, Cout, ldi, ldo), "rd_wino_conv3x3: unsupported shape %dx%d %d->%d (ld %d / %d)", H, W, Cin, Cout, ldi, ldo);
+    RD_CHECK_ARG(!addend || ld_add % 4 == 0, "rd_wino_conv3x3: addend stride %d", ld_add);
+    WinoArgs a;
+    a.in = in;
+    a.u = static_cast<const unsigned short*>(u_packed);
+    a.out = out;
+    a.addend = addend;
+    a.stat = stat_partial;
+    a.N = N; a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout; a.ldi = ldi; a.ldo = ldo; a.ld_add = ld_add;
+    a.tiles_h = (H + 1) / 2;
+    a.tiles_w = (W + 1) / 2;
+    a.bh = (a.tiles_h + WN_TBH - 1) / WN_TBH;
+    a.bw = (a.tiles_w + WN_TBW - 1) / WN_TBW;
+    a.n_cot = Cout / WN_CB;
+    static const int dbg = getenv("RD_WINO_DEBUG") ? atoi(getenv("RD_WINO_DEBUG")) : 0;
+    a.dbg = dbg;
+    const int grid = N * a.bh * a.bw * a.n_cot;
+    const size_t lds = 2 * (size_t)WN_BUF;
+    static std::atomic<unsigned long long> attr_set{0};
+    RD_SET_ATTR_ONCE(attr_set, hipFuncSetAttribute(reinterpret_cast<const void*>(wino_split_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    hipLaunchKernelGGL(wino_split_kernel, dim3(grid), dim3(512), lds, static_cast<hipStream_t>(stream), a);
+    RD_CHECK_LAUNCH("wino_split_kernel");
+    return RD_OK;
+}

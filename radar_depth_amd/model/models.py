@@ -220,7 +220,8 @@ class _ModuleFunction(torch.autograd.Function):
             raise RuntimeError("this module ran another forward since the one being differentiated: its saved activations are static "
                                "buffers, so call backward() before the next training-mode forward of the same input shape")
         dx = plan.backward_nchw(gout.contiguous().float())
-        return (None, dx) + tuple(plan.m._grad_view(p) for p in ctx.params)
+        gv = plan.m._arena_root()._ensure_arenas()["gviews"]      # (looked up ONCE: _grad_view walks the module tree on every call)
+        return (None, dx) + tuple(gv[id(p)] for p in ctx.params)
 
 
 class _StandaloneForward:
@@ -442,5 +443,8 @@ class _PlanFunction(torch.autograd.Function):
                                "(batch, size) -- e.g. accumulate gradients one batch at a time")
         plan.run_backward(gout.contiguous())
         own = {id(p) for p in plan.m.parameters()}
-        grads = [plan.m._grad_view(p) if id(p) in own else None for p in ctx.params]
+        # (the arena state is looked up ONCE: _grad_view re-validates the arenas -- a walk over every parameter -- on each call, which made
+        #  this return statement 163 module-tree walks, ~10 ms of host time per backward at the headline geometry: bench.py alt_eager)
+        gv = plan.m._arena_root()._ensure_arenas()["gviews"]
+        grads = [gv[id(p)] if id(p) in own else None for p in ctx.params]
         return (None, None) + tuple(grads)

@@ -177,5 +177,6 @@ class _MultistageFunction(torch.autograd.Function):
         mp.run_backward(None if g1 is None else g1.contiguous(), None if g2 is None else g2.contiguous())
         root = mp.p1.m._arena_root()
         staged = {id(p) for p in mp.p1.m.parameters()} | {id(p) for p in mp.p2.m.parameters()}
-        grads = [root._grad_view(p) if id(p) in staged else None for p in ctx.params]
+        gv = root._ensure_arenas()["gviews"]
+        grads = [gv[id(p)] if id(p) in staged else None for p in ctx.params]
         return (None, None) + tuple(grads)

@@ -273,3 +273,33 @@ def wgrad_split_reduce(desc, slabs, grad, co_off=0, accumulate=False):
     o, i, kh, kw = grad.shape
     check(lib().rd_wgrad_split_reduce(C.byref(desc), ptr(slabs), ptr(grad), o, i, kh, kw, co_off, int(accumulate), current_stream()),
           "rd_wgrad_split_reduce")
+
+
+# ------------------------------------------------------------------ Winograd F(2x2, 3x3) on the split pipeline (csrc/wino_split.hip)
+def wino_supported(H, W, cin, cout, ldi=None, ldo=None):
+    return lib().rd_wino_supported(H, W, cin, cout, cin if ldi is None else ldi, cout if ldo is None else ldo) == 1
+
+
+def wino_pack(w_oihw, flip=False):
+    """G g G^T of an [O,I,3,3] weight tensor as the three-piece bf16 operand of rd_wino_conv3x3 (flip: the input-gradient operand --
+    channels transposed, taps rotated by 180 degrees)."""
+    o, i, kh, kw = w_oihw.shape
+    assert kh == 3 and kw == 3
+    lib().rd_wino_packed_bytes.restype = C.c_int64
+    nbytes = int(lib().rd_wino_packed_bytes(o, i, int(flip)))
+    u = torch.empty(nbytes // 2, dtype=torch.bfloat16, device=w_oihw.device)
+    check(lib().rd_wino_pack(ptr(_f32(w_oihw.contiguous())), o, i, int(flip), ptr(u), current_stream()), "rd_wino_pack")
+    return u
+
+
+def wino_conv3x3(x_nhwc, u_packed, out_nhwc, addend=None, stat=None):
+    """3x3 / stride 1 / pad 1 convolution of an NHWC fp32 tensor (channel slices allowed: strides are taken from the tensors)."""
+    n, h, w, cin = x_nhwc.shape
+    cout = out_nhwc.shape[3]
+    check(lib().rd_wino_conv3x3(ptr(_f32(x_nhwc)), n, h, w, cin, x_nhwc.stride(2), ptr(u_packed), ptr(_f32(out_nhwc)), cout, out_nhwc.stride(2),
+                                ptr(addend), 0 if addend is None else addend.stride(2), ptr(stat), current_stream()), "rd_wino_conv3x3")
+    return out_nhwc
+
+
+def wino_stat_tiles(n, h, w):
+    return int(lib().rd_wino_stat_tiles(n, h, w))

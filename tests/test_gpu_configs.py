@@ -297,7 +297,7 @@ def test_config5_multistage_bf16_step_vs_emulated_oracle(geom):
     ts = HipTrainStep(hm, b, h, w, lr=1.0, momentum=0.0, weight_decay=0.0, loss_weights=hw_, operands="bf16")
     loss, pred = ts.step(x.cuda(), t.cuda())
     torch.cuda.synchronize()
-    want4 = np.array([ex["d1"].item(), ex["d2"].item(), ex["smooth"].item(), lo])
+    want4 = np.array([ex["d1"].item(), ex["d2"].item(), ex["smooth"].item(), lo.item()])
     got4 = _t(ts.loss4)
     e_loss = np.abs(got4 - want4).max() / np.abs(want4).max()
     # Stage 2 is compared TEACHER-FORCED: the oracle's stage 2 (same rounding points) fed with the HIP stage-1 prediction.  End to

@@ -76,14 +76,17 @@ def test_gradients_as_close_to_fp64_as_the_fp32_oracle(operands):
     assert e_hip[names.index("conv3.weight")] <= 1e-5 * n64[names.index("conv3.weight")]
 
 
-def test_split_plan_gradients_below_the_decision_floor_over_seeds():
+@pytest.mark.parametrize("b,h,w", [(2, 97, 161), (1, 49, 81)])
+def test_split_plan_gradients_below_the_decision_floor_over_seeds(b, h, w):
     """the single-seed test above cannot tell one flipped ReLU / sign(pred - target) decision (amplified by the network
-    to ~1e-2 in the deep tensors) from a genuine 1e-3-level defect of a deep layer's gradient in the split plan.  Eight seeds at b = 2,
-    97 x 161; per seed the worst per-tensor distance to the fp64 oracle's gradient, relative to the tensor's norm, for the CPU fp32
-    oracle (the reference's arithmetic), the fp32-MFMA plan and the split plan.  An arithmetic is CLEAN on a seed when it is within
-    1e-4 in every tensor (no discrete decision differs from the fp64 run; clean runs sit at ~1e-5).  Asserted:
-      * wherever the reference's own arithmetic is clean AND the split plan is clean, the split plan is per tensor within 10x the
-        fp32-MFMA plan's distance or 5e-5 -- below the decision floor the split plan has the fp32 plan's accuracy, tensor by tensor;
+    to ~1e-2 in the deep tensors) from a genuine 1e-3-level defect of a deep layer's gradient in the split plan.  Eight seeds each at
+    b = 2, 97 x 161 (where nearly every run of every arithmetic flips something: ~10^7 activations at relative distances of 1e-6) and
+    at b = 1, 49 x 81 (fewer activations, more decision-free runs); per seed the worst per-tensor distance to the fp64 oracle's
+    gradient, relative to the tensor's norm, for the CPU fp32 oracle (the reference's arithmetic), the fp32-MFMA plan and the split plan.
+    An arithmetic is CLEAN on a seed when it is within 1e-4 in every tensor (no discrete decision differs from the fp64 run).  Asserted:
+      * a clean run of the split plan is within 5e-5 in EVERY tensor (measured ~1e-5): below the decision floor nothing of the 1e-3
+        class exists in any layer's gradient;
+      * where the fp32-MFMA plan is clean too, the split plan is per tensor within 10x its distance or 5e-5;
       * the split plan is clean at least as often as the fp32-MFMA plan minus one, and as the CPU oracle minus one (decisions flip at
         the same rate as in the other fp32 arithmetics: no extra error pushes activations across their thresholds);
       * on flipped seeds the old bar holds (4x the oracle's own distance + 1e-2 of the norm)."""
@@ -91,7 +94,6 @@ def test_split_plan_gradients_below_the_decision_floor_over_seeds():
     from oracle.criteria import MaskedL1Loss as OL1
     from radar_depth_amd.main import HipTrainStep
     from radar_depth_amd.synthetic import make_batch
-    b, h, w = 2, 97, 161
     m, o32 = _pair(h, w)
     o64 = copy.deepcopy(o32).double()
     steps = {op: HipTrainStep(m, b, h, w, lr=0.0, momentum=0.0, weight_decay=0.0, operands=op) for op in ("fp32", "split")}   # lr 0: parameters stay put
@@ -116,24 +118,24 @@ def test_split_plan_gradients_below_the_decision_floor_over_seeds():
         for k in clean:
             clean[k] += is_clean[k]
         rows.append((seed, dist, is_clean))
+        print("[b=%d %dx%d] " % (b, h, w), end="")
         print("seed %d: worst / median per-tensor distance to fp64: oracle32 %.2e / %.2e %s | fp32-MFMA %.2e / %.2e %s | split %.2e / %.2e %s"
               % (seed, dist["oracle32"].max(), np.median(dist["oracle32"]), "clean" if is_clean["oracle32"] else "FLIP ",
                  dist["fp32"].max(), np.median(dist["fp32"]), "clean" if is_clean["fp32"] else "FLIP ",
                  dist["split"].max(), np.median(dist["split"]), "clean" if is_clean["split"] else "FLIP "))
         kept = [n for n, k in zip(names, keep) if k]
-        if is_clean["oracle32"] and is_clean["split"]:
-            bar = np.maximum(10.0 * dist["fp32"], 5e-5)
+        if is_clean["split"]:
+            bar = np.maximum(10.0 * dist["fp32"], 5e-5) if is_clean["fp32"] else np.full_like(dist["split"], 5e-5)
             bad = [(n, a, c) for n, a, c, lim in zip(kept, dist["split"], dist["fp32"], bar) if a > lim]
             assert not bad, (seed, bad[:6])
         else:
             lim = 4.0 * dist["oracle32"] + 1e-2
             bad = [(n, a, c) for n, a, c, l_ in zip(kept, dist["split"], dist["oracle32"], lim) if a > l_]
             assert not bad, (seed, bad[:6])
-    print("clean seeds of 8 (every tensor within 1e-4 of fp64): CPU oracle fp32 %d, fp32-MFMA plan %d, split plan %d"
-          % (clean["oracle32"], clean["fp32"], clean["split"]))
+    print("[b=%d %dx%d] clean seeds of 8 (every tensor within 1e-4 of fp64): CPU oracle fp32 %d, fp32-MFMA plan %d, split plan %d"
+          % (b, h, w, clean["oracle32"], clean["fp32"], clean["split"]))
     assert clean["split"] >= clean["fp32"] - 1 and clean["split"] >= clean["oracle32"] - 1, clean
-    both = [r for r in rows if r[2]["oracle32"] and r[2]["split"]]
-    assert both, "no seed on which both the reference's arithmetic and the split plan are decision-free: pick other seeds"
+    assert clean["split"] >= 1, "no seed on which the split plan is decision-free at this geometry: pick other seeds"
 
 
 @pytest.mark.slow
