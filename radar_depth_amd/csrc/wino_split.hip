@@ -15,12 +15,16 @@
 //   * A^T m A in the epilogue: rows inside the wave that owns a column of the 4x4 position grid, columns across the four MFMA waves
 //     through LDS; BatchNorm partial sums, residual addend and the NHWC store from there.
 //
-//   workgroup : 8 waves, ONE per CU (144 KB of LDS).  Waves 0-3 own the accumulators -- wave w holds column j = w of the 4x4 position
-//               grid, all four rows i, for 32 tiles x 64 output channels: 4 x 2 tiles of 32 x 32 = 128 accumulator registers -- and do
-//               nothing but fragment reads and MFMAs; waves 4-7 stage.
-//   phase     : half a 16-channel chunk's positions (rows i = 2 hf, 2 hf + 1): A 24 KB + B 48 KB, two buffers; one barrier per phase.
-//               The staging waves transform a chunk when its loads have landed (in the chunk's second phase), write the first half's
-//               pieces at once and keep the second half's sixteen values in registers for the next phase.
+//   workgroup : 8 waves, ONE per CU.  Waves 0-3 own the accumulators -- wave w holds column j = w of the 4x4 position grid, all four
+//               rows i, for 32 tiles x 64 output channels: 4 x 2 tiles of 32 x 32 = 128 accumulator registers -- and do nothing but
+//               fragment reads and MFMAs; waves 4-7 stage the A operand.
+//   operands  : A (transformed patch) through LDS, one 16-channel chunk = all sixteen positions per phase (48 KB, two buffers, one
+//               barrier per chunk); B (transformed weights) straight from global memory / L2 into the MFMA waves' registers, two steps
+//               (positions) ahead -- the first version copied it through LDS (48 KB per half-chunk phase, issued and awaited by the
+//               staging waves inside the phase that preceded its use): the copy's latency was exposed in every phase and the kernel ran
+//               at 0.85x of the direct split kernel (profiles/r06_wino_gate.txt).
+//   staging   : a lane owns (tile, channel pair): sixteen 8-byte loads per chunk, fetched TWO chunks ahead (HBM latency under load is
+//               ~3 k clocks, a chunk ~1.6 k), 64 adds, sixteen three-way splits, 48 ds_write_b32.
 //   tile block: 4 x 8 Winograd tiles = 8 x 16 output pixels; odd sizes (113, 57, 29, 15) by masking the last tile row / column.
 #include <stdlib.h>
 
@@ -38,21 +42,21 @@ typedef __bf16 wbf16x2 __attribute__((ext_vector_type(2)));
 constexpr int WN_TBH = 4, WN_TBW = 8;              // tiles per block
 constexpr int WN_T = WN_TBH * WN_TBW;              // 32 tiles = one MFMA M tile
 constexpr int WN_CB = 64;                          // output channels per workgroup
-constexpr int WN_AH = 8 * 3 * 2 * 512;             // A image of a phase: [pos 8][piece 3][k half 2][tile 32] x 16 B
-constexpr int WN_BH = 8 * 3 * 2 * 1024;            // B image of a phase: [pos 8][piece 3][k half 2][co 64] x 16 B
-constexpr int WN_BUF = WN_AH + WN_BH;              // 73,728 B
+constexpr int WN_AH = 16 * 3 * 2 * 512;            // A image of a chunk: [pos 16][piece 3][k half 2][tile 32] x 16 B = 48 KB
+constexpr int WN_BH = 16 * 3 * 2 * 1024;           // B operand of a chunk and a 64-channel block: [pos 16][piece 3][k half 2][co 64] x 16 B = 96 KB
+constexpr int WN_BUF = WN_AH;
 constexpr int WN_ZP = 68;                          // floats per (tile) row of the epilogue's exchange buffer (64 + 4: 16-byte aligned rows)
 constexpr unsigned WN_OOB = 0x80000000u;
 
 struct WinoArgs {
     const float* in;
-    const unsigned short* u;      // rd_wino_pack's operand: [cot][phase][WN_BH bytes]
+    const unsigned short* u;      // rd_wino_pack's operand: [cot][chunk][WN_BH bytes]
     float* out;
     const float* addend;
     float* stat;
     int N, H, W, Cin, Cout, ldi, ldo, ld_add;
     int tiles_h, tiles_w, bh, bw, n_cot;
-    int dbg;                      // diagnostics (RD_WINO_DEBUG; results are then garbage): 1 no MFMAs, 2 no A staging, 4 no B copies, 8 no epilogue
+    int dbg;                      // diagnostics (RD_WINO_DEBUG; results are then garbage): 1 no MFMAs, 2 no split / A stores, 4 no weight loads, 8 no epilogue
 };
 
 __device__ __forceinline__ unsigned wn_cvt_pk(float a, float b) {
@@ -62,6 +66,7 @@ __device__ __forceinline__ unsigned wn_cvt_pk(float a, float b) {
     return __builtin_bit_cast(unsigned, __builtin_convertvector(v, wbf16x2));
 }
 
+template <bool NOMMA>      // (diagnostics instantiation: no MFMAs -- a run-time test would split the basic blocks the load / MFMA schedule lives in)
 __global__ __launch_bounds__(512) void wino_split_kernel(const WinoArgs a) {
     extern __shared__ __attribute__((aligned(16))) char wsm[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -77,14 +82,12 @@ __global__ __launch_bounds__(512) void wino_split_kernel(const WinoArgs a) {
     const int rem = pt - n * nb_img;
     const int by = rem / a.bw, bx = rem - by * a.bw;
     const int nchunks = a.Cin >> 4;
-    const int nphases = 2 * nchunks;
 
     f32x16 acc[4][2];
 
     if (loader) {
         // ---------------------------------------------------------------------------------------------- staging waves
         const int sw = wave - 4;
-        const int ltid = tid - 256;
         const int tl = (sw & 1) * 16 + (lane >> 2);      // tile of this lane
         const int q4 = lane & 3, kh = sw >> 1;           // channel pair q4 of k half kh: channels kh * 8 + q4 * 2, + 1 of the chunk
         const int ty = by * WN_TBH + (tl >> 3), tx = bx * WN_TBW + (tl & 7);
@@ -100,25 +103,16 @@ __global__ __launch_bounds__(512) void wino_split_kernel(const WinoArgs a) {
             }
         const char* in_n = reinterpret_cast<const char*>(a.in) + (size_t)n * a.H * a.W * a.ldi * 4;
         const unsigned img_bytes = (unsigned)(a.H * a.W * a.ldi) * 4u;
-        const unsigned a_dst = (unsigned)(kh * 512 + tl * 16 + q4 * 4);       // inside one (position, piece) plane pair of an A image
-        const char* u_wg = reinterpret_cast<const char*>(a.u) + (size_t)cot * nphases * WN_BH;
+        const unsigned a_dst = (unsigned)(size_t)wsm + (unsigned)(kh * 512 + tl * 16 + q4 * 4);       // inside one (position, piece) plane pair
 
-        wf32x2 raw[16];
-        auto fetch = [&](int c) {
+        wf32x2 raw[2][16];
+        auto fetch = [&](int c, wf32x2 (&rw)[16]) {
             const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(in_n + c * 64), 0, img_bytes - c * 64, 0x00020000);
 #pragma unroll
-            for (int p = 0; p < 16; ++p) raw[p] = __builtin_bit_cast(wf32x2, __builtin_amdgcn_raw_buffer_load_b64(r, (int)off[p], 0, 0));
+            for (int p = 0; p < 16; ++p) rw[p] = __builtin_bit_cast(wf32x2, __builtin_amdgcn_raw_buffer_load_b64(r, (int)off[p], 0, 0));
         };
-        auto issue_b = [&](int ph) {
-            if (a.dbg & 4) return;
-            const char* src = u_wg + (size_t)ph * WN_BH;
-            char* dst = wsm + (ph & 1) * WN_BUF + WN_AH;
-#pragma unroll
-            for (int k = 0; k < WN_BH / (256 * 16); ++k)
-                glds16(reinterpret_cast<const float*>(src + (k * 256 + ltid) * 16), reinterpret_cast<float*>(dst + (k * 256 + sw * 64) * 16));
-        };
-        // split the two channels' values of position p8 (of the phase's eight) into three packed pieces and store them
-        auto put = [&](char* abuf, int p8, wf32x2 v) {
+        // split the two channels' values of position p into three packed pieces and store them
+        auto put = [&](unsigned abuf, int p, wf32x2 v) {
             float x = v[0], y = v[1];
             const unsigned u0 = wn_cvt_pk(x, y);
             x -= __uint_as_float(u0 << 16);
@@ -127,68 +121,68 @@ __global__ __launch_bounds__(512) void wino_split_kernel(const WinoArgs a) {
             x -= __uint_as_float(u1 << 16);
             y -= __uint_as_float(u1 & 0xffff0000u);
             const unsigned u2 = wn_cvt_pk(x, y);
-            const unsigned ad = (unsigned)(size_t)abuf + a_dst + p8 * (3 * 1024);
+            const unsigned ad = abuf + p * (3 * 1024);
             asm volatile("ds_write_b32 %0, %1" ::"v"(ad), "v"(u0) : "memory");
             asm volatile("ds_write_b32 %0, %1 offset:1024" ::"v"(ad), "v"(u1) : "memory");
             asm volatile("ds_write_b32 %0, %1 offset:2048" ::"v"(ad), "v"(u2) : "memory");
         };
-        wf32x2 vhi[8];      // positions of rows i = 2, 3 of the chunk whose first half was written last
-        // B^T d B of the fetched chunk: rows i = 0, 1 stored into abuf, rows 2, 3 kept in vhi
-        auto transform = [&](char* abuf) {
+        // B^T d B of a fetched chunk, split and stored into A buffer `slot`
+        auto transform = [&](const wf32x2 (&rw)[16], int slot) {
+            const unsigned abuf = a_dst + slot * WN_BUF;
             wf32x2 t[4][4];
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
-                t[0][c] = raw[0 * 4 + c] - raw[2 * 4 + c];
-                t[1][c] = raw[1 * 4 + c] + raw[2 * 4 + c];
-                t[2][c] = raw[2 * 4 + c] - raw[1 * 4 + c];
-                t[3][c] = raw[1 * 4 + c] - raw[3 * 4 + c];
+                t[0][c] = rw[0 * 4 + c] - rw[2 * 4 + c];
+                t[1][c] = rw[1 * 4 + c] + rw[2 * 4 + c];
+                t[2][c] = rw[2 * 4 + c] - rw[1 * 4 + c];
+                t[3][c] = rw[1 * 4 + c] - rw[3 * 4 + c];
+            }
+            if (a.dbg & 2) {
+                // (diagnostics: keep the adds alive without the split arithmetic and the stores)
+                wf32x2 acc_ = t[0][0];
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) acc_ += t[i][c];
+                if (acc_[0] == 12345.678f) put(abuf, 0, acc_);
+                return;
             }
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                const wf32x2 v0 = t[i][0] - t[i][2], v1 = t[i][1] + t[i][2], v2 = t[i][2] - t[i][1], v3 = t[i][1] - t[i][3];
-                if (i < 2) {
-                    if (!(a.dbg & 2)) {
-                        put(abuf, i * 4 + 0, v0);
-                        put(abuf, i * 4 + 1, v1);
-                        put(abuf, i * 4 + 2, v2);
-                        put(abuf, i * 4 + 3, v3);
-                    }
-                } else {
-                    vhi[(i - 2) * 4 + 0] = v0;
-                    vhi[(i - 2) * 4 + 1] = v1;
-                    vhi[(i - 2) * 4 + 2] = v2;
-                    vhi[(i - 2) * 4 + 3] = v3;
-                }
+                put(abuf, i * 4 + 0, t[i][0] - t[i][2]);
+                put(abuf, i * 4 + 1, t[i][1] + t[i][2]);
+                put(abuf, i * 4 + 2, t[i][2] - t[i][1]);
+                put(abuf, i * 4 + 3, t[i][1] - t[i][3]);
+                __builtin_amdgcn_sched_barrier(0);
             }
         };
-        // prologue: chunk 0's first half + the weights of phase 0
-        issue_b(0);
-        fetch(0);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        transform(wsm);
-        glds_wait();
+        // prologue: chunk 0 into buffer 0; chunks 1 and 2 in flight
+        fetch(0, raw[0]);
+        if (nchunks > 1) fetch(1, raw[1]);
+        if (nchunks > 1) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        transform(raw[0], 0);
+        if (nchunks > 2) fetch(2, raw[0]);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
-        for (int c = 0; c < nchunks; ++c) {
-            // phase (c, 0): the compute waves read buffer 0; buffer 1 <- rows 2, 3 of chunk c + the weights of phase 2c + 1; the next chunk's loads go out
-            issue_b(2 * c + 1);
-            if (c + 1 < nchunks) fetch(c + 1);
-            if (!(a.dbg & 2)) {
-#pragma unroll
-                for (int p = 0; p < 8; ++p) put(wsm + WN_BUF, p, vhi[p]);
-            }
-            // (the weight copies must have landed at the barrier; the 16 patch loads issued behind them need not)
-            if (c + 1 < nchunks) asm volatile("s_waitcnt vmcnt(16) lgkmcnt(0)" ::: "memory");
-            else glds_wait();
-            __builtin_amdgcn_s_barrier();
-            // phase (c, 1): the compute waves read buffer 1; buffer 0 <- rows 0, 1 of chunk c + 1 + the weights of phase 2c + 2
+        // interval c: the compute waves read buffer c & 1; buffer (c + 1) & 1 <- chunk c + 1 (fetched two intervals ago); chunk c + 3 goes out
+        auto interval = [&](int c, auto par_) {
+            constexpr int par = decltype(par_)::value;      // == (c + 1) & 1: the register set AND the buffer of chunk c + 1
             if (c + 1 < nchunks) {
-                issue_b(2 * c + 2);
-                asm volatile("s_waitcnt vmcnt(12)" ::: "memory");      // the patch loads (older than the 12 weight copies just issued) are in
-                transform(wsm);
+                if (c + 2 < nchunks) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");      // chunk c + 1 is in, chunk c + 2 may still be in flight
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                transform(raw[par], par);
+                if (c + 3 < nchunks) fetch(c + 3, raw[par]);
             }
-            glds_wait();
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
+        };
+        int c = 0;
+        for (; c + 2 <= nchunks; c += 2) {
+            interval(c, std::integral_constant<int, 1>{});
+            interval(c + 1, std::integral_constant<int, 0>{});
         }
+        if (c < nchunks) interval(c, std::integral_constant<int, 1>{});
     } else {
         // ---------------------------------------------------------------------------------------------- compute waves
 #pragma unroll
@@ -197,42 +191,67 @@ __global__ __launch_bounds__(512) void wino_split_kernel(const WinoArgs a) {
             for (int nb = 0; nb < 2; ++nb)
 #pragma unroll
                 for (int k = 0; k < 16; ++k) acc[i][nb][k] = 0.f;
-        const int a_off = hh * 512 + l31 * 16;
-        const int b_off = WN_AH + hh * 1024 + l31 * 16;
+        const int a_off = hh * 512 + l31 * 16 + wave * (3 * 1024);
+        // B fragments of step (chunk c, row i): position i * 4 + wave of the chunk's block, 3 pieces x 2 N tiles, 16 bytes per lane each
+        const char* u_lane = reinterpret_cast<const char*>(a.u) + (size_t)cot * nchunks * WN_BH + wave * (3 * 2048) + hh * 1024 + l31 * 16;
+        const int nsteps = 4 * nchunks;
+        // (branch-free: steps beyond the last re-read the last step's fragments, never used; dbg 4: every chunk reads chunk 0's block --
+        //  L2 / L1 hits instead of fresh lines.  A conditional here makes the compiler wait for ALL outstanding loads at every step.)
+        const size_t ustride = (a.dbg & 4) ? 0 : (size_t)WN_BH;
+        auto loadB = [&](int step, wbf16x8 (&B)[3][2]) {
+            step = min(step, nsteps - 1);
+            const char* src = u_lane + (size_t)(step >> 2) * ustride + (step & 3) * (4 * 3 * 2048);
+#pragma unroll
+            for (int p = 0; p < 3; ++p)
+#pragma unroll
+                for (int nb = 0; nb < 2; ++nb) B[p][nb] = *reinterpret_cast<const wbf16x8*>(src + p * 2048 + nb * 512);
+        };
+        wbf16x8 Bq[3][3][2];      // ring of three steps: B of step s lives in Bq[s % 3]
+        wbf16x8 A[2][3];
+        loadB(0, Bq[0]);
+        loadB(1, Bq[1]);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
-        auto phase = [&](const char* base, auto hf_) {
-            constexpr int hf = decltype(hf_)::value;
-            wbf16x8 A[2][3], B[2][3][2];
+        // twelve steps (three chunks) per trip: ring index and accumulator row are compile-time
+        auto step = [&](const char* abuf, int st, auto i_, auto ring_) {
+            constexpr int i = decltype(i_)::value, ring = decltype(ring_)::value;
+            // this step's A fragments (the phase's first are read behind its barrier, the others one step ahead -- see below)
+            loadB(st + 2, Bq[(ring + 2) % 3]);
+            if (i < 3) {
 #pragma unroll
-            for (int s = 0; s < 2; ++s) {
-                const int p8 = wave + 4 * s;
-#pragma unroll
-                for (int p = 0; p < 3; ++p) {
-                    A[s][p] = *reinterpret_cast<const wbf16x8*>(base + a_off + (p8 * 3 + p) * 1024);
-#pragma unroll
-                    for (int nb = 0; nb < 2; ++nb) B[s][p][nb] = *reinterpret_cast<const wbf16x8*>(base + b_off + (p8 * 3 + p) * 2048 + nb * 512);
-                }
+                for (int p = 0; p < 3; ++p) A[(i + 1) & 1][p] = *reinterpret_cast<const wbf16x8*>(abuf + a_off + ((i + 1) * 4 * 3 + p) * 1024);
             }
-            if (!(a.dbg & 1)) {
 #pragma unroll
-                for (int s = 0; s < 2; ++s)
-#pragma unroll
-                    for (int nb = 0; nb < 2; ++nb) {
-                        f32x16 c = acc[2 * hf + s][nb];
-                        RD_SPLIT_TERMS(c, A[s][0], A[s][1], A[s][2], B[s][0][nb], B[s][1][nb], B[s][2][nb])
-                        acc[2 * hf + s][nb] = c;
-                    }
+            for (int nb = 0; nb < 2; ++nb) {
+                f32x16 cc = acc[i][nb];
+                if constexpr (NOMMA) {
+                    cc[0] += (float)A[i & 1][0][0] + (float)Bq[ring][0][nb][0] + (float)A[i & 1][1][0] + (float)Bq[ring][1][nb][0] + (float)A[i & 1][2][0] + (float)Bq[ring][2][nb][0];
+                } else {
+                    RD_SPLIT_TERMS(cc, A[i & 1][0], A[i & 1][1], A[i & 1][2], Bq[ring][0][nb], Bq[ring][1][nb], Bq[ring][2][nb])
+                }
+                acc[i][nb] = cc;
             }
         };
-        for (int c = 0; c < nchunks; ++c) {
-            phase(wsm, std::integral_constant<int, 0>{});
+        auto chunk = [&](int c, auto r0_) {
+            constexpr int r0 = decltype(r0_)::value;       // ring index of the chunk's first step = (4 c) % 3
+            const char* abuf = wsm + (c & 1) * WN_BUF;
+#pragma unroll
+            for (int p = 0; p < 3; ++p) A[0][p] = *reinterpret_cast<const wbf16x8*>(abuf + a_off + p * 1024);
+            step(abuf, 4 * c + 0, std::integral_constant<int, 0>{}, std::integral_constant<int, (r0 + 0) % 3>{});
+            step(abuf, 4 * c + 1, std::integral_constant<int, 1>{}, std::integral_constant<int, (r0 + 1) % 3>{});
+            step(abuf, 4 * c + 2, std::integral_constant<int, 2>{}, std::integral_constant<int, (r0 + 2) % 3>{});
+            step(abuf, 4 * c + 3, std::integral_constant<int, 3>{}, std::integral_constant<int, (r0 + 3) % 3>{});
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
-            phase(wsm + WN_BUF, std::integral_constant<int, 1>{});
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();
+        };
+        int c = 0;
+        for (; c + 3 <= nchunks; c += 3) {
+            chunk(c, std::integral_constant<int, 0>{});
+            chunk(c + 1, std::integral_constant<int, 1>{});
+            chunk(c + 2, std::integral_constant<int, 2>{});
         }
+        if (c < nchunks) { chunk(c, std::integral_constant<int, 0>{}); ++c; }
+        if (c < nchunks) { chunk(c, std::integral_constant<int, 1>{}); ++c; }
     }
     if (a.dbg & 8) return;
 
@@ -304,7 +323,7 @@ __global__ __launch_bounds__(512) void wino_split_kernel(const WinoArgs a) {
 }
 
 // U = G g G^T of every (reduction channel, output channel) pair in fp64, rounded once to fp32, split into three bf16 pieces, in the
-// layout the kernel copies linearly: [cot][phase = 2 * chunk + half][pos 8][piece 3][k half 2][co 64][8 reduction channels].
+// layout the MFMA waves read as fragments: [cot][chunk][pos 16][piece 3][k half 2][co 64][8 reduction channels].
 // flip = 0: forward (reduction = the I of OIHW, output = O); flip = 1: input gradient (reduction = O, output = I, taps rotated by 180 degrees).
 __global__ __launch_bounds__(256) void wino_pack_kernel(const float* __restrict__ w, int O, int I, int flip, unsigned short* __restrict__ u) {
     const int R = flip ? O : I, Q = flip ? I : O;
@@ -312,7 +331,7 @@ __global__ __launch_bounds__(256) void wino_pack_kernel(const float* __restrict_
     const int e = blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= Q * r8n) return;
     const int q = e / r8n, r8 = e - q * r8n;
-    const int nph = 2 * (R >> 4);
+    const int nck = R >> 4;
     const int cot = q >> 6, ql = q & 63;
     const int chunk = r8 >> 1, kh8 = r8 & 1;
     unsigned short pc[16][3][8];
@@ -356,8 +375,7 @@ __global__ __launch_bounds__(256) void wino_pack_kernel(const float* __restrict_
         for (int j = 0; j < 4; ++j)
 #pragma unroll
             for (int p = 0; p < 3; ++p) {
-                const int ph = 2 * chunk + (i >> 1), p8 = (i & 1) * 4 + j;
-                const size_t o = ((size_t)cot * nph + ph) * WN_BH + ((p8 * 3 + p) * 2 + kh8) * 1024 + ql * 16;
+                const size_t o = ((size_t)cot * nck + chunk) * WN_BH + (((i * 4 + j) * 3 + p) * 2 + kh8) * 1024 + ql * 16;
                 uint4 v;
                 v.x = pc[i * 4 + j][p][0] | ((unsigned)pc[i * 4 + j][p][1] << 16);
                 v.y = pc[i * 4 + j][p][2] | ((unsigned)pc[i * 4 + j][p][3] << 16);
@@ -376,7 +394,7 @@ static bool wino_shape_ok(int H, int W, int Cin, int Cout, int ldi, int ldo) {
 // bytes of the packed operand for an O x I x 3 x 3 weight tensor (flip as in rd_wino_pack)
 extern "C" int64_t rd_wino_packed_bytes(int32_t O, int32_t I, int32_t flip) {
     const int R = flip ? O : I, Q = flip ? I : O;
-    return (int64_t)((Q + 63) / 64) * (2 * (R / 16)) * rd::WN_BH;
+    return (int64_t)((Q + 63) / 64) * (R / 16) * rd::WN_BH;
 }
 
 extern "C" int rd_wino_pack(const float* w_oihw, int32_t O, int32_t I, int32_t flip, void* u_packed, void* stream) {
@@ -423,8 +441,15 @@ extern "C" int rd_wino_conv3x3(const float* in, int32_t N, int32_t H, int32_t W,
     const int grid = N * a.bh * a.bw * a.n_cot;
     const size_t lds = 2 * (size_t)WN_BUF;
     static std::atomic<unsigned long long> attr_set{0};
-    RD_SET_ATTR_ONCE(attr_set, hipFuncSetAttribute(reinterpret_cast<const void*>(wino_split_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    hipLaunchKernelGGL(wino_split_kernel, dim3(grid), dim3(512), lds, static_cast<hipStream_t>(stream), a);
+    if (dbg & 1) {
+        static std::atomic<unsigned long long> attr_dbg{0};
+        RD_SET_ATTR_ONCE(attr_dbg, hipFuncSetAttribute(reinterpret_cast<const void*>(wino_split_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        hipLaunchKernelGGL(wino_split_kernel<true>, dim3(grid), dim3(512), lds, static_cast<hipStream_t>(stream), a);
+        RD_CHECK_LAUNCH("wino_split_kernel");
+        return RD_OK;
+    }
+    RD_SET_ATTR_ONCE(attr_set, hipFuncSetAttribute(reinterpret_cast<const void*>(wino_split_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    hipLaunchKernelGGL(wino_split_kernel<false>, dim3(grid), dim3(512), lds, static_cast<hipStream_t>(stream), a);
     RD_CHECK_LAUNCH("wino_split_kernel");
     return RD_OK;
 }
