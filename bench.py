@@ -59,6 +59,8 @@ def kernel_identity(L, kind, d, io16=False):
         return "gconv_bf16_kernel<%d,%d,%s,%s>" % (info[0], info[1], tb_(info[2] >= 1000), tb_(io16))
     if kind == "conv16_split":
         return "conv16_split_kernel<stat|add>"
+    if kind == "wino":
+        return "wino_split_kernel<false>"
     if kind == "gconv_split":
         info = (C.c_int32 * 8)()
         L.rd_gconv_split_plan_info(C.byref(d), info)          # MT, NT, TH, TW, PP, lds, workgroups, tap groups + 100 * double-buffered patch

@@ -508,6 +508,12 @@ int rd_nhwc_to_nchw(const float* src, float* dst, int32_t N, int32_t C, int32_t 
 int64_t rd_wino_packed_bytes(int32_t O, int32_t I, int32_t flip);
 int rd_wino_pack(const float* w_oihw, int32_t O, int32_t I, int32_t flip, void* u_packed, void* stream);
 int rd_wino_supported(int32_t H, int32_t W, int32_t Cin, int32_t Cout, int32_t ldi, int32_t ldo);
+/* planner rule from the kernel-level measurements (1: the Winograd form is expected to beat rd_gconv_split[_pre] for this layer) */
+int rd_wino_preferred(int32_t H, int32_t W, int32_t Cin, int32_t Cout, int32_t ldi, int32_t ldo);
+/* every Winograd operand of a plan in one launch: jobs = device array of 32-byte records { const float* w; void* u; int32 O, I, flip,
+ * first_block }, block_job[b] = the job of block b, a job takes rd_wino_pack_blocks(O, I, flip) consecutive blocks from first_block */
+int rd_wino_pack_blocks(int32_t O, int32_t I, int32_t flip);
+int rd_wino_pack_batched(const void* jobs, const int32_t* block_job, int32_t n_blocks, void* stream);
 int rd_wino_stat_tiles(int32_t N, int32_t H, int32_t W);
 int rd_wino_conv3x3(const float* in, int32_t N, int32_t H, int32_t W, int32_t Cin, int32_t ldi, const void* u_packed, float* out,
                     int32_t Cout, int32_t ldo, const float* addend, int32_t ld_add, float* stat_partial, void* stream);

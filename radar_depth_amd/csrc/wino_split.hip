@@ -82,6 +82,14 @@ __global__ __launch_bounds__(512) void wino_split_kernel(const WinoArgs a) {
     const int rem = pt - n * nb_img;
     const int by = rem / a.bw, bx = rem - by * a.bw;
     const int nchunks = a.Cin >> 4;
+    // Every workgroup walks the 16-channel chunks in its own rotation (first chunk = workgroup index mod the chunk count): workgroups that
+    // run side by side would otherwise ask the L2 for the SAME 96 KB weight block at the same moment -- one channel serving 32 CUs
+    // (the "2-4 k clocks for a copy to land" of gconv_split.hip, with 5x its weight traffic per output pixel).  The summation order over the
+    // chunks therefore depends on the tile block; it is fixed for a given geometry (run-to-run bit-identical).
+    // MEASURED (profiles/r06_wino_gate.txt): 512-channel layer 134 -> 223 us, 256-channel 137 -> 147, 64-channel unchanged -- rotated, the chip
+    // touches every chunk's weights at once (25 MB at 512 channels: out of the 4 MB L2s), in lockstep it streams them.  Off; dbg 16 turns it on.
+    const int c_rot = (a.dbg & 16) ? vid % nchunks : 0;
+    auto rot = [&](int c) { const int cc = c + c_rot; return cc >= nchunks ? cc - nchunks : cc; };
 
     f32x16 acc[4][2];
 
@@ -107,7 +115,8 @@ __global__ __launch_bounds__(512) void wino_split_kernel(const WinoArgs a) {
 
         wf32x2 raw[2][16];
         auto fetch = [&](int c, wf32x2 (&rw)[16]) {
-            const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(in_n + c * 64), 0, img_bytes - c * 64, 0x00020000);
+            const int cc = rot(c);
+            const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(in_n + cc * 64), 0, img_bytes - cc * 64, 0x00020000);
 #pragma unroll
             for (int p = 0; p < 16; ++p) rw[p] = __builtin_bit_cast(wf32x2, __builtin_amdgcn_raw_buffer_load_b64(r, (int)off[p], 0, 0));
         };
@@ -156,6 +165,10 @@ __global__ __launch_bounds__(512) void wino_split_kernel(const WinoArgs a) {
                 __builtin_amdgcn_sched_barrier(0);
             }
         };
+        if (a.dbg & 32) {      // diagnostics: the staging waves only keep the barriers
+            for (int c = 0; c <= nchunks; ++c) __builtin_amdgcn_s_barrier();
+            goto epilogue;
+        }
         // prologue: chunk 0 into buffer 0; chunks 1 and 2 in flight
         fetch(0, raw[0]);
         if (nchunks > 1) fetch(1, raw[1]);
@@ -191,6 +204,10 @@ __global__ __launch_bounds__(512) void wino_split_kernel(const WinoArgs a) {
             for (int nb = 0; nb < 2; ++nb)
 #pragma unroll
                 for (int k = 0; k < 16; ++k) acc[i][nb][k] = 0.f;
+        if (a.dbg & 64) {      // diagnostics: the compute waves only keep the barriers
+            for (int c = 0; c <= nchunks; ++c) __builtin_amdgcn_s_barrier();
+            goto epilogue;
+        }
         const int a_off = hh * 512 + l31 * 16 + wave * (3 * 1024);
         // B fragments of step (chunk c, row i): position i * 4 + wave of the chunk's block, 3 pieces x 2 N tiles, 16 bytes per lane each
         const char* u_lane = reinterpret_cast<const char*>(a.u) + (size_t)cot * nchunks * WN_BH + wave * (3 * 2048) + hh * 1024 + l31 * 16;
@@ -200,7 +217,7 @@ __global__ __launch_bounds__(512) void wino_split_kernel(const WinoArgs a) {
         const size_t ustride = (a.dbg & 4) ? 0 : (size_t)WN_BH;
         auto loadB = [&](int step, wbf16x8 (&B)[3][2]) {
             step = min(step, nsteps - 1);
-            const char* src = u_lane + (size_t)(step >> 2) * ustride + (step & 3) * (4 * 3 * 2048);
+            const char* src = u_lane + (size_t)rot(step >> 2) * ustride + (step & 3) * (4 * 3 * 2048);
 #pragma unroll
             for (int p = 0; p < 3; ++p)
 #pragma unroll
@@ -253,6 +270,7 @@ __global__ __launch_bounds__(512) void wino_split_kernel(const WinoArgs a) {
         if (c < nchunks) { chunk(c, std::integral_constant<int, 0>{}); ++c; }
         if (c < nchunks) { chunk(c, std::integral_constant<int, 1>{}); ++c; }
     }
+epilogue:
     if (a.dbg & 8) return;
 
     // ---- epilogue.  Rows of A^T m A inside the wave (Z_r = sum_i A^T[r][i] m_i, the wave's column j), columns across the waves:
@@ -325,10 +343,9 @@ __global__ __launch_bounds__(512) void wino_split_kernel(const WinoArgs a) {
 // U = G g G^T of every (reduction channel, output channel) pair in fp64, rounded once to fp32, split into three bf16 pieces, in the
 // layout the MFMA waves read as fragments: [cot][chunk][pos 16][piece 3][k half 2][co 64][8 reduction channels].
 // flip = 0: forward (reduction = the I of OIHW, output = O); flip = 1: input gradient (reduction = O, output = I, taps rotated by 180 degrees).
-__global__ __launch_bounds__(256) void wino_pack_kernel(const float* __restrict__ w, int O, int I, int flip, unsigned short* __restrict__ u) {
+__device__ __forceinline__ void wino_pack_body(const float* __restrict__ w, int O, int I, int flip, unsigned short* __restrict__ u, int e) {
     const int R = flip ? O : I, Q = flip ? I : O;
     const int r8n = R >> 3;
-    const int e = blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= Q * r8n) return;
     const int q = e / r8n, r8 = e - q * r8n;
     const int nck = R >> 4;
@@ -385,6 +402,21 @@ __global__ __launch_bounds__(256) void wino_pack_kernel(const float* __restrict_
             }
 }
 
+__global__ __launch_bounds__(256) void wino_pack_kernel(const float* __restrict__ w, int O, int I, int flip, unsigned short* __restrict__ u) {
+    wino_pack_body(w, O, I, flip, u, blockIdx.x * blockDim.x + threadIdx.x);
+}
+
+// one launch for every Winograd operand of a plan (rd_wino_pack_batched): block -> job through a block table, like rd_pack_weights_batched
+struct WinoPackJob {
+    const float* w;
+    unsigned short* u;
+    int32_t O, I, flip, first_block;
+};
+__global__ __launch_bounds__(256) void wino_pack_batched_kernel(const WinoPackJob* __restrict__ jobs, const int32_t* __restrict__ block_job) {
+    const WinoPackJob j = jobs[block_job[blockIdx.x]];
+    wino_pack_body(j.w, j.O, j.I, j.flip, j.u, (blockIdx.x - j.first_block) * blockDim.x + threadIdx.x);
+}
+
 static bool wino_shape_ok(int H, int W, int Cin, int Cout, int ldi, int ldo) {
     return H >= 2 && W >= 2 && Cin >= 64 && Cin % 16 == 0 && Cout >= 64 && Cout % 64 == 0 && ldi % 4 == 0 && ldo % 4 == 0 &&
            (long long)H * W * ldi * 4 < 0x7fffffffll;
@@ -406,6 +438,34 @@ extern "C" int rd_wino_pack(const float* w_oihw, int32_t O, int32_t I, int32_t f
                        static_cast<unsigned short*>(u_packed));
     RD_CHECK_LAUNCH("wino_pack_kernel");
     return RD_OK;
+}
+
+// jobs: device array of { const float* w; void* u; int32 O, I, flip, first_block } (24 bytes + 8 of pointers = 32-byte records);
+// block_job[b] = index of the job block b works on; a job of an O x I tensor takes ceil(Q * (R / 8) / 256) blocks (rd_wino_pack_blocks)
+extern "C" int rd_wino_pack_blocks(int32_t O, int32_t I, int32_t flip) {
+    const int R = flip ? O : I, Q = flip ? I : O;
+    return (Q * (R / 8) + 255) / 256;
+}
+extern "C" int rd_wino_pack_batched(const void* jobs, const int32_t* block_job, int32_t n_blocks, void* stream) {
+    RD_CHECK_ARG(jobs && block_job && n_blocks > 0, "rd_wino_pack_batched: bad arguments");
+    static_assert(sizeof(rd::WinoPackJob) == 32, "job record layout");
+    hipLaunchKernelGGL(rd::wino_pack_batched_kernel, dim3(n_blocks), dim3(256), 0, static_cast<hipStream_t>(stream),
+                       static_cast<const rd::WinoPackJob*>(jobs), block_job);
+    RD_CHECK_LAUNCH("wino_pack_batched_kernel");
+    return RD_OK;
+}
+
+// Planner rule, from the kernel-level gate at b = 16 (profiles/r06_wino_gate.txt): the Winograd form beats the direct split kernels
+// where the direct kernels are weakest -- 512-channel layers (1.30x) and the small maps with <= 128 channels (29 x 50 / 30 x 50 / 15 x 25:
+// 1.32-1.41x) -- and loses or ties on the large maps (64 channels at 113 x 200: 0.94x; 128 at 57 x 100: 1.10x; 256 at 29 x 50: 1.00x),
+// where its 16 / 9 larger weight operand (96 KB per 16-channel chunk and 32-tile block, all of it through the CU's 64 B/clk vector L1)
+// and the un-coalesced 4 x 4 patch gathers cost more than the 2.25x fewer MFMAs save.  RD_WINO=0 never, RD_WINO=all wherever supported.
+extern "C" int rd_wino_preferred(int32_t H, int32_t W, int32_t Cin, int32_t Cout, int32_t ldi, int32_t ldo) {
+    if (!rd::wino_shape_ok(H, W, Cin, Cout, ldi, ldo)) return 0;
+    static const char* env = getenv("RD_WINO");
+    if (env && !strcmp(env, "0")) return 0;
+    if (env && !strcmp(env, "all")) return 1;
+    return (Cin >= 512 || ((long long)H * W <= 1536 && Cin <= 128)) ? 1 : 0;
 }
 
 extern "C" int rd_wino_supported(int32_t H, int32_t W, int32_t Cin, int32_t Cout, int32_t ldi, int32_t ldo) {

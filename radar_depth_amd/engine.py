@@ -139,6 +139,7 @@ class LateFusionPlan:
         self.probes = []       # (name, stream index, torch timing event): RD_TAIL_EVENTS=1
         self.evalcoef_jobs = []   # (C, bn, scale ptr, shift ptr) of the folded BatchNorms of an inference plan
         self.pack_jobs = []    # (src, dst, O, I, T, ldc, off, rows_total, transpose, scale, quad): packed in ONE launch per forward
+        self.wino_jobs = []    # (weight OIHW, packed operand, O, I, flip): G g G^T of every Winograd layer in ONE launch per forward
         self.taps = {}         # name -> Act of intermediate tensors (tests / debugging)
         self.meta = {}         # op name -> (kernel family, descriptor) for the conv launches (bench roofline accounting)
         self.keep = []         # keep ctypes descriptors and tensors alive
@@ -345,6 +346,13 @@ class LateFusionPlan:
         # split plans: each of the two operands (forward, input gradient) is packed as three bf16 piece planes when the library has a
         # split plan for that descriptor, and stays the fp32 operand of rd_gconv otherwise
         sp_f = sp_d = pre_f = pre_d = c16 = False
+        # Winograd F(2x2,3x3) on the split pipeline (csrc/wino_split.hip) for the 3x3 / stride-1 layers where the kernel-level gate measured
+        # it ahead of the direct split kernels (rd_wino_preferred: 512-channel layers, small maps with <= 128 channels); forward and input
+        # gradient decided separately (the input gradient is the same kernel on the flipped operand, channels swapped)
+        wino_f = wino_d = False
+        if self.split and self.train and not upproj and k == 3 and stride == 1 and pad == 1 and len(weights) == 1 and weights[0][1] == 0:
+            wino_f = self.L.rd_wino_preferred(H, W, cin, cout, x.ld, out.ld if out is not None else cout) == 1
+            wino_d = self.L.rd_wino_preferred(H, W, cout, cin, cout, cin) == 1
         if self.split:
             sp_f = self.L.rd_gconv_split_supported(C.byref(d)) == 1
             dd0 = (cd.upproj_dgrad(N, H, W, cin, cout) if upproj else cd.conv_dgrad(N, H, W, cin, cout, k, stride, pad)[0])
@@ -358,15 +366,35 @@ class LateFusionPlan:
             pre_d = (self.pre and cout % 16 == 0 and self.L.rd_gconv_split_pre_supported(C.byref(dd0)) == 1
                      and self.L.rd_gconv_split_pre_preferred(C.byref(dd0)) == 1)
             sp_d = sp_d or pre_d
-        wp = self.buf(3, S, cin, cout, dtype=torch.bfloat16) if sp_f else self.buf(S, cin, cout, dtype=wdt)
-        wd = self.buf(3, S, cout, cin, dtype=torch.bfloat16) if sp_d else self.buf(S, cout, cin, dtype=wdt)
+            if wino_f:
+                sp_f = pre_f = False
+            if wino_d:
+                sp_d = pre_d = False
+        self.L.rd_wino_packed_bytes.restype = C.c_int64
+        uf = ud = None
+        if wino_f:
+            wp = None
+            uf = self.buf(int(self.L.rd_wino_packed_bytes(cout, cin, 0)) // 2, dtype=torch.bfloat16)
+            self.wino_jobs.append((weights[0][0], uf, cout, cin, 0))
+        else:
+            wp = self.buf(3, S, cin, cout, dtype=torch.bfloat16) if sp_f else self.buf(S, cin, cout, dtype=wdt)
+        if wino_d:
+            wd = None
+            ud = self.buf(int(self.L.rd_wino_packed_bytes(cout, cin, 1)) // 2, dtype=torch.bfloat16)
+            self.wino_jobs.append((weights[0][0], ud, cout, cin, 1))
+        else:
+            wd = self.buf(3, S, cout, cin, dtype=torch.bfloat16) if sp_d else self.buf(S, cout, cin, dtype=wdt)
         for w, off in weights:
             o, i, kh, kw = w.shape
-            self.pack_jobs.append((w, wp, o, i, kh * kw, cout, off, i, 0, None, 3 if sp_f else quad))
-            self.pack_jobs.append((w, wd, o, i, kh * kw, cin, off, cout, 1, None, 3 if sp_d else quad))
-        if not sp_f:
+            if not wino_f:
+                self.pack_jobs.append((w, wp, o, i, kh * kw, cout, off, i, 0, None, 3 if sp_f else quad))
+            if not wino_d:
+                self.pack_jobs.append((w, wd, o, i, kh * kw, cin, off, cout, 1, None, 3 if sp_d else quad))
+        if not sp_f and not wino_f:
             self._tune(d)
-        if self.bf16 and not sp_f:
+        if wino_f:
+            tiles = self.L.rd_wino_stat_tiles(N, H, W)
+        elif self.bf16 and not sp_f:
             tiles = self.L.rd_gconv_bf16_stat_tiles_t(self.dt, C.byref(d))      # (bf16 storage: the persistent kernel's own tiling)
         else:
             tiles = (self.L.rd_gconv_split_pre_stat_tiles if pre_f else self.L.rd_gconv_split_stat_tiles if sp_f else
@@ -375,7 +403,11 @@ class LateFusionPlan:
             check(tiles, "rd_gconv_stat_tiles(%s)" % name)
         stat = self.buf(tiles, 2, cout) if self.train else None
         self.keep.append(d)
-        if pre_f:
+        if wino_f:
+            if self.L.rd_wino_supported(H, W, cin, cout, x.ld, out.ld) != 1:
+                raise RuntimeError("%s: planned as a Winograd layer, but the library does not serve %dx%d %d->%d with strides %d / %d" % (name, H, W, cin, cout, x.ld, out.ld))
+            self.op(lst, name, self.L.rd_wino_conv3x3, x.ptr, N, H, W, cin, x.ld, _p(uf), out.ptr, cout, out.ld, C.c_void_p(0), 0, _p(stat), self.stream)
+        elif pre_f:
             xp, xplane = self.pc_in(x, lst)
             self.op(lst, name, self.L.rd_gconv_split_pre, C.byref(d), xp, xplane, _p(wp), C.c_int64(S * cin * cout), out.ptr, C.c_void_p(0), 0, 0,
                     C.c_void_p(0), 0, _p(stat), self.stream)
@@ -394,9 +426,9 @@ class LateFusionPlan:
             ws = self._gconv_ws(d, name)
             self.op(lst, name, self.L.rd_gconv_ws, C.byref(d), x.ptr, _p(wp), out.ptr, C.c_void_p(0), 0, _p(stat), _p(ws), self.stream)
         self.taps[name] = out
-        self.meta[name] = ("gconv_split_pre" if pre_f else "gconv_split" if sp_f else "gconv_bf16" if self.bf16 else "conv16_split" if c16 else "gconv", d)
+        self.meta[name] = ("wino" if wino_f else "gconv_split_pre" if pre_f else "gconv_split" if sp_f else "gconv_bf16" if self.bf16 else "conv16_split" if c16 else "gconv", d)
         ctx = dict(name=name, d=d, x=x, out=out, weights=weights, wd=wd, k=k, stride=stride, pad=pad, upproj=upproj,
-                   stat=stat, tiles=tiles, cin=cin, cout=cout, split_dgrad=sp_d, pre_dgrad=self.split and pre_d)
+                   stat=stat, tiles=tiles, cin=cin, cout=cout, split_dgrad=sp_d, pre_dgrad=self.split and pre_d, wino_dgrad=wino_d, ud=ud)
         return out, ctx
 
     def _c16_split(self, d):
@@ -511,6 +543,17 @@ class LateFusionPlan:
                 self.op(self.bwd, name + ".zero", self.L.rd_fill, dx.ptr, C.c_int64(dx.t.numel() * dx.t.element_size() // 4), C.c_float(0.0),
                         self.stream)
         sp_d = bool(ctx.get("split_dgrad"))
+        if ctx.get("wino_dgrad"):
+            # the input gradient of a Winograd layer: the same kernel on the flipped operand (channels swapped, taps rotated by 180 degrees)
+            if zero_fill or self.L.rd_wino_supported(H, W, cout, cin, dout.ld, dx.ld) != 1:
+                raise RuntimeError("%s: planned as a Winograd input gradient, but the library does not serve %dx%d %d->%d with strides %d / %d"
+                                   % (name, H, W, cout, cin, dout.ld, dx.ld))
+            self.meta[name + ".dgrad"] = ("wino", dd)
+            self.op(self.bwd, name + ".dgrad", self.L.rd_wino_conv3x3, dout.ptr, N, H, W, cout, dout.ld, _p(ctx["ud"]), dx.ptr, cin, dx.ld,
+                    addend.ptr if addend is not None else C.c_void_p(0), addend.ld if addend is not None else 0, C.c_void_p(0), self.stream)
+            if late:
+                launch_wgrad()
+            return dx
         dg_pre = dg_pre and sp_d and self.L.rd_gconv_split_pre_supported(C.byref(dd)) == 1
         if sp_d and not dg_pre and self.L.rd_gconv_split_supported(C.byref(dd)) != 1:
             raise RuntimeError("%s: the input-gradient operand was packed as three bf16 pieces, but the library has neither a split plan for "
@@ -1069,6 +1112,24 @@ class LateFusionPlan:
             self.op(self.prep, name, self.L.rd_pack_weights_batched, _p(table), _p(blocks), nb, self.stream)
             return table, blocks
 
+        def emit_wino():
+            if not self.wino_jobs:
+                return
+
+            class WJob(C.Structure):
+                _fields_ = [("w", C.c_void_p), ("u", C.c_void_p), ("O", C.c_int32), ("I", C.c_int32), ("flip", C.c_int32), ("first_block", C.c_int32)]
+            wj = (WJob * len(self.wino_jobs))()
+            block_job, nb = [], 0
+            for q, (w, u, o, i, flip) in enumerate(self.wino_jobs):
+                n = self.L.rd_wino_pack_blocks(o, i, flip)
+                wj[q] = WJob(w.data_ptr(), u.data_ptr(), o, i, flip, nb)
+                block_job += [q] * n
+                nb += n
+            table = torch.from_numpy(np.frombuffer(bytes(wj), dtype=np.uint8).copy()).to(self.dev)
+            blocks = torch.tensor(block_job, dtype=torch.int32, device=self.dev)
+            self.keep += [table, blocks]
+            self.op(self.prep, "pack_wino", self.L.rd_wino_pack_batched, _p(table), _p(blocks), nb, self.stream)
+
         stems = [j for j in self.pack_jobs if j[4] == 49 and j[10] == 0]          # (7x7 taps, plain layout: the two stem convolutions)
         rest = [j for j in self.pack_jobs if not (j[4] == 49 and j[10] == 0)]
         if getattr(self, "pack_overlap", False) and stems and rest:
@@ -1076,8 +1137,10 @@ class LateFusionPlan:
             self.edge(self.prep, "pack_fork", 0, 2)          # (behind the previous step's SGD update, which ends on stream 0)
             with self.on(2):
                 self.pack_table, self.pack_blocks = emit("pack_all", rest)
+                emit_wino()
         else:
             self.pack_table, self.pack_blocks = emit("pack_all", self.pack_jobs)
+            emit_wino()
 
     def _build_backward(self):
         """Backward as four bucket-aligned segments (self.bwd_segments): every segment ends with all streams joined, so
