@@ -296,7 +296,10 @@ def wino_conv3x3(x_nhwc, u_packed, out_nhwc, addend=None, stat=None):
     """3x3 / stride 1 / pad 1 convolution of an NHWC fp32 tensor (channel slices allowed: strides are taken from the tensors)."""
     n, h, w, cin = x_nhwc.shape
     cout = out_nhwc.shape[3]
-    check(lib().rd_wino_conv3x3(ptr(_f32(x_nhwc)), n, h, w, cin, x_nhwc.stride(2), ptr(u_packed), ptr(_f32(out_nhwc)), cout, out_nhwc.stride(2),
+    for t in (x_nhwc, out_nhwc) + ((addend,) if addend is not None else ()):
+        assert t.dtype == torch.float32 and t.is_cuda and t.stride(3) == 1 and t.stride(1) == t.shape[2] * t.stride(2) and t.stride(0) == t.shape[1] * t.stride(1), \
+            "expected an NHWC CUDA float32 tensor (a channel slice of a wider buffer is fine)"
+    check(lib().rd_wino_conv3x3(ptr(x_nhwc), n, h, w, cin, x_nhwc.stride(2), ptr(u_packed), ptr(out_nhwc), cout, out_nhwc.stride(2),
                                 ptr(addend), 0 if addend is None else addend.stride(2), ptr(stat), current_stream()), "rd_wino_conv3x3")
     return out_nhwc
 
