@@ -1097,6 +1097,8 @@ class LateFusionPlan:
         chunk = self.L.rd_pack_chunk()
 
         def emit(name, job_list):
+            if not job_list:          # (a module whose every convolution is a Winograd layer: nothing for rd_pack_weights_batched)
+                return None, None
             jobs = (Job * len(job_list))()
             block_job, nb = [], 0
             for k, (src, dst, o, i, t, ldc, off, rows, tr, scale, quad) in enumerate(job_list):

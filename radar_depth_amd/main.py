@@ -222,6 +222,7 @@ class HipTrainStep:
         self._warm = 0                 # plain launches issued by THIS object: hipGraph capture only after one warm, un-captured step
         self._table, self._ops, self._ranges, self._bucket_events, self._cs = None, None, None, None, None
         self._bind_sites, self._bound = None, None          # where the step's ops take the input / target pointer, and what they point at now
+        self._bound_refs = None                             # the caller's tensors the plan currently points at (kept alive while bound)
         self._zero_copy = os.environ.get("RD_ZERO_COPY_INPUT", "1") == "1"
         # hipGraph capture is illegal on the legacy default stream: the step owns a stream and fences it against the caller's
         self.side = torch.cuda.Stream(device=dev)   # default priority: raising any stream's priority measured 17-29 % slower
@@ -428,7 +429,12 @@ class HipTrainStep:
             want = [inputs.data_ptr(), target.data_ptr()]
             inputs.record_stream(self.side)
             target.record_stream(self.side)
+            # the plan's stem plane tables and the step's op arguments keep pointing at these tensors after step() returns (the cached plan
+            # is shared with the eager forward and other steps, which re-bind only when THEY run): hold them until the next binding replaces
+            # them, so that nothing of the plan ever points at freed memory
+            self._bound_refs = (inputs, target)
         else:
+            self._bound_refs = None
             p.x_in.copy_(inputs[:, :p.x_in.shape[1]])
             self.target.copy_(target)
             want = [p.x_in.data_ptr(), self.target.data_ptr()]
