@@ -1,10 +1,10 @@
 #!/bin/bash
 # LOCAL wrapper of the end-of-round evidence collection: refuses a dirty tree, stamps `git rev-parse HEAD` into
 # every profile (the GPU box has no .git), runs tools/collect_round.sh on an MI355X through gpurun, then copies the summaries into
-# profiles/<round>_*.   usage: RD_ROUND=r05 bash tools/gpu_collect.sh [extra gpurun --timeout seconds]
+# profiles/<round>_*.   usage: RD_ROUND=r06 bash tools/gpu_collect.sh [extra gpurun --timeout seconds]
 set -e
 cd "$(dirname "$0")/.."
-RD_ROUND=${RD_ROUND:-r05}
+RD_ROUND=${RD_ROUND:-r06}
 if [ -n "$(git status --porcelain --untracked-files=no)" ]; then
     echo "tools/gpu_collect.sh: the working tree has uncommitted changes -- commit first: profiles must describe a commit" >&2
     git status --short --untracked-files=no >&2

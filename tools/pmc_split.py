@@ -21,8 +21,10 @@ for (ci, co, h, w) in [(64, 64, 113, 200), (128, 128, 57, 100), (256, 256, 29, 5
     dy = torch.randn(B, h, w, co, device="cuda")
     slabs = torch.empty(ops.wgrad_split_workspace_floats(d), device="cuda")
     xp = ops.split_pieces(x)
+    u = ops.wino_pack(wt)
     for _ in range(3):
         ops.gconv_split(d, x, ws, y)
         ops.gconv_split_pre(d, xp, ws, y)          # gconv_sp2_kernel (pre-split input, two workgroups per CU)
         ops.wgrad_split(d, x, dy, slabs)
+        ops.wino_conv3x3(x, u, y)                  # wino_split_kernel (round 6)
 torch.cuda.synchronize()
