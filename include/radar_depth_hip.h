@@ -656,6 +656,11 @@ int rd_optable_add(void* table, const char* entry, int32_t nargs, const uint64_t
 int rd_optable_size(const void* table);
 int rd_optable_set_word(void* table, int32_t op, int32_t arg, uint64_t word);
 int rd_optable_run(void* table, int32_t begin, int32_t end, void* const* streams, int32_t n_streams, int32_t* failed_op);
+/* The same replay from n_lanes host threads (1..8): the ops of stream slot s are issued, in table order, by lane s % n_lanes; an
+ * rd_stream_wait_event is issued only after the rd_event_record it pairs with (the last record of that event before it in the table) has
+ * been issued by its lane.  Lanes 1.. are persistent threads of the library.  Not under stream capture.  (The step is 480-960 launches on
+ * three streams; the HIP launch path costs 10-16 us of host time per op.) */
+int rd_optable_run_mt(void* table, int32_t begin, int32_t end, void* const* streams, int32_t n_streams, int32_t n_lanes, int32_t* failed_op);
 
 #ifdef __cplusplus
 }

@@ -224,6 +224,7 @@ class HipTrainStep:
         self._bind_sites, self._bound = None, None          # where the step's ops take the input / target pointer, and what they point at now
         self._bound_refs = None                             # the caller's tensors the plan currently points at (kept alive while bound)
         self._zero_copy = os.environ.get("RD_ZERO_COPY_INPUT", "1") == "1"
+        self._issue_threads = max(1, int(os.environ.get("RD_ISSUE_THREADS", "1")))
         # hipGraph capture is illegal on the legacy default stream: the step owns a stream and fences it against the caller's
         self.side = torch.cuda.Stream(device=dev)   # default priority: raising any stream's priority measured 17-29 % slower
         offs = _param_offsets(model)
@@ -486,10 +487,11 @@ class HipTrainStep:
         caller.wait_stream(self.side)
         return self.loss, self.plans[-1].pred
 
-    def _issue(self, begin, end):
+    def _issue(self, begin, end, capturing=False):
         if self.plan._diagnostic_loop():                       # RD_POISON_LDS / RD_TRACE_OPS: host hook between ops
             return self.plan._run(self._ops[begin:end])
-        self._table.run(begin, end)
+        # RD_ISSUE_THREADS=n: the step's ops are issued from n host threads, one per stream (rd_optable_run_mt)
+        self._table.run(begin, end, lanes=1 if capturing else self._issue_threads)
 
     def _step_on_side(self, inputs, target):
         p = self.plan
@@ -522,7 +524,7 @@ class HipTrainStep:
                 if kind != "piece":
                     continue
                 check(self.L.rd_graph_begin(p.streams[0]), "graph_begin")
-                self._issue(b, e)
+                self._issue(b, e, capturing=True)
                 g = C.c_void_p(0)
                 check(self.L.rd_graph_end(p.streams[0], C.byref(g)), "graph_end")
                 self.graphs[k] = g

@@ -72,11 +72,15 @@ class OpTable:
     def __len__(self):
         return len(self.names)
 
-    def run(self, begin=0, end=None):
+    def run(self, begin=0, end=None, lanes=1):
+        """lanes > 1: issue from that many host threads, one per stream slot modulo lanes (rd_optable_run_mt; never under capture)."""
         end = len(self.names) if end is None else end
         for k, s in enumerate(self.stream_objs):
             self._vals[k] = s.value
-        rc = self.L.rd_optable_run(self.h, begin, end, self._vals, len(self.stream_objs), C.byref(self._failed))
+        if lanes > 1:
+            rc = self.L.rd_optable_run_mt(self.h, begin, end, self._vals, len(self.stream_objs), lanes, C.byref(self._failed))
+        else:
+            rc = self.L.rd_optable_run(self.h, begin, end, self._vals, len(self.stream_objs), C.byref(self._failed))
         if rc != 0:
             k = self._failed.value
             check(rc, self.names[k] if 0 <= k < len(self.names) else "rd_optable_run")

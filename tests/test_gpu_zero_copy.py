@@ -83,3 +83,36 @@ def test_eager_forward_after_an_in_place_step_reads_its_own_input(monkeypatch):
     l2, _ = ts.step(xa, ta)
     torch.cuda.synchronize()
     assert ts.plan._x_bound == xa.data_ptr() and l2.item() == l1
+
+
+@pytest.mark.parametrize("arch,lanes", [("resnet18_latefusion", 3), ("resnet18_multistage_uncertainty_fixs", 3), ("resnet18_latefusion", 2)])
+def test_multithreaded_issue_is_bit_identical(monkeypatch, arch, lanes):
+    """RD_ISSUE_THREADS=n: the step's ops are issued from n host threads, one per plan stream (rd_optable_run_mt; every
+    rd_stream_wait_event behind its rd_event_record).  Same launches in the same per-stream order: losses and parameters bit for bit
+    those of the single-threaded issue, over several steps."""
+    import types
+    from radar_depth_amd.main import HipTrainStep, create_model
+    from radar_depth_amd.synthetic import make_batch, procedural_fill_
+    b, h, w = 2, 97, 161
+    args = types.SimpleNamespace(arch=arch, decoder="upproj", modality="rgbd", pretrained=False)
+
+    def build():
+        torch.manual_seed(0)
+        made = create_model(args, [h, w])
+        m, lw = made if isinstance(made, tuple) else (made, None)
+        procedural_fill_(m)
+        return m.cuda(), lw
+    (m1, lw1), (m2, lw2) = build(), build()
+    monkeypatch.setenv("RD_ISSUE_THREADS", "1")
+    t1 = HipTrainStep(m1, b, h, w, loss_weights=lw1)
+    monkeypatch.setenv("RD_ISSUE_THREADS", str(lanes))
+    t2 = HipTrainStep(m2, b, h, w, loss_weights=lw2)
+    assert t1._issue_threads == 1 and t2._issue_threads == lanes
+    for it in range(4):
+        x, t = [v.cuda() for v in make_batch(b, h, w, 40 + it, ref_pixels=h * w)]
+        l1, _ = t1.step(x, t)
+        l2, _ = t2.step(x, t)
+        torch.cuda.synchronize()
+        assert l1.item() == l2.item(), (it, l1.item(), l2.item())
+    for p, q in zip(m1.parameters(), m2.parameters()):
+        assert torch.equal(p, q)
