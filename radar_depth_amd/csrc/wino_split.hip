@@ -75,9 +75,14 @@ __global__ __launch_bounds__(512) void wino_split_kernel(const WinoArgs a) {
     const int l31 = lane & 31, hh = lane >> 5;
 
     const int vid = xcd_remap(blockIdx.x, gridDim.x);
-    const int cot = vid % a.n_cot;
-    const int pt = vid / a.n_cot;
     const int nb_img = a.bh * a.bw;
+    // Many output-channel blocks (>= 256 channels): channel-block-major order -- xcd_remap hands every XCD a contiguous range of ids, so an XCD
+    // then works on ONE or two 64-channel blocks' weights (3.1 MB at 512 channels: inside its 4 MB L2) over all pixel blocks, instead of every
+    // XCD streaming all 25 MB of transformed weights out of the memory-side cache.  Few blocks: pixel-block-major (neighbours share halos).
+    const int n_pt = a.N * nb_img;
+    const bool cot_major = a.n_cot >= 4 && !(a.dbg & 128);
+    const int cot = cot_major ? vid / n_pt : vid % a.n_cot;
+    const int pt = cot_major ? vid - cot * n_pt : vid / a.n_cot;
     const int n = pt / nb_img;
     const int rem = pt - n * nb_img;
     const int by = rem / a.bw, bx = rem - by * a.bw;
