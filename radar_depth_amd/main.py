@@ -422,6 +422,13 @@ class HipTrainStep:
             xin, tgt = p.x_in.data_ptr(), self.target.data_ptr()
             self._bind_sites = [(i, k, a, 0 if a.value == xin else 1) for i, (_, _, args) in enumerate(self._ops) for k, a in enumerate(args)
                                 if isinstance(a, C.c_void_p) and a.value in (xin, tgt)]
+            # bind sites are found by pointer VALUE: an op that took the input at an offset (x_in + k) would keep reading the plan's static
+            # buffer after a re-binding, silently.  No op does -- the stems read x_in through their plane tables -- and this keeps it so.
+            spans = ((xin, p.x_in.numel() * p.x_in.element_size()), (tgt, self.target.numel() * self.target.element_size()))
+            inside = [(name, k) for name, _, args in self._ops for k, a in enumerate(args)
+                      if isinstance(a, C.c_void_p) and a.value and any(b < a.value < b + n for b, n in spans)]
+            if inside:
+                raise RuntimeError("ops take the input / target buffer at an interior offset, which zero-copy binding cannot re-point: %s" % inside[:4])
             self._bound = [xin, tgt]
         zc = (self._zero_copy and not self.use_graph and inputs.dtype == torch.float32 and target.dtype == torch.float32
               and inputs.is_contiguous() and target.is_contiguous() and inputs.shape[1] == p.x_in.shape[1]
