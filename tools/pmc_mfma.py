@@ -31,7 +31,7 @@ print("# rocprofv3 --pmc pass (--kernel-trace only) on tools/pmc_conv.py: B=16 f
 print("# layer2 3x3 128 @57x100, layer4 3x3 512 @15x25.  Averages per dispatch.  MFMA pipe utilisation =")
 print("# SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE/8 XCDs * 1024 SIMDs)   [GRBM_GUI_ACTIVE is summed over the 8 XCDs]")
 for (name, grid), (n, c) in sorted(agg.items(), key=lambda kv: -kv[1][1].get("GRBM_GUI_ACTIVE", 0)):
-    if "gconv" not in name and "wgrad" not in name:
+    if "gconv" not in name and "wgrad" not in name and "wino" not in name:
         continue
     g = {k: v / n for k, v in c.items()}
     if "SQ_LDS_IDX_ACTIVE" in g:       # the LDS pass (SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE): extra cycles / all LDS-array cycles
