@@ -56,7 +56,7 @@ struct WinoArgs {
     float* stat;
     int N, H, W, Cin, Cout, ldi, ldo, ld_add;
     int tiles_h, tiles_w, bh, bw, n_cot;
-    int dbg;                      // diagnostics (RD_WINO_DEBUG; results are then garbage): 1 no MFMAs, 2 no split / A stores, 4 no weight loads, 8 no epilogue
+    int dbg;                      // diagnostics (RD_WINO_DEBUG; results are then garbage): 1 no MFMAs, 2 no split / A stores, 4 no weight loads, 8 no epilogue, 32 / 64 staging / MFMA waves idle, 128 pixel-block-major order, 256 no patch loads
 };
 
 __device__ __forceinline__ unsigned wn_cvt_pk(float a, float b) {
@@ -118,8 +118,13 @@ __global__ __launch_bounds__(512) void wino_split_kernel(const WinoArgs a) {
         const unsigned img_bytes = (unsigned)(a.H * a.W * a.ldi) * 4u;
         const unsigned a_dst = (unsigned)(size_t)wsm + (unsigned)(kh * 512 + tl * 16 + q4 * 4);       // inside one (position, piece) plane pair
 
-        wf32x2 raw[3][16];      // three chunks in flight: HBM / L2 latency under load is ~3 k clocks, a chunk ~1.6 k
+        wf32x2 raw[2][16];
         auto fetch = [&](int c, wf32x2 (&rw)[16]) {
+            if (a.dbg & 256) {      // diagnostics: no patch loads (every value = the lane's tile index)
+#pragma unroll
+                for (int p = 0; p < 16; ++p) { rw[p][0] = (float)tl; rw[p][1] = (float)(p + c); }
+                return;
+            }
             const int cc = rot(c);
             const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(in_n + cc * 64), 0, img_bytes - cc * 64, 0x00020000);
 #pragma unroll
@@ -177,47 +182,30 @@ __global__ __launch_bounds__(512) void wino_split_kernel(const WinoArgs a) {
         // prologue: chunk 0 into buffer 0; chunks 1 and 2 in flight
         fetch(0, raw[0]);
         if (nchunks > 1) fetch(1, raw[1]);
-        if (nchunks > 2) fetch(2, raw[2]);
-        if (nchunks > 2) asm volatile("s_waitcnt vmcnt(32)" ::: "memory");
-        else if (nchunks > 1) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+        if (nchunks > 1) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         transform(raw[0], 0);
+        if (nchunks > 2) fetch(2, raw[0]);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
-        // interval c: the compute waves read buffer c & 1.  First thing, chunk c + 3 goes out (into the register set chunk c left in the
-        // previous interval): TWO full intervals of lead; then buffer (c + 1) & 1 <- chunk c + 1, which has had them.
-        auto interval = [&](int c, auto set_, auto slot_) {
-            constexpr int set = decltype(set_)::value, slot = decltype(slot_)::value;      // == (c + 1) % 3, (c + 1) & 1
-            constexpr int nset = (set + 2) % 3;                                              // == (c + 3) % 3: chunk c's set, free
-            if (c + 3 < nchunks) fetch(c + 3, raw[nset]);
+        // interval c: the compute waves read buffer c & 1; buffer (c + 1) & 1 <- chunk c + 1 (fetched two intervals ago); chunk c + 3 goes out
+        auto interval = [&](int c, auto par_) {
+            constexpr int par = decltype(par_)::value;      // == (c + 1) & 1: the register set AND the buffer of chunk c + 1
             if (c + 1 < nchunks) {
-                // outstanding, oldest first: chunk c + 1, c + 2, c + 3 (those that exist)
-                if (c + 3 < nchunks) asm volatile("s_waitcnt vmcnt(32)" ::: "memory");
-                else if (c + 2 < nchunks) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+                if (c + 2 < nchunks) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");      // chunk c + 1 is in, chunk c + 2 may still be in flight
                 else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                transform(raw[set], slot);
+                transform(raw[par], par);
+                if (c + 3 < nchunks) fetch(c + 3, raw[par]);
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
         };
-        using I0 = std::integral_constant<int, 0>;
-        using I1 = std::integral_constant<int, 1>;
-        using I2 = std::integral_constant<int, 2>;
         int c = 0;
-        for (;;) {      // six intervals per trip: register set and buffer are compile-time
-            if (c >= nchunks) break;
-            interval(c++, I1{}, I1{});
-            if (c >= nchunks) break;
-            interval(c++, I2{}, I0{});
-            if (c >= nchunks) break;
-            interval(c++, I0{}, I1{});
-            if (c >= nchunks) break;
-            interval(c++, I1{}, I0{});
-            if (c >= nchunks) break;
-            interval(c++, I2{}, I1{});
-            if (c >= nchunks) break;
-            interval(c++, I0{}, I0{});
+        for (; c + 2 <= nchunks; c += 2) {
+            interval(c, std::integral_constant<int, 1>{});
+            interval(c + 1, std::integral_constant<int, 0>{});
         }
+        if (c < nchunks) interval(c, std::integral_constant<int, 1>{});
     } else {
         // ---------------------------------------------------------------------------------------------- compute waves
 #pragma unroll
@@ -245,18 +233,17 @@ __global__ __launch_bounds__(512) void wino_split_kernel(const WinoArgs a) {
 #pragma unroll
                 for (int nb = 0; nb < 2; ++nb) B[p][nb] = *reinterpret_cast<const wbf16x8*>(src + p * 2048 + nb * 512);
         };
-        wbf16x8 Bq[4][3][2];      // ring of four steps = one slot per row i: B of step (c, i) lives in Bq[i], fetched THREE steps ahead
+        wbf16x8 Bq[3][3][2];      // ring of three steps: B of step s lives in Bq[s % 3]
         wbf16x8 A[2][3];
         loadB(0, Bq[0]);
         loadB(1, Bq[1]);
-        loadB(2, Bq[2]);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
-        auto step = [&](const char* abuf, int st, auto i_) {
-            constexpr int i = decltype(i_)::value, ring = i;
-            // (the chunk's first A fragments are read behind its barrier, the others one step ahead)
-            loadB(st + 3, Bq[(i + 3) & 3]);
-            __builtin_amdgcn_sched_barrier(0);      // (the scheduler otherwise sinks these loads next to their uses, three steps later: no lead)
+        // twelve steps (three chunks) per trip: ring index and accumulator row are compile-time
+        auto step = [&](const char* abuf, int st, auto i_, auto ring_) {
+            constexpr int i = decltype(i_)::value, ring = decltype(ring_)::value;
+            // this step's A fragments (the phase's first are read behind its barrier, the others one step ahead -- see below)
+            loadB(st + 2, Bq[(ring + 2) % 3]);
             if (i < 3) {
 #pragma unroll
                 for (int p = 0; p < 3; ++p) A[(i + 1) & 1][p] = *reinterpret_cast<const wbf16x8*>(abuf + a_off + ((i + 1) * 4 * 3 + p) * 1024);
@@ -271,20 +258,27 @@ __global__ __launch_bounds__(512) void wino_split_kernel(const WinoArgs a) {
                 }
                 acc[i][nb] = cc;
             }
-            __builtin_amdgcn_sched_barrier(0);
         };
-        auto chunk = [&](int c) {
+        auto chunk = [&](int c, auto r0_) {
+            constexpr int r0 = decltype(r0_)::value;       // ring index of the chunk's first step = (4 c) % 3
             const char* abuf = wsm + (c & 1) * WN_BUF;
 #pragma unroll
             for (int p = 0; p < 3; ++p) A[0][p] = *reinterpret_cast<const wbf16x8*>(abuf + a_off + p * 1024);
-            step(abuf, 4 * c + 0, std::integral_constant<int, 0>{});
-            step(abuf, 4 * c + 1, std::integral_constant<int, 1>{});
-            step(abuf, 4 * c + 2, std::integral_constant<int, 2>{});
-            step(abuf, 4 * c + 3, std::integral_constant<int, 3>{});
+            step(abuf, 4 * c + 0, std::integral_constant<int, 0>{}, std::integral_constant<int, (r0 + 0) % 3>{});
+            step(abuf, 4 * c + 1, std::integral_constant<int, 1>{}, std::integral_constant<int, (r0 + 1) % 3>{});
+            step(abuf, 4 * c + 2, std::integral_constant<int, 2>{}, std::integral_constant<int, (r0 + 2) % 3>{});
+            step(abuf, 4 * c + 3, std::integral_constant<int, 3>{}, std::integral_constant<int, (r0 + 3) % 3>{});
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
         };
-        for (int c = 0; c < nchunks; ++c) chunk(c);
+        int c = 0;
+        for (; c + 3 <= nchunks; c += 3) {
+            chunk(c, std::integral_constant<int, 0>{});
+            chunk(c + 1, std::integral_constant<int, 1>{});
+            chunk(c + 2, std::integral_constant<int, 2>{});
+        }
+        if (c < nchunks) { chunk(c, std::integral_constant<int, 0>{}); ++c; }
+        if (c < nchunks) { chunk(c, std::integral_constant<int, 1>{}); ++c; }
     }
 epilogue:
     if (a.dbg & 8) return;
