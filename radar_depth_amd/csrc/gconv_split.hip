@@ -416,7 +416,15 @@ __global__ __launch_bounds__(512) void gconv_split_kernel(const GsArgs a) {
             const bool more = c + 1 < nchunks;
             for (int g = 0; g < ngroups; ++g, ++it) {
                 if (ltr && it < 30) ltr[2 * it] = __builtin_readcyclecounter();
-                rd_sync();                        // B1(it)
+                // B1(it) as a RAW s_barrier behind an explicit LDS wait (round 6).  rd_sync()'s __syncthreads is a workgroup-scope release fence:
+                // with stores possibly in flight -- the diagnostic stamps of `ltr` above are global stores, taken or not -- hipcc puts an
+                // s_waitcnt vmcnt(0) in front of the barrier, and on gfx9 that counter also holds this wave's LOADS: the next chunk's patch
+                // fetch, which the counted wait at the end of the previous iteration had deliberately left in flight, was drained at every
+                // tap group (ISA: `s_waitcnt vmcnt(0) lgkmcnt(0); s_barrier` in this loop).  What this barrier publishes -- the weight
+                // copies and the patch stores of the previous iteration -- has been waited for explicitly at that iteration's end.
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+                asm volatile("" ::: "memory");
                 if (ltr && it < 30) ltr[2 * it + 1] = __builtin_readcyclecounter();
                 // this group's weight copies first: the split arithmetic / the patch stores below run while they are in flight
                 if (it + 2 < total_groups) issue_slab(wi, c2 * GS_CKP, g2);
@@ -429,7 +437,11 @@ __global__ __launch_bounds__(512) void gconv_split_kernel(const GsArgs a) {
                     //  layer3 -- and without -- 170 -> 189 us on layer1: in the first group the patch loads have not landed yet)
                     if (g == gsplit) split_units(U0, UN);
                     if (g == ngroups - 1) {
-                        if constexpr (!PDB) rd_sync();    // B2: the compute waves are done with this chunk's patch
+                        if constexpr (!PDB) {             // B2: the compute waves are done with this chunk's patch (raw barrier: see B1)
+                            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                            __builtin_amdgcn_s_barrier();
+                            asm volatile("" ::: "memory");
+                        }
                         put_units(PDB ? ((c + 1) & 1) : 0, U0, UN);
                     }
                 }
