@@ -158,6 +158,15 @@ int rd_gconv_split_plan_info(const RdConvDesc* d, int32_t* out);
  * issue nothing but global_load_lds copies.  Same result bit for bit as rd_gconv_split on the tensor the planes were made from when
  * both run the same tile; the plan (hence rd_gconv_split_pre_stat_tiles) is its own. */
 int rd_split_pieces(const float* x, int32_t ldx, int64_t M, int32_t C, void* pieces, int64_t piece_elems, void* stream);
+/* rd_gconv_bnbwd's contract on the split kernels (round 6): the input-gradient launch of a conv -> BatchNorm -> act -> conv chain also
+ * emits that BatchNorm's backward sums (red_partial [rd_gconv_split[_pre]_stat_tiles(d)][3][Cout]: slot 0 = sum g, slot 1 = sum g (x - mean),
+ * g = dx * act'(scale x + shift)); no addend, four-channel alignment, not for one-tap descriptors.  pre != 0 asks about the pre-split form. */
+int rd_gconv_split_bnbwd_supported(const RdConvDesc* d, int32_t pre);
+int rd_gconv_split_bnbwd(const RdConvDesc* d, const float* in, const void* w_split, int64_t piece_elems, float* out, const float* bn_x,
+                         int32_t bn_ld, const float* mean, const float* scale, const float* shift, int32_t bn_act, float* red_partial, void* stream);
+int rd_gconv_split_pre_bnbwd(const RdConvDesc* d, const void* in_pieces, int64_t in_piece_elems, const void* w_split, int64_t piece_elems,
+                             float* out, const float* bn_x, int32_t bn_ld, const float* mean, const float* scale, const float* shift,
+                             int32_t bn_act, float* red_partial, void* stream);
 int rd_gconv_split_pre_supported(const RdConvDesc* d);
 /* 1 when the pre-split form is expected to be the fastest plan for d including its producer's extra piece pass (planner rule from the
  * measurements in profiles/r04_*): what engine.py asks before it routes a convolution through rd_gconv_split_pre */
@@ -517,6 +526,12 @@ int rd_wino_pack_batched(const void* jobs, const int32_t* block_job, int32_t n_b
 int rd_wino_stat_tiles(int32_t N, int32_t H, int32_t W);
 int rd_wino_conv3x3(const float* in, int32_t N, int32_t H, int32_t W, int32_t Cin, int32_t ldi, const void* u_packed, float* out,
                     int32_t Cout, int32_t ldo, const float* addend, int32_t ld_add, float* stat_partial, void* stream);
+/* the input gradient of a Winograd layer + the backward sums of the BatchNorm in front of the convolution in one launch: rd_gconv_bnbwd's
+ * contract (bn_x = that BatchNorm's input [N,H,W,Cout], channel stride bn_ld; red_partial [rd_wino_stat_tiles][3][Cout]: sum g,
+ * sum g (x - mean), g = dx * act'(scale x + shift)).  Replaces the rd_bn_bwd_reduce_x_t pass of a conv -> BN -> act -> conv chain. */
+int rd_wino_conv3x3_bnbwd(const float* in, int32_t N, int32_t H, int32_t W, int32_t Cin, int32_t ldi, const void* u_packed, float* out,
+                          int32_t Cout, int32_t ldo, const float* bn_x, int32_t bn_ld, const float* mean, const float* scale, const float* shift,
+                          int32_t bn_act, float* red_partial, void* stream);
 
 /* Diagnostics (bench.py `roofline.shader_clock_mhz`): n_blocks (<= 64) one-wave workgroups each sleep for duration_us and write
  * out[4 * block + 0..3] = { shader clocks elapsed (s_memtime), 10-ns ticks elapsed (s_memrealtime), XCC_ID, start tick }:

@@ -78,6 +78,14 @@ struct GsArgs {
     // pad columns) and the table [phase][BM]: (r << 16) | c of the tile pixel slot m holds, -(1 + residue of the lane) for an empty slot
     int ppitch[RD_MAX_PHASES];
     const int* slots;
+    // BNB instantiations (rd_gconv_split_bnbwd / rd_gconv_split_pre_bnbwd): this launch is the input gradient of a convolution whose forward
+    // input was act(BatchNorm(bnb_x)); the epilogue also emits that BatchNorm's backward sums -- sum g and sum g (x - mean), g = dx * act'
+    // -- into stat as [tile][3][Cout] (gconv.hip's BNB contract: the separate reduce pass over dx and x disappears)
+    const float* bnb_x;
+    const float* bnb_scale;
+    const float* bnb_shift;
+    const float* bnb_mean;
+    int bnb_ld, bnb_act;
 };
 
 // wait until at most n of this wave's vector-memory operations (global_load_lds copies included) are outstanding, n known only at
@@ -128,7 +136,7 @@ __device__ __forceinline__ void split8(const float4 v0, const float4 v1, sbf16x8
 // rows land as [piece][8-channel unit][patch pixel] x 16 B (lane-linear: consecutive pixels in consecutive 16-byte slots, which is
 // also what keeps the compute waves' ds_read_b128 passes conflict-free), out-of-image positions are zeroed once per workgroup and
 // never written again (their lanes are masked in every copy).
-template <int MT, int NT, bool PDB, bool PRE>
+template <int MT, int NT, bool PDB, bool PRE, bool BNB = false>
 __global__ __launch_bounds__(512) void gconv_split_kernel(const GsArgs a) {
     static_assert(!PRE || PDB, "the pre-split form copies the next chunk's patch while the current one is read: two patch buffers");
     constexpr int BM = 4 * MT * 32;
@@ -684,11 +692,21 @@ __global__ __launch_bounds__(512) void gconv_split_kernel(const GsArgs a) {
             if (a.vec4) {
                 any4 = true;
                 const int cq = co0 + 4 * k4l;
-                float4 addv[NT][4];
-                if (has_add) {
+                float4 addv[NT][4];      // the residual addend, or (BNB) the BatchNorm input x at the output pixels
+                float4 bS[NT], bT[NT], bM[NT];
+                if constexpr (BNB) {
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt) {
+                        const bool on = cq + nt * 32 < D.Cout;
+                        bS[nt] = on ? ld4(a.bnb_scale + cq + nt * 32) : make_float4(0.f, 0.f, 0.f, 0.f);
+                        bT[nt] = on ? ld4(a.bnb_shift + cq + nt * 32) : make_float4(0.f, 0.f, 0.f, 0.f);
+                        bM[nt] = on ? ld4(a.bnb_mean + cq + nt * 32) : make_float4(0.f, 0.f, 0.f, 0.f);
+                    }
+                }
+                if (has_add || BNB) {
 #pragma unroll
                     for (int g = 0; g < 4; ++g) {
-                        const float* ap = a.addend + (size_t)ro4[g] * a.ld_add + cq;
+                        const float* ap = BNB ? a.bnb_x + (size_t)ro4[g] * a.bnb_ld + cq : a.addend + (size_t)ro4[g] * a.ld_add + cq;
 #pragma unroll
                         for (int nt = 0; nt < NT; ++nt) addv[nt][g] = (cq + nt * 32 < D.Cout) ? ld4(ap + nt * 32) : make_float4(0.f, 0.f, 0.f, 0.f);
                     }
@@ -703,15 +721,26 @@ __global__ __launch_bounds__(512) void gconv_split_kernel(const GsArgs a) {
                         float e0 = acc[mt][nt][4 * g], e1 = acc[mt][nt][4 * g + 1], e2 = acc[mt][nt][4 * g + 2], e3 = acc[mt][nt][4 * g + 3];
                         quad_transpose(e0, e1, e2, e3, odd1, odd2);
                         float4 v = make_float4(e0 + b4.x, e1 + b4.y, e2 + b4.z, e3 + b4.w);
-                        if (has_add) { v.x += addv[nt][g].x; v.y += addv[nt][g].y; v.z += addv[nt][g].z; v.w += addv[nt][g].w; }
+                        if (has_add && !BNB) { v.x += addv[nt][g].x; v.y += addv[nt][g].y; v.z += addv[nt][g].z; v.w += addv[nt][g].w; }
                         const int cc = cq + nt * 32;
                         if (cc < a.act_cols) {
                             v.x = act_fwd(v.x, a.act); v.y = act_fwd(v.y, a.act); v.z = act_fwd(v.z, a.act); v.w = act_fwd(v.w, a.act);
                         }
                         if (cok4 && rok4[g]) st4(a.out + (size_t)ro4[g] * D.ldo + cc, v);
                         if (want_stat && rok4[g]) {
-                            ssum4[nt].x += v.x; ssum4[nt].y += v.y; ssum4[nt].z += v.z; ssum4[nt].w += v.w;
-                            ssq4[nt].x += v.x * v.x; ssq4[nt].y += v.y * v.y; ssq4[nt].z += v.z * v.z; ssq4[nt].w += v.w * v.w;
+                            if constexpr (BNB) {
+                                const float4 xv = addv[nt][g];
+                                const float gx = v.x * act_grad_from_out(fmaf(bS[nt].x, xv.x, bT[nt].x), a.bnb_act);
+                                const float gy = v.y * act_grad_from_out(fmaf(bS[nt].y, xv.y, bT[nt].y), a.bnb_act);
+                                const float gz = v.z * act_grad_from_out(fmaf(bS[nt].z, xv.z, bT[nt].z), a.bnb_act);
+                                const float gw = v.w * act_grad_from_out(fmaf(bS[nt].w, xv.w, bT[nt].w), a.bnb_act);
+                                ssum4[nt].x += gx; ssum4[nt].y += gy; ssum4[nt].z += gz; ssum4[nt].w += gw;
+                                ssq4[nt].x += gx * (xv.x - bM[nt].x); ssq4[nt].y += gy * (xv.y - bM[nt].y);
+                                ssq4[nt].z += gz * (xv.z - bM[nt].z); ssq4[nt].w += gw * (xv.w - bM[nt].w);
+                            } else {
+                                ssum4[nt].x += v.x; ssum4[nt].y += v.y; ssum4[nt].z += v.z; ssum4[nt].w += v.w;
+                                ssq4[nt].x += v.x * v.x; ssq4[nt].y += v.y * v.y; ssq4[nt].z += v.z * v.z; ssq4[nt].w += v.w * v.w;
+                            }
                         }
                     }
                 }
@@ -771,7 +800,7 @@ __global__ __launch_bounds__(512) void gconv_split_kernel(const GsArgs a) {
 #pragma unroll
             for (int w = 0; w < 4; ++w) s += red[(w * 2 + which) * BN + j];
             const int co = co0 + j;
-            if (co < D.Cout) a.stat[((size_t)pt * 2 + which) * D.Cout + co] = s;
+            if (co < D.Cout) a.stat[((size_t)pt * (BNB ? 3 : 2) + which) * D.Cout + co] = s;
         }
     }
     if (a.trace && a.trace_role == 1 && tid == 0) a.trace[(size_t)blockIdx.x * 64 + 61] = __builtin_readcyclecounter();
@@ -795,7 +824,7 @@ __global__ __launch_bounds__(512) void gconv_split_kernel(const GsArgs a) {
 //               copy issued at the start of each group.
 //   loop      : per tap group: wait for the own copies, barrier, issue the next group's weights, three MFMA steps with the next step's
 //               fragment reads interleaved; per chunk one more barrier before the patch is overwritten.
-template <int MT, int NT, int DBG = 0>      // DBG (diagnostics, tools/ablate_gconv_split.py): 1 no MFMAs, 2 no fragment reads -- compile-time: a
+template <int MT, int NT, int DBG = 0, bool BNB = false>      // DBG (diagnostics, tools/ablate_gconv_split.py): 1 no MFMAs, 2 no fragment reads -- compile-time: a
                                             // run-time test inside the step splits the basic block the read / MFMA interleaving lives in
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void gconv_sp2_kernel(const GsArgs a) {
     constexpr int BM = 4 * MT * 32;
@@ -1066,11 +1095,21 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void g
             if (a.vec4) {
                 any4 = true;
                 const int cq = co0 + 4 * k4l;
-                float4 addv[NT][4];
-                if (has_add) {
+                float4 addv[NT][4];      // the residual addend, or (BNB) the BatchNorm input x at the output pixels
+                float4 bS[NT], bT[NT], bM[NT];
+                if constexpr (BNB) {
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt) {
+                        const bool on = cq + nt * 32 < D.Cout;
+                        bS[nt] = on ? ld4(a.bnb_scale + cq + nt * 32) : make_float4(0.f, 0.f, 0.f, 0.f);
+                        bT[nt] = on ? ld4(a.bnb_shift + cq + nt * 32) : make_float4(0.f, 0.f, 0.f, 0.f);
+                        bM[nt] = on ? ld4(a.bnb_mean + cq + nt * 32) : make_float4(0.f, 0.f, 0.f, 0.f);
+                    }
+                }
+                if (has_add || BNB) {
 #pragma unroll
                     for (int q = 0; q < 4; ++q) {
-                        const float* ap = a.addend + (size_t)ro4[q] * a.ld_add + cq;
+                        const float* ap = BNB ? a.bnb_x + (size_t)ro4[q] * a.bnb_ld + cq : a.addend + (size_t)ro4[q] * a.ld_add + cq;
 #pragma unroll
                         for (int nt = 0; nt < NT; ++nt) addv[nt][q] = (cq + nt * 32 < D.Cout) ? ld4(ap + nt * 32) : make_float4(0.f, 0.f, 0.f, 0.f);
                     }
@@ -1085,15 +1124,26 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void g
                         float e0 = acc[mt][nt][4 * q], e1 = acc[mt][nt][4 * q + 1], e2 = acc[mt][nt][4 * q + 2], e3 = acc[mt][nt][4 * q + 3];
                         quad_transpose(e0, e1, e2, e3, odd1, odd2);
                         float4 v = make_float4(e0 + b4.x, e1 + b4.y, e2 + b4.z, e3 + b4.w);
-                        if (has_add) { v.x += addv[nt][q].x; v.y += addv[nt][q].y; v.z += addv[nt][q].z; v.w += addv[nt][q].w; }
+                        if (has_add && !BNB) { v.x += addv[nt][q].x; v.y += addv[nt][q].y; v.z += addv[nt][q].z; v.w += addv[nt][q].w; }
                         const int cc = cq + nt * 32;
                         if (cc < a.act_cols) {
                             v.x = act_fwd(v.x, a.act); v.y = act_fwd(v.y, a.act); v.z = act_fwd(v.z, a.act); v.w = act_fwd(v.w, a.act);
                         }
                         if (cok4 && rok4[q]) st4(a.out + (size_t)ro4[q] * D.ldo + cc, v);
                         if (want_stat && rok4[q]) {
-                            ssum4[nt].x += v.x; ssum4[nt].y += v.y; ssum4[nt].z += v.z; ssum4[nt].w += v.w;
-                            ssq4[nt].x += v.x * v.x; ssq4[nt].y += v.y * v.y; ssq4[nt].z += v.z * v.z; ssq4[nt].w += v.w * v.w;
+                            if constexpr (BNB) {
+                                const float4 xv = addv[nt][q];
+                                const float gx = v.x * act_grad_from_out(fmaf(bS[nt].x, xv.x, bT[nt].x), a.bnb_act);
+                                const float gy = v.y * act_grad_from_out(fmaf(bS[nt].y, xv.y, bT[nt].y), a.bnb_act);
+                                const float gz = v.z * act_grad_from_out(fmaf(bS[nt].z, xv.z, bT[nt].z), a.bnb_act);
+                                const float gw = v.w * act_grad_from_out(fmaf(bS[nt].w, xv.w, bT[nt].w), a.bnb_act);
+                                ssum4[nt].x += gx; ssum4[nt].y += gy; ssum4[nt].z += gz; ssum4[nt].w += gw;
+                                ssq4[nt].x += gx * (xv.x - bM[nt].x); ssq4[nt].y += gy * (xv.y - bM[nt].y);
+                                ssq4[nt].z += gz * (xv.z - bM[nt].z); ssq4[nt].w += gw * (xv.w - bM[nt].w);
+                            } else {
+                                ssum4[nt].x += v.x; ssum4[nt].y += v.y; ssum4[nt].z += v.z; ssum4[nt].w += v.w;
+                                ssq4[nt].x += v.x * v.x; ssq4[nt].y += v.y * v.y; ssq4[nt].z += v.z * v.z; ssq4[nt].w += v.w * v.w;
+                            }
                         }
                     }
                 }
@@ -1151,7 +1201,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void g
 #pragma unroll
             for (int w = 0; w < 4; ++w) s += red[(w * 2 + which) * BN + j];
             const int co = co0 + j;
-            if (co < D.Cout) a.stat[((size_t)pt * 2 + which) * D.Cout + co] = s;
+            if (co < D.Cout) a.stat[((size_t)pt * (BNB ? 3 : 2) + which) * D.Cout + co] = s;
         }
     }
     if (a.trace && a.trace_role == 1 && tid == 0) {
@@ -1345,20 +1395,20 @@ static bool plan_sp2(const RdConvDesc& d, GsPlan& best) {
     return best_cost > 0;
 }
 
-template <int MT, int NT, int DBG = 0>
+template <int MT, int NT, int DBG = 0, bool BNB = false>
 static int launch_sp2(const GsArgs& a, int grid, size_t lds, hipStream_t s) {
     static std::atomic<unsigned long long> attr_set{0};
-    auto k = gconv_sp2_kernel<MT, NT, DBG>;
+    auto k = gconv_sp2_kernel<MT, NT, DBG, BNB>;
     RD_SET_ATTR_ONCE(attr_set, hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
     hipLaunchKernelGGL(k, dim3(grid), dim3(256), lds, s, a);
     RD_CHECK_LAUNCH("gconv_sp2_kernel");
     return RD_OK;
 }
 
-template <int MT, int NT, bool PDB, bool PRE>
+template <int MT, int NT, bool PDB, bool PRE, bool BNB = false>
 static int launch_gs(const GsArgs& a, int grid, size_t lds, hipStream_t s) {
     static std::atomic<unsigned long long> attr_set{0};
-    auto k = gconv_split_kernel<MT, NT, PDB, PRE>;
+    auto k = gconv_split_kernel<MT, NT, PDB, PRE, BNB>;
     RD_SET_ATTR_ONCE(attr_set, hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     hipLaunchKernelGGL(k, dim3(grid), dim3(512), lds, s, a);
     RD_CHECK_LAUNCH("gconv_split_kernel");
@@ -1542,12 +1592,24 @@ extern "C" int rd_gconv_split_stat_tiles(const RdConvDesc* d) {
     return d->N * pl.tiles_total;
 }
 
+struct GsBnb {      // rd_gconv_split[_pre]_bnbwd: the BatchNorm whose backward sums this input-gradient launch also emits (x == nullptr: none)
+    const float* x = nullptr;
+    int ld = 0;
+    const float* mean = nullptr;
+    const float* scale = nullptr;
+    const float* shift = nullptr;
+    int act = 0;
+};
+
 static int gs_launch(const RdConvDesc* d, const float* in, const void* in_pieces, int64_t in_piece_elems, const void* w_split, int64_t piece_elems,
-                     float* out, const float* bias, int32_t act, int32_t act_cols, const float* addend, int32_t ld_add, float* stat_partial, void* stream) {
+                     float* out, const float* bias, int32_t act, int32_t act_cols, const float* addend, int32_t ld_add, float* stat_partial, void* stream,
+                     const GsBnb& bnb = GsBnb()) {
     const bool pre = in_pieces != nullptr;
     RD_CHECK_ARG(d && (in || in_pieces) && w_split && out, "gconv_split: null argument");
-    if (!pre && gemm1_split_supported(d))
+    if (!pre && gemm1_split_supported(d)) {
+        RD_CHECK_ARG(!bnb.x, "gconv_split_bnbwd: one-tap descriptors are not served (rd_gconv_split_bnbwd_supported)");
         return launch_gemm1_split(d, in, w_split, piece_elems, out, bias, act, act_cols, addend, ld_add, stat_partial, static_cast<hipStream_t>(stream));
+    }
     GsArgs a;
     GsPlan pl;
     if (gs_plan_query(d, pl, a.d, pre) != 1) { set_error("gconv_split: descriptor not supported (rd_gconv_split_supported)"); return RD_EINVAL; }
@@ -1579,6 +1641,13 @@ static int gs_launch(const RdConvDesc* d, const float* in, const void* in_pieces
         for (int t = 0; t < p.n_taps; ++t) a.tapoff[i][t] = ((p.dh[t] - p.dh_min) * PW_ + (p.dw[t] - p.dw_min)) * (pre ? 16 : GS_PSB);
     }
     for (int i = 0; i < RD_MAX_PHASES; ++i) a.ppitch[i] = pl.ppitch[i];
+    a.bnb_x = bnb.x; a.bnb_ld = bnb.ld; a.bnb_mean = bnb.mean; a.bnb_scale = bnb.scale; a.bnb_shift = bnb.shift; a.bnb_act = bnb.act;
+    if (bnb.x) {
+        RD_CHECK_ARG(bnb.mean && bnb.scale && bnb.shift && stat_partial && !addend && !bias && act == 0, "gconv_split_bnbwd: bad arguments");
+        RD_CHECK_ARG(a.vec4 && bnb.ld % 4 == 0 && reinterpret_cast<uintptr_t>(bnb.x) % 16 == 0 && reinterpret_cast<uintptr_t>(bnb.mean) % 16 == 0 &&
+                         reinterpret_cast<uintptr_t>(bnb.scale) % 16 == 0 && reinterpret_cast<uintptr_t>(bnb.shift) % 16 == 0,
+                     "gconv_split_bnbwd: four-channel alignment of every tensor and stride required");
+    }
     a.slots = gs_slot_table(d, pre, pl);
     if (!a.slots) { set_error("gconv_split: cannot allocate the slot table of the plan"); return RD_ELAUNCH; }
     const int grid = d->N * pl.tiles_total * pl.n_cotiles;
@@ -1598,6 +1667,24 @@ static int gs_launch(const RdConvDesc* d, const float* in, const void* in_pieces
             a.trace = g_gs_trace;
             a.trace_role = atoi(tr);
         }
+    }
+    if (bnb.x) {
+        // the BNB instantiations (epilogue also emits the BatchNorm-backward sums)
+        if (pl.sp2) {
+            if (pl.MT == 2 && pl.NT == 2) return launch_sp2<2, 2, 0, true>(a, grid, pl.lds_bytes, s);
+            if (pl.MT == 1 && pl.NT == 2) return launch_sp2<1, 2, 0, true>(a, grid, pl.lds_bytes, s);
+            if (pl.MT == 2 && pl.NT == 1) return launch_sp2<2, 1, 0, true>(a, grid, pl.lds_bytes, s);
+            if (pl.MT == 1 && pl.NT == 1) return launch_sp2<1, 1, 0, true>(a, grid, pl.lds_bytes, s);
+            if (pl.MT == 3 && pl.NT == 1) return launch_sp2<3, 1, 0, true>(a, grid, pl.lds_bytes, s);
+        }
+#define RD_GSB(MT_, NT_)                                                                                                              \
+    if (pl.MT == MT_ && pl.NT == NT_)                                                                                                 \
+        return pre ? launch_gs<MT_, NT_, true, true, true>(a, grid, pl.lds_bytes, s)                                                  \
+                   : pl.pdb ? launch_gs<MT_, NT_, true, false, true>(a, grid, pl.lds_bytes, s) : launch_gs<MT_, NT_, false, false, true>(a, grid, pl.lds_bytes, s);
+        RD_GSB(3, 2) RD_GSB(2, 2) RD_GSB(1, 2) RD_GSB(2, 1) RD_GSB(1, 1)
+#undef RD_GSB
+        set_error("gconv_split_bnbwd: no kernel for tile %dx%d", pl.MT, pl.NT);
+        return RD_EINVAL;
     }
     if (pl.sp2) {
         if (pl.MT == 2 && pl.NT == 2 && (a.dbg & 3) == 1) return launch_sp2<2, 2, 1>(a, grid, pl.lds_bytes, s);      // (ablations of the main tile only)
@@ -1632,6 +1719,34 @@ extern "C" int rd_gconv_split_pre(const RdConvDesc* d, const void* in_pieces, in
                                   const float* bias, int32_t act, int32_t act_cols, const float* addend, int32_t ld_add, float* stat_partial, void* stream) {
     RD_CHECK_ARG(in_pieces != nullptr, "gconv_split_pre: null argument");
     return gs_launch(d, nullptr, in_pieces, in_piece_elems, w_split, piece_elems, out, bias, act, act_cols, addend, ld_add, stat_partial, stream);
+}
+
+// Input gradient + the BatchNorm-backward sums of the BatchNorm in front of the convolution, in one launch (rd_gconv_bnbwd's contract on the
+// split kernels): d is the input-gradient descriptor, out = dx (no addend), bn_x = the BatchNorm's input (the raw output of the previous
+// convolution, [N,Ho,Wo,Cout] with channel stride bn_ld), mean / scale / shift its per-channel coefficients, act the activation behind it;
+// red_partial [rd_gconv_split[_pre]_stat_tiles(d)][3][Cout]: slot 0 = sum g, slot 1 = sum g (x - mean), g = dx * act'(scale x + shift)
+// -- what rd_bn_bwd_reduce_x_t computes in a pass of its own over dx and x.  Not for one-tap descriptors.
+extern "C" int rd_gconv_split_bnbwd_supported(const RdConvDesc* d, int32_t pre) {
+    GsPlan pl; RdConvDesc dd;
+    if (!d || d->Cout % 4 != 0 || d->ldo % 4 != 0) return 0;
+    if (!pre && gemm1_split_supported(d)) return 0;
+    return gs_plan_query(d, pl, dd, pre != 0);
+}
+extern "C" int rd_gconv_split_bnbwd(const RdConvDesc* d, const float* in, const void* w_split, int64_t piece_elems, float* out, const float* bn_x,
+                                    int32_t bn_ld, const float* mean, const float* scale, const float* shift, int32_t bn_act, float* red_partial,
+                                    void* stream) {
+    RD_CHECK_ARG(in && bn_x, "gconv_split_bnbwd: null argument");
+    GsBnb b;
+    b.x = bn_x; b.ld = bn_ld; b.mean = mean; b.scale = scale; b.shift = shift; b.act = bn_act;
+    return gs_launch(d, in, nullptr, 0, w_split, piece_elems, out, nullptr, 0, 0, nullptr, 0, red_partial, stream, b);
+}
+extern "C" int rd_gconv_split_pre_bnbwd(const RdConvDesc* d, const void* in_pieces, int64_t in_piece_elems, const void* w_split, int64_t piece_elems,
+                                        float* out, const float* bn_x, int32_t bn_ld, const float* mean, const float* scale, const float* shift,
+                                        int32_t bn_act, float* red_partial, void* stream) {
+    RD_CHECK_ARG(in_pieces && bn_x, "gconv_split_pre_bnbwd: null argument");
+    GsBnb b;
+    b.x = bn_x; b.ld = bn_ld; b.mean = mean; b.scale = scale; b.shift = shift; b.act = bn_act;
+    return gs_launch(d, nullptr, in_pieces, in_piece_elems, w_split, piece_elems, out, nullptr, 0, 0, nullptr, 0, red_partial, stream, b);
 }
 
 extern "C" int rd_gconv_split_pre_supported(const RdConvDesc* d) {

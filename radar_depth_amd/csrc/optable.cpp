@@ -78,7 +78,7 @@ const std::unordered_map<std::string, Entry>& registry() {
         RD_ENTRY(rd_event_record), RD_ENTRY(rd_stream_wait_event), RD_ENTRY(rd_allreduce_bucket), RD_ENTRY(rd_broadcast),
         RD_ENTRY(rd_debug_poison_lds),
         RD_ENTRY(rd_gconv_split_pre), RD_ENTRY(rd_wgrad_split_pre), RD_ENTRY(rd_split_pieces),
-        RD_ENTRY(rd_wino_conv3x3), RD_ENTRY(rd_wino_pack_batched),
+        RD_ENTRY(rd_wino_conv3x3), RD_ENTRY(rd_wino_pack_batched), RD_ENTRY(rd_wino_conv3x3_bnbwd), RD_ENTRY(rd_gconv_split_bnbwd), RD_ENTRY(rd_gconv_split_pre_bnbwd),
         RD_ENTRY(rd_bn_act_p), RD_ENTRY(rd_bn_bwd_apply_p), RD_ENTRY(rd_bn_bwd_apply_x_p), RD_ENTRY(rd_bn_bwd_apply_x2_p), RD_ENTRY(rd_bnact_maxpool_fwd_p),
     };
     return r;

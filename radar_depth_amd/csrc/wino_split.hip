@@ -56,6 +56,13 @@ struct WinoArgs {
     float* stat;
     int N, H, W, Cin, Cout, ldi, ldo, ld_add;
     int tiles_h, tiles_w, bh, bw, n_cot;
+    // rd_wino_conv3x3_bnbwd: the launch is an input gradient whose epilogue also emits the BatchNorm-backward sums of the BatchNorm in front of
+    // the convolution (bnb_x = that BatchNorm's input at the output pixels; stat then holds [tile][3][Cout]: sum g, sum g (x - mean))
+    const float* bnb_x;
+    const float* bnb_scale;
+    const float* bnb_shift;
+    const float* bnb_mean;
+    int bnb_ld, bnb_act;
     int dbg;                      // diagnostics (RD_WINO_DEBUG; results are then garbage): 1 no MFMAs, 2 no split / A stores, 4 no weight loads, 8 no epilogue, 32 / 64 staging / MFMA waves idle, 128 pixel-block-major order, 256 no patch loads
 };
 
@@ -304,6 +311,22 @@ epilogue:
     const int c4 = tid & 15;                 // channel quad of this thread (both of its items)
     const int co = cot * WN_CB + c4 * 4;
     float4 ssum = make_float4(0.f, 0.f, 0.f, 0.f), ssq = ssum;
+    const bool bnb = a.bnb_x != nullptr;
+    float4 bS = ssum, bT = ssum, bM = ssum;
+    if (bnb && co < a.Cout) { bS = ld4(a.bnb_scale + co); bT = ld4(a.bnb_shift + co); bM = ld4(a.bnb_mean + co); }
+    // statistics of one stored pixel: its values and squares, or (bnb) g = y * act'(scale x + shift) and g (x - mean)
+    auto account = [&](const float4 y, size_t px) {
+        if (bnb) {
+            const float4 xv = ld4(a.bnb_x + px * a.bnb_ld + co);
+            const float gx = y.x * act_grad_from_out(fmaf(bS.x, xv.x, bT.x), a.bnb_act), gy = y.y * act_grad_from_out(fmaf(bS.y, xv.y, bT.y), a.bnb_act);
+            const float gz = y.z * act_grad_from_out(fmaf(bS.z, xv.z, bT.z), a.bnb_act), gw = y.w * act_grad_from_out(fmaf(bS.w, xv.w, bT.w), a.bnb_act);
+            ssum.x += gx; ssum.y += gy; ssum.z += gz; ssum.w += gw;
+            ssq.x += gx * (xv.x - bM.x); ssq.y += gy * (xv.y - bM.y); ssq.z += gz * (xv.z - bM.z); ssq.w += gw * (xv.w - bM.w);
+        } else {
+            ssum.x += y.x; ssum.y += y.y; ssum.z += y.z; ssum.w += y.w;
+            ssq.x += y.x * y.x; ssq.y += y.y * y.y; ssq.z += y.z * y.z; ssq.w += y.w * y.w;
+        }
+    };
 #pragma unroll
     for (int it = 0; it < 2; ++it) {
         const int rt = (tid >> 4) + 32 * it;   // 0..63 = tile * 2 + r
@@ -323,13 +346,11 @@ epilogue:
         }
         if (ok0) {
             st4(a.out + pix * a.ldo + co, y0);
-            ssum.x += y0.x; ssum.y += y0.y; ssum.z += y0.z; ssum.w += y0.w;
-            ssq.x += y0.x * y0.x; ssq.y += y0.y * y0.y; ssq.z += y0.z * y0.z; ssq.w += y0.w * y0.w;
+            if (a.stat) account(y0, pix);
         }
         if (ok1) {
             st4(a.out + (pix + 1) * a.ldo + co, y1);
-            ssum.x += y1.x; ssum.y += y1.y; ssum.z += y1.z; ssum.w += y1.w;
-            ssq.x += y1.x * y1.x; ssq.y += y1.y * y1.y; ssq.z += y1.z * y1.z; ssq.w += y1.w * y1.w;
+            if (a.stat) account(y1, pix + 1);
         }
     }
     if (a.stat) {
@@ -345,7 +366,7 @@ epilogue:
             float s = 0.f;
 #pragma unroll 8
             for (int rw = 0; rw < 32; ++rw) s += red[(rw * 2 + which) * 64 + j];
-            if (cot * WN_CB + j < a.Cout) a.stat[((size_t)pt * 2 + which) * a.Cout + cot * WN_CB + j] = s;
+            if (cot * WN_CB + j < a.Cout) a.stat[((size_t)pt * (bnb ? 3 : 2) + which) * a.Cout + cot * WN_CB + j] = s;
         }
     }
 }
@@ -488,8 +509,9 @@ extern "C" int rd_wino_stat_tiles(int32_t N, int32_t H, int32_t W) {
     return N * ((th + rd::WN_TBH - 1) / rd::WN_TBH) * ((tw + rd::WN_TBW - 1) / rd::WN_TBW);
 }
 
-extern "C" int rd_wino_conv3x3(const float* in, int32_t N, int32_t H, int32_t W, int32_t Cin, int32_t ldi, const void* u_packed, float* out,
-                               int32_t Cout, int32_t ldo, const float* addend, int32_t ld_add, float* stat_partial, void* stream) {
+static int wino_launch(const float* in, int32_t N, int32_t H, int32_t W, int32_t Cin, int32_t ldi, const void* u_packed, float* out,
+                       int32_t Cout, int32_t ldo, const float* addend, int32_t ld_add, float* stat_partial, void* stream, const float* bn_x,
+                       int32_t bn_ld, const float* bn_mean, const float* bn_scale, const float* bn_shift, int32_t bn_act) {
     using namespace rd;
     RD_CHECK_ARG(in && u_packed && out && N > 0, "rd_wino_conv3x3: bad arguments");
     RD_CHECK_ARG(wino_shape_ok(H, W, Cin, Cout, ldi, ldo), "rd_wino_conv3x3: unsupported shape %dx%d %d->%d (ld %d / %d)", H, W, Cin, Cout, ldi, ldo);
@@ -501,6 +523,8 @@ extern "C" int rd_wino_conv3x3(const float* in, int32_t N, int32_t H, int32_t W,
     a.addend = addend;
     a.stat = stat_partial;
     a.N = N; a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout; a.ldi = ldi; a.ldo = ldo; a.ld_add = ld_add;
+    a.bnb_x = bn_x; a.bnb_ld = bn_ld; a.bnb_mean = bn_mean; a.bnb_scale = bn_scale; a.bnb_shift = bn_shift; a.bnb_act = bn_act;
+    RD_CHECK_ARG(!bn_x || (bn_mean && bn_scale && bn_shift && stat_partial && !addend && bn_ld % 4 == 0), "rd_wino_conv3x3_bnbwd: bad arguments");
     a.tiles_h = (H + 1) / 2;
     a.tiles_w = (W + 1) / 2;
     a.bh = (a.tiles_h + WN_TBH - 1) / WN_TBH;
@@ -522,4 +546,19 @@ extern "C" int rd_wino_conv3x3(const float* in, int32_t N, int32_t H, int32_t W,
     hipLaunchKernelGGL(wino_split_kernel<false>, dim3(grid), dim3(512), lds, static_cast<hipStream_t>(stream), a);
     RD_CHECK_LAUNCH("wino_split_kernel");
     return RD_OK;
+}
+
+extern "C" int rd_wino_conv3x3(const float* in, int32_t N, int32_t H, int32_t W, int32_t Cin, int32_t ldi, const void* u_packed, float* out,
+                               int32_t Cout, int32_t ldo, const float* addend, int32_t ld_add, float* stat_partial, void* stream) {
+    return wino_launch(in, N, H, W, Cin, ldi, u_packed, out, Cout, ldo, addend, ld_add, stat_partial, stream, nullptr, 0, nullptr, nullptr, nullptr, 0);
+}
+
+// The input gradient of a Winograd layer (u_packed = the flipped operand) that also emits the backward sums of the BatchNorm in front of the
+// convolution -- rd_gconv_bnbwd's contract: bn_x [N,H,W,Cout] (channel stride bn_ld) = that BatchNorm's input, red_partial
+// [rd_wino_stat_tiles(N,H,W)][3][Cout]: slot 0 = sum g, slot 1 = sum g (x - mean), g = dx * act'(scale x + shift).
+extern "C" int rd_wino_conv3x3_bnbwd(const float* in, int32_t N, int32_t H, int32_t W, int32_t Cin, int32_t ldi, const void* u_packed, float* out,
+                                     int32_t Cout, int32_t ldo, const float* bn_x, int32_t bn_ld, const float* mean, const float* scale,
+                                     const float* shift, int32_t bn_act, float* red_partial, void* stream) {
+    RD_CHECK_ARG(bn_x != nullptr, "rd_wino_conv3x3_bnbwd: null argument");
+    return wino_launch(in, N, H, W, Cin, ldi, u_packed, out, Cout, ldo, nullptr, 0, red_partial, stream, bn_x, bn_ld, mean, scale, shift, bn_act);
 }

@@ -543,14 +543,28 @@ class LateFusionPlan:
                 self.op(self.bwd, name + ".zero", self.L.rd_fill, dx.ptr, C.c_int64(dx.t.numel() * dx.t.element_size() // 4), C.c_float(0.0),
                         self.stream)
         sp_d = bool(ctx.get("split_dgrad"))
+        # split plans (round 6): reduce-in-epilogue for the conv -> BN -> act -> conv chains, like rd_gconv_bnbwd on the fp32 plan (RD_SPLIT_BNB=0: off)
+        split_bnb = (bnb is not None and addend is None and not zero_fill and self.fuse_bn_bwd and self.split
+                     and os.environ.get("RD_SPLIT_BNB", "1") == "1" and dx.C % 4 == 0 and dx.ld % 4 == 0)
         if ctx.get("wino_dgrad"):
             # the input gradient of a Winograd layer: the same kernel on the flipped operand (channels swapped, taps rotated by 180 degrees)
             if zero_fill or self.L.rd_wino_supported(H, W, cout, cin, dout.ld, dx.ld) != 1:
                 raise RuntimeError("%s: planned as a Winograd input gradient, but the library does not serve %dx%d %d->%d with strides %d / %d"
                                    % (name, H, W, cout, cin, dout.ld, dx.ld))
             self.meta[name + ".dgrad"] = ("wino", dd)
-            self.op(self.bwd, name + ".dgrad", self.L.rd_wino_conv3x3, dout.ptr, N, H, W, cout, dout.ld, _p(ctx["ud"]), dx.ptr, cin, dx.ld,
-                    addend.ptr if addend is not None else C.c_void_p(0), addend.ld if addend is not None else 0, C.c_void_p(0), self.stream)
+            if split_bnb:
+                # the BatchNorm behind this convolution's forward input takes its backward sums from this launch's epilogue (one
+                # rd_bn_bwd_reduce_x_t pass over dx and x less per conv -> BN -> ReLU -> conv chain; VERDICT r5 item 2b, second half)
+                tiles = self.L.rd_wino_stat_tiles(N, H, W)
+                red = self.buf(tiles, 3, dx.C)
+                xb, co = bnb["x"], bnb["co"]
+                assert xb.M == dx.M and xb.C == dx.C
+                self.op(self.bwd, name + ".dgrad", self.L.rd_wino_conv3x3_bnbwd, dout.ptr, N, H, W, cout, dout.ld, _p(ctx["ud"]), dx.ptr, cin, dx.ld,
+                        xb.ptr, xb.ld, _p(co["mean"]), _p(co["scale"]), _p(co["shift"]), bnb["act"], _p(red), self.stream)
+                self.bnb_out = (red, tiles)
+            else:
+                self.op(self.bwd, name + ".dgrad", self.L.rd_wino_conv3x3, dout.ptr, N, H, W, cout, dout.ld, _p(ctx["ud"]), dx.ptr, cin, dx.ld,
+                        addend.ptr if addend is not None else C.c_void_p(0), addend.ld if addend is not None else 0, C.c_void_p(0), self.stream)
             if late:
                 launch_wgrad()
             return dx
@@ -562,7 +576,19 @@ class LateFusionPlan:
         # (bf16 plans keep the separate BatchNorm-backward reduce pass: the same fusion in gconv_bf16's epilogue -- parity-green in
         #  round 3 -- made the bf16-storage step 5 % SLOWER, 1790 -> 1697 samples/s: that kernel's epilogue is already its longest
         #  phase, and the extra x loads sit on it)
-        if dg_pre:
+        if (dg_pre or sp_d) and split_bnb and self.L.rd_gconv_split_bnbwd_supported(C.byref(dd), 1 if dg_pre else 0) == 1:
+            tiles = (self.L.rd_gconv_split_pre_stat_tiles if dg_pre else self.L.rd_gconv_split_stat_tiles)(C.byref(dd))
+            red = self.buf(tiles, 3, dx.C)
+            xb, co = bnb["x"], bnb["co"]
+            assert xb.M == dx.M and xb.C == dx.C
+            if dg_pre:
+                self.op(self.bwd, name + ".dgrad", self.L.rd_gconv_split_pre_bnbwd, C.byref(dd), yp, yplane, _p(ctx["wd"]), C.c_int64(k * k * cin * cout),
+                        dx.ptr, xb.ptr, xb.ld, _p(co["mean"]), _p(co["scale"]), _p(co["shift"]), bnb["act"], _p(red), self.stream)
+            else:
+                self.op(self.bwd, name + ".dgrad", self.L.rd_gconv_split_bnbwd, C.byref(dd), dout.ptr, _p(ctx["wd"]), C.c_int64(k * k * cin * cout),
+                        dx.ptr, xb.ptr, xb.ld, _p(co["mean"]), _p(co["scale"]), _p(co["shift"]), bnb["act"], _p(red), self.stream)
+            self.bnb_out = (red, tiles)
+        elif dg_pre:
             self.op(self.bwd, name + ".dgrad", self.L.rd_gconv_split_pre, C.byref(dd), yp, yplane, _p(ctx["wd"]), C.c_int64(k * k * cin * cout), dx.ptr,
                     C.c_void_p(0), 0, 0, addend.ptr if addend is not None else C.c_void_p(0), addend.ld if addend is not None else 0,
                     C.c_void_p(0), self.stream)

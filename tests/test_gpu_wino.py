@@ -104,3 +104,34 @@ def test_headline_plan_runs_its_measured_winners_on_winograd(monkeypatch):
     print("winograd launches:", names)
     assert kinds.count("wino") >= 16, names
     assert any(n.startswith("layer4.1.conv1") for n in names) and any("decoder.layer1" in n or "dec" in n for n in names)
+
+
+@pytest.mark.parametrize("c,h,w,kind", [(128, 29, 50, "wino"), (512, 15, 25, "wino"), (256, 29, 50, "gconv_split"), (64, 57, 100, "any"), (32, 60, 100, "gconv_split_pre")])
+def test_reduce_in_epilogue_matches_the_separate_reduce_pass(monkeypatch, c, h, w, kind):
+    """VERDICT r5 item 2b (second half): the input gradient of conv2 in a conv1 -> BN -> ReLU -> conv2 chain also emits that BatchNorm's
+    backward sums from its epilogue (rd_wino_conv3x3_bnbwd / rd_gconv_split_bnbwd / rd_gconv_split_pre_bnbwd) instead of an
+    rd_bn_bwd_reduce_x_t pass over dx and x.  One BasicBlock, forward + backward, with and without (RD_SPLIT_BNB=0): the same sums in another
+    summation order -- every parameter gradient and the input gradient within 2e-6 of each tensor's max."""
+    from radar_depth_amd.model.models import BasicBlock
+    from radar_depth_amd.synthetic import procedural_fill_
+    res = {}
+    for flag in ("1", "0"):
+        monkeypatch.setenv("RD_SPLIT_BNB", flag)
+        torch.manual_seed(5)
+        blk = BasicBlock(c, c)
+        procedural_fill_(blk)
+        blk = blk.cuda().train()
+        x = torch.randn(2, c, h, w, device="cuda", requires_grad=True)
+        y = blk(x)
+        y.backward(torch.randn(2, c, h, w, device="cuda", generator=torch.Generator("cuda").manual_seed(9)))
+        torch.cuda.synchronize()
+        plan = list(blk.__dict__["_module_plans"].values())[0]
+        fns = [f.__name__ for _, f, _ in plan.bwd if hasattr(f, "__name__")]
+        n_bnb = sum(f.endswith("_bnbwd") for f in fns)
+        assert n_bnb == (1 if flag == "1" else 0), fns
+        assert fns.count("rd_bn_bwd_reduce_x_t") == (0 if flag == "1" else 1)
+        if flag == "1" and kind != "any":
+            assert plan.meta["m.conv2.dgrad"][0] == kind, plan.meta["m.conv2.dgrad"][0]
+        res[flag] = [x.grad.clone()] + [p.grad.clone() for p in blk.parameters()]
+    for a, b in zip(res["1"], res["0"]):
+        assert ((a - b).abs().max() / b.abs().max().clamp_min(1e-30)).item() <= 2e-6

@@ -303,8 +303,9 @@ def test_state_broadcast_packing_round_trip():
 def test_split_plan_routes_supported_convolutions():
     """operands="split": every forward / input-gradient convolution the library has a split plan for goes to rd_gconv_split with a
     three-piece bf16 operand (pack quad 3); the rest keeps rd_gconv with the fp32 operand; the 3x3 / stride-1 weight gradients go to
-    rd_wgrad_split (same slabs and reduction order), the others stay on rd_wgrad; the BatchNorm
-    reduce passes are all present (no rd_gconv_bnbwd fusion on split input gradients)."""
+    rd_wgrad_split (same slabs and reduction order), the others stay on rd_wgrad; since round 6 the input gradients of the
+    conv -> BN -> ReLU -> conv chains also emit that BatchNorm's backward sums (rd_gconv_split[_pre]_bnbwd / rd_wino_conv3x3_bnbwd) and their
+    rd_bn_bwd_reduce_x_t passes are gone (RD_SPLIT_BNB=0 restores them)."""
     import ctypes as C
     from radar_depth_amd.engine import LateFusionPlan
     m = _model(450, 800)
@@ -327,7 +328,12 @@ def test_split_plan_routes_supported_convolutions():
     names = [n for n, _, _ in plan.fwd + plan.bwd]
     assert any(n.endswith(".dgrad") for n in names)
     fns = collections.Counter(f.__name__ if hasattr(f, "__name__") else str(f) for _, f, _ in plan.fwd + plan.bwd)
-    assert fns["rd_gconv_split"] == kinds["gconv_split"]
+    assert fns["rd_gconv_split"] + fns["rd_gconv_split_bnbwd"] == kinds["gconv_split"]
+    assert fns["rd_gconv_split_pre"] + fns["rd_gconv_split_pre_bnbwd"] == kinds["gconv_split_pre"]
+    assert fns["rd_wino_conv3x3"] + fns["rd_wino_conv3x3_bnbwd"] == kinds["wino"] >= 16
+    n_bnb = fns["rd_gconv_split_bnbwd"] + fns["rd_gconv_split_pre_bnbwd"] + fns["rd_wino_conv3x3_bnbwd"]
+    ref_reduce = collections.Counter(f.__name__ for _, f, _ in ref.bwd if hasattr(f, "__name__"))["rd_bn_bwd_reduce_x_t"]
+    assert n_bnb >= 14 and fns["rd_bn_bwd_reduce_x_t"] <= 8, (n_bnb, fns["rd_bn_bwd_reduce_x_t"], ref_reduce)
     assert fns["rd_wgrad_split"] == kinds["wgrad_split"] and fns["rd_wgrad_split_reduce"] >= kinds["wgrad_split"]
 
 
