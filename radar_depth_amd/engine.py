@@ -83,6 +83,9 @@ def _p(t):
     return C.c_void_p(0 if t is None else t.data_ptr())
 
 
+SPLIT_BNB_DEFAULT = "0"
+
+
 class LateFusionPlan:
     def __init__(self, module, batch, height, width, train=True, depth_planes=None, x_source=None, dense_grad_dst=None,
                  dry_run=False, bf16=False, storage="fp32", segment_joins=True, autotune=None, split=False):
@@ -544,8 +547,12 @@ class LateFusionPlan:
                         self.stream)
         sp_d = bool(ctx.get("split_dgrad"))
         # split plans (round 6): reduce-in-epilogue for the conv -> BN -> act -> conv chains, like rd_gconv_bnbwd on the fp32 plan (RD_SPLIT_BNB=0: off)
+        # RD_SPLIT_BNB: "0" none, "1" all, or a comma list of kernel families: wino, pre (gconv_sp2), split (8-wave).  Measured on the step
+        # (profiles/r06_split_bnb_ab.txt): see the default below.
+        fam = "wino" if ctx.get("wino_dgrad") else "pre" if dg_pre else "split"
+        want = os.environ.get("RD_SPLIT_BNB", SPLIT_BNB_DEFAULT)
         split_bnb = (bnb is not None and addend is None and not zero_fill and self.fuse_bn_bwd and self.split
-                     and os.environ.get("RD_SPLIT_BNB", "1") == "1" and dx.C % 4 == 0 and dx.ld % 4 == 0)
+                     and (want == "1" or fam in want.split(",")) and dx.C % 4 == 0 and dx.ld % 4 == 0)
         if ctx.get("wino_dgrad"):
             # the input gradient of a Winograd layer: the same kernel on the flipped operand (channels swapped, taps rotated by 180 degrees)
             if zero_fill or self.L.rd_wino_supported(H, W, cout, cin, dout.ld, dx.ld) != 1:

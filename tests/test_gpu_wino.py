@@ -110,8 +110,9 @@ def test_headline_plan_runs_its_measured_winners_on_winograd(monkeypatch):
 def test_reduce_in_epilogue_matches_the_separate_reduce_pass(monkeypatch, c, h, w, kind):
     """VERDICT r5 item 2b (second half): the input gradient of conv2 in a conv1 -> BN -> ReLU -> conv2 chain also emits that BatchNorm's
     backward sums from its epilogue (rd_wino_conv3x3_bnbwd / rd_gconv_split_bnbwd / rd_gconv_split_pre_bnbwd) instead of an
-    rd_bn_bwd_reduce_x_t pass over dx and x.  One BasicBlock, forward + backward, with and without (RD_SPLIT_BNB=0): the same sums in another
-    summation order -- every parameter gradient and the input gradient within 2e-6 of each tensor's max."""
+    rd_bn_bwd_reduce_x_t pass over dx and x.  One BasicBlock, forward + backward, with (RD_SPLIT_BNB=1) and without (0, the default: the fold
+    measured -0.7 ... -1 % on the step, profiles/r06_split_bnb_ab.txt): the same sums in another summation order -- every parameter gradient and
+    the input gradient within 2e-6 of each tensor's max."""
     from radar_depth_amd.model.models import BasicBlock
     from radar_depth_amd.synthetic import procedural_fill_
     res = {}

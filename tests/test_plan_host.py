@@ -300,15 +300,18 @@ def test_state_broadcast_packing_round_trip():
     assert all(torch.equal(a, b) for a, b in zip(bufs, want)) and ptrs == [b.data_ptr() for b in bufs]
 
 
-def test_split_plan_routes_supported_convolutions():
+def test_split_plan_routes_supported_convolutions(monkeypatch):
     """operands="split": every forward / input-gradient convolution the library has a split plan for goes to rd_gconv_split with a
     three-piece bf16 operand (pack quad 3); the rest keeps rd_gconv with the fp32 operand; the 3x3 / stride-1 weight gradients go to
-    rd_wgrad_split (same slabs and reduction order), the others stay on rd_wgrad; since round 6 the input gradients of the
-    conv -> BN -> ReLU -> conv chains also emit that BatchNorm's backward sums (rd_gconv_split[_pre]_bnbwd / rd_wino_conv3x3_bnbwd) and their
-    rd_bn_bwd_reduce_x_t passes are gone (RD_SPLIT_BNB=0 restores them)."""
+    rd_wgrad_split (same slabs and reduction order), the others stay on rd_wgrad.  RD_SPLIT_BNB=1 (round 6; off by default: it measured
+    -0.7 ... -1 % on the step, profiles/r06_split_bnb_ab.txt): the input gradients of the conv -> BN -> ReLU -> conv chains also emit that
+    BatchNorm's backward sums (rd_gconv_split[_pre]_bnbwd / rd_wino_conv3x3_bnbwd) and their rd_bn_bwd_reduce_x_t passes are gone."""
     import ctypes as C
     from radar_depth_amd.engine import LateFusionPlan
     m = _model(450, 800)
+    default = LateFusionPlan(m, 16, 450, 800, train=True, dry_run=True, split=True)
+    assert not any(getattr(f, "__name__", "").endswith("_bnbwd") for _, f, _ in default.bwd)
+    monkeypatch.setenv("RD_SPLIT_BNB", "1")
     plan = LateFusionPlan(m, 16, 450, 800, train=True, dry_run=True, split=True)
     ref = LateFusionPlan(m, 16, 450, 800, train=True, dry_run=True)
     kinds = collections.Counter(k for k, _ in plan.meta.values())
