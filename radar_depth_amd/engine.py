@@ -549,10 +549,10 @@ class LateFusionPlan:
         # split plans (round 6): reduce-in-epilogue for the conv -> BN -> act -> conv chains, like rd_gconv_bnbwd on the fp32 plan (RD_SPLIT_BNB=0: off)
         # RD_SPLIT_BNB: "0" none, "1" all, or a comma list of kernel families: wino, pre (gconv_sp2), split (8-wave).  Measured on the step
         # (profiles/r06_split_bnb_ab.txt): see the default below.
-        fam = "wino" if ctx.get("wino_dgrad") else "pre" if dg_pre else "split"
+        bnb_fam = "wino" if ctx.get("wino_dgrad") else "pre" if dg_pre else "split"
         want = os.environ.get("RD_SPLIT_BNB", SPLIT_BNB_DEFAULT)
         split_bnb = (bnb is not None and addend is None and not zero_fill and self.fuse_bn_bwd and self.split
-                     and (want == "1" or fam in want.split(",")) and dx.C % 4 == 0 and dx.ld % 4 == 0)
+                     and (want == "1" or bnb_fam in want.split(",")) and dx.C % 4 == 0 and dx.ld % 4 == 0)
         if ctx.get("wino_dgrad"):
             # the input gradient of a Winograd layer: the same kernel on the flipped operand (channels swapped, taps rotated by 180 degrees)
             if zero_fill or self.L.rd_wino_supported(H, W, cout, cin, dout.ld, dx.ld) != 1:

@@ -102,7 +102,7 @@ def test_headline_plan_runs_its_measured_winners_on_winograd(monkeypatch):
     kinds = [k for k, _ in plan.meta.values()]
     names = sorted(n for n, (k, _) in plan.meta.items() if k == "wino")
     print("winograd launches:", names)
-    assert kinds.count("wino") >= 16, names
+    assert kinds.count("wino") == 20, names
     assert any(n.startswith("layer4.1.conv1") for n in names) and any("decoder.layer1" in n or "dec" in n for n in names)
 
 
