@@ -405,7 +405,7 @@ def test_config3_per_gpu_workload_b16_450x800_bf16_storage():
     assert all(torch.isfinite(p).all() for p in hm.parameters())
 
 
-@pytest.mark.parametrize("b", [2, pytest.param(8, marks=pytest.mark.slow)])
+@pytest.mark.parametrize("b", [pytest.param(2, marks=pytest.mark.slow), pytest.param(8, marks=pytest.mark.slow)])      # (900x1600 stays in the default run through test_gpu_model.py::test_large_geometry_900x1600 and test_gpu_bf16.py::test_bf16_large_geometry_900x1600)
 def test_config5_geometry_multistage_900x1600_bf16_storage(b):
     """BASELINE configs[4]'s network and geometry (multistage_uncertainty_fixs, 900x1600) under bf16 storage, at b=2 and at the
     configuration's own per-GPU batch b=8 (what `bench.py --config 5` runs): the four loss terms of the fused step against the
